@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE (read-only,
+/root/reference) in this container.  Output = data only (inputs + expected outputs, .npz);
+no reference source is copied.  Re-run:  python tests/golden/make_golden.py [--only NAME]
+
+The reference has no tests or golden vectors of its own, so these fixtures
+are what pins the oracle (oracle/nirrt_oracle.c) and, through it, the HIP path.
+
+Families:
+  geom2d / geom3d      segment-vs-obstacle, point-in-obstacle, point-validity known answers
+  run_*                seeded whole planner runs with the recorded node_rand sequence
+                       (L1 replay + L2 seeded parity), per-iteration trace for small runs
+  random_*             planning_random() per-iteration best-cost lists
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import random
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+import refshim  # noqa: E402
+
+refshim.install()
+import numpy as np  # noqa: E402
+
+from nirrt_star_amd import worlds  # noqa: E402
+
+from path_planning_classes.rrt_star_2d import RRTStar2D  # noqa: E402
+from path_planning_classes.irrt_star_2d import IRRTStar2D  # noqa: E402
+from path_planning_classes.rrt_utils_2d import Utils as Utils2D  # noqa: E402
+from path_planning_classes_3d.rrt_star_3d import RRTStar3D  # noqa: E402
+from path_planning_classes_3d.irrt_star_3d import IRRTStar3D  # noqa: E402
+from path_planning_classes_3d.rrt_utils_3d import Utils as Utils3D  # noqa: E402
+from path_planning_utils.rrt_env import Env as RefEnv2D  # noqa: E402
+from path_planning_utils_3d.rrt_env_3d import Env as RefEnv3D  # noqa: E402
+
+STEP_LEN = 10
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KiB)" % (path, os.path.getsize(path) / 1024))
+
+
+def env_json(env_dict):
+    return np.array(json.dumps(env_dict))
+
+
+# ----------------------------------------------------------------------------------
+# geometry known answers
+# ----------------------------------------------------------------------------------
+def geom2d():
+    rng = np.random.default_rng(7)
+    out = {}
+    worlds_ = [worlds.random_world_2d(0, "ref2d"), worlds.random_world_2d(1, "b30"),
+               worlds.random_world_2d(2, "ref2d")]
+    # hand-made world for boundary-exact cases (integer geometry so every case is exact in f64)
+    edge_world = {"env_dims": (224, 224), "rectangle_obstacles": [[100, 100, 20, 10]],
+                  "circle_obstacles": [[50, 50, 10]], "start": [[5, 5]], "goal": [[200, 200]]}
+    worlds_.append(edge_world)
+    for wi, ed in enumerate(worlds_):
+        u = Utils2D(RefEnv2D(ed), 3)
+        n = 4000
+        a = rng.uniform(-5, 229, size=(n, 2))
+        # short segments (like tree edges, <= ~14 long) and a tail of long ones
+        d = rng.normal(size=(n, 2)) * rng.choice([3.0, 10.0, 60.0], size=(n, 1), p=[0.3, 0.5, 0.2])
+        b = a + d
+        if wi == 3:
+            special = [
+                # tangent to inflated circle (r+c = 13): horizontal line y = 63
+                ([30, 63], [70, 63]), ([30, 63.0000001], [70, 63.0000001]), ([30, 62.9999999], [70, 62.9999999]),
+                # endpoint exactly on inflated circle boundary / zero-length segments
+                ([63, 50], [80, 50]), ([63, 50], [63, 50]), ([64, 50], [64, 50]), ([50, 50], [50, 50]),
+                # rectangle inflated: x in [97,123], y in [97,113]
+                ([90, 97], [130, 97]),        # collinear with inflated bottom edge
+                ([90, 96.9999], [130, 96.9999]),
+                ([97, 90], [97, 120]),        # collinear with inflated left edge
+                ([90, 90], [97, 97]),         # ends exactly on the corner
+                ([90, 104], [104, 90]),       # passes exactly through corner (97,97)
+                ([90, 103.9], [103.9, 90]),   # just misses the corner
+                ([97, 97], [97, 97]),         # zero-length on the corner
+                ([110, 105], [110, 105]),     # zero-length inside
+                ([80, 105], [140, 105]),      # crosses
+                ([80, 120], [140, 120]),      # parallel, outside
+                ([124, 90], [124, 120]),      # parallel to right edge, outside by 1
+                ([123, 90], [123, 120]),      # on right edge
+            ]
+            sa = np.array([s[0] for s in special], dtype=np.float64)
+            sb = np.array([s[1] for s in special], dtype=np.float64)
+            a = np.concatenate([sa, a[: n - len(sa)]])
+            b = np.concatenate([sb, b[: n - len(sb)]])
+        col = np.array([u.is_collision(a[i], b[i]) for i in range(n)], dtype=np.uint8)
+        pts = rng.uniform(-5, 229, size=(n, 2))
+        if wi == 3:
+            sp = np.array([[63, 50], [50, 63], [62.9999999, 50], [97, 97], [123, 113], [123.0000001, 113],
+                           [96.9999999, 100], [110, 105], [3, 3], [221, 221], [2.9999, 50], [221.0001, 50],
+                           [3, 224], [0, 0]], dtype=np.float64)
+            pts[: len(sp)] = sp
+        inside = np.array([u.is_inside_obs(pts[i]) for i in range(n)], dtype=np.uint8)
+        valid = np.array([u.is_valid(pts[i]) for i in range(n)], dtype=np.uint8)
+        inrange = np.array([u.is_in_range(pts[i]) for i in range(n)], dtype=np.uint8)
+        out["w%d_env" % wi] = env_json(ed)
+        out["w%d_seg_a" % wi] = a
+        out["w%d_seg_b" % wi] = b
+        out["w%d_collision" % wi] = col
+        out["w%d_pts" % wi] = pts
+        out["w%d_inside" % wi] = inside
+        out["w%d_valid" % wi] = valid
+        out["w%d_inrange" % wi] = inrange
+    out["n_worlds"] = np.array(len(worlds_))
+    out["clearance"] = np.array(3.0)
+    save("geom2d", **out)
+
+
+def geom3d():
+    rng = np.random.default_rng(11)
+    out = {}
+    worlds_ = [worlds.random_world_3d(0), worlds.random_world_3d(1)]
+    edge_world = {"env_dims": [50, 50, 50], "box_obstacles": [[20, 20, 20, 10, 8, 6]],
+                  "ball_obstacles": [[10, 10, 10, 5]], "start": [[3, 3, 3]], "goal": [[45, 45, 45]]}
+    worlds_.append(edge_world)
+    for wi, ed in enumerate(worlds_):
+        u = Utils3D(RefEnv3D(ed), 2)
+        n = 4000
+        a = rng.uniform(-3, 53, size=(n, 3))
+        d = rng.normal(size=(n, 3)) * rng.choice([2.0, 6.0, 25.0], size=(n, 1), p=[0.3, 0.5, 0.2])
+        b = a + d
+        if wi == 2:
+            special = [
+                # ball inflated radius 7: tangent line at z = 17 through (x, 10, 17)
+                ([0, 10, 17], [20, 10, 17]), ([0, 10, 17.0000001], [20, 10, 17.0000001]),
+                ([17, 10, 10], [30, 10, 10]), ([17, 10, 10], [17, 10, 10]), ([10, 10, 10], [10, 10, 10]),
+                ([17.0000001, 10, 10], [17.0000001, 10, 10]),
+                ([3, 10, 10], [1, 10, 10]),     # t<=0 branch, start exactly on the sphere
+                ([0, 10, 10], [3, 10, 10]),     # t>=1 branch, end exactly on the sphere
+                # box inflated: x [18,32], y [18,30], z [18,28]
+                ([10, 18, 23], [40, 18, 23]),   # along a face
+                ([10, 17.9999, 23], [40, 17.9999, 23]),
+                ([18, 18, 10], [18, 18, 40]),   # along an edge
+                ([10, 10, 10], [18, 18, 18]),   # ends on the corner
+                ([18, 18, 18], [18, 18, 18]),   # zero length on corner
+                ([25, 24, 23], [25, 24, 23]),   # zero length inside
+                ([10, 26, 10], [26, 10, 10]),   # diagonal far below the box
+                ([16, 24, 23], [34, 24, 23]),   # through
+                ([33, 10, 23], [33, 40, 23]),   # parallel outside
+                ([32, 10, 23], [32, 40, 23]),   # on face
+            ]
+            sa = np.array([s[0] for s in special], dtype=np.float64)
+            sb = np.array([s[1] for s in special], dtype=np.float64)
+            a = np.concatenate([sa, a[: n - len(sa)]])
+            b = np.concatenate([sb, b[: n - len(sb)]])
+        col = np.array([u.is_collision(a[i], b[i]) for i in range(n)], dtype=np.uint8)
+        pts = rng.uniform(-3, 53, size=(n, 3))
+        if wi == 2:
+            sp = np.array([[17, 10, 10], [10, 17, 10], [16.9999999, 10, 10], [18, 18, 18], [32, 30, 28],
+                           [32.0000001, 30, 28], [25, 24, 23], [2, 2, 2], [48, 48, 48], [1.9999, 25, 25],
+                           [48.0001, 25, 25], [0, 0, 0]], dtype=np.float64)
+            pts[: len(sp)] = sp
+        inside = np.array([u.is_inside_obs(pts[i]) for i in range(n)], dtype=np.uint8)
+        valid = np.array([u.is_valid(pts[i]) for i in range(n)], dtype=np.uint8)
+        out["w%d_env" % wi] = env_json(ed)
+        out["w%d_seg_a" % wi] = a
+        out["w%d_seg_b" % wi] = b
+        out["w%d_collision" % wi] = col
+        out["w%d_pts" % wi] = pts
+        out["w%d_inside" % wi] = inside
+        out["w%d_valid" % wi] = valid
+    out["n_worlds"] = np.array(len(worlds_))
+    out["clearance"] = np.array(2.0)
+    save("geom3d", **out)
+
+
+# ----------------------------------------------------------------------------------
+# whole runs
+# ----------------------------------------------------------------------------------
+class Recorder:
+    """Wrap a reference planner instance to log node_rand and per-iteration decisions."""
+
+    def __init__(self, planner, trace):
+        self.p = planner
+        self.samples = []
+        self.trace = trace
+        self.nearest = []
+        self.near_off = [0]
+        self.near_idx = []
+        gen = planner.generate_random_node
+
+        def rec_gen(*a, **k):
+            r = gen(*a, **k)
+            self.samples.append(np.array(r, dtype=np.float64))
+            return r
+
+        planner.generate_random_node = rec_gen
+        if trace:
+            nn = planner.nearest_neighbor
+
+            def rec_nn(node_list, n):
+                r = nn(node_list, n)
+                self.nearest.append(int(r[1]))
+                return r
+
+            planner.nearest_neighbor = rec_nn
+            fn = planner.find_near_neighbors
+
+            def rec_fn(node_new, node_new_index=None):
+                r = fn(node_new, node_new_index)
+                # pad the offset table so that entry k belongs to iteration k (not every
+                # iteration reaches find_near_neighbors)
+                while len(self.near_off) < len(self.nearest):
+                    self.near_off.append(self.near_off[-1])
+                self.near_idx.extend(int(v) for v in r)
+                self.near_off.append(len(self.near_idx))
+                return r
+
+            planner.find_near_neighbors = rec_fn
+
+    def arrays(self):
+        out = {"samples": np.array(self.samples)}
+        if self.trace:
+            while len(self.near_off) < len(self.nearest) + 1:
+                self.near_off.append(self.near_off[-1])
+            out["trace_nearest"] = np.array(self.nearest, dtype=np.int32)
+            out["trace_near_off"] = np.array(self.near_off, dtype=np.int32)
+            out["trace_near_idx"] = np.array(self.near_idx, dtype=np.int32)
+        return out
+
+
+def make_problem(dim, world_kind, world_seed, pair):
+    if dim == 2:
+        ed = worlds.random_world_2d(world_seed, world_kind)
+        pr = worlds.problem_2d(ed, pair)
+        clearance = 3
+    else:
+        ed = worlds.random_world_3d(world_seed)
+        np.random.seed(world_seed)  # gamma estimate consumes the global RNG; pin it
+        pr = worlds.problem_3d(ed)
+        clearance = 2
+    return pr, clearance
+
+
+def run_planner(name, algo, dim, world_kind, world_seed, pair, iters, seed, trace=False, mode="planning",
+                iter_after_initial=0):
+    t0 = time.time()
+    pr, clearance = make_problem(dim, world_kind, world_seed, pair)
+    cls = {("rrt", 2): RRTStar2D, ("irrt", 2): IRRTStar2D, ("rrt", 3): RRTStar3D, ("irrt", 3): IRRTStar3D}[(algo, dim)]
+    env = RefEnv2D(pr["env_dict"]) if dim == 2 else RefEnv3D(pr["env_dict"])
+    planner = cls(pr["x_start"], pr["x_goal"], STEP_LEN, pr["search_radius"], iters, env, clearance)
+    rec = Recorder(planner, trace)
+    np.random.seed(seed)
+    random.seed(seed)
+    with quiet():
+        if mode == "planning":
+            planner.planning()
+            extra = {}
+        else:
+            lst = planner.planning_random(iter_after_initial)
+            extra = {"path_len_list": np.array(lst, dtype=np.float64),
+                     "iter_after_initial": np.array(iter_after_initial)}
+    n = planner.num_vertices
+    path = np.array(planner.path, dtype=np.float64).reshape(-1, dim) if len(planner.path) else np.zeros((0, dim))
+    arrays = dict(
+        env=env_json(pr["env_dict"]), dim=np.array(dim), algo=np.array(algo), seed=np.array(seed),
+        iter_max=np.array(iters), step_len=np.array(float(STEP_LEN)), clearance=np.array(float(clearance)),
+        search_radius=np.array(float(pr["search_radius"])),
+        x_start=np.array(pr["x_start"], dtype=np.float64), x_goal=np.array(pr["x_goal"], dtype=np.float64),
+        n=np.array(n), vertices=planner.vertices[:n].copy(), parents=planner.vertex_parents[:n].astype(np.int64),
+        path=path, path_len=np.array(float(planner.get_path_len(planner.path))),
+        path_solutions=np.array(getattr(planner, "path_solutions", []), dtype=np.int64),
+        **rec.arrays(), **extra)
+    save(name, **arrays)
+    print("   %s: n=%d path_len=%.6f  (%.1fs)" % (name, n, float(arrays["path_len"]), time.time() - t0))
+
+
+JOBS = {
+    "geom2d": geom2d,
+    "geom3d": geom3d,
+    # config 1 of BASELINE.json: rrt_star random_2d iter_max=500
+    "run_rrt2d_500": lambda: run_planner("run_rrt2d_500", "rrt", 2, "ref2d", 0, 0, 500, 1000, trace=True),
+    "run_rrt2d_3000": lambda: run_planner("run_rrt2d_3000", "rrt", 2, "ref2d", 3, 1, 3000, 1003),
+    "run_rrt2d_b30_2000": lambda: run_planner("run_rrt2d_b30_2000", "rrt", 2, "b30", 5, 0, 2000, 1005, trace=True),
+    "run_irrt2d_800": lambda: run_planner("run_irrt2d_800", "irrt", 2, "ref2d", 0, 0, 800, 1000, trace=True),
+    "run_irrt2d_3000": lambda: run_planner("run_irrt2d_3000", "irrt", 2, "b30", 7, 2, 3000, 1007),
+    "run_rrt3d_500": lambda: run_planner("run_rrt3d_500", "rrt", 3, "ref3d", 0, 0, 500, 1000, trace=True),
+    "run_rrt3d_3000": lambda: run_planner("run_rrt3d_3000", "rrt", 3, "ref3d", 2, 0, 3000, 1002),
+    "run_irrt3d_3000": lambda: run_planner("run_irrt3d_3000", "irrt", 3, "ref3d", 1, 0, 3000, 1001, trace=True),
+    "random_rrt2d": lambda: run_planner("random_rrt2d", "rrt", 2, "ref2d", 4, 0, 5000, 1004, mode="random", iter_after_initial=300),
+    "random_irrt2d": lambda: run_planner("random_irrt2d", "irrt", 2, "ref2d", 4, 0, 5000, 1004, mode="random", iter_after_initial=300),
+    "random_rrt3d": lambda: run_planner("random_rrt3d", "rrt", 3, "ref3d", 3, 0, 5000, 1003, mode="random", iter_after_initial=300),
+    "random_irrt3d": lambda: run_planner("random_irrt3d", "irrt", 3, "ref3d", 3, 0, 5000, 1003, mode="random", iter_after_initial=300),
+}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    for name, job in JOBS.items():
+        if args.only and name not in args.only:
+            continue
+        job()

@@ -1,0 +1,34 @@
+"""Import shim for the READ-ONLY reference at /root/reference (this container only).
+
+Used solely by ``make_golden.py`` to generate fixtures; nothing under ``tests/`` that runs
+on the GPU box imports this (``/root/reference`` does not exist there).
+
+* the reference has no ``__init__.py`` anywhere, and site-packages holds an unrelated
+  ``datasets`` (HuggingFace) that shadows its ``datasets/`` namespace package -> pre-seed;
+* cv2 and open3d are not installed -> stubbed (open3d's FPS is replaced by a recorder, so
+  fixtures are defined downstream of the point cloud);
+* never write bytecode into the reference tree.
+"""
+import os
+import sys
+import types
+
+REF = "/root/reference"
+
+
+def install():
+    sys.dont_write_bytecode = True
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for name in ("datasets", "datasets_3d"):
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF, name)]
+        sys.modules[name] = m
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    if "open3d" not in sys.modules:
+        o3d = types.ModuleType("open3d")
+        o3d.geometry = types.SimpleNamespace()
+        o3d.utility = types.SimpleNamespace()
+        sys.modules["open3d"] = o3d
+    return REF

@@ -1,0 +1,57 @@
+"""L1 replay parity of the oracle: feed the recorded node_rand sequence of a seeded reference
+run through oracle.step() and require the reference's tree bit-for-bit."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, make_oracle_tree
+
+RUNS = ["run_rrt2d_500", "run_rrt2d_3000", "run_rrt2d_b30_2000", "run_irrt2d_800", "run_irrt2d_3000",
+        "run_rrt3d_500", "run_rrt3d_3000", "run_irrt3d_3000"]
+
+
+@pytest.mark.parametrize("name", RUNS)
+def test_replay_reproduces_reference_tree(oracle, name):
+    g = load_golden(name)
+    irrt = str(g["algo"]) == "irrt"
+    t = make_oracle_tree(oracle, g)
+    samples = g["samples"]
+    assert len(samples) == int(g["iter_max"])
+    have_trace = "trace_nearest" in g
+    for k, q in enumerate(samples):
+        r = t.step(q, irrt)
+        if have_trace:
+            assert r.nearest_idx == g["trace_nearest"][k], "iteration %d" % k
+            lo, hi = g["trace_near_off"][k], g["trace_near_off"][k + 1]
+            assert r.n_near == hi - lo, "iteration %d" % k
+    assert t.n == int(g["n"])
+    assert np.array_equal(t.parents, g["parents"])
+    assert np.array_equal(t.vertices, g["vertices"])  # bit-equal (same libm on this box)
+    if irrt:
+        assert np.array_equal(t.solutions, g["path_solutions"])
+        if len(g["path_solutions"]):
+            c_best, x_best = t.best_solution()
+            assert abs(c_best - float(g["path_len"])) <= 1e-9 * max(1.0, c_best)
+    else:
+        gp = t.search_goal_parent()
+        if np.isfinite(float(g["path_len"])):
+            assert gp >= 0
+            assert abs(t.path_len(gp) - float(g["path_len"])) <= 1e-9 * float(g["path_len"])
+            # path = start ... goal_parent, goal
+            assert np.array_equal(g["path"][-2], t.vertices[gp])
+        else:
+            assert gp < 0 or not np.isfinite(t.path_len(gp)) or len(g["path"]) == 0
+    t.close()
+
+
+def test_near_sets_match_trace(oracle):
+    """Near-set membership (ascending indices) from the per-iteration trace of a small run."""
+    g = load_golden("run_rrt2d_b30_2000")
+    t = make_oracle_tree(oracle, g)
+    for k, q in enumerate(g["samples"]):
+        r = t.step(q, False)
+        lo, hi = g["trace_near_off"][k], g["trace_near_off"][k + 1]
+        if hi > lo and k % 7 == 0:
+            # recompute Near on the post-iteration tree: parents changed but membership did not
+            idx = t.near(np.array(r.node_new[: t.dim]), r.new_idx)
+            assert np.array_equal(idx, g["trace_near_idx"][lo:hi])
+    t.close()
