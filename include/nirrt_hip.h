@@ -1,0 +1,172 @@
+/*
+ * nirrt_hip.h — C ABI of libnirrt_hip.so, the MI355X (gfx950) implementation of the
+ * RRT* / Informed-RRT* planning inner loop of tedhuang96/nirrt_star.
+ *
+ * The reference is pure Python and has no FFI; each entry point below replaces one Python-level
+ * function of the reference's hot path (file:line cited per function, paths relative to the
+ * reference checkout).  INTEGRATION.md shows the ctypes binding a maintainer of the reference
+ * would add to call them from path_planning_classes{,_3d}/.
+ *
+ * Conventions
+ *   - plain C: opaque handle, plain pointers + sizes, no C++/torch types.
+ *   - every function returns 0 on success or a negative NIRRT_E_* code; nothing throws.
+ *   - the caller owns all host buffers (C-contiguous float64 / int64 / uint8, like the numpy
+ *     arrays the reference passes around); the library owns device memory until nirrt_destroy.
+ *   - one tree = one opaque handle = one HIP stream; a handle is not thread-safe.
+ *   - vertices cross the boundary as (n, dim) row-major float64 (the reference's
+ *     `self.vertices[:n]`), parents as int64 (`self.vertex_parents[:n]`).  In HBM the tree is a
+ *     flat SoA: x[cap], y[cap](, z[cap]) f64 + parent[cap] i32.
+ *   - all planner arithmetic is float64 and follows the reference's per-call-site formulas
+ *     (SURVEY.md Appendix A); integer bookkeeping (indices, parents, n) is exact.
+ */
+#ifndef NIRRT_HIP_H
+#define NIRRT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NIRRT_OK 0
+#define NIRRT_E_ARG (-1)      /* bad argument (dim, sizes, NULL)                      */
+#define NIRRT_E_HIP (-2)      /* a HIP runtime call failed (see nirrt_last_error)      */
+#define NIRRT_E_CAPACITY (-3) /* tree / Near-set / obstacle / solution capacity hit    */
+#define NIRRT_E_NODEVICE (-4) /* no gfx950 device visible                              */
+#define NIRRT_E_STREAM (-5)   /* random-word stream exhausted inside nirrt_run         */
+
+#define NIRRT_MAX_OBSTACLES 64 /* per kind (round / box) */
+#define NIRRT_NEAR_CAPACITY 1024
+
+typedef struct nirrt_tree nirrt_tree;
+
+/* Problem description = the constructor arguments of RRTStar2D/3D (rrt_star_2d.py:10-30,
+ * rrt_base_2d.py:8-37) plus the obstacle tables Utils builds (rrt_utils_2d.py:5-17,
+ * rrt_utils_3d.py:7-20). */
+typedef struct nirrt_config {
+    int32_t dim;       /* 2 or 3 */
+    int32_t device_id; /* HIP device ordinal */
+    int64_t iter_max;  /* capacity = 1 + iter_max vertices */
+    double x_start[3];
+    double x_goal[3];
+    double step_len;
+    double search_radius; /* gamma of the RRT* Near radius */
+    double clearance;
+    double range_lo[3]; /* x_range[0], y_range[0], z_range[0] */
+    double range_hi[3];
+    int32_t n_round;         /* circles (2D) / balls (3D) */
+    const double *round_obs; /* (n_round, dim+1): cx, cy[, cz], r */
+    int32_t n_box;           /* rectangles (2D) / boxes (3D) */
+    const double *box_obs;   /* (n_box, 2*dim): x, y[, z], w, h[, d] */
+} nirrt_config;
+
+/* flags for nirrt_step / nirrt_extend / nirrt_run */
+#define NIRRT_F_IRRT 1u      /* IRRT*: InGoalRegion bookkeeping + best-solution report           */
+#define NIRRT_F_GOAL_SCAN 2u /* RRT* planning_random: search_goal_parent + path length each step */
+
+/* What one loop body did (rrt_star_2d.py:37-55 / irrt_star_2d.py:51-73). */
+typedef struct nirrt_step_result {
+    int32_t collided;   /* edge nearest->new hit an obstacle: iteration ended there      */
+    int32_t inserted;   /* a vertex was appended (0 in the "same point" case, :41-45)    */
+    int64_t nearest_idx;
+    int64_t new_idx;    /* index of node_new, -1 if collided                              */
+    int32_t n_near;     /* size of the filtered Near set                                  */
+    int32_t reparented; /* choose_parent changed parent[new]                              */
+    int32_t n_rewired;
+    int32_t in_goal;    /* IRRT*: node_new appended to path_solutions                     */
+    int64_t n;          /* num_vertices after the iteration                               */
+    double node_new[3];
+    double c_best;      /* F_IRRT: find_best_path_solution cost (inf if none);
+                           F_GOAL_SCAN: get_path_len(extract_path(search_goal_parent()))  */
+    int64_t x_best;     /* goal-parent vertex index of that solution, -1 if none          */
+    int64_t n_solutions;
+    int32_t status;     /* 0 or NIRRT_E_CAPACITY                                          */
+    int32_t reserved;
+} nirrt_step_result;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+const char *nirrt_last_error(void);
+int nirrt_device_count(int *count);
+/* RRTBase2D/3D.__init__ (rrt_base_2d.py:8-37, rrt_base_3d.py:8-38): allocate the tree in HBM,
+ * vertex 0 = x_start, parent[0] = 0, num_vertices = 1. */
+int nirrt_create(const nirrt_config *cfg, nirrt_tree **out);
+int nirrt_destroy(nirrt_tree *t);
+int nirrt_reset(nirrt_tree *t);
+/* test/bring-up helper: load a frozen tree (vertices (n,dim) f64, parents (n,) i64) */
+int nirrt_upload(nirrt_tree *t, int64_t n, const double *vertices, const int64_t *parents);
+/* `self.vertices[:n]`, `self.vertex_parents[:n]`, `self.num_vertices`; either pointer may be NULL */
+int nirrt_download(nirrt_tree *t, double *vertices, int64_t *parents, int64_t *n);
+int nirrt_num_vertices(nirrt_tree *t, int64_t *n);
+
+/* ---- primitives (one kernel each; bring-up + parity tests) ---------------------------------- */
+/* nearest_neighbor, rrt_base_2d.py:94-107 / rrt_base_3d.py:100-113 (np.argmin: lowest index on ties) */
+int nirrt_nearest(nirrt_tree *t, const double *q, int64_t *idx);
+/* Utils.is_collision, rrt_utils_2d.py:19-33 -> check_collision_line_circles_rectangles
+ * (collision_check_utils.py:158-218); 3D rrt_utils_3d.py:22-36 -> check_collision_line_balls_boxes
+ * (collision_check_utils_3d.py:151-216).  seg = (n_seg, 2, dim) f64; out[i] = 0/1. */
+int nirrt_collision_batch(nirrt_tree *t, int64_t n_seg, const double *seg, uint8_t *out);
+/* Utils.is_inside_obs / Utils.is_valid (rrt_utils_2d.py:35-79, rrt_utils_3d.py:39-86);
+ * pts = (n, dim); either output may be NULL. */
+int nirrt_points_in_obs(nirrt_tree *t, int64_t n, const double *pts, uint8_t *inside, uint8_t *valid);
+/* find_near_neighbors, rrt_star_2d.py:125-144 / rrt_star_3d.py:125-145: ascending indices of the
+ * collision-free vertices within r(n) of node_new, excluding new_idx; *k = count (<= cap written). */
+int nirrt_near(nirrt_tree *t, const double *node_new, int64_t new_idx, int64_t *k, int64_t *idx_out, int64_t cap);
+/* RRTBase.cost, rrt_base_2d.py:54-61 / rrt_base_3d.py:60-67, for a batch of vertex indices */
+int nirrt_cost(nirrt_tree *t, int64_t n_idx, const int64_t *idx, double *out);
+/* search_goal_parent (rrt_star_2d.py:101-117): *idx = -1 for None; *path_len = get_path_len of the
+ * extracted path (rrt_base_2d.py:79-85), inf if None */
+int nirrt_search_goal_parent(nirrt_tree *t, int64_t *idx, double *path_len);
+/* find_best_path_solution (irrt_star_2d.py:84-97): *x_best = -1 and *c_best = inf if no solution */
+int nirrt_best_solution(nirrt_tree *t, double *c_best, int64_t *x_best);
+/* `self.path_solutions` */
+int nirrt_solutions(nirrt_tree *t, int64_t *n_sol, int64_t *out, int64_t cap);
+
+/* ---- one whole iteration --------------------------------------------------------------------- */
+/* Loop body of RRTStar2D.planning (rrt_star_2d.py:37-55) / IRRTStar2D.planning
+ * (irrt_star_2d.py:54-73) given node_rand: nearest -> steer -> edge collision -> insert -> Near ->
+ * choose_parent -> rewire [-> InGoalRegion].  Steer runs on the device (2D: device libm
+ * atan2/cos/sin, not bit-identical to glibc; 3D: IEEE ops only, bit-identical). */
+int nirrt_step(nirrt_tree *t, const double *node_rand, uint32_t flags, nirrt_step_result *res);
+/* Same body with the steer done by the caller (bit-exact 2D vertices): nearest_idx from
+ * nirrt_nearest, node_new = new_state(node_nearest, node_rand) computed on the host. */
+int nirrt_extend(nirrt_tree *t, int64_t nearest_idx, const double *node_new, uint32_t flags, nirrt_step_result *res);
+
+/* ---- device-resident loop over many trees ----------------------------------------------------- */
+/* One persistent workgroup per tree runs `iters` loop bodies back to back without leaving the GPU.
+ *   samples != NULL : node_rand is replayed from samples[(i*iters + k)*dim ...] (host, (n_trees,
+ *                     iters, dim) f64) - valid whenever sampling does not depend on the tree
+ *                     (RRT*: SampleFree, rrt_base_2d.py:46-52).
+ *   samples == NULL : sampling happens in the kernel (SampleFree / SampleInformedSubset,
+ *                     irrt_star_2d.py:99-151, irrt_star_3d.py:95-158) and consumes raw MT19937
+ *                     32-bit outputs of the two host generators the reference uses, exactly as
+ *                     numpy's legacy RandomState / CPython's `random` would:
+ *                       np_words[i] : stream of numpy's global RandomState  (n_np per tree)
+ *                       py_words[i] : stream of python's `random` module    (n_py per tree)
+ *                     On return np_used[i] / py_used[i] say how many words each tree consumed so the
+ *                     host can advance its generators by exactly that much.
+ * cost_trace (optional, (n_trees, iters) f64): per-iteration best cost -
+ *   F_IRRT: c_best as used for sampling iteration k (irrt_star_2d.py:241: list entry k);
+ *   F_GOAL_SCAN: path length after iteration k (rrt_star_2d.py:223-229).
+ * iters_done[i] < iters only if a word stream ran dry or a capacity was hit (status[i] != 0). */
+typedef struct nirrt_run_args {
+    uint32_t flags;
+    int32_t reserved;
+    int64_t iters;
+    const double *samples;
+    const uint32_t *const *np_words;
+    const int64_t *n_np;
+    const uint32_t *const *py_words;
+    const int64_t *n_py;
+    double *cost_trace;
+    int64_t *np_used;
+    int64_t *py_used;
+    int64_t *iters_done;
+    int32_t *status;
+    double *kernel_ms; /* optional: device time of the persistent kernel (hipEvent) */
+} nirrt_run_args;
+int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *args);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIRRT_HIP_H */

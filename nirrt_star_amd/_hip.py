@@ -1,0 +1,305 @@
+"""ctypes binding of libnirrt_hip.so (C ABI: include/nirrt_hip.h).
+
+There is NO fallback: if the shared library is missing, or no gfx950 device is visible when a tree
+is created, this raises.  (The CPU oracle under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libnirrt_hip.so")
+
+F_IRRT = 1
+F_GOAL_SCAN = 2
+
+E_ARG, E_HIP, E_CAPACITY, E_NODEVICE, E_STREAM = -1, -2, -3, -4, -5
+NEAR_CAPACITY = 1024
+MAX_OBSTACLES = 64
+
+EXPORTS = [
+    "nirrt_last_error", "nirrt_device_count", "nirrt_create", "nirrt_destroy", "nirrt_reset", "nirrt_upload",
+    "nirrt_download", "nirrt_num_vertices", "nirrt_nearest", "nirrt_collision_batch", "nirrt_points_in_obs",
+    "nirrt_near", "nirrt_cost", "nirrt_search_goal_parent", "nirrt_best_solution", "nirrt_solutions",
+    "nirrt_step", "nirrt_extend", "nirrt_run",
+]
+
+
+class NirrtError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("device_id", C.c_int32), ("iter_max", C.c_int64),
+                ("x_start", C.c_double * 3), ("x_goal", C.c_double * 3),
+                ("step_len", C.c_double), ("search_radius", C.c_double), ("clearance", C.c_double),
+                ("range_lo", C.c_double * 3), ("range_hi", C.c_double * 3),
+                ("n_round", C.c_int32), ("round_obs", C.POINTER(C.c_double)),
+                ("n_box", C.c_int32), ("box_obs", C.POINTER(C.c_double))]
+
+
+class StepResult(C.Structure):
+    _fields_ = [("collided", C.c_int32), ("inserted", C.c_int32), ("nearest_idx", C.c_int64),
+                ("new_idx", C.c_int64), ("n_near", C.c_int32), ("reparented", C.c_int32),
+                ("n_rewired", C.c_int32), ("in_goal", C.c_int32), ("n", C.c_int64),
+                ("node_new", C.c_double * 3), ("c_best", C.c_double), ("x_best", C.c_int64),
+                ("n_solutions", C.c_int64), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RunArgs(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("reserved", C.c_int32), ("iters", C.c_int64),
+                ("samples", C.POINTER(C.c_double)),
+                ("np_words", C.POINTER(C.POINTER(C.c_uint32))), ("n_np", C.POINTER(C.c_int64)),
+                ("py_words", C.POINTER(C.POINTER(C.c_uint32))), ("n_py", C.POINTER(C.c_int64)),
+                ("cost_trace", C.POINTER(C.c_double)), ("np_used", C.POINTER(C.c_int64)),
+                ("py_used", C.POINTER(C.c_int64)), ("iters_done", C.POINTER(C.c_int64)),
+                ("status", C.POINTER(C.c_int32)), ("kernel_ms", C.POINTER(C.c_double))]
+
+
+_lib = None
+
+
+def load():
+    """Load libnirrt_hip.so; raises NirrtError (never falls back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise NirrtError("libnirrt_hip.so is not built (%s). Run `python -m nirrt_star_amd.build` "
+                         "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    dp, ip, up = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)
+    vp = C.c_void_p
+    L.nirrt_last_error.restype = C.c_char_p
+    L.nirrt_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.nirrt_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.nirrt_destroy.argtypes = [vp]
+    L.nirrt_reset.argtypes = [vp]
+    L.nirrt_upload.argtypes = [vp, C.c_int64, dp, ip]
+    L.nirrt_download.argtypes = [vp, dp, ip, ip]
+    L.nirrt_num_vertices.argtypes = [vp, ip]
+    L.nirrt_nearest.argtypes = [vp, dp, ip]
+    L.nirrt_collision_batch.argtypes = [vp, C.c_int64, dp, up]
+    L.nirrt_points_in_obs.argtypes = [vp, C.c_int64, dp, up, up]
+    L.nirrt_near.argtypes = [vp, dp, C.c_int64, ip, ip, C.c_int64]
+    L.nirrt_cost.argtypes = [vp, C.c_int64, ip, dp]
+    L.nirrt_search_goal_parent.argtypes = [vp, ip, dp]
+    L.nirrt_best_solution.argtypes = [vp, dp, ip]
+    L.nirrt_solutions.argtypes = [vp, ip, ip, C.c_int64]
+    L.nirrt_step.argtypes = [vp, dp, C.c_uint32, C.POINTER(StepResult)]
+    L.nirrt_extend.argtypes = [vp, C.c_int64, dp, C.c_uint32, C.POINTER(StepResult)]
+    L.nirrt_run.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(RunArgs)]
+    for name in EXPORTS:
+        if name != "nirrt_last_error":
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def device_count():
+    n = C.c_int(0)
+    load().nirrt_device_count(C.byref(n))
+    return n.value
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load().nirrt_last_error().decode(errors="replace")
+        raise NirrtError("libnirrt_hip error %d: %s" % (rc, msg))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _f64(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+
+
+def obstacle_tables(env, dim):
+    """(round (n,dim+1), box (n,2*dim), lo, hi) float64 from an Env / Env3D-like object
+    (rrt_utils_2d.py:5-17 / rrt_utils_3d.py:7-20 build the same tables)."""
+    if dim == 2:
+        rnd = np.asarray(env.obs_circle, dtype=np.float64).reshape(-1, 3)
+        box = np.asarray(env.obs_rectangle, dtype=np.float64).reshape(-1, 4)
+        lo = np.array([env.x_range[0], env.y_range[0]], dtype=np.float64)
+        hi = np.array([env.x_range[1], env.y_range[1]], dtype=np.float64)
+    else:
+        rnd = np.asarray(env.obs_ball, dtype=np.float64).reshape(-1, 4)
+        box = np.asarray(env.obs_box, dtype=np.float64).reshape(-1, 6)
+        lo = np.array([env.x_range[0], env.y_range[0], env.z_range[0]], dtype=np.float64)
+        hi = np.array([env.x_range[1], env.y_range[1], env.z_range[1]], dtype=np.float64)
+    return np.ascontiguousarray(rnd), np.ascontiguousarray(box), lo, hi
+
+
+class HipTree:
+    """One planning tree resident in HBM (opaque nirrt_tree handle)."""
+
+    def __init__(self, dim, iter_max, x_start, x_goal, step_len, search_radius, clearance, env, device_id=0):
+        L = load()
+        self.L = L
+        self.dim = int(dim)
+        self.iter_max = int(iter_max)
+        rnd, box, lo, hi = obstacle_tables(env, self.dim)
+        self._keep = (rnd, box)
+        cfg = Config()
+        cfg.dim = self.dim
+        cfg.device_id = int(device_id)
+        cfg.iter_max = self.iter_max
+        xs, xg = _f64(x_start), _f64(x_goal)
+        for k in range(self.dim):
+            cfg.x_start[k] = xs[k]
+            cfg.x_goal[k] = xg[k]
+            cfg.range_lo[k] = lo[k]
+            cfg.range_hi[k] = hi[k]
+        cfg.step_len = float(step_len)
+        cfg.search_radius = float(search_radius)
+        cfg.clearance = float(clearance)
+        cfg.n_round = len(rnd)
+        cfg.round_obs = _dp(rnd) if len(rnd) else None
+        cfg.n_box = len(box)
+        cfg.box_obs = _dp(box) if len(box) else None
+        h = C.c_void_p()
+        _check(L.nirrt_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self._res = StepResult()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.nirrt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state ----
+    def reset(self):
+        _check(self.L.nirrt_reset(self.h))
+
+    def upload(self, vertices, parents):
+        v = _f64(vertices)
+        p = np.ascontiguousarray(parents, dtype=np.int64)
+        _check(self.L.nirrt_upload(self.h, len(v), _dp(v), _ip(p)))
+
+    @property
+    def n(self):
+        n = C.c_int64(0)
+        _check(self.L.nirrt_num_vertices(self.h, C.byref(n)))
+        return n.value
+
+    def download(self):
+        n = self.n
+        v = np.zeros((n, self.dim), dtype=np.float64)
+        p = np.zeros(n, dtype=np.int64)
+        nn = C.c_int64(0)
+        _check(self.L.nirrt_download(self.h, _dp(v), _ip(p), C.byref(nn)))
+        return v, p
+
+    def download_into(self, vertices, parents):
+        """fill caller arrays sized (>=n, dim) / (>=n,) - the reference's preallocated buffers"""
+        nn = C.c_int64(0)
+        _check(self.L.nirrt_download(self.h, _dp(vertices), _ip(parents), C.byref(nn)))
+        return nn.value
+
+    @property
+    def solutions(self):
+        ns = C.c_int64(0)
+        _check(self.L.nirrt_solutions(self.h, C.byref(ns), None, 0))
+        out = np.zeros(ns.value, dtype=np.int64)
+        if ns.value:
+            _check(self.L.nirrt_solutions(self.h, C.byref(ns), _ip(out), len(out)))
+        return out
+
+    # ---- primitives ----
+    def nearest(self, q):
+        q = _f64(q)
+        i = C.c_int64(0)
+        _check(self.L.nirrt_nearest(self.h, _dp(q), C.byref(i)))
+        return i.value
+
+    def collision_batch(self, seg):
+        seg = _f64(seg).reshape(-1, 2, self.dim)
+        out = np.zeros(len(seg), dtype=np.uint8)
+        _check(self.L.nirrt_collision_batch(self.h, len(seg), _dp(seg), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def is_collision(self, a, b):
+        return bool(self.collision_batch(np.stack([_f64(a), _f64(b)])[None])[0])
+
+    def points_in_obs(self, pts):
+        pts = _f64(pts).reshape(-1, self.dim)
+        ins = np.zeros(len(pts), dtype=np.uint8)
+        val = np.zeros(len(pts), dtype=np.uint8)
+        u8 = C.POINTER(C.c_uint8)
+        _check(self.L.nirrt_points_in_obs(self.h, len(pts), _dp(pts), ins.ctypes.data_as(u8), val.ctypes.data_as(u8)))
+        return ins, val
+
+    def near(self, node_new, new_idx):
+        q = _f64(node_new)
+        k = C.c_int64(0)
+        out = np.zeros(NEAR_CAPACITY, dtype=np.int64)
+        _check(self.L.nirrt_near(self.h, _dp(q), int(new_idx), C.byref(k), _ip(out), len(out)))
+        return out[:k.value].copy()
+
+    def cost(self, idx):
+        idx = np.ascontiguousarray(np.atleast_1d(idx), dtype=np.int64)
+        out = np.zeros(len(idx), dtype=np.float64)
+        _check(self.L.nirrt_cost(self.h, len(idx), _ip(idx), _dp(out)))
+        return out
+
+    def search_goal_parent(self):
+        i = C.c_int64(0)
+        d = C.c_double(0)
+        _check(self.L.nirrt_search_goal_parent(self.h, C.byref(i), C.byref(d)))
+        return i.value, d.value
+
+    def best_solution(self):
+        i = C.c_int64(0)
+        d = C.c_double(0)
+        _check(self.L.nirrt_best_solution(self.h, C.byref(d), C.byref(i)))
+        return d.value, i.value
+
+    # ---- whole iteration ----
+    def step(self, node_rand, flags=0):
+        q = _f64(node_rand)
+        _check(self.L.nirrt_step(self.h, _dp(q), int(flags), C.byref(self._res)))
+        return self._res
+
+    def extend(self, nearest_idx, node_new, flags=0):
+        q = _f64(node_new)
+        _check(self.L.nirrt_extend(self.h, int(nearest_idx), _dp(q), int(flags), C.byref(self._res)))
+        return self._res
+
+
+def run_replay(trees, samples, flags=0, want_trace=False):
+    """Device-resident loop over many trees with replayed samples (n_trees, iters, dim).
+    Returns dict(iters_done, status, kernel_ms, cost_trace)."""
+    L = load()
+    nt = len(trees)
+    samples = _f64(samples)
+    assert samples.ndim == 3 and samples.shape[0] == nt and samples.shape[2] == trees[0].dim
+    iters = samples.shape[1]
+    handles = (C.c_void_p * nt)(*[t.h for t in trees])
+    done = np.zeros(nt, dtype=np.int64)
+    status = np.zeros(nt, dtype=np.int32)
+    ms = C.c_double(0)
+    trace = np.zeros((nt, iters), dtype=np.float64) if want_trace else None
+    a = RunArgs()
+    a.flags = int(flags)
+    a.iters = iters
+    a.samples = _dp(samples)
+    a.cost_trace = _dp(trace) if want_trace else None
+    a.iters_done = _ip(done)
+    a.status = status.ctypes.data_as(C.POINTER(C.c_int32))
+    a.kernel_ms = C.pointer(ms)
+    _check(L.nirrt_run(handles, nt, C.byref(a)))
+    return {"iters_done": done, "status": status, "kernel_ms": ms.value, "cost_trace": trace}

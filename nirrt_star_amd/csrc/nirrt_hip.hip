@@ -1,0 +1,646 @@
+// nirrt_hip.hip — kernels + C ABI (include/nirrt_hip.h) of libnirrt_hip.so, gfx950 only.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+#include "nirrt_device.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+// kernels: one workgroup per tree
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(NT) void k_init(TreeDev *tp)
+{
+    __shared__ Lds s;
+    TreeDev &t = *tp;
+    stage_obstacles(s, t);
+    if (threadIdx.x == 0) { t.n_gc = 0; t.n_sol = 0; t.status = 0; }
+    __syncthreads();
+    // goal-candidate list over the current vertices, ascending (n == 1 after create/reset; n > 1 after upload)
+    int n = t.n;
+    for (int i = 0; i < n; i++) {  // uniform loop; cheap for n == 1, acceptable for test uploads
+        double v[D];
+        load_vertex<D>(t, i, v);
+        wg_goal_candidate<D>(s, t, i, v);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(NT) void k_nearest(TreeDev *tp, double q0, double q1, double q2, int *out_idx, double *out_d)
+{
+    __shared__ Lds s;
+    TreeDev &t = *tp;
+    double q[3] = {q0, q1, q2};
+    double bd;
+    int bi = wg_nearest<D>(s, t, t.n, q, bd);
+    if (threadIdx.x == 0) { *out_idx = bi; *out_d = bd; }
+}
+
+template <int D>
+__global__ __launch_bounds__(NT) void k_collision_batch(TreeDev *tp, long long n_seg, const double *seg, unsigned char *out)
+{
+    __shared__ Lds s;
+    TreeDev &t = *tp;
+    stage_obstacles(s, t);
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n_seg; i += (long long)gridDim.x * NT) {
+        double a[D], b[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) { a[k] = seg[i * 2 * D + k]; b[k] = seg[i * 2 * D + D + k]; }
+        out[i] = seg_all<D>(s, a, b, t.clearance) ? 1 : 0;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(NT) void k_points(TreeDev *tp, long long n, const double *pts, unsigned char *inside,
+                                               unsigned char *valid)
+{
+    __shared__ Lds s;
+    TreeDev &t = *tp;
+    stage_obstacles(s, t);
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        double p[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) p[k] = pts[i * D + k];
+        bool in = point_in_obs<D>(s, p, t.clearance);
+        if (inside) inside[i] = in ? 1 : 0;
+        if (valid) valid[i] = (point_in_range<D>(t, p) && !in) ? 1 : 0;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(NT) void k_near(TreeDev *tp, double q0, double q1, double q2, int new_idx, int *out_k,
+                                             int *out_idx)
+{
+    __shared__ Lds s;
+    TreeDev &t = *tp;
+    stage_obstacles(s, t);
+    double q[3] = {q0, q1, q2};
+    int k = wg_near<D>(s, t, t.n, q, new_idx);
+    if (threadIdx.x == 0) *out_k = k;
+    for (int a = threadIdx.x; a < k; a += NT) out_idx[a] = s.near_idx[a];
+}
+
+template <int D>
+__global__ __launch_bounds__(NT) void k_cost(TreeDev *tp, long long n_idx, const long long *idx, double *out)
+{
+    TreeDev &t = *tp;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n_idx; i += (long long)gridDim.x * NT)
+        out[i] = walk_cost<D>(t, (int)idx[i], nullptr, nullptr);
+}
+
+template <int D>
+__global__ __launch_bounds__(NT) void k_goal_parent(TreeDev *tp, int *out_idx, double *out_len)
+{
+    __shared__ Lds s;
+    TreeDev &t = *tp;
+    int gp;
+    double len;
+    wg_goal_parent<D>(s, t, gp, len);
+    if (threadIdx.x == 0) { *out_idx = gp; *out_len = len; }
+}
+
+template <int D>
+__global__ __launch_bounds__(NT) void k_best_solution(TreeDev *tp, int *out_idx, double *out_c)
+{
+    __shared__ Lds s;
+    TreeDev &t = *tp;
+    double cb;
+    int xb;
+    wg_best_solution<D>(s, t, cb, xb);
+    if (threadIdx.x == 0) { *out_idx = xb; *out_c = cb; }
+}
+
+template <int D>
+__global__ __launch_bounds__(NT) void k_step(TreeDev *tp, double q0, double q1, double q2, int host_steer, int nearest_in,
+                                             unsigned flags, nirrt_step_result *res)
+{
+    __shared__ Lds s;
+    TreeDev &t = *tp;
+    stage_obstacles(s, t);
+    double q[3] = {q0, q1, q2};
+    wg_iteration<D>(s, t, q, host_steer != 0, nearest_in, flags, res);
+}
+
+// persistent loop, replayed samples: block b owns trees[b]
+struct RunDev {
+    unsigned flags;
+    int pad;
+    long long iters;
+    const double *samples;  // (n_trees, iters, D) or nullptr
+    double *cost_trace;     // (n_trees, iters) or nullptr
+    long long *iters_done;  // (n_trees,)
+};
+
+template <int D>
+__global__ __launch_bounds__(NT) void k_run_replay(TreeDev *const *trees, RunDev a)
+{
+    __shared__ Lds s;
+    TreeDev &t = *trees[blockIdx.x];
+    stage_obstacles(s, t);
+    const double *smp = a.samples + (long long)blockIdx.x * a.iters * D;
+    double *trace = a.cost_trace ? a.cost_trace + (long long)blockIdx.x * a.iters : nullptr;
+    long long k = 0;
+    for (; k < a.iters; k++) {
+        double q[3] = {0., 0., 0.};
+#pragma unroll
+        for (int c = 0; c < D; c++) q[c] = smp[k * D + c];
+        wg_iteration<D>(s, t, q, false, 0, a.flags, nullptr);
+        if (trace) {
+            double cb = __builtin_inf();
+            int xb = -1;
+            if (a.flags & NIRRT_F_IRRT) wg_best_solution<D>(s, t, cb, xb);
+            else if (a.flags & NIRRT_F_GOAL_SCAN) wg_goal_parent<D>(s, t, xb, cb);
+            if (threadIdx.x == 0) trace[k] = cb;
+        }
+        if (t.status != 0) { k++; break; }
+    }
+    if (threadIdx.x == 0) a.iters_done[blockIdx.x] = k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+            return NIRRT_E_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+struct Scratch {  // pinned, device-visible result slots
+    nirrt_step_result step;
+    int i[4];
+    double d[4];
+};
+
+struct nirrt_tree {
+    nirrt_config cfg;
+    int dim;
+    int cap;
+    int device;
+    hipStream_t stream;
+    TreeDev host;    // host mirror of the descriptor (pointers are device pointers)
+    TreeDev *dev;    // descriptor in HBM
+    double *near_r;  // device table
+    Scratch *scratch;      // pinned host memory
+    Scratch *scratch_dev;  // device alias of the same memory
+    int *d_near;     // device scratch for nirrt_near
+};
+
+extern "C" const char *nirrt_last_error(void) { return g_err.c_str(); }
+
+extern "C" int nirrt_device_count(int *count)
+{
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { c = 0; (void)hipGetLastError(); }
+    if (count) *count = c;
+    return NIRRT_OK;
+}
+
+#define DISPATCH_DIM(t, KERNEL, grid, ...)                                                     \
+    do {                                                                                       \
+        if ((t)->dim == 2) hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(NT), 0, (t)->stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL<3>, dim3(grid), dim3(NT), 0, (t)->stream, __VA_ARGS__); \
+    } while (0)
+
+static int sync_check(nirrt_tree *t)
+{
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(t->stream));
+    return NIRRT_OK;
+}
+
+static int push_desc(nirrt_tree *t)
+{
+    HIPCHK(hipMemcpyAsync(t->dev, &t->host, sizeof(TreeDev), hipMemcpyHostToDevice, t->stream));
+    return NIRRT_OK;
+}
+
+extern "C" int nirrt_destroy(nirrt_tree *t)
+{
+    if (!t) return NIRRT_OK;
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    for (int k = 0; k < 3; k++)
+        if (t->host.c[k]) (void)hipFree(t->host.c[k]);
+    if (t->host.parent) (void)hipFree(t->host.parent);
+    if (t->host.sol) (void)hipFree(t->host.sol);
+    if (t->host.gc_idx) (void)hipFree(t->host.gc_idx);
+    if (t->host.gc_dist) (void)hipFree(t->host.gc_dist);
+    if (t->host.gc_col) (void)hipFree(t->host.gc_col);
+    if (t->near_r) (void)hipFree(t->near_r);
+    if (t->d_near) (void)hipFree(t->d_near);
+    if (t->dev) (void)hipFree(t->dev);
+    if (t->scratch) (void)hipHostFree(t->scratch);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+    return NIRRT_OK;
+}
+
+extern "C" int nirrt_reset(nirrt_tree *t)
+{
+    if (!t) return NIRRT_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    for (int k = 0; k < t->dim; k++)
+        HIPCHK(hipMemcpyAsync(t->host.c[k], &t->cfg.x_start[k], sizeof(double), hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipMemsetAsync(t->host.parent, 0, sizeof(int), t->stream));
+    t->host.n = 1;
+    t->host.n_sol = 0;
+    t->host.n_gc = 0;
+    t->host.status = 0;
+    int rc = push_desc(t);
+    if (rc) return rc;
+    DISPATCH_DIM(t, k_init, 1, t->dev);
+    return sync_check(t);
+}
+
+extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
+{
+    if (!cfg || !out) { g_err = "null argument"; return NIRRT_E_ARG; }
+    *out = nullptr;
+    if (cfg->dim != 2 && cfg->dim != 3) { g_err = "dim must be 2 or 3"; return NIRRT_E_ARG; }
+    if (cfg->iter_max < 0 || cfg->iter_max + 1 > (1ll << 30)) { g_err = "iter_max out of range"; return NIRRT_E_ARG; }
+    if (cfg->n_round < 0 || cfg->n_round > MAX_OBS || cfg->n_box < 0 || cfg->n_box > MAX_OBS) {
+        g_err = "too many obstacles (NIRRT_MAX_OBSTACLES per kind)";
+        return NIRRT_E_CAPACITY;
+    }
+    if ((cfg->n_round > 0 && !cfg->round_obs) || (cfg->n_box > 0 && !cfg->box_obs)) { g_err = "null obstacle table"; return NIRRT_E_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        g_err = "no HIP device visible";
+        return NIRRT_E_NODEVICE;
+    }
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) { g_err = "device_id out of range"; return NIRRT_E_ARG; }
+
+    nirrt_tree *t = new nirrt_tree();
+    std::memset(&t->host, 0, sizeof(TreeDev));
+    t->cfg = *cfg;
+    t->cfg.round_obs = nullptr;
+    t->cfg.box_obs = nullptr;
+    t->dim = cfg->dim;
+    t->cap = (int)(cfg->iter_max + 1);
+    t->device = cfg->device_id;
+    t->stream = nullptr;
+    t->dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->d_near = nullptr;
+    const int D = t->dim;
+    auto fail = [&](int rc) { nirrt_destroy(t); return rc; };
+#define HIPCHK_T(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+            return fail(NIRRT_E_HIP);                                                         \
+        }                                                                                     \
+    } while (0)
+    HIPCHK_T(hipSetDevice(t->device));
+    HIPCHK_T(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    TreeDev &h = t->host;
+    for (int k = 0; k < D; k++) HIPCHK_T(hipMalloc(&h.c[k], sizeof(double) * (size_t)t->cap));
+    HIPCHK_T(hipMalloc(&h.parent, sizeof(int) * (size_t)t->cap));
+    h.cap = t->cap;
+    h.dim = D;
+    h.cap_sol = t->cap;
+    HIPCHK_T(hipMalloc(&h.sol, sizeof(int) * (size_t)h.cap_sol));
+    HIPCHK_T(hipMalloc(&h.gc_idx, sizeof(int) * (size_t)t->cap));
+    HIPCHK_T(hipMalloc(&h.gc_dist, sizeof(double) * (size_t)t->cap));
+    HIPCHK_T(hipMalloc(&h.gc_col, (size_t)t->cap));
+    HIPCHK_T(hipMalloc(&t->near_r, sizeof(double) * (size_t)(t->cap + 1)));
+    HIPCHK_T(hipMalloc(&t->d_near, sizeof(int) * NEAR_CAP));
+    HIPCHK_T(hipMalloc(&t->dev, sizeof(TreeDev)));
+    HIPCHK_T(hipHostMalloc((void **)&t->scratch, sizeof(Scratch), hipHostMallocMapped));
+    HIPCHK_T(hipHostGetDevicePointer((void **)&t->scratch_dev, t->scratch, 0));
+    // Near radius table with the host libm (the reference's math.sqrt/math.log/float pow):
+    // rrt_star_2d.py:133  r = min(gamma*sqrt(log(n)/n), step_len);  rrt_star_3d.py:134 cube root
+    {
+        std::vector<double> r((size_t)t->cap + 1, 0.0);
+        for (int n = 1; n <= t->cap; n++) {
+            double x = std::log((double)n) / (double)n;
+            double v = D == 2 ? cfg->search_radius * std::sqrt(x) : cfg->search_radius * std::pow(x, 1 / 3.);
+            r[(size_t)n] = v < cfg->step_len ? v : cfg->step_len;
+        }
+        HIPCHK_T(hipMemcpy(t->near_r, r.data(), sizeof(double) * r.size(), hipMemcpyHostToDevice));
+    }
+    h.near_r = t->near_r;
+    for (int k = 0; k < 3; k++) {
+        h.start[k] = k < D ? cfg->x_start[k] : 0.;
+        h.goal[k] = k < D ? cfg->x_goal[k] : 0.;
+        h.lo[k] = k < D ? cfg->range_lo[k] : 0.;
+        h.hi[k] = k < D ? cfg->range_hi[k] : 0.;
+    }
+    h.step_len = cfg->step_len;
+    h.clearance = cfg->clearance;
+    h.n_round = cfg->n_round;
+    h.n_box = cfg->n_box;
+    for (int i = 0; i < cfg->n_round; i++) {
+        const double *c = cfg->round_obs + (size_t)i * (D + 1);
+        h.rnd[i][0] = c[0]; h.rnd[i][1] = c[1]; h.rnd[i][2] = D == 3 ? c[2] : 0.; h.rnd[i][3] = c[D];
+    }
+    for (int i = 0; i < cfg->n_box; i++) {
+        const double *b = cfg->box_obs + (size_t)i * 2 * D;
+        h.box[i][0] = b[0]; h.box[i][1] = b[1]; h.box[i][2] = D == 3 ? b[2] : 0.;
+        h.box[i][3] = b[D]; h.box[i][4] = b[D + 1]; h.box[i][5] = D == 3 ? b[D + 2] : 0.;
+    }
+    h.c_min = 0.;
+    for (int k = 0; k < 9; k++) h.Crot[k] = (k % 4 == 0) ? 1. : 0.;
+    int rc = nirrt_reset(t);
+    if (rc) return fail(rc);
+    *out = t;
+    return NIRRT_OK;
+#undef HIPCHK_T
+}
+
+extern "C" int nirrt_num_vertices(nirrt_tree *t, int64_t *n)
+{
+    if (!t || !n) return NIRRT_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    TreeDev tmp;
+    HIPCHK(hipMemcpyAsync(&tmp, t->dev, sizeof(TreeDev), hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    *n = tmp.n;
+    return NIRRT_OK;
+}
+
+extern "C" int nirrt_upload(nirrt_tree *t, int64_t n, const double *vertices, const int64_t *parents)
+{
+    if (!t || !vertices || !parents || n < 1 || n > t->cap) { g_err = "bad upload arguments"; return NIRRT_E_ARG; }
+    HIPCHK(hipSetDevice(t->device));
+    const int D = t->dim;
+    std::vector<double> col((size_t)n);
+    for (int k = 0; k < D; k++) {
+        for (int64_t i = 0; i < n; i++) col[(size_t)i] = vertices[i * D + k];
+        HIPCHK(hipMemcpy(t->host.c[k], col.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    std::vector<int> p((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        if (parents[i] < 0 || parents[i] >= n) { g_err = "parent index out of range"; return NIRRT_E_ARG; }
+        p[(size_t)i] = (int)parents[i];
+    }
+    HIPCHK(hipMemcpy(t->host.parent, p.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    t->host.n = (int)n;
+    t->host.n_sol = 0;
+    t->host.n_gc = 0;
+    t->host.status = 0;
+    int rc = push_desc(t);
+    if (rc) return rc;
+    DISPATCH_DIM(t, k_init, 1, t->dev);
+    return sync_check(t);
+}
+
+extern "C" int nirrt_download(nirrt_tree *t, double *vertices, int64_t *parents, int64_t *n_out)
+{
+    if (!t) return NIRRT_E_ARG;
+    int64_t n = 0;
+    int rc = nirrt_num_vertices(t, &n);
+    if (rc) return rc;
+    const int D = t->dim;
+    if (vertices) {
+        std::vector<double> col((size_t)n);
+        for (int k = 0; k < D; k++) {
+            HIPCHK(hipMemcpy(col.data(), t->host.c[k], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n; i++) vertices[i * D + k] = col[(size_t)i];
+        }
+    }
+    if (parents) {
+        std::vector<int> p((size_t)n);
+        HIPCHK(hipMemcpy(p.data(), t->host.parent, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; i++) parents[i] = p[(size_t)i];
+    }
+    if (n_out) *n_out = n;
+    return NIRRT_OK;
+}
+
+extern "C" int nirrt_nearest(nirrt_tree *t, const double *q, int64_t *idx)
+{
+    if (!t || !q || !idx) return NIRRT_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    DISPATCH_DIM(t, k_nearest, 1, t->dev, q[0], q[1], t->dim == 3 ? q[2] : 0., &t->scratch_dev->i[0], &t->scratch_dev->d[0]);
+    int rc = sync_check(t);
+    if (rc) return rc;
+    *idx = t->scratch->i[0];
+    return NIRRT_OK;
+}
+
+static int grid_for(long long n)
+{
+    long long g = (n + NT - 1) / NT;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (int)g;
+}
+
+extern "C" int nirrt_collision_batch(nirrt_tree *t, int64_t n_seg, const double *seg, uint8_t *out)
+{
+    if (!t || n_seg < 0 || (n_seg > 0 && (!seg || !out))) return NIRRT_E_ARG;
+    if (n_seg == 0) return NIRRT_OK;
+    HIPCHK(hipSetDevice(t->device));
+    double *d_seg = nullptr;
+    unsigned char *d_out = nullptr;
+    size_t bytes = sizeof(double) * (size_t)n_seg * 2 * t->dim;
+    HIPCHK(hipMalloc(&d_seg, bytes));
+    HIPCHK(hipMalloc(&d_out, (size_t)n_seg));
+    HIPCHK(hipMemcpyAsync(d_seg, seg, bytes, hipMemcpyHostToDevice, t->stream));
+    DISPATCH_DIM(t, k_collision_batch, grid_for(n_seg), t->dev, (long long)n_seg, (const double *)d_seg, d_out);
+    HIPCHK(hipMemcpyAsync(out, d_out, (size_t)n_seg, hipMemcpyDeviceToHost, t->stream));
+    int rc = sync_check(t);
+    (void)hipFree(d_seg);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+extern "C" int nirrt_points_in_obs(nirrt_tree *t, int64_t n, const double *pts, uint8_t *inside, uint8_t *valid)
+{
+    if (!t || n < 0 || (n > 0 && !pts)) return NIRRT_E_ARG;
+    if (n == 0) return NIRRT_OK;
+    HIPCHK(hipSetDevice(t->device));
+    double *d_pts = nullptr;
+    unsigned char *d_in = nullptr, *d_va = nullptr;
+    size_t bytes = sizeof(double) * (size_t)n * t->dim;
+    HIPCHK(hipMalloc(&d_pts, bytes));
+    HIPCHK(hipMalloc(&d_in, (size_t)n));
+    HIPCHK(hipMalloc(&d_va, (size_t)n));
+    HIPCHK(hipMemcpyAsync(d_pts, pts, bytes, hipMemcpyHostToDevice, t->stream));
+    DISPATCH_DIM(t, k_points, grid_for(n), t->dev, (long long)n, (const double *)d_pts, d_in, d_va);
+    if (inside) HIPCHK(hipMemcpyAsync(inside, d_in, (size_t)n, hipMemcpyDeviceToHost, t->stream));
+    if (valid) HIPCHK(hipMemcpyAsync(valid, d_va, (size_t)n, hipMemcpyDeviceToHost, t->stream));
+    int rc = sync_check(t);
+    (void)hipFree(d_pts);
+    (void)hipFree(d_in);
+    (void)hipFree(d_va);
+    return rc;
+}
+
+extern "C" int nirrt_near(nirrt_tree *t, const double *node_new, int64_t new_idx, int64_t *k, int64_t *idx_out, int64_t cap)
+{
+    if (!t || !node_new || !k) return NIRRT_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    DISPATCH_DIM(t, k_near, 1, t->dev, node_new[0], node_new[1], t->dim == 3 ? node_new[2] : 0., (int)new_idx,
+                 &t->scratch_dev->i[0], t->d_near);
+    int rc = sync_check(t);
+    if (rc) return rc;
+    int kk = t->scratch->i[0];
+    if (kk < 0) { g_err = "Near set exceeds NIRRT_NEAR_CAPACITY"; return NIRRT_E_CAPACITY; }
+    *k = kk;
+    if (idx_out && kk > 0) {
+        std::vector<int> tmp((size_t)kk);
+        HIPCHK(hipMemcpy(tmp.data(), t->d_near, sizeof(int) * (size_t)kk, hipMemcpyDeviceToHost));
+        for (int i = 0; i < kk && i < cap; i++) idx_out[i] = tmp[(size_t)i];
+    }
+    return NIRRT_OK;
+}
+
+extern "C" int nirrt_cost(nirrt_tree *t, int64_t n_idx, const int64_t *idx, double *out)
+{
+    if (!t || n_idx < 0 || (n_idx > 0 && (!idx || !out))) return NIRRT_E_ARG;
+    if (n_idx == 0) return NIRRT_OK;
+    HIPCHK(hipSetDevice(t->device));
+    long long *d_idx = nullptr;
+    double *d_out = nullptr;
+    HIPCHK(hipMalloc(&d_idx, sizeof(long long) * (size_t)n_idx));
+    HIPCHK(hipMalloc(&d_out, sizeof(double) * (size_t)n_idx));
+    HIPCHK(hipMemcpyAsync(d_idx, idx, sizeof(long long) * (size_t)n_idx, hipMemcpyHostToDevice, t->stream));
+    DISPATCH_DIM(t, k_cost, grid_for(n_idx), t->dev, (long long)n_idx, (const long long *)d_idx, d_out);
+    HIPCHK(hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)n_idx, hipMemcpyDeviceToHost, t->stream));
+    int rc = sync_check(t);
+    (void)hipFree(d_idx);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+extern "C" int nirrt_search_goal_parent(nirrt_tree *t, int64_t *idx, double *path_len)
+{
+    if (!t || !idx) return NIRRT_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    DISPATCH_DIM(t, k_goal_parent, 1, t->dev, &t->scratch_dev->i[0], &t->scratch_dev->d[0]);
+    int rc = sync_check(t);
+    if (rc) return rc;
+    *idx = t->scratch->i[0];
+    if (path_len) *path_len = t->scratch->d[0];
+    return NIRRT_OK;
+}
+
+extern "C" int nirrt_best_solution(nirrt_tree *t, double *c_best, int64_t *x_best)
+{
+    if (!t || !c_best || !x_best) return NIRRT_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    DISPATCH_DIM(t, k_best_solution, 1, t->dev, &t->scratch_dev->i[0], &t->scratch_dev->d[0]);
+    int rc = sync_check(t);
+    if (rc) return rc;
+    *x_best = t->scratch->i[0];
+    *c_best = t->scratch->d[0];
+    return NIRRT_OK;
+}
+
+extern "C" int nirrt_solutions(nirrt_tree *t, int64_t *n_sol, int64_t *out, int64_t cap)
+{
+    if (!t || !n_sol) return NIRRT_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    TreeDev tmp;
+    HIPCHK(hipMemcpyAsync(&tmp, t->dev, sizeof(TreeDev), hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    *n_sol = tmp.n_sol;
+    if (out && tmp.n_sol > 0) {
+        std::vector<int> s((size_t)tmp.n_sol);
+        HIPCHK(hipMemcpy(s.data(), t->host.sol, sizeof(int) * (size_t)tmp.n_sol, hipMemcpyDeviceToHost));
+        for (int i = 0; i < tmp.n_sol && i < cap; i++) out[i] = s[(size_t)i];
+    }
+    return NIRRT_OK;
+}
+
+static int do_step(nirrt_tree *t, const double *p, int host_steer, int64_t nearest_idx, uint32_t flags, nirrt_step_result *res)
+{
+    if (!t || !p || !res) return NIRRT_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    DISPATCH_DIM(t, k_step, 1, t->dev, p[0], p[1], t->dim == 3 ? p[2] : 0., host_steer, (int)nearest_idx, (unsigned)flags,
+                 &t->scratch_dev->step);
+    int rc = sync_check(t);
+    if (rc) return rc;
+    *res = t->scratch->step;
+    if (res->status) { g_err = "capacity exceeded inside step"; return res->status; }
+    return NIRRT_OK;
+}
+
+extern "C" int nirrt_step(nirrt_tree *t, const double *node_rand, uint32_t flags, nirrt_step_result *res)
+{
+    return do_step(t, node_rand, 0, 0, flags, res);
+}
+
+extern "C" int nirrt_extend(nirrt_tree *t, int64_t nearest_idx, const double *node_new, uint32_t flags, nirrt_step_result *res)
+{
+    if (t && (nearest_idx < 0 || nearest_idx >= t->cap)) return NIRRT_E_ARG;
+    return do_step(t, node_new, 1, nearest_idx, flags, res);
+}
+
+extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *a)
+{
+    if (!trees || n_trees <= 0 || !a || a->iters < 0) return NIRRT_E_ARG;
+    nirrt_tree *t0 = trees[0];
+    for (int i = 0; i < n_trees; i++) {
+        if (!trees[i] || trees[i]->device != t0->device || trees[i]->dim != t0->dim) {
+            g_err = "nirrt_run: all trees must share device and dim";
+            return NIRRT_E_ARG;
+        }
+    }
+    if (!a->samples) { g_err = "nirrt_run: in-kernel sampling not built in this version"; return NIRRT_E_ARG; }
+    HIPCHK(hipSetDevice(t0->device));
+    const int D = t0->dim;
+    hipStream_t st = t0->stream;
+    for (int i = 1; i < n_trees; i++) HIPCHK(hipStreamSynchronize(trees[i]->stream));
+    std::vector<TreeDev *> ptrs((size_t)n_trees);
+    for (int i = 0; i < n_trees; i++) ptrs[(size_t)i] = trees[i]->dev;
+    TreeDev **d_ptrs = nullptr;
+    double *d_samples = nullptr, *d_trace = nullptr;
+    long long *d_done = nullptr;
+    size_t sbytes = sizeof(double) * (size_t)n_trees * (size_t)a->iters * D;
+    HIPCHK(hipMalloc(&d_ptrs, sizeof(TreeDev *) * (size_t)n_trees));
+    HIPCHK(hipMalloc(&d_samples, sbytes ? sbytes : 8));
+    HIPCHK(hipMalloc(&d_done, sizeof(long long) * (size_t)n_trees));
+    if (a->cost_trace) HIPCHK(hipMalloc(&d_trace, sizeof(double) * (size_t)n_trees * (size_t)a->iters));
+    HIPCHK(hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(TreeDev *) * (size_t)n_trees, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_samples, a->samples, sbytes, hipMemcpyHostToDevice, st));
+    RunDev rd;
+    rd.flags = a->flags; rd.pad = 0; rd.iters = a->iters; rd.samples = d_samples; rd.cost_trace = d_trace; rd.iters_done = d_done;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, st));
+    if (D == 2) hipLaunchKernelGGL(k_run_replay<2>, dim3(n_trees), dim3(NT), 0, st, (TreeDev *const *)d_ptrs, rd);
+    else hipLaunchKernelGGL(k_run_replay<3>, dim3(n_trees), dim3(NT), 0, st, (TreeDev *const *)d_ptrs, rd);
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (a->kernel_ms) *a->kernel_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    std::vector<long long> done((size_t)n_trees);
+    HIPCHK(hipMemcpy(done.data(), d_done, sizeof(long long) * (size_t)n_trees, hipMemcpyDeviceToHost));
+    if (a->cost_trace)
+        HIPCHK(hipMemcpy(a->cost_trace, d_trace, sizeof(double) * (size_t)n_trees * (size_t)a->iters, hipMemcpyDeviceToHost));
+    int rc_all = NIRRT_OK;
+    for (int i = 0; i < n_trees; i++) {
+        if (a->iters_done) a->iters_done[i] = done[(size_t)i];
+        if (a->np_used) a->np_used[i] = 0;
+        if (a->py_used) a->py_used[i] = 0;
+        TreeDev tmp;
+        HIPCHK(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
+        if (a->status) a->status[i] = tmp.status;
+        if (tmp.status) rc_all = tmp.status;
+    }
+    (void)hipFree(d_ptrs);
+    (void)hipFree(d_samples);
+    (void)hipFree(d_done);
+    if (d_trace) (void)hipFree(d_trace);
+    return rc_all;
+}

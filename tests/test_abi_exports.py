@@ -1,0 +1,44 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every
+symbol include/nirrt_hip.h declares; the product refuses to run (loudly) when no device exists."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nirrt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nirrt_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nirrt_star_amd import _hip, build
+    build.build()
+    L = _hip.load()
+    syms = _declared_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(L, s), "missing export %s" % s
+    assert set(_hip.EXPORTS) == set(syms)
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from nirrt_star_amd import _hip
+    # nirrt_step_result: 2*i32, 2*i64, 4*i32, i64, 3*f64, f64, i64, i64, 2*i32
+    assert C.sizeof(_hip.StepResult) == 8 + 16 + 16 + 8 + 24 + 8 + 8 + 8 + 8
+    assert _hip.StepResult.c_best.offset == 72
+    assert C.sizeof(_hip.Config) == 8 + 8 + 24 + 24 + 24 + 24 + 24 + 8 + 8 + 8 + 8
+    assert C.sizeof(_hip.RunArgs) == 8 + 8 + 8 * 11
+
+
+def test_no_silent_cpu_fallback_without_device():
+    from nirrt_star_amd import _hip, worlds
+    if _hip.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    pr = worlds.problem_2d(worlds.random_world_2d(0), 0)
+    with pytest.raises(_hip.NirrtError):
+        _hip.HipTree(2, 100, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], 3, pr["env"])

@@ -1,0 +1,208 @@
+"""GPU parity tests proper: libnirrt_hip.so (through its C ABI) vs the oracle / golden fixtures.
+
+Bars: integer bookkeeping (n, parents, Near sets, solution lists, booleans)
+bit-exact; float64 values that involve only IEEE ops (cost walks, 3D vertices, host-steered 2D
+vertices) bit-exact; 2D vertices steered with the device libm <= 1e-9 absolute; path cost <= 1e-5.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, make_oracle_tree
+
+pytestmark = pytest.mark.gpu
+
+
+def make_hip_tree(g, iter_max=None):
+    from nirrt_star_amd import _hip
+    from nirrt_star_amd.env import Env, Env3D
+    dim = int(g["dim"])
+    env = Env(g["env"]) if dim == 2 else Env3D(g["env"])
+    return _hip.HipTree(dim, int(iter_max if iter_max is not None else g["iter_max"]), g["x_start"], g["x_goal"],
+                        float(g["step_len"]), float(g["search_radius"]), float(g["clearance"]), env)
+
+
+@pytest.mark.parametrize("name,dim", [("geom2d", 2), ("geom3d", 3)])
+def test_geometry_known_answers(name, dim):
+    from nirrt_star_amd import _hip
+    from nirrt_star_amd.env import Env, Env3D
+    g = load_golden(name)
+    for wi in range(int(g["n_worlds"])):
+        ed = g["w%d_env" % wi]
+        env = Env(ed) if dim == 2 else Env3D(ed)
+        t = _hip.HipTree(dim, 10, ed["start"][0], ed["goal"][0], 10.0, 100.0, float(g["clearance"]), env)
+        seg = np.stack([g["w%d_seg_a" % wi], g["w%d_seg_b" % wi]], axis=1)
+        assert np.array_equal(t.collision_batch(seg), g["w%d_collision" % wi]), "world %d" % wi
+        ins, val = t.points_in_obs(g["w%d_pts" % wi])
+        assert np.array_equal(ins, g["w%d_inside" % wi])
+        assert np.array_equal(val, g["w%d_valid" % wi])
+        t.close()
+
+
+def test_empty_world_and_zero_batches():
+    from nirrt_star_amd import _hip
+    from nirrt_star_amd.env import Env
+    ed = {"env_dims": (224, 224), "rectangle_obstacles": [], "circle_obstacles": [], "start": [[5, 5]], "goal": [[200, 200]]}
+    t = _hip.HipTree(2, 50, (5, 5), (200, 200), 10.0, 100.0, 3.0, Env(ed))
+    assert len(t.collision_batch(np.zeros((0, 2, 2)))) == 0
+    assert not t.is_collision((1, 1), (220, 220))
+    ins, val = t.points_in_obs(np.array([[1.0, 1.0], [100.0, 100.0]]))
+    assert list(ins) == [0, 0] and list(val) == [0, 1]
+    assert t.n == 1 and t.nearest((7, 7)) == 0
+    assert len(t.near((5.0, 5.0), 0)) == 0
+    gp, ln = t.search_goal_parent()
+    assert gp == -1 and np.isinf(ln)
+    c, x = t.best_solution()
+    assert np.isinf(c) and x == -1
+    t.close()
+
+
+@pytest.mark.parametrize("name", ["run_rrt2d_3000", "run_irrt3d_3000"])
+def test_primitives_on_frozen_tree(oracle, name):
+    g = load_golden(name)
+    dim = int(g["dim"])
+    t = make_hip_tree(g)
+    o = make_oracle_tree(oracle, g)
+    t.upload(g["vertices"], g["parents"])
+    o.load(g["vertices"], g["parents"])
+    n = int(g["n"])
+    v, p = t.download()
+    assert np.array_equal(v, g["vertices"]) and np.array_equal(p, g["parents"])
+    # cost walks: bit-exact float64 (math.hypot restatement, leaf->root order)
+    idx = np.arange(n)
+    c_hip = t.cost(idx)
+    c_orc = np.array([o.cost(i) for i in idx])
+    assert np.array_equal(c_hip, c_orc)
+    rng = np.random.default_rng(3)
+    hi = 224.0 if dim == 2 else 50.0
+    qs = rng.uniform(0, hi, size=(300, dim))
+    # exact-tie queries: midpoints between two vertices, and the vertices themselves
+    qs[:20] = 0.5 * (g["vertices"][10:30] + g["vertices"][40:60])
+    qs[20:40] = g["vertices"][100:120]
+    for q in qs:
+        assert t.nearest(q) == o.nearest(q)
+    for q in qs[:150]:
+        a, b = t.near(q, n), o.near(q, n)
+        assert np.array_equal(a, b)
+    # a frozen tree with exactly duplicated queries on vertices: Near excludes new_idx
+    for i in (5, 77, n - 1):
+        assert np.array_equal(t.near(g["vertices"][i], i), o.near(g["vertices"][i], i))
+    gp, ln = t.search_goal_parent()
+    assert gp == o.search_goal_parent()
+    if gp >= 0:
+        assert abs(ln - o.path_len(gp)) <= 1e-9 * max(1.0, ln)
+    t.close()
+    o.close()
+
+
+RUNS = ["run_rrt2d_500", "run_rrt2d_3000", "run_rrt2d_b30_2000", "run_irrt2d_800", "run_irrt2d_3000",
+        "run_rrt3d_500", "run_rrt3d_3000", "run_irrt3d_3000"]
+
+
+def _check_final(t, g, irrt, exact_vertices):
+    from nirrt_star_amd import _hip
+    v, p = t.download()
+    assert len(v) == int(g["n"])
+    assert np.array_equal(p, g["parents"])
+    if exact_vertices:
+        assert np.array_equal(v, g["vertices"])
+    else:
+        assert np.max(np.abs(v - g["vertices"])) <= 1e-9
+    if irrt:
+        assert np.array_equal(t.solutions, g["path_solutions"])
+        if len(g["path_solutions"]):
+            c, x = t.best_solution()
+            assert abs(c - float(g["path_len"])) <= 1e-5
+    else:
+        gp, ln = t.search_goal_parent()
+        if np.isfinite(float(g["path_len"])):
+            assert abs(ln - float(g["path_len"])) <= 1e-5
+            assert np.max(np.abs(v[gp] - g["path"][-2])) <= 1e-9
+
+
+@pytest.mark.parametrize("name", RUNS)
+def test_step_replay_host_steer_bit_exact(oracle, name):
+    """nearest on the GPU, new_state on the host (glibc, like the reference), rest on the GPU."""
+    from nirrt_star_amd import _hip
+    g = load_golden(name)
+    irrt = str(g["algo"]) == "irrt"
+    flags = _hip.F_IRRT if irrt else 0
+    t = make_hip_tree(g)
+    o = make_oracle_tree(oracle, g)  # only used as the host-side steer implementation (glibc libm)
+    verts = np.zeros((int(g["iter_max"]) + 1, int(g["dim"])))
+    verts[0] = g["x_start"]
+    have_trace = "trace_nearest" in g
+    for k, q in enumerate(g["samples"]):
+        ni = t.nearest(q)
+        if have_trace:
+            assert ni == g["trace_nearest"][k], "iteration %d" % k
+        node_new = o.steer(verts[ni], q)
+        r = t.extend(ni, node_new, flags)
+        if r.inserted:
+            verts[r.new_idx] = node_new
+        if have_trace:
+            lo, hi = g["trace_near_off"][k], g["trace_near_off"][k + 1]
+            assert r.n_near == hi - lo, "iteration %d" % k
+    _check_final(t, g, irrt, exact_vertices=True)
+    t.close()
+    o.close()
+
+
+@pytest.mark.parametrize("name", RUNS)
+def test_step_replay_device_steer(name):
+    from nirrt_star_amd import _hip
+    g = load_golden(name)
+    irrt = str(g["algo"]) == "irrt"
+    flags = _hip.F_IRRT if irrt else 0
+    t = make_hip_tree(g)
+    have_trace = "trace_nearest" in g
+    for k, q in enumerate(g["samples"]):
+        r = t.step(q, flags)
+        if have_trace:
+            assert r.nearest_idx == g["trace_nearest"][k], "iteration %d" % k
+    # 3D steer is IEEE-only -> bit-exact; 2D goes through the device libm
+    _check_final(t, g, irrt, exact_vertices=int(g["dim"]) == 3)
+    t.close()
+
+
+def test_resident_loop_replay_many_trees():
+    """nirrt_run: persistent one-workgroup-per-tree loop, several different problems in one launch."""
+    from nirrt_star_amd import _hip
+    names = ["run_rrt2d_3000", "run_rrt2d_b30_2000", "run_rrt2d_500"]
+    gs = [load_golden(n) for n in names]
+    iters = max(int(g["iter_max"]) for g in gs)
+    trees = [make_hip_tree(g, iter_max=iters) for g in gs]
+    samples = np.zeros((len(gs), iters, 2))
+    for i, g in enumerate(gs):
+        samples[i, : len(g["samples"])] = g["samples"]
+        # pad with a sample that cannot extend the tree: the start point itself (duplicate, no neighbours change)
+        samples[i, len(g["samples"]):] = g["x_start"]
+    # the padded iterations are "same point" iterations on the root: they may rewire through the root,
+    # exactly as the reference would; so only compare trees that need no padding bit-for-bit
+    res = _hip.run_replay(trees, samples, flags=0)
+    assert list(res["iters_done"]) == [iters] * len(gs) and not res["status"].any()
+    for t, g in zip(trees, gs):
+        if int(g["iter_max"]) == iters:
+            _check_final(t, g, False, exact_vertices=False)
+        t.close()
+
+
+def test_resident_loop_3d_with_goal_trace(oracle):
+    from nirrt_star_amd import _hip
+    g = load_golden("run_rrt3d_3000")
+    t = make_hip_tree(g)
+    o = make_oracle_tree(oracle, g)
+    res = _hip.run_replay([t], g["samples"][None], flags=_hip.F_GOAL_SCAN, want_trace=True)
+    _check_final(t, g, False, exact_vertices=True)
+    # per-iteration path length == oracle's search_goal_parent + path_len after each iteration
+    exp = []
+    for q in g["samples"]:
+        o.step(q, False)
+        gp = o.search_goal_parent()
+        exp.append(o.path_len(gp) if gp >= 0 else np.inf)
+    exp = np.array(exp)
+    got = res["cost_trace"][0]
+    assert np.array_equal(np.isinf(got), np.isinf(exp))
+    m = np.isfinite(exp)
+    assert np.max(np.abs(got[m] - exp[m])) <= 1e-9 * np.max(exp[m])
+    t.close()
+    o.close()
