@@ -36,7 +36,7 @@ extern "C" {
 #define NIRRT_E_STREAM (-5)   /* random-word stream exhausted inside nirrt_run         */
 
 #define NIRRT_MAX_OBSTACLES 64 /* per kind (round / box) */
-#define NIRRT_NEAR_CAPACITY 1024
+#define NIRRT_NEAR_CAPACITY 0 /* unlimited: Near-set scratch is sized like the tree */
 
 typedef struct nirrt_tree nirrt_tree;
 

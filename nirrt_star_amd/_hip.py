@@ -16,7 +16,6 @@ F_IRRT = 1
 F_GOAL_SCAN = 2
 
 E_ARG, E_HIP, E_CAPACITY, E_NODEVICE, E_STREAM = -1, -2, -3, -4, -5
-NEAR_CAPACITY = 1024
 MAX_OBSTACLES = 64
 
 EXPORTS = [
@@ -246,7 +245,7 @@ class HipTree:
     def near(self, node_new, new_idx):
         q = _f64(node_new)
         k = C.c_int64(0)
-        out = np.zeros(NEAR_CAPACITY, dtype=np.int64)
+        out = np.zeros(self.iter_max + 1, dtype=np.int64)   # a Near set can never exceed the tree
         _check(self.L.nirrt_near(self.h, _dp(q), int(new_idx), C.byref(k), _ip(out), len(out)))
         return out[:k.value].copy()
 

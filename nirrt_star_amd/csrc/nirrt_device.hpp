@@ -1,54 +1,79 @@
 // nirrt_device.hpp — gfx950 device code of the RRT*/IRRT* inner loop.
 //
-// Execution model: ONE workgroup (NT threads = NT/64 wave64s) owns ONE tree.  Every O(n) pass
-// (nearest, Near) is a coalesced grid-stride scan of the SoA coordinate arrays by the whole
-// workgroup with a wave64 __shfl_xor reduction + an LDS cross-wave step; everything O(k) (fan of
-// segment tests, parent-chain cost walks, choose-parent, rewire) runs lane-parallel out of LDS.
-// The same device functions back the one-kernel-per-primitive entry points, the fused
-// one-iteration kernel and the persistent many-trees loop.
+// Execution model: ONE workgroup of NT threads (NT/64 wave64s) owns ONE tree; a launch runs many
+// trees (one per workgroup, several workgroups per CU) so that one tree's dependent-latency phases
+// (parent-chain walks, barriers) overlap another tree's streaming scans.
 //
-// Arithmetic: float64 everywhere, compiled with -ffp-contract=off; each distance uses the formula
-// the reference resolves to at that call site:
-//   np.hypot            -> hypot_np()   glibc 2.35 __hypot, non-FMA kernel, IEEE ops only
-//   math.hypot          -> hypot_py<D>()  CPython 3.10 vector_norm
-//   np.linalg.norm axis -> norm_axis<D>() sqrt of left-to-right unfused sum of squares
-//   np.linalg.norm 1-D  -> norm_1d<D>()   sqrt of the BLAS ddot forward FMA chain
-//   np.dot (2-vectors)  -> dot_blas<D>()
+//   * O(n) passes (nearest, Near): every wave streams a CONTIGUOUS segment of the SoA coordinate
+//     arrays with 16-byte loads (2 vertices per lane, 1 KiB per wave-instruction).  The per-vertex
+//     work is a squared distance and a compare; the reference's distance formula (glibc hypot /
+//     sqrt) is only evaluated for vertices inside a 2^-48 guard band around the decision threshold,
+//     which keeps the scans HBM-bound while every decision stays bit-identical to the reference.
+//     Reductions: wave64 __shfl_xor butterflies, then one LDS step across waves.
+//     Near hits are staged in index order with wave ballots (no atomics, no sort).
+//   * O(k) work (fan of segment tests, cost walks, choose-parent, rewire) is lane-parallel; walks
+//     chase one 16-byte {edge_len, parent, mark} record per hop.
+//
+// Arithmetic: float64, compiled with -ffp-contract=off; per-call-site formulas of SURVEY.md App. A:
+//   np.hypot -> hypot_np()   math.hypot -> hypot_py<D>()   np.linalg.norm(axis) -> norm_axis<D>()
+//   np.linalg.norm 1-D -> norm_1d<D>()   np.dot -> dot_blas<D>()
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/nirrt_hip.h"
 
-#define NT 1024            // threads per workgroup (16 wave64)
-#define NW (NT / 64)
-#define NEAR_CAP NIRRT_NEAR_CAPACITY
 #define MAX_OBS NIRRT_MAX_OBSTACLES
+#define SCAN_PAD 256     // extra elements allocated behind every per-vertex array (vector loads may overrun n)
+#define ANC_MAX 3        // marked ancestors remembered per neighbour (more -> "overflow": always re-walk)
+#define WALK_R 4         // parent chains chased concurrently per lane
 
 // ------------------------------------------------------------------------------------------------
 // per-tree state in HBM
 // ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) Aux {
+    double elen;  // math.hypot(v - v_parent): the term cost() adds for this vertex (0 for the root)
+    int parent;
+    int mark;     // == current iteration stamp  <=>  vertex is in the current Near set
+};
+
 struct TreeDev {
-    // flat SoA vertex store
-    double *c[3];   // x[cap], y[cap], z[cap]
-    int *parent;    // parent[cap], parent[0] = 0
+    double *c[3];   // SoA coordinates x[cap], y[cap], z[cap]
+    Aux *aux;       // aux[cap]
+    int *rank_of;   // rank in the current Near set (valid where aux.mark == stamp)
     int cap;
     int n;          // num_vertices
     int dim;
     int status;     // sticky NIRRT_E_* code
-    // IRRT*: path_solutions (goal-parent indices, duplicates allowed)
+    int stamp;      // iteration stamp for aux.mark (monotonic, never 0)
+    int pad0;
+    // Near-set working arrays (capacity cap: a Near set can never exceed the tree)
+    int *st_idx;     // ordered staging of scan hits, one region per wave segment
+    int *nr_idx;     // neighbour vertex index, ascending
+    int *nr_flag;    // segment (new -> neighbour) hits an obstacle
+    int *nr_anc;     // [4*j]: count (ANC_MAX+1 = overflow), [4*j+1..3]: ranks of marked ancestors
+    double *nr_dist; // scan distance new <-> neighbour (np.hypot / axis norm)
+    double *nr_c0;   // cost(neighbour)
+    double *nr_c1;   // cost(new) if parent[new] were this neighbour
+    // IRRT*: path_solutions (goal-parent indices, duplicates allowed) + cached costs
     int *sol;
+    double *sol_cost;
     int n_sol;
     int cap_sol;
-    // RRT*: vertices within step_len of the goal (ascending index) with their distance and the
-    // result of the vertex->goal segment test (vertices never move, so this is append-only)
+    int sol_dirty;   // some parent changed since sol_cost[] was computed
+    int sol_best;    // argmin position in sol[] (first minimum), -1 if none
+    double sol_best_cost;
+    // RRT*: vertices within step_len of the goal (ascending index), distance, segment test result
     int *gc_idx;
     double *gc_dist;
+    double *gc_cost;
     unsigned char *gc_col;
     int n_gc;
-    int pad0;
-    // Near radius r(n) = min(gamma*sqrt(ln n/n), step_len) [2D] / cube root [3D], tabulated on the
-    // host with glibc (rrt_star_2d.py:133, rrt_star_3d.py:134); index = num_vertices
+    int gc_dirty;
+    int gc_best;
+    int pad1;
+    double gc_best_cost;
+    // Near radius r(n), tabulated on the host with glibc (rrt_star_2d.py:133, rrt_star_3d.py:134)
     const double *near_r;
     // problem constants
     double start[3], goal[3];
@@ -60,28 +85,22 @@ struct TreeDev {
     // informed sampling constants (IRRT*.init, irrt_star_2d.py:35-40 / irrt_star_3d.py:32-36)
     double c_min;
     double x_center[3];
-    double Crot[9];          // rotation to world frame, row-major 3x3
+    double CL_C[9];          // rotation-to-world matrix C, row-major 3x3
 };
 
 // ------------------------------------------------------------------------------------------------
 // LDS working set of one workgroup
 // ------------------------------------------------------------------------------------------------
+template <int NT>
 struct Lds {
+    static constexpr int NW = NT / 64;
     int n_round, n_box;
     double rnd[MAX_OBS][4];
     double box[MAX_OBS][6];
     double red_val[NW];
+    double red_val2[NW];
     int red_idx[NW];
     int wave_tot[NW];
-    int counter;
-    int flag;
-    int near_idx[NEAR_CAP];
-    int near_idx2[NEAR_CAP];
-    double near_dist[NEAR_CAP];
-    double near_dist2[NEAR_CAP];
-    double near_c0[NEAR_CAP];  // cost(j)
-    double near_c1[NEAR_CAP];  // cost(new) if parent[new] were j
-    int near_col[NEAR_CAP];
     double bc_d[8];
     int bc_i[8];
 };
@@ -122,33 +141,32 @@ __device__ __forceinline__ double hypot_np(double x, double y)
     return s == 1.0 ? h : h * s;
 }
 
-template <int D>
-__device__ __forceinline__ double hypot_py(const double *d)
+// CPython 3.10 Modules/mathmodule.c vector_norm() on (x, y[, z]); z == 0 contributes exact zeros,
+// so the 2-argument call is the same code with z = 0.
+__device__ __noinline__ double hypot_py3(double x0, double x1, double x2, int nd)
 {
-    // CPython 3.10 Modules/mathmodule.c vector_norm()
     const double T27 = 134217729.0;
-    double vec[D], mx = 0.0;
-#pragma unroll
-    for (int i = 0; i < D; i++) {
-        vec[i] = fabs(d[i]);
-        if (vec[i] > mx) mx = vec[i];
-    }
+    double vec[3] = {fabs(x0), fabs(x1), fabs(x2)};
+    double mx = vec[0] > vec[1] ? vec[0] : vec[1];
+    if (nd == 3) mx = vec[2] > mx ? vec[2] : mx;
     if (mx == 0.0) return mx;
     int max_e;
     (void)frexp(mx, &max_e);
     double scale = ldexp(1.0, -max_e);
     double x, oldcsum, csum = 1.0, frac1 = 0.0, frac2 = 0.0, frac3 = 0.0, t, hi, lo, h;
 #pragma unroll
-    for (int i = 0; i < D; i++) {
-        x = vec[i] * scale;
-        t = x * T27;
-        hi = t - (t - x);
-        lo = x - hi;
-        x = hi * hi;
-        oldcsum = csum; csum += x; frac1 += (oldcsum - csum) + x;
-        x = 2.0 * hi * lo;
-        oldcsum = csum; csum += x; frac2 += (oldcsum - csum) + x;
-        frac3 += lo * lo;
+    for (int i = 0; i < 3; i++) {
+        if (i < nd) {
+            x = vec[i] * scale;
+            t = x * T27;
+            hi = t - (t - x);
+            lo = x - hi;
+            x = hi * hi;
+            oldcsum = csum; csum += x; frac1 += (oldcsum - csum) + x;
+            x = 2.0 * hi * lo;
+            oldcsum = csum; csum += x; frac2 += (oldcsum - csum) + x;
+            frac3 += lo * lo;
+        }
     }
     h = __builtin_sqrt(csum - 1.0 + (frac1 + frac2 + frac3));
     x = h;
@@ -163,6 +181,12 @@ __device__ __forceinline__ double hypot_py(const double *d)
     oldcsum = csum; csum += x; frac3 += (oldcsum - csum) + x;
     x = csum - 1.0 + (frac1 + frac2 + frac3);
     return (h + x / (2.0 * h)) / scale;
+}
+
+template <int D>
+__device__ __forceinline__ double hypot_py(const double *d)
+{
+    return hypot_py3(d[0], d[1], D == 3 ? d[D - 1] : 0.0, D);
 }
 
 template <int D>
@@ -188,7 +212,7 @@ __device__ __forceinline__ double norm_1d(const double *d)
     return __builtin_sqrt(dot_blas<D>(d, d));
 }
 
-// distance of the O(n) scans and of choose_parent / rewire / goal scan
+// the reference's distance in the O(n) scans and in choose_parent / rewire / goal scan
 template <int D>
 __device__ __forceinline__ double dist_scan(const double *d)
 {
@@ -196,9 +220,21 @@ __device__ __forceinline__ double dist_scan(const double *d)
     return norm_axis<3>(d);
 }
 
+// cheap monotone proxy of dist_scan used to filter: plain sum of squares (relative error < 2^-51)
+template <int D>
+__device__ __forceinline__ double dist2(const double *d)
+{
+    double s = d[0] * d[0] + d[1] * d[1];
+    if (D == 3) s = s + d[2] * d[2];
+    return s;
+}
+// |dist_scan^2 / dist2 - 1| < 2^-50; decisions whose squared operands differ by more than this
+// band are already decided by dist2, anything inside is re-decided with dist_scan itself.
+#define BAND_HI (1.0 + 0x1p-48)
+#define BAND_LO (1.0 - 0x1p-48)
+
 // ------------------------------------------------------------------------------------------------
-// segment / point tests against ONE obstacle (the AABB prefilter of the reference is kept: it
-// decides which obstacles reach the exact test, and the exact tests are not monotone in it)
+// segment / point tests against ONE obstacle (the AABB prefilter of the reference is kept)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool line_intersection(const double *l1, const double *l2)
 {
@@ -323,8 +359,8 @@ __device__ __forceinline__ bool seg_box_3d(const double *p0, const double *p1, c
 }
 
 // segment vs obstacle #o of the LDS tables (o < n_round: round, else box)
-template <int D>
-__device__ __forceinline__ bool seg_obstacle(const Lds &s, int o, const double *a, const double *b, double clr)
+template <int D, int NT>
+__device__ __forceinline__ bool seg_obstacle(const Lds<NT> &s, int o, const double *a, const double *b, double clr)
 {
     if (o < s.n_round) {
         if (D == 2) return seg_round_2d(a, b, s.rnd[o], clr);
@@ -335,20 +371,20 @@ __device__ __forceinline__ bool seg_obstacle(const Lds &s, int o, const double *
     return seg_box_3d(a, b, s.box[o], clr);
 }
 
-// whole segment test by ONE lane (used in lane-parallel fans over many segments)
-template <int D>
-__device__ __forceinline__ bool seg_all(const Lds &s, const double *a, const double *b, double clr)
+// whole segment test by ONE lane (lane-parallel fans over many segments)
+template <int D, int NT>
+__device__ __forceinline__ bool seg_all(const Lds<NT> &s, const double *a, const double *b, double clr)
 {
     int M = s.n_round + s.n_box;
     for (int o = 0; o < M; o++)
-        if (seg_obstacle<D>(s, o, a, b, clr)) return true;
+        if (seg_obstacle<D, NT>(s, o, a, b, clr)) return true;
     return false;
 }
 
 // points_in_circles / points_in_balls: strict <  (collision_check_utils.py:292, _3d.py:299)
 // points_in_rectangles / points_in_boxes: inclusive (:254, _3d.py:260)
-template <int D>
-__device__ __forceinline__ bool point_in_obs(const Lds &s, const double *p, double clr)
+template <int D, int NT>
+__device__ __forceinline__ bool point_in_obs(const Lds<NT> &s, const double *p, double clr)
 {
     for (int i = 0; i < s.n_round; i++) {
         double rc = s.rnd[i][3] + clr;
@@ -386,7 +422,8 @@ __device__ __forceinline__ bool point_in_range(const TreeDev &t, const double *p
 // ------------------------------------------------------------------------------------------------
 // workgroup collectives
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stage_obstacles(Lds &s, const TreeDev &t)
+template <int NT>
+__device__ __forceinline__ void stage_obstacles(Lds<NT> &s, const TreeDev &t)
 {
     int tid = threadIdx.x;
     if (tid == 0) { s.n_round = t.n_round; s.n_box = t.n_box; }
@@ -397,7 +434,8 @@ __device__ __forceinline__ void stage_obstacles(Lds &s, const TreeDev &t)
 
 // lexicographic (value, index) minimum over the workgroup; every thread gets the result.
 // Ties keep the LOWEST index (np.argmin).  Threads with nothing pass idx = INT_MAX, v = +inf.
-__device__ __forceinline__ void block_argmin(Lds &s, double &v, int &idx)
+template <int NT>
+__device__ __forceinline__ void block_argmin(Lds<NT> &s, double &v, int &idx)
 {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -412,18 +450,37 @@ __device__ __forceinline__ void block_argmin(Lds &s, double &v, int &idx)
     v = s.red_val[0];
     idx = s.red_idx[0];
 #pragma unroll
-    for (int i = 1; i < NW; i++) {
+    for (int i = 1; i < NT / 64; i++) {
         double ov = s.red_val[i];
         int oi = s.red_idx[i];
         if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
     }
 }
 
-// workgroup OR
+// minimum index over the workgroup (INT_MAX if none)
+template <int NT>
+__device__ __forceinline__ int block_min_int(Lds<NT> &s, int v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        int o = __shfl_xor(v, off);
+        v = o < v ? o : v;
+    }
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) s.red_idx[w] = v;
+    __syncthreads();
+    v = s.red_idx[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; i++) v = s.red_idx[i] < v ? s.red_idx[i] : v;
+    return v;
+}
+
 __device__ __forceinline__ bool block_any(bool p) { return __syncthreads_or(p ? 1 : 0) != 0; }
 
 // ordered compaction: threads with keep get their output slot (ascending thread order); returns total
-__device__ __forceinline__ int block_compact(Lds &s, bool keep, int &pos)
+template <int NT>
+__device__ __forceinline__ int block_compact(Lds<NT> &s, bool keep, int &pos)
 {
     unsigned long long m = __ballot(keep);
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -433,7 +490,7 @@ __device__ __forceinline__ int block_compact(Lds &s, bool keep, int &pos)
     __syncthreads();
     int off = 0, tot = 0;
 #pragma unroll
-    for (int i = 0; i < NW; i++) {
+    for (int i = 0; i < NT / 64; i++) {
         int c = s.wave_tot[i];
         if (i < w) off += c;
         tot += c;
@@ -452,9 +509,21 @@ __device__ __forceinline__ void load_vertex(const TreeDev &t, int i, double *v)
     for (int k = 0; k < D; k++) v[k] = t.c[k][i];
 }
 
-// nearest_neighbor: argmin_i dist(q, v_i), lowest index on ties
-template <int D>
-__device__ __forceinline__ int wg_nearest(Lds &s, const TreeDev &t, int n, const double *q, double &best_d)
+// wave segment of the scans: wave w streams [beg, end), `per` a multiple of 128
+template <int NT>
+__device__ __forceinline__ void wave_segment(int n, int &beg, int &end)
+{
+    constexpr int NW = NT / 64;
+    int per = ((n + NW * 128 - 1) / (NW * 128)) * 128;
+    int w = threadIdx.x >> 6;
+    beg = w * per;
+    end = beg + per < n ? beg + per : n;
+    if (beg > n) beg = n;
+}
+
+// exact (reference-formula) nearest scan; only used when the filtered scan sees a near-tie
+template <int D, int NT>
+__device__ __noinline__ int wg_nearest_exact(Lds<NT> &s, const TreeDev &t, int n, const double *q)
 {
     double bd = __builtin_inf();
     int bi = 0x7fffffff;
@@ -465,40 +534,129 @@ __device__ __forceinline__ int wg_nearest(Lds &s, const TreeDev &t, int n, const
         double h = dist_scan<D>(d);
         if (h < bd) { bd = h; bi = i; }
     }
-    block_argmin(s, bd, bi);
-    best_d = bd;
+    block_argmin<NT>(s, bd, bi);
     return bi;
 }
 
-// cost walk leaf -> root (RRTBase.cost).  Returns cost(idx); if c1 != nullptr also the cost the
-// vertex `from` would have if its parent were idx:  ((e(from,idx) + e(idx,p)) + ...)  which is how
-// cost(from) sums when walking from `from` (cost() restarts its accumulator at the leaf).
-template <int D>
-__device__ __forceinline__ double walk_cost(const TreeDev &t, int idx, const double *from, double *c1)
+// nearest_neighbor: argmin_i dist(q, v_i), lowest index on ties (np.argmin).
+// Squared distances decide; if a second vertex lies within the guard band of the minimum the
+// reference formula decides instead (wg_nearest_exact).
+template <int D, int NT>
+__device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, const double *q)
 {
-    double v[D];
-    load_vertex<D>(t, idx, v);
-    double acc0 = 0., acc1 = 0.;
-    if (c1) {
-        double d[D];
-#pragma unroll
-        for (int k = 0; k < D; k++) d[k] = from[k] - v[k];
-        acc1 = hypot_py<D>(d);
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int beg, end;
+    wave_segment<NT>(n, beg, end);
+    double m1 = __builtin_inf(), m2 = __builtin_inf();
+    int i1 = 0x7fffffff;
+    const double2 *X = reinterpret_cast<const double2 *>(t.c[0]);
+    const double2 *Y = reinterpret_cast<const double2 *>(t.c[1]);
+    const double2 *Z = reinterpret_cast<const double2 *>(t.c[D - 1]);
+    for (int base = beg + 2 * lane; base < end; base += 128) {
+        double2 xv = X[base >> 1], yv = Y[base >> 1], zv;
+        if (D == 3) zv = Z[base >> 1];
+        double da[3] = {q[0] - xv.x, q[1] - yv.x, D == 3 ? q[D - 1] - zv.x : 0.};
+        double db[3] = {q[0] - xv.y, q[1] - yv.y, D == 3 ? q[D - 1] - zv.y : 0.};
+        double va = dist2<D>(da);
+        double vb = base + 1 < end ? dist2<D>(db) : __builtin_inf();
+        if (va < m1) { m2 = m1; m1 = va; i1 = base; } else if (va < m2) m2 = va;
+        if (vb < m1) { m2 = m1; m1 = vb; i1 = base + 1; } else if (vb < m2) m2 = vb;
     }
+    // wave: minimum (m1, i1) and the second-smallest value seen by the wave
+    double wm = m1;
+    int wi = i1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double ov = __shfl_xor(wm, off);
+        int oi = __shfl_xor(wi, off);
+        if (ov < wm || (ov == wm && oi < wi)) { wm = ov; wi = oi; }
+    }
+    double ws = (i1 == wi) ? m2 : m1;  // this lane's best that is NOT the wave winner
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double ov = __shfl_xor(ws, off);
+        ws = ov < ws ? ov : ws;
+    }
+    __syncthreads();
+    if (lane == 0) { s.red_val[w] = wm; s.red_idx[w] = wi; s.red_val2[w] = ws; }
+    __syncthreads();
+    double g1 = s.red_val[0];
+    int gi = s.red_idx[0], gw = 0;
+#pragma unroll
+    for (int i = 1; i < NW; i++) {
+        double ov = s.red_val[i];
+        int oi = s.red_idx[i];
+        if (ov < g1 || (ov == g1 && oi < gi)) { g1 = ov; gi = oi; gw = i; }
+    }
+    double g2 = __builtin_inf();
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        double c = (i == gw) ? s.red_val2[i] : s.red_val[i];
+        g2 = c < g2 ? c : g2;
+    }
+    if (g2 <= g1 * BAND_HI) return wg_nearest_exact<D, NT>(s, t, n, q);  // uniform branch (rare)
+    return gi;
+}
+
+// chase parent chains leaf -> root (RRTBase.cost).  Up to WALK_R chains per lane are walked
+// concurrently so that their dependent 16-byte loads overlap.
+//   idx[r] < 0: inactive slot.  acc0[r] += every edge; acc1[r] likewise (caller pre-loads e(new, idx)).
+//   If anc != nullptr: anc[r][0] = number of marked ancestors met (capped ANC_MAX+1), anc[r][1..] their ranks.
+template <int D>
+__device__ __forceinline__ void walk_chains(const TreeDev &t, int (&idx)[WALK_R], double (&acc0)[WALK_R],
+                                            double (&acc1)[WALK_R], int (*anc)[ANC_MAX + 1], int stamp)
+{
+    bool first[WALK_R];
     int guard = t.cap + 1;
-    while (idx != 0 && guard-- > 0) {
-        int p = t.parent[idx];
-        double pv[D], d[D];
-        load_vertex<D>(t, p, pv);
 #pragma unroll
-        for (int k = 0; k < D; k++) { d[k] = v[k] - pv[k]; v[k] = pv[k]; }
-        double e = hypot_py<D>(d);
-        acc0 += e;
-        acc1 += e;
-        idx = p;
+    for (int r = 0; r < WALK_R; r++) {
+        first[r] = true;
+        if (anc) anc[r][0] = 0;
     }
-    if (c1) *c1 = acc1;
-    return acc0;
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < WALK_R; r++) any = any || idx[r] > 0;
+        if (!any || guard-- <= 0) break;
+        Aux a[WALK_R];
+#pragma unroll
+        for (int r = 0; r < WALK_R; r++)
+            if (idx[r] > 0) a[r] = t.aux[idx[r]];
+#pragma unroll
+        for (int r = 0; r < WALK_R; r++) {
+            if (idx[r] > 0) {
+                if (anc && !first[r] && a[r].mark == stamp) {
+                    int c = anc[r][0];
+                    if (c < ANC_MAX) {
+                        int rk = t.rank_of[idx[r]];
+#pragma unroll
+                        for (int cc = 0; cc < ANC_MAX; cc++)
+                            if (c == cc) anc[r][1 + cc] = rk;
+                    }
+                    anc[r][0] = c < ANC_MAX + 1 ? c + 1 : c;
+                }
+                first[r] = false;
+                acc0[r] += a[r].elen;
+                acc1[r] += a[r].elen;
+                idx[r] = a[r].parent;
+            }
+        }
+    }
+}
+
+// single chain, plain cost
+template <int D>
+__device__ __forceinline__ double walk_cost(const TreeDev &t, int i)
+{
+    double acc = 0.;
+    int guard = t.cap + 1;
+    while (i > 0 && guard-- > 0) {
+        Aux a = t.aux[i];
+        acc += a.elen;
+        i = a.parent;
+    }
+    return acc;
 }
 
 // steer (new_state).  2D: rrt_star_2d.py:67-78, device atan2/cos/sin; 3D: rrt_star_3d.py:67-78, IEEE only.
@@ -526,121 +684,243 @@ __device__ __forceinline__ void steer(const TreeDev &t, const double *from, cons
 }
 
 // segment test spread over the workgroup: lane o tests obstacle o, OR-reduced
-template <int D>
-__device__ __forceinline__ bool wg_collision(const Lds &s, const double *a, const double *b, double clr)
+template <int D, int NT>
+__device__ __forceinline__ bool wg_collision(const Lds<NT> &s, const double *a, const double *b, double clr)
 {
     int M = s.n_round + s.n_box;
     bool hit = false;
-    for (int o = threadIdx.x; o < M; o += NT) hit = hit || seg_obstacle<D>(s, o, a, b, clr);
+    for (int o = threadIdx.x; o < M; o += NT) hit = hit || seg_obstacle<D, NT>(s, o, a, b, clr);
     return block_any(hit);
 }
 
-// Near set of node_new on the current tree (find_near_neighbors).  On return
-// s.near_idx[0..k) ascending, s.near_dist[0..k) the matching scan distances.  Returns k (or -1 on
-// Near-capacity overflow).
-template <int D>
-__device__ __forceinline__ int wg_near(Lds &s, const TreeDev &t, int n, const double *node_new, int new_idx)
+// Near set of node_new on the current tree (find_near_neighbors, rrt_star_2d.py:125-144).
+// On return t.nr_idx[0..k) ascending, t.nr_dist[0..k) the reference scan distances, and every
+// member carries aux.mark = stamp, rank_of = its rank.  Returns k.
+template <int D, int NT>
+__device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const double *node_new, int new_idx, int stamp)
 {
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
     const double r = t.near_r[n];
+    const double r2 = r * r, r2lo = r2 * BAND_LO, r2hi = r2 * BAND_HI;
     const double clr = t.clearance;
-    if (threadIdx.x == 0) s.counter = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += NT) {
-        double d[D];
-#pragma unroll
-        for (int k = 0; k < D; k++) d[k] = node_new[k] - t.c[k][i];
-        double h = dist_scan<D>(d);
-        if (h <= r) {
-            int pos = atomicAdd(&s.counter, 1);
-            if (pos < NEAR_CAP) { s.near_idx2[pos] = i; s.near_dist2[pos] = h; }
+    int beg, end;
+    wave_segment<NT>(n, beg, end);
+    const double2 *X = reinterpret_cast<const double2 *>(t.c[0]);
+    const double2 *Y = reinterpret_cast<const double2 *>(t.c[1]);
+    const double2 *Z = reinterpret_cast<const double2 *>(t.c[D - 1]);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int cnt = 0;  // wave-uniform
+    for (int cb = beg; cb < end; cb += 128) {
+        int base = cb + 2 * lane;
+        bool ha = false, hb = false;
+        if (base < end) {
+            double2 xv = X[base >> 1], yv = Y[base >> 1], zv;
+            if (D == 3) zv = Z[base >> 1];
+            double da[3] = {node_new[0] - xv.x, node_new[1] - yv.x, D == 3 ? node_new[D - 1] - zv.x : 0.};
+            double db[3] = {node_new[0] - xv.y, node_new[1] - yv.y, D == 3 ? node_new[D - 1] - zv.y : 0.};
+            double va = dist2<D>(da), vb = dist2<D>(db);
+            ha = va <= r2lo;
+            if (!ha && va <= r2hi) ha = dist_scan<D>(da) <= r;   // inside the guard band: reference formula
+            if (base + 1 < end) {
+                hb = vb <= r2lo;
+                if (!hb && vb <= r2hi) hb = dist_scan<D>(db) <= r;
+            }
+        }
+        unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+        if (ma | mb) {
+            int pre = __popcll(ma & lt) + __popcll(mb & lt);
+            if (ha) t.st_idx[beg + cnt + pre] = base;
+            if (hb) t.st_idx[beg + cnt + pre + (ha ? 1 : 0)] = base + 1;
+            cnt += __popcll(ma) + __popcll(mb);
         }
     }
     __syncthreads();
-    int kraw = s.counter;
-    if (kraw > NEAR_CAP) return -1;
-    // rank sort -> ascending vertex index (np.where order)
-    for (int a = threadIdx.x; a < kraw; a += NT) {
-        int me = s.near_idx2[a], rank = 0;
-        for (int b = 0; b < kraw; b++) rank += (s.near_idx2[b] < me);
-        s.near_idx[rank] = me;
-        s.near_dist[rank] = s.near_dist2[a];
-        s.near_col[a] = 0;
+    if (lane == 0) s.wave_tot[w] = cnt;
+    __syncthreads();
+    int woff[NW + 1];
+    woff[0] = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) woff[i + 1] = woff[i] + s.wave_tot[i];
+    const int kraw = woff[NW];
+    const int per = ((n + NW * 128 - 1) / (NW * 128)) * 128;
+    // gather the staged hits (already ascending) into the candidate list
+    for (int a = tid; a < kraw; a += NT) {
+        int ww = 0, offw = 0;
+#pragma unroll
+        for (int i = 1; i < NW; i++)
+            if (a >= woff[i]) { ww = i; offw = woff[i]; }
+        int v = t.st_idx[ww * per + (a - offw)];
+        t.nr_idx[a] = v;
+        t.nr_flag[a] = (v == new_idx) ? 1 : 0;   // excluded like the colliding ones
     }
     __syncthreads();
     // fan of segment tests (node_new -> v_j) x obstacles, one (segment, obstacle) pair per lane
-    int M = s.n_round + s.n_box;
+    const int M = s.n_round + s.n_box;
     if (M > 0) {
-        int pairs = kraw * M;
-        for (int p = threadIdx.x; p < pairs; p += NT) {
+        const int pairs = kraw * M;
+        for (int p = tid; p < pairs; p += NT) {
             int j = p / M, o = p - j * M;
             double vj[D];
-            load_vertex<D>(t, s.near_idx[j], vj);
-            if (seg_obstacle<D>(s, o, node_new, vj, clr)) s.near_col[j] = 1;
+            load_vertex<D>(t, t.nr_idx[j], vj);
+            if (seg_obstacle<D, NT>(s, o, node_new, vj, clr)) t.nr_flag[j] = 1;
         }
     }
     __syncthreads();
-    // stable filter: collision-free and != new_idx
+    // stable in-place filter
     int k = 0;
     for (int base = 0; base < kraw; base += NT) {
-        int a = base + threadIdx.x;
-        bool keep = a < kraw && s.near_col[a] == 0 && s.near_idx[a] != new_idx;
+        int a = base + tid;
         int vi = 0;
-        double vd = 0;
-        if (a < kraw) { vi = s.near_idx[a]; vd = s.near_dist[a]; }
+        bool keep = false;
+        if (a < kraw) { vi = t.nr_idx[a]; keep = t.nr_flag[a] == 0; }
         int pos;
-        int tot = block_compact(s, keep, pos);
-        if (keep) { s.near_idx2[k + pos] = vi; s.near_dist2[k + pos] = vd; }
+        int tot = block_compact<NT>(s, keep, pos);
+        if (keep) t.nr_idx[k + pos] = vi;
         k += tot;
     }
     __syncthreads();
-    for (int a = threadIdx.x; a < k; a += NT) {
-        s.near_idx[a] = s.near_idx2[a];
-        s.near_dist[a] = s.near_dist2[a];
+    // reference distances of the survivors + Near-set marks
+    for (int a = tid; a < k; a += NT) {
+        int vi = t.nr_idx[a];
+        double v[D], d[D];
+        load_vertex<D>(t, vi, v);
+#pragma unroll
+        for (int c = 0; c < D; c++) d[c] = node_new[c] - v[c];
+        t.nr_dist[a] = dist_scan<D>(d);
+        t.aux[vi].mark = stamp;
+        t.rank_of[vi] = a;
     }
     __syncthreads();
     return k;
 }
 
-// find_best_path_solution (irrt_star_2d.py:84-97): argmin_s cost(sol[s]) + Line(v, goal), first minimum
-template <int D>
-__device__ __forceinline__ void wg_best_solution(Lds &s, const TreeDev &t, double &c_best, int &x_best)
+// walk phase of one iteration: cost(j) and cost-of-new-via-j for every neighbour j < k, plus the
+// same for `extra` (the nearest vertex) stored at slot k.
+template <int D, int NT>
+__device__ __forceinline__ void wg_walk_neighbours(TreeDev &t, int k, int extra, const double *node_new, int stamp,
+                                                   int from_rank, bool with_c1)
 {
-    double bv = __builtin_inf();
-    int bs = 0x7fffffff;
-    int ns = t.n_sol;
-    for (int q = threadIdx.x; q < ns; q += NT) {
-        int idx = t.sol[q];
-        double v[D], d[D];
-        load_vertex<D>(t, idx, v);
+    const int tid = threadIdx.x;
+    const int total = k + (extra >= 0 ? 1 : 0);
+    for (int base = from_rank; base < total; base += NT * WALK_R) {
+        int idx[WALK_R], slot[WALK_R];
+        double acc0[WALK_R], acc1[WALK_R];
+        int anc[WALK_R][ANC_MAX + 1];
 #pragma unroll
-        for (int k = 0; k < D; k++) d[k] = t.goal[k] - v[k];
-        double c = walk_cost<D>(t, idx, nullptr, nullptr) + hypot_py<D>(d);
-        if (c < bv) { bv = c; bs = q; }
+        for (int r = 0; r < WALK_R; r++) {
+            int a = base + r * NT + tid;
+            slot[r] = a < total ? a : -1;
+            idx[r] = -1;
+            acc0[r] = 0.;
+            acc1[r] = 0.;
+            if (a < total) {
+                int vi = a < k ? t.nr_idx[a] : extra;
+                idx[r] = vi;
+                if (with_c1) {
+                    double v[D], d[D];
+                    load_vertex<D>(t, vi, v);
+#pragma unroll
+                    for (int c = 0; c < D; c++) d[c] = node_new[c] - v[c];
+                    acc1[r] = hypot_py<D>(d);
+                }
+            }
+        }
+        walk_chains<D>(t, idx, acc0, acc1, anc, stamp);
+#pragma unroll
+        for (int r = 0; r < WALK_R; r++) {
+            int a = slot[r];
+            if (a >= 0) {
+                t.nr_c0[a] = acc0[r];
+                if (with_c1) t.nr_c1[a] = acc1[r];
+                if (a < k) {
+                    t.nr_anc[4 * a] = anc[r][0];
+#pragma unroll
+                    for (int c = 0; c < ANC_MAX; c++) t.nr_anc[4 * a + 1 + c] = anc[r][1 + c];
+                }
+            }
+        }
     }
-    block_argmin(s, bv, bs);
-    c_best = bv;
-    x_best = (ns > 0 && bs != 0x7fffffff) ? t.sol[bs] : -1;
-    if (ns > 0 && bs == 0x7fffffff) x_best = t.sol[0];  // all +inf cannot happen (costs finite); keep argmin semantics
+}
+
+// find_best_path_solution (irrt_star_2d.py:84-97) with exact caching: the per-solution costs only
+// change when some parent changed (sol_dirty); otherwise only solutions appended since are new.
+template <int D, int NT>
+__device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double &c_best, int &x_best)
+{
+    const int tid = threadIdx.x;
+    const int ns = t.n_sol;
+    if (ns == 0) { c_best = __builtin_inf(); x_best = -1; return; }
+    if (t.sol_dirty) {   // uniform
+        double bv = __builtin_inf();
+        int bs = 0x7fffffff;
+        for (int q = tid; q < ns; q += NT) {
+            int idx = t.sol[q];
+            double v[D], d[D];
+            load_vertex<D>(t, idx, v);
+#pragma unroll
+            for (int k = 0; k < D; k++) d[k] = t.goal[k] - v[k];
+            double c = walk_cost<D>(t, idx) + hypot_py<D>(d);
+            t.sol_cost[q] = c;
+            if (c < bv) { bv = c; bs = q; }
+        }
+        block_argmin<NT>(s, bv, bs);
+        if (bs == 0x7fffffff) bs = 0;
+        if (tid == 0) { t.sol_dirty = 0; t.sol_best = bs; t.sol_best_cost = bv; }
+        __syncthreads();
+    }
+    c_best = t.sol_best_cost;
+    x_best = t.sol[t.sol_best];
+}
+
+// append a solution (InGoalRegion true) keeping the cache exact.  Uniform; thread 0 writes.
+template <int D, int NT>
+__device__ __forceinline__ void wg_append_solution(Lds<NT> &s, TreeDev &t, int idx, const double *v)
+{
+    if (threadIdx.x == 0) {
+        if (t.n_sol < t.cap_sol) {
+            int q = t.n_sol;
+            t.sol[q] = idx;
+            if (!t.sol_dirty) {
+                double d[D];
+#pragma unroll
+                for (int k = 0; k < D; k++) d[k] = t.goal[k] - v[k];
+                double c = walk_cost<D>(t, idx) + hypot_py<D>(d);
+                t.sol_cost[q] = c;
+                if (q == 0 || c < t.sol_best_cost) { t.sol_best = q; t.sol_best_cost = c; }  // first minimum stays
+            }
+            t.n_sol = q + 1;
+        } else {
+            t.status = NIRRT_E_CAPACITY;
+        }
+    }
+    __syncthreads();
 }
 
 // search_goal_parent (rrt_star_2d.py:101-117) over the maintained candidate list + path length
-template <int D>
-__device__ __forceinline__ void wg_goal_parent(Lds &s, const TreeDev &t, int &gp, double &path_len)
+template <int D, int NT>
+__device__ __forceinline__ void wg_goal_parent(Lds<NT> &s, TreeDev &t, int &gp, double &path_len)
 {
-    double bv = __builtin_inf();
-    int bq = 0x7fffffff;
-    int ng = t.n_gc;
-    for (int q = threadIdx.x; q < ng; q += NT) {
-        double c = __builtin_inf();
-        if (!t.gc_col[q]) c = walk_cost<D>(t, t.gc_idx[q], nullptr, nullptr) + t.gc_dist[q];
-        if (c < bv) { bv = c; bq = q; }
-    }
-    block_argmin(s, bv, bq);
+    const int tid = threadIdx.x;
+    const int ng = t.n_gc;
     if (ng == 0) { gp = -1; path_len = __builtin_inf(); return; }
-    if (bq == 0x7fffffff) bq = 0;  // every candidate collides: np.argmin of all-inf = 0
-    gp = t.gc_idx[bq];
+    if (t.gc_dirty) {
+        double bv = __builtin_inf();
+        int bq = 0x7fffffff;
+        for (int q = tid; q < ng; q += NT) {
+            double c = __builtin_inf();
+            if (!t.gc_col[q]) c = walk_cost<D>(t, t.gc_idx[q]) + t.gc_dist[q];
+            t.gc_cost[q] = c;
+            if (c < bv) { bv = c; bq = q; }
+        }
+        block_argmin<NT>(s, bv, bq);
+        if (bq == 0x7fffffff) bq = 0;  // every candidate collides: np.argmin of all-inf = 0
+        if (tid == 0) { t.gc_dirty = 0; t.gc_best = bq; t.gc_best_cost = bv; }
+        __syncthreads();
+    }
+    gp = t.gc_idx[t.gc_best];
     // get_path_len(extract_path(gp)): sum of segment norms, goal <- gp <- ... <- start
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         double len = 0., prev[D], v[D], d[D];
 #pragma unroll
         for (int k = 0; k < D; k++) prev[k] = t.goal[k];
@@ -651,7 +931,7 @@ __device__ __forceinline__ void wg_goal_parent(Lds &s, const TreeDev &t, int &gp
             for (int k = 0; k < D; k++) { d[k] = prev[k] - v[k]; prev[k] = v[k]; }
             len += norm_axis<D>(d);
             if (i == 0 || guard-- <= 0) break;
-            i = t.parent[i];
+            i = t.aux[i].parent;
         }
         s.bc_d[7] = len;
     }
@@ -662,20 +942,27 @@ __device__ __forceinline__ void wg_goal_parent(Lds &s, const TreeDev &t, int &gp
 
 // bookkeeping when a vertex (idx, coordinates v) has just been appended: RRT* goal-candidate list.
 // Block-uniform control flow; `v` identical in all threads.
-template <int D>
-__device__ __forceinline__ void wg_goal_candidate(Lds &s, TreeDev &t, int idx, const double *v)
+template <int D, int NT>
+__device__ __forceinline__ void wg_goal_candidate(Lds<NT> &s, TreeDev &t, int idx, const double *v)
 {
     double d[D];
 #pragma unroll
     for (int k = 0; k < D; k++) d[k] = t.goal[k] - v[k];
+    if (dist2<D>(d) > t.step_len * t.step_len * BAND_HI) return;   // uniform: clearly outside
     double h = dist_scan<D>(d);
     if (h <= t.step_len) {  // uniform
-        bool col = wg_collision<D>(s, v, t.goal, t.clearance);
+        bool col = wg_collision<D, NT>(s, v, t.goal, t.clearance);
         if (threadIdx.x == 0) {
             int q = t.n_gc;
             t.gc_idx[q] = idx;
             t.gc_dist[q] = h;
             t.gc_col[q] = col ? 1 : 0;
+            double c = __builtin_inf();
+            if (!t.gc_dirty) {
+                if (!col) c = walk_cost<D>(t, idx) + h;
+                t.gc_cost[q] = c;
+                if (q == 0 || c < t.gc_best_cost) { t.gc_best = q; t.gc_best_cost = c; }
+            }
             t.n_gc = q + 1;
         }
         __syncthreads();
@@ -687,13 +974,14 @@ __device__ __forceinline__ void wg_goal_candidate(Lds &s, TreeDev &t, int idx, c
 //   host_steer: node_in = node_new computed by the caller and nearest_in its nearest index
 //   else      : node_in = node_rand
 // ------------------------------------------------------------------------------------------------
-template <int D>
-__device__ __forceinline__ void wg_iteration(Lds &s, TreeDev &t, const double *node_in, bool host_steer,
+template <int D, int NT>
+__device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const double *node_in, bool host_steer,
                                              int nearest_in, unsigned flags, nirrt_step_result *res)
 {
     const int tid = threadIdx.x;
     const double clr = t.clearance;
     int n = t.n;
+    const int stamp = t.stamp + 1;   // published by thread 0 at the end of the iteration
     int ni;
     double node_new[D], nearest[D];
     if (host_steer) {
@@ -702,8 +990,7 @@ __device__ __forceinline__ void wg_iteration(Lds &s, TreeDev &t, const double *n
 #pragma unroll
         for (int k = 0; k < D; k++) node_new[k] = node_in[k];
     } else {
-        double bd;
-        ni = wg_nearest<D>(s, t, n, node_in, bd);
+        ni = wg_nearest<D, NT>(s, t, n, node_in);
         load_vertex<D>(t, ni, nearest);
         steer<D>(t, nearest, node_in, node_new);
     }
@@ -712,13 +999,14 @@ __device__ __forceinline__ void wg_iteration(Lds &s, TreeDev &t, const double *n
         res->reparented = 0; res->n_rewired = 0; res->in_goal = 0; res->status = 0; res->reserved = 0;
         res->node_new[0] = node_new[0]; res->node_new[1] = node_new[1]; res->node_new[2] = D == 3 ? node_new[D - 1] : 0.;
     }
-    bool collided = wg_collision<D>(s, nearest, node_new, clr);
+    bool collided = wg_collision<D, NT>(s, nearest, node_new, clr);
     int new_idx = -1;
     if (!collided) {
         double diff[D];
 #pragma unroll
         for (int k = 0; k < D; k++) diff[k] = node_new[k] - nearest[k];
         const bool dup = norm_1d<D>(diff) < 1e-8;
+        const double edge_new = dup ? 0. : hypot_py<D>(diff);   // Line(nearest, new) == cost() term of new
         bool inserted = false;
         if (dup) {
             new_idx = ni;
@@ -732,91 +1020,101 @@ __device__ __forceinline__ void wg_iteration(Lds &s, TreeDev &t, const double *n
             if (tid == 0) {
 #pragma unroll
                 for (int k = 0; k < D; k++) t.c[k][new_idx] = node_new[k];
-                t.parent[new_idx] = ni;
+                Aux a;
+                a.elen = edge_new; a.parent = ni; a.mark = 0;
+                t.aux[new_idx] = a;
                 t.n = n + 1;
             }
             n = n + 1;
             inserted = true;
             __syncthreads();
-            wg_goal_candidate<D>(s, t, new_idx, node_new);
         }
         if (new_idx >= 0) {
-            int k = wg_near<D>(s, t, n, node_new, new_idx);
-            if (k < 0) {
-                if (tid == 0) t.status = NIRRT_E_CAPACITY;
-                k = 0;
-            }
+            int k = wg_near<D, NT>(s, t, n, node_new, new_idx, stamp);
             int reparented = 0, n_rewired = 0;
             if (k > 0) {
-                // parent-chain walks: lane j < k walks neighbour j, lane k walks `nearest`
-                double c0 = 0., c1 = 0.;
-                if (tid < k) {
-                    c0 = walk_cost<D>(t, s.near_idx[tid], node_new, &c1);
-                    s.near_c0[tid] = c0;
-                    s.near_c1[tid] = c1;
-                } else if (tid == k) {
-                    c0 = walk_cost<D>(t, ni, node_new, &c1);
-                    // curr_node_new_cost: rrt_star_2d.py:45 (same point) / :51
-                    double curr = c0;
-                    if (!dup) curr = c0 + hypot_py<D>(diff);
-                    s.bc_d[0] = curr;
-                    s.bc_d[1] = dup ? c0 : c1;  // cost(new) while parent[new] is unchanged
-                }
-                // (k may exceed NT only if NEAR_CAP > NT; NEAR_CAP == NT here)
+                // parent-chain walks: slot j < k = neighbour j, slot k = `nearest`
+                wg_walk_neighbours<D, NT>(t, k, ni, node_new, stamp, 0, true);
                 __syncthreads();
                 // choose_parent (rrt_star_2d.py:80-90)
                 double cand = __builtin_inf();
                 int cj = 0x7fffffff;
-                if (tid < k) { cand = s.near_c0[tid] + s.near_dist[tid]; cj = tid; }
-                block_argmin(s, cand, cj);
-                const double curr = s.bc_d[0];
-                double new_cost = s.bc_d[1];
+                for (int a = tid; a < k; a += NT) {
+                    double c = t.nr_c0[a] + t.nr_dist[a];
+                    if (c < cand) { cand = c; cj = a; }
+                }
+                block_argmin<NT>(s, cand, cj);
+                // curr_node_new_cost (rrt_star_2d.py:45 same point / :51) and cost(new) with parent unchanged
+                const double c0n = t.nr_c0[k];
+                const double curr = dup ? c0n : c0n + edge_new;
+                double new_cost = dup ? c0n : t.nr_c1[k];
                 if (cand < curr) {
                     reparented = 1;
-                    if (tid == 0) t.parent[new_idx] = s.near_idx[cj];
-                    new_cost = s.near_c1[cj];
+                    new_cost = t.nr_c1[cj];
+                    if (tid == 0) {
+                        int bj = t.nr_idx[cj];
+                        double v[D], d[D];
+                        load_vertex<D>(t, bj, v);
+#pragma unroll
+                        for (int c = 0; c < D; c++) d[c] = node_new[c] - v[c];
+                        t.aux[new_idx].parent = bj;
+                        t.aux[new_idx].elen = hypot_py<D>(d);
+                        if (dup) { t.sol_dirty = 1; t.gc_dirty = 1; }
+                    }
                     __syncthreads();
                     if (dup) {
                         // node_new is an existing vertex that just moved in the tree: every neighbour
                         // below it changed cost -> re-walk before rewiring
-                        if (tid < k) s.near_c0[tid] = walk_cost<D>(t, s.near_idx[tid], nullptr, nullptr);
+                        wg_walk_neighbours<D, NT>(t, k, -1, node_new, stamp, 0, false);
                         __syncthreads();
                     }
                 }
                 // rewire (rrt_star_2d.py:92-99): sequential semantics.  All decisions up to and
-                // including the first "true" are exact with the costs in hand; after a re-parenting the
-                // remaining neighbours are re-walked (a rewired vertex may be their ancestor).
+                // including the first "true" are exact with the costs in hand; after a re-parenting only
+                // neighbours that have the re-parented vertex among their (marked) ancestors change cost.
                 int start = 0;
                 while (start < k) {
                     int first = 0x7fffffff;
-                    double dummy = __builtin_inf();
-                    if (tid >= start && tid < k && s.near_c0[tid] > new_cost + s.near_dist[tid]) { first = tid; dummy = 0.; }
-                    block_argmin(s, dummy, first);
+                    for (int a = start + tid; a < k; a += NT) {
+                        if (t.nr_c0[a] > new_cost + t.nr_dist[a]) { first = a; break; }
+                    }
+                    first = block_min_int<NT>(s, first);
                     if (first == 0x7fffffff) break;
-                    if (tid == 0) t.parent[s.near_idx[first]] = new_idx;
+                    if (tid == 0) {
+                        int vj = t.nr_idx[first];
+                        double v[D], d[D];
+                        load_vertex<D>(t, vj, v);
+#pragma unroll
+                        for (int c = 0; c < D; c++) d[c] = v[c] - node_new[c];
+                        t.aux[vj].parent = new_idx;
+                        t.aux[vj].elen = hypot_py<D>(d);
+                        t.sol_dirty = 1;
+                        t.gc_dirty = 1;
+                    }
                     n_rewired++;
                     start = first + 1;
                     __syncthreads();
-                    if (start < k) {
-                        if (tid >= start && tid < k) s.near_c0[tid] = walk_cost<D>(t, s.near_idx[tid], nullptr, nullptr);
-                        __syncthreads();
+                    // affected later neighbours: re-walk (plain cost; their ancestor lists stay valid supersets)
+                    for (int a = start + tid; a < k; a += NT) {
+                        int na = t.nr_anc[4 * a];
+                        bool hit = na > ANC_MAX;
+                        for (int c = 0; c < ANC_MAX; c++) hit = hit || (c < na && t.nr_anc[4 * a + 1 + c] == first);
+                        if (hit) t.nr_c0[a] = walk_cost<D>(t, t.nr_idx[a]);
                     }
+                    __syncthreads();
                 }
             }
+            if (inserted) wg_goal_candidate<D, NT>(s, t, new_idx, node_new);
             int in_goal = 0;
             if (flags & NIRRT_F_IRRT) {
                 // InGoalRegion (rrt_base_2d.py:87-89): Line(node_new, goal) < step_len and collision-free
                 double d[D];
 #pragma unroll
                 for (int kk = 0; kk < D; kk++) d[kk] = t.goal[kk] - node_new[kk];
-                if (hypot_py<D>(d) < t.step_len) {
-                    if (!wg_collision<D>(s, node_new, t.goal, clr)) {
+                if (dist2<D>(d) < t.step_len * t.step_len * BAND_HI && hypot_py<D>(d) < t.step_len) {
+                    if (!wg_collision<D, NT>(s, node_new, t.goal, clr)) {
                         in_goal = 1;
-                        if (tid == 0) {
-                            if (t.n_sol < t.cap_sol) { t.sol[t.n_sol] = new_idx; t.n_sol = t.n_sol + 1; }
-                            else t.status = NIRRT_E_CAPACITY;
-                        }
-                        __syncthreads();
+                        wg_append_solution<D, NT>(s, t, new_idx, node_new);
                     }
                 }
             }
@@ -830,15 +1128,16 @@ __device__ __forceinline__ void wg_iteration(Lds &s, TreeDev &t, const double *n
     } else if (res && tid == 0) {
         res->collided = 1;
     }
+    if (tid == 0) t.stamp = stamp;
     __syncthreads();
-    if (res) {
-        double cb = __builtin_inf();
-        int xb = -1;
-        if (flags & NIRRT_F_IRRT) wg_best_solution<D>(s, t, cb, xb);
-        else if (flags & NIRRT_F_GOAL_SCAN) wg_goal_parent<D>(s, t, xb, cb);
-        if (tid == 0) {
-            res->c_best = cb; res->x_best = xb; res->n_solutions = t.n_sol; res->n = t.n; res->status = t.status;
-        }
-    }
-    __syncthreads();
+}
+
+// end-of-iteration report shared by the step kernel and the persistent loop
+template <int D, int NT>
+__device__ __forceinline__ void wg_report(Lds<NT> &s, TreeDev &t, unsigned flags, double &cb, int &xb)
+{
+    cb = __builtin_inf();
+    xb = -1;
+    if (flags & NIRRT_F_IRRT) wg_best_solution<D, NT>(s, t, cb, xb);
+    else if (flags & NIRRT_F_GOAL_SCAN) wg_goal_parent<D, NT>(s, t, xb, cb);
 }

@@ -11,47 +11,52 @@
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------
-// kernels: one workgroup per tree
+// kernels: one workgroup (NT threads) per tree
 // ------------------------------------------------------------------------------------------------
+#define NT 256   // 4 wave64 = one wave per SIMD; several trees share a CU
+
 template <int D>
 __global__ __launch_bounds__(NT) void k_init(TreeDev *tp)
 {
-    __shared__ Lds s;
+    __shared__ Lds<NT> s;
     TreeDev &t = *tp;
-    stage_obstacles(s, t);
-    if (threadIdx.x == 0) { t.n_gc = 0; t.n_sol = 0; t.status = 0; }
+    stage_obstacles<NT>(s, t);
+    if (threadIdx.x == 0) {
+        t.n_gc = 0; t.n_sol = 0; t.status = 0;
+        t.sol_dirty = 1; t.gc_dirty = 1; t.sol_best = -1; t.gc_best = -1;
+        t.sol_best_cost = __builtin_inf(); t.gc_best_cost = __builtin_inf();
+    }
     __syncthreads();
     // goal-candidate list over the current vertices, ascending (n == 1 after create/reset; n > 1 after upload)
     int n = t.n;
     for (int i = 0; i < n; i++) {  // uniform loop; cheap for n == 1, acceptable for test uploads
         double v[D];
         load_vertex<D>(t, i, v);
-        wg_goal_candidate<D>(s, t, i, v);
+        wg_goal_candidate<D, NT>(s, t, i, v);
     }
 }
 
 template <int D>
-__global__ __launch_bounds__(NT) void k_nearest(TreeDev *tp, double q0, double q1, double q2, int *out_idx, double *out_d)
+__global__ __launch_bounds__(NT) void k_nearest(TreeDev *tp, double q0, double q1, double q2, int *out_idx)
 {
-    __shared__ Lds s;
+    __shared__ Lds<NT> s;
     TreeDev &t = *tp;
     double q[3] = {q0, q1, q2};
-    double bd;
-    int bi = wg_nearest<D>(s, t, t.n, q, bd);
-    if (threadIdx.x == 0) { *out_idx = bi; *out_d = bd; }
+    int bi = wg_nearest<D, NT>(s, t, t.n, q);
+    if (threadIdx.x == 0) *out_idx = bi;
 }
 
 template <int D>
 __global__ __launch_bounds__(NT) void k_collision_batch(TreeDev *tp, long long n_seg, const double *seg, unsigned char *out)
 {
-    __shared__ Lds s;
+    __shared__ Lds<NT> s;
     TreeDev &t = *tp;
-    stage_obstacles(s, t);
+    stage_obstacles<NT>(s, t);
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n_seg; i += (long long)gridDim.x * NT) {
         double a[D], b[D];
 #pragma unroll
         for (int k = 0; k < D; k++) { a[k] = seg[i * 2 * D + k]; b[k] = seg[i * 2 * D + D + k]; }
-        out[i] = seg_all<D>(s, a, b, t.clearance) ? 1 : 0;
+        out[i] = seg_all<D, NT>(s, a, b, t.clearance) ? 1 : 0;
     }
 }
 
@@ -59,30 +64,30 @@ template <int D>
 __global__ __launch_bounds__(NT) void k_points(TreeDev *tp, long long n, const double *pts, unsigned char *inside,
                                                unsigned char *valid)
 {
-    __shared__ Lds s;
+    __shared__ Lds<NT> s;
     TreeDev &t = *tp;
-    stage_obstacles(s, t);
+    stage_obstacles<NT>(s, t);
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
         double p[D];
 #pragma unroll
         for (int k = 0; k < D; k++) p[k] = pts[i * D + k];
-        bool in = point_in_obs<D>(s, p, t.clearance);
+        bool in = point_in_obs<D, NT>(s, p, t.clearance);
         if (inside) inside[i] = in ? 1 : 0;
         if (valid) valid[i] = (point_in_range<D>(t, p) && !in) ? 1 : 0;
     }
 }
 
 template <int D>
-__global__ __launch_bounds__(NT) void k_near(TreeDev *tp, double q0, double q1, double q2, int new_idx, int *out_k,
-                                             int *out_idx)
+__global__ __launch_bounds__(NT) void k_near(TreeDev *tp, double q0, double q1, double q2, int new_idx, int *out_k)
 {
-    __shared__ Lds s;
+    __shared__ Lds<NT> s;
     TreeDev &t = *tp;
-    stage_obstacles(s, t);
+    stage_obstacles<NT>(s, t);
     double q[3] = {q0, q1, q2};
-    int k = wg_near<D>(s, t, t.n, q, new_idx);
-    if (threadIdx.x == 0) *out_k = k;
-    for (int a = threadIdx.x; a < k; a += NT) out_idx[a] = s.near_idx[a];
+    const int stamp = t.stamp + 1;
+    __syncthreads();
+    int k = wg_near<D, NT>(s, t, t.n, q, new_idx, stamp);   // result left in t.nr_idx[0..k)
+    if (threadIdx.x == 0) { *out_k = k; t.stamp = stamp; }
 }
 
 template <int D>
@@ -90,40 +95,64 @@ __global__ __launch_bounds__(NT) void k_cost(TreeDev *tp, long long n_idx, const
 {
     TreeDev &t = *tp;
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n_idx; i += (long long)gridDim.x * NT)
-        out[i] = walk_cost<D>(t, (int)idx[i], nullptr, nullptr);
+        out[i] = walk_cost<D>(t, (int)idx[i]);
 }
 
 template <int D>
 __global__ __launch_bounds__(NT) void k_goal_parent(TreeDev *tp, int *out_idx, double *out_len)
 {
-    __shared__ Lds s;
+    __shared__ Lds<NT> s;
     TreeDev &t = *tp;
     int gp;
     double len;
-    wg_goal_parent<D>(s, t, gp, len);
+    wg_goal_parent<D, NT>(s, t, gp, len);
     if (threadIdx.x == 0) { *out_idx = gp; *out_len = len; }
 }
 
 template <int D>
 __global__ __launch_bounds__(NT) void k_best_solution(TreeDev *tp, int *out_idx, double *out_c)
 {
-    __shared__ Lds s;
+    __shared__ Lds<NT> s;
     TreeDev &t = *tp;
     double cb;
     int xb;
-    wg_best_solution<D>(s, t, cb, xb);
+    wg_best_solution<D, NT>(s, t, cb, xb);
     if (threadIdx.x == 0) { *out_idx = xb; *out_c = cb; }
 }
 
 template <int D>
-__global__ __launch_bounds__(NT) void k_step(TreeDev *tp, double q0, double q1, double q2, int host_steer, int nearest_in,
+__global__ __launch_bounds__(NT, 4) void k_step(TreeDev *tp, double q0, double q1, double q2, int host_steer, int nearest_in,
                                              unsigned flags, nirrt_step_result *res)
 {
-    __shared__ Lds s;
+    __shared__ Lds<NT> s;
     TreeDev &t = *tp;
-    stage_obstacles(s, t);
+    stage_obstacles<NT>(s, t);
     double q[3] = {q0, q1, q2};
-    wg_iteration<D>(s, t, q, host_steer != 0, nearest_in, flags, res);
+    wg_iteration<D, NT>(s, t, q, host_steer != 0, nearest_in, flags, res);
+    double cb;
+    int xb;
+    wg_report<D, NT>(s, t, flags, cb, xb);
+    if (threadIdx.x == 0) {
+        res->c_best = cb; res->x_best = xb; res->n_solutions = t.n_sol; res->n = t.n; res->status = t.status;
+    }
+}
+
+// The persistent loops call the loop body through a real function call: inlined into the loop the
+// compiler hoists the tree descriptor into registers across iterations and spills.
+template <int D>
+__device__ __noinline__ void iteration_call(Lds<NT> *sp, TreeDev *tp, double q0, double q1, double q2, unsigned flags)
+{
+    double q[3] = {q0, q1, q2};
+    wg_iteration<D, NT>(*sp, *tp, q, false, 0, flags, nullptr);
+}
+
+template <int D>
+__device__ __noinline__ double report_call(Lds<NT> *sp, TreeDev *tp, unsigned flags)
+{
+    double cb;
+    int xb;
+    wg_report<D, NT>(*sp, *tp, flags, cb, xb);
+    return cb;
 }
 
 // persistent loop, replayed samples: block b owns trees[b]
@@ -137,11 +166,11 @@ struct RunDev {
 };
 
 template <int D>
-__global__ __launch_bounds__(NT) void k_run_replay(TreeDev *const *trees, RunDev a)
+__global__ __launch_bounds__(NT, 4) void k_run_replay(TreeDev *const *trees, RunDev a)
 {
-    __shared__ Lds s;
+    __shared__ Lds<NT> s;
     TreeDev &t = *trees[blockIdx.x];
-    stage_obstacles(s, t);
+    stage_obstacles<NT>(s, t);
     const double *smp = a.samples + (long long)blockIdx.x * a.iters * D;
     double *trace = a.cost_trace ? a.cost_trace + (long long)blockIdx.x * a.iters : nullptr;
     long long k = 0;
@@ -149,12 +178,9 @@ __global__ __launch_bounds__(NT) void k_run_replay(TreeDev *const *trees, RunDev
         double q[3] = {0., 0., 0.};
 #pragma unroll
         for (int c = 0; c < D; c++) q[c] = smp[k * D + c];
-        wg_iteration<D>(s, t, q, false, 0, a.flags, nullptr);
+        iteration_call<D>(&s, &t, q[0], q[1], q[2], a.flags);
         if (trace) {
-            double cb = __builtin_inf();
-            int xb = -1;
-            if (a.flags & NIRRT_F_IRRT) wg_best_solution<D>(s, t, cb, xb);
-            else if (a.flags & NIRRT_F_GOAL_SCAN) wg_goal_parent<D>(s, t, xb, cb);
+            double cb = report_call<D>(&s, &t, a.flags);
             if (threadIdx.x == 0) trace[k] = cb;
         }
         if (t.status != 0) { k++; break; }
@@ -176,6 +202,33 @@ static thread_local std::string g_err;
         }                                                                                     \
     } while (0)
 
+// host twin of hypot_py (CPython vector_norm) for nirrt_upload's edge-length column
+static double host_hypot_py(int n, const double *d)
+{
+    const double T27 = 134217729.0;
+    double vec[3], mx = 0.0;
+    for (int i = 0; i < n; i++) { vec[i] = std::fabs(d[i]); if (vec[i] > mx) mx = vec[i]; }
+    if (mx == 0.0) return mx;
+    int max_e;
+    (void)std::frexp(mx, &max_e);
+    double scale = std::ldexp(1.0, -max_e);
+    volatile double x, oldcsum, csum = 1.0, frac1 = 0.0, frac2 = 0.0, frac3 = 0.0, t, hi, lo, h;
+    for (int i = 0; i < n; i++) {
+        x = vec[i] * scale;
+        t = x * T27; hi = t - (t - x); lo = x - hi;
+        x = hi * hi; oldcsum = csum; csum = csum + x; frac1 = frac1 + ((oldcsum - csum) + x);
+        x = 2.0 * hi * lo; oldcsum = csum; csum = csum + x; frac2 = frac2 + ((oldcsum - csum) + x);
+        frac3 = frac3 + lo * lo;
+    }
+    h = std::sqrt(csum - 1.0 + (frac1 + frac2 + frac3));
+    x = h; t = x * T27; hi = t - (t - x); lo = x - hi;
+    x = -hi * hi; oldcsum = csum; csum = csum + x; frac1 = frac1 + ((oldcsum - csum) + x);
+    x = -2.0 * hi * lo; oldcsum = csum; csum = csum + x; frac2 = frac2 + ((oldcsum - csum) + x);
+    x = -lo * lo; oldcsum = csum; csum = csum + x; frac3 = frac3 + ((oldcsum - csum) + x);
+    x = csum - 1.0 + (frac1 + frac2 + frac3);
+    return (h + x / (2.0 * h)) / scale;
+}
+
 struct Scratch {  // pinned, device-visible result slots
     nirrt_step_result step;
     int i[4];
@@ -193,7 +246,6 @@ struct nirrt_tree {
     double *near_r;  // device table
     Scratch *scratch;      // pinned host memory
     Scratch *scratch_dev;  // device alias of the same memory
-    int *d_near;     // device scratch for nirrt_near
 };
 
 extern "C" const char *nirrt_last_error(void) { return g_err.c_str(); }
@@ -231,15 +283,11 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     if (!t) return NIRRT_OK;
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
-    for (int k = 0; k < 3; k++)
-        if (t->host.c[k]) (void)hipFree(t->host.c[k]);
-    if (t->host.parent) (void)hipFree(t->host.parent);
-    if (t->host.sol) (void)hipFree(t->host.sol);
-    if (t->host.gc_idx) (void)hipFree(t->host.gc_idx);
-    if (t->host.gc_dist) (void)hipFree(t->host.gc_dist);
-    if (t->host.gc_col) (void)hipFree(t->host.gc_col);
-    if (t->near_r) (void)hipFree(t->near_r);
-    if (t->d_near) (void)hipFree(t->d_near);
+    TreeDev &h = t->host;
+    void *bufs[] = {h.c[0], h.c[1], h.c[2], h.aux, h.rank_of, h.st_idx, h.nr_idx, h.nr_flag, h.nr_anc, h.nr_dist,
+                    h.nr_c0, h.nr_c1, h.sol, h.sol_cost, h.gc_idx, h.gc_dist, h.gc_cost, h.gc_col, t->near_r};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
     if (t->dev) (void)hipFree(t->dev);
     if (t->scratch) (void)hipHostFree(t->scratch);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -253,11 +301,12 @@ extern "C" int nirrt_reset(nirrt_tree *t)
     HIPCHK(hipSetDevice(t->device));
     for (int k = 0; k < t->dim; k++)
         HIPCHK(hipMemcpyAsync(t->host.c[k], &t->cfg.x_start[k], sizeof(double), hipMemcpyHostToDevice, t->stream));
-    HIPCHK(hipMemsetAsync(t->host.parent, 0, sizeof(int), t->stream));
+    HIPCHK(hipMemsetAsync(t->host.aux, 0, sizeof(Aux) * (size_t)(t->cap + SCAN_PAD), t->stream));  // parent 0, elen 0, mark 0
     t->host.n = 1;
     t->host.n_sol = 0;
     t->host.n_gc = 0;
     t->host.status = 0;
+    t->host.stamp = 0;
     int rc = push_desc(t);
     if (rc) return rc;
     DISPATCH_DIM(t, k_init, 1, t->dev);
@@ -292,7 +341,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     t->cap = (int)(cfg->iter_max + 1);
     t->device = cfg->device_id;
     t->stream = nullptr;
-    t->dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->d_near = nullptr;
+    t->dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr;
     const int D = t->dim;
     auto fail = [&](int rc) { nirrt_destroy(t); return rc; };
 #define HIPCHK_T(expr)                                                                        \
@@ -306,17 +355,30 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     HIPCHK_T(hipSetDevice(t->device));
     HIPCHK_T(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     TreeDev &h = t->host;
-    for (int k = 0; k < D; k++) HIPCHK_T(hipMalloc(&h.c[k], sizeof(double) * (size_t)t->cap));
-    HIPCHK_T(hipMalloc(&h.parent, sizeof(int) * (size_t)t->cap));
+    const size_t np = (size_t)t->cap + SCAN_PAD;   // padded element count of every per-vertex array
+    for (int k = 0; k < D; k++) {
+        HIPCHK_T(hipMalloc(&h.c[k], sizeof(double) * np));
+        HIPCHK_T(hipMemset(h.c[k], 0, sizeof(double) * np));
+    }
+    HIPCHK_T(hipMalloc(&h.aux, sizeof(Aux) * np));
+    HIPCHK_T(hipMalloc(&h.rank_of, sizeof(int) * np));
+    HIPCHK_T(hipMalloc(&h.st_idx, sizeof(int) * np));
+    HIPCHK_T(hipMalloc(&h.nr_idx, sizeof(int) * np));
+    HIPCHK_T(hipMalloc(&h.nr_flag, sizeof(int) * np));
+    HIPCHK_T(hipMalloc(&h.nr_anc, sizeof(int) * 4 * np));
+    HIPCHK_T(hipMalloc(&h.nr_dist, sizeof(double) * np));
+    HIPCHK_T(hipMalloc(&h.nr_c0, sizeof(double) * np));
+    HIPCHK_T(hipMalloc(&h.nr_c1, sizeof(double) * np));
     h.cap = t->cap;
     h.dim = D;
     h.cap_sol = t->cap;
-    HIPCHK_T(hipMalloc(&h.sol, sizeof(int) * (size_t)h.cap_sol));
-    HIPCHK_T(hipMalloc(&h.gc_idx, sizeof(int) * (size_t)t->cap));
-    HIPCHK_T(hipMalloc(&h.gc_dist, sizeof(double) * (size_t)t->cap));
-    HIPCHK_T(hipMalloc(&h.gc_col, (size_t)t->cap));
+    HIPCHK_T(hipMalloc(&h.sol, sizeof(int) * np));
+    HIPCHK_T(hipMalloc(&h.sol_cost, sizeof(double) * np));
+    HIPCHK_T(hipMalloc(&h.gc_idx, sizeof(int) * np));
+    HIPCHK_T(hipMalloc(&h.gc_dist, sizeof(double) * np));
+    HIPCHK_T(hipMalloc(&h.gc_cost, sizeof(double) * np));
+    HIPCHK_T(hipMalloc(&h.gc_col, np));
     HIPCHK_T(hipMalloc(&t->near_r, sizeof(double) * (size_t)(t->cap + 1)));
-    HIPCHK_T(hipMalloc(&t->d_near, sizeof(int) * NEAR_CAP));
     HIPCHK_T(hipMalloc(&t->dev, sizeof(TreeDev)));
     HIPCHK_T(hipHostMalloc((void **)&t->scratch, sizeof(Scratch), hipHostMallocMapped));
     HIPCHK_T(hipHostGetDevicePointer((void **)&t->scratch_dev, t->scratch, 0));
@@ -352,7 +414,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         h.box[i][3] = b[D]; h.box[i][4] = b[D + 1]; h.box[i][5] = D == 3 ? b[D + 2] : 0.;
     }
     h.c_min = 0.;
-    for (int k = 0; k < 9; k++) h.Crot[k] = (k % 4 == 0) ? 1. : 0.;
+    for (int k = 0; k < 9; k++) h.CL_C[k] = (k % 4 == 0) ? 1. : 0.;
     int rc = nirrt_reset(t);
     if (rc) return fail(rc);
     *out = t;
@@ -381,12 +443,16 @@ extern "C" int nirrt_upload(nirrt_tree *t, int64_t n, const double *vertices, co
         for (int64_t i = 0; i < n; i++) col[(size_t)i] = vertices[i * D + k];
         HIPCHK(hipMemcpy(t->host.c[k], col.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
     }
-    std::vector<int> p((size_t)n);
+    std::vector<Aux> ax((size_t)n);
     for (int64_t i = 0; i < n; i++) {
         if (parents[i] < 0 || parents[i] >= n) { g_err = "parent index out of range"; return NIRRT_E_ARG; }
-        p[(size_t)i] = (int)parents[i];
+        double d[3] = {0., 0., 0.};
+        for (int k = 0; k < D; k++) d[k] = vertices[i * D + k] - vertices[parents[i] * D + k];
+        ax[(size_t)i].elen = i == 0 ? 0. : host_hypot_py(D, d);
+        ax[(size_t)i].parent = (int)parents[i];
+        ax[(size_t)i].mark = 0;
     }
-    HIPCHK(hipMemcpy(t->host.parent, p.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t->host.aux, ax.data(), sizeof(Aux) * (size_t)n, hipMemcpyHostToDevice));
     t->host.n = (int)n;
     t->host.n_sol = 0;
     t->host.n_gc = 0;
@@ -412,9 +478,9 @@ extern "C" int nirrt_download(nirrt_tree *t, double *vertices, int64_t *parents,
         }
     }
     if (parents) {
-        std::vector<int> p((size_t)n);
-        HIPCHK(hipMemcpy(p.data(), t->host.parent, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < n; i++) parents[i] = p[(size_t)i];
+        std::vector<Aux> ax((size_t)n);
+        HIPCHK(hipMemcpy(ax.data(), t->host.aux, sizeof(Aux) * (size_t)n, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; i++) parents[i] = ax[(size_t)i].parent;
     }
     if (n_out) *n_out = n;
     return NIRRT_OK;
@@ -424,7 +490,7 @@ extern "C" int nirrt_nearest(nirrt_tree *t, const double *q, int64_t *idx)
 {
     if (!t || !q || !idx) return NIRRT_E_ARG;
     HIPCHK(hipSetDevice(t->device));
-    DISPATCH_DIM(t, k_nearest, 1, t->dev, q[0], q[1], t->dim == 3 ? q[2] : 0., &t->scratch_dev->i[0], &t->scratch_dev->d[0]);
+    DISPATCH_DIM(t, k_nearest, 1, t->dev, q[0], q[1], t->dim == 3 ? q[2] : 0., &t->scratch_dev->i[0]);
     int rc = sync_check(t);
     if (rc) return rc;
     *idx = t->scratch->i[0];
@@ -485,15 +551,14 @@ extern "C" int nirrt_near(nirrt_tree *t, const double *node_new, int64_t new_idx
     if (!t || !node_new || !k) return NIRRT_E_ARG;
     HIPCHK(hipSetDevice(t->device));
     DISPATCH_DIM(t, k_near, 1, t->dev, node_new[0], node_new[1], t->dim == 3 ? node_new[2] : 0., (int)new_idx,
-                 &t->scratch_dev->i[0], t->d_near);
+                 &t->scratch_dev->i[0]);
     int rc = sync_check(t);
     if (rc) return rc;
     int kk = t->scratch->i[0];
-    if (kk < 0) { g_err = "Near set exceeds NIRRT_NEAR_CAPACITY"; return NIRRT_E_CAPACITY; }
-    *k = kk;
+        *k = kk;
     if (idx_out && kk > 0) {
         std::vector<int> tmp((size_t)kk);
-        HIPCHK(hipMemcpy(tmp.data(), t->d_near, sizeof(int) * (size_t)kk, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tmp.data(), t->host.nr_idx, sizeof(int) * (size_t)kk, hipMemcpyDeviceToHost));
         for (int i = 0; i < kk && i < cap; i++) idx_out[i] = tmp[(size_t)i];
     }
     return NIRRT_OK;
