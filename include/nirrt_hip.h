@@ -150,7 +150,8 @@ int nirrt_extend(nirrt_tree *t, int64_t nearest_idx, const double *node_new, uin
  * iters_done[i] < iters only if a word stream ran dry or a capacity was hit (status[i] != 0). */
 typedef struct nirrt_run_args {
     uint32_t flags;
-    int32_t reserved;
+    int32_t inputs_on_device; /* != 0: samples / np_words[i] / py_words[i] are DEVICE pointers already resident
+                                 in HBM (e.g. torch.cuda tensors); 0: host pointers, copied in by nirrt_run */
     int64_t iters;
     const double *samples;
     const uint32_t *const *np_words;
@@ -162,7 +163,9 @@ typedef struct nirrt_run_args {
     int64_t *py_used;
     int64_t *iters_done;
     int32_t *status;
-    double *kernel_ms; /* optional: device time of the persistent kernel (hipEvent) */
+    double *kernel_ms;   /* optional: device time of the persistent kernel (hipEvent) */
+    int64_t *scan_elems; /* optional (n_trees,): vertices streamed by the nearest + Near passes of this call,
+                            i.e. algorithmic bytes = scan_elems * dim * 8 */
 } nirrt_run_args;
 int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *args);
 

@@ -48,13 +48,14 @@ class StepResult(C.Structure):
 
 
 class RunArgs(C.Structure):
-    _fields_ = [("flags", C.c_uint32), ("reserved", C.c_int32), ("iters", C.c_int64),
+    _fields_ = [("flags", C.c_uint32), ("inputs_on_device", C.c_int32), ("iters", C.c_int64),
                 ("samples", C.POINTER(C.c_double)),
                 ("np_words", C.POINTER(C.POINTER(C.c_uint32))), ("n_np", C.POINTER(C.c_int64)),
                 ("py_words", C.POINTER(C.POINTER(C.c_uint32))), ("n_py", C.POINTER(C.c_int64)),
                 ("cost_trace", C.POINTER(C.c_double)), ("np_used", C.POINTER(C.c_int64)),
                 ("py_used", C.POINTER(C.c_int64)), ("iters_done", C.POINTER(C.c_int64)),
-                ("status", C.POINTER(C.c_int32)), ("kernel_ms", C.POINTER(C.c_double))]
+                ("status", C.POINTER(C.c_int32)), ("kernel_ms", C.POINTER(C.c_double)),
+                ("scan_elems", C.POINTER(C.c_int64))]
 
 
 _lib = None
@@ -279,14 +280,17 @@ class HipTree:
         return self._res
 
 
-def run_replay(trees, samples, flags=0, want_trace=False):
+def run_replay(trees, samples, flags=0, want_trace=False, device_ptr=None, iters=None):
     """Device-resident loop over many trees with replayed samples (n_trees, iters, dim).
-    Returns dict(iters_done, status, kernel_ms, cost_trace)."""
+    `samples` is a host array, or pass device_ptr (int address of an (n_trees, iters, dim) f64
+    buffer already in HBM, e.g. torch tensor.data_ptr()) together with iters.
+    Returns dict(iters_done, status, kernel_ms, cost_trace, scan_elems)."""
     L = load()
     nt = len(trees)
-    samples = _f64(samples)
-    assert samples.ndim == 3 and samples.shape[0] == nt and samples.shape[2] == trees[0].dim
-    iters = samples.shape[1]
+    if device_ptr is None:
+        samples = _f64(samples)
+        assert samples.ndim == 3 and samples.shape[0] == nt and samples.shape[2] == trees[0].dim
+        iters = samples.shape[1]
     handles = (C.c_void_p * nt)(*[t.h for t in trees])
     done = np.zeros(nt, dtype=np.int64)
     status = np.zeros(nt, dtype=np.int32)
@@ -295,10 +299,16 @@ def run_replay(trees, samples, flags=0, want_trace=False):
     a = RunArgs()
     a.flags = int(flags)
     a.iters = iters
-    a.samples = _dp(samples)
+    if device_ptr is None:
+        a.samples = _dp(samples)
+    else:
+        a.inputs_on_device = 1
+        a.samples = C.cast(C.c_void_p(int(device_ptr)), C.POINTER(C.c_double))
+    scan = np.zeros(nt, dtype=np.int64)
+    a.scan_elems = _ip(scan)
     a.cost_trace = _dp(trace) if want_trace else None
     a.iters_done = _ip(done)
     a.status = status.ctypes.data_as(C.POINTER(C.c_int32))
     a.kernel_ms = C.pointer(ms)
     _check(L.nirrt_run(handles, nt, C.byref(a)))
-    return {"iters_done": done, "status": status, "kernel_ms": ms.value, "cost_trace": trace}
+    return {"iters_done": done, "status": status, "kernel_ms": ms.value, "cost_trace": trace, "scan_elems": scan}

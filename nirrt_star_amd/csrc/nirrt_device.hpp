@@ -47,6 +47,7 @@ struct TreeDev {
     int status;     // sticky NIRRT_E_* code
     int stamp;      // iteration stamp for aux.mark (monotonic, never 0)
     int pad0;
+    long long scan_elems;  // vertices streamed by nearest + Near passes (roofline accounting)
     // Near-set working arrays (capacity cap: a Near set can never exceed the tree)
     int *st_idx;     // ordered staging of scan hits, one region per wave segment
     int *nr_idx;     // neighbour vertex index, ascending
@@ -982,6 +983,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
     const double clr = t.clearance;
     int n = t.n;
     const int stamp = t.stamp + 1;   // published by thread 0 at the end of the iteration
+    long long scanned = host_steer ? 0 : n;
     int ni;
     double node_new[D], nearest[D];
     if (host_steer) {
@@ -1031,6 +1033,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         }
         if (new_idx >= 0) {
             int k = wg_near<D, NT>(s, t, n, node_new, new_idx, stamp);
+            scanned += n;
             int reparented = 0, n_rewired = 0;
             if (k > 0) {
                 // parent-chain walks: slot j < k = neighbour j, slot k = `nearest`
@@ -1128,7 +1131,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
     } else if (res && tid == 0) {
         res->collided = 1;
     }
-    if (tid == 0) t.stamp = stamp;
+    if (tid == 0) { t.stamp = stamp; t.scan_elems += scanned; }
     __syncthreads();
 }
 

@@ -307,6 +307,7 @@ extern "C" int nirrt_reset(nirrt_tree *t)
     t->host.n_gc = 0;
     t->host.status = 0;
     t->host.stamp = 0;
+    t->host.scan_elems = 0;
     int rc = push_desc(t);
     if (rc) return rc;
     DISPATCH_DIM(t, k_init, 1, t->dev);
@@ -668,11 +669,18 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
     long long *d_done = nullptr;
     size_t sbytes = sizeof(double) * (size_t)n_trees * (size_t)a->iters * D;
     HIPCHK(hipMalloc(&d_ptrs, sizeof(TreeDev *) * (size_t)n_trees));
-    HIPCHK(hipMalloc(&d_samples, sbytes ? sbytes : 8));
+    std::vector<long long> scan0((size_t)n_trees, 0);
+    for (int i = 0; i < n_trees; i++) {
+        TreeDev tmp;
+        HIPCHK(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
+        scan0[(size_t)i] = tmp.scan_elems;
+    }
+    if (a->inputs_on_device) d_samples = const_cast<double *>(a->samples);
+    else HIPCHK(hipMalloc(&d_samples, sbytes ? sbytes : 8));
     HIPCHK(hipMalloc(&d_done, sizeof(long long) * (size_t)n_trees));
     if (a->cost_trace) HIPCHK(hipMalloc(&d_trace, sizeof(double) * (size_t)n_trees * (size_t)a->iters));
     HIPCHK(hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(TreeDev *) * (size_t)n_trees, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_samples, a->samples, sbytes, hipMemcpyHostToDevice, st));
+    if (!a->inputs_on_device) HIPCHK(hipMemcpyAsync(d_samples, a->samples, sbytes, hipMemcpyHostToDevice, st));
     RunDev rd;
     rd.flags = a->flags; rd.pad = 0; rd.iters = a->iters; rd.samples = d_samples; rd.cost_trace = d_trace; rd.iters_done = d_done;
     hipEvent_t e0, e1;
@@ -701,10 +709,11 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
         TreeDev tmp;
         HIPCHK(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
         if (a->status) a->status[i] = tmp.status;
+        if (a->scan_elems) a->scan_elems[i] = tmp.scan_elems - scan0[(size_t)i];
         if (tmp.status) rc_all = tmp.status;
     }
     (void)hipFree(d_ptrs);
-    (void)hipFree(d_samples);
+    if (!a->inputs_on_device) (void)hipFree(d_samples);
     (void)hipFree(d_done);
     if (d_trace) (void)hipFree(d_trace);
     return rc_all;
