@@ -121,6 +121,11 @@ int nirrt_best_solution(nirrt_tree *t, double *c_best, int64_t *x_best);
 /* `self.path_solutions` */
 int nirrt_solutions(nirrt_tree *t, int64_t *n_sol, int64_t *out, int64_t cap);
 
+/* IRRTStar.init (irrt_star_2d.py:35-40 / irrt_star_3d.py:32-36): informed-sampling frame computed by
+ * the caller exactly like the reference (math.hypot, numpy SVD): c_min, x_center (dim), C (3x3 row-major).
+ * Only needed before nirrt_run with in-kernel IRRT* sampling. */
+int nirrt_set_informed(nirrt_tree *t, double c_min, const double *x_center, const double *C);
+
 /* ---- one whole iteration --------------------------------------------------------------------- */
 /* Loop body of RRTStar2D.planning (rrt_star_2d.py:37-55) / IRRTStar2D.planning
  * (irrt_star_2d.py:54-73) given node_rand: nearest -> steer -> edge collision -> insert -> Near ->

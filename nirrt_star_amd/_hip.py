@@ -22,7 +22,7 @@ EXPORTS = [
     "nirrt_last_error", "nirrt_device_count", "nirrt_create", "nirrt_destroy", "nirrt_reset", "nirrt_upload",
     "nirrt_download", "nirrt_num_vertices", "nirrt_nearest", "nirrt_collision_batch", "nirrt_points_in_obs",
     "nirrt_near", "nirrt_cost", "nirrt_search_goal_parent", "nirrt_best_solution", "nirrt_solutions",
-    "nirrt_step", "nirrt_extend", "nirrt_run",
+    "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed",
 ]
 
 
@@ -91,6 +91,7 @@ def load():
     L.nirrt_step.argtypes = [vp, dp, C.c_uint32, C.POINTER(StepResult)]
     L.nirrt_extend.argtypes = [vp, C.c_int64, dp, C.c_uint32, C.POINTER(StepResult)]
     L.nirrt_run.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(RunArgs)]
+    L.nirrt_set_informed.argtypes = [vp, C.c_double, dp, dp]
     for name in EXPORTS:
         if name != "nirrt_last_error":
             getattr(L, name).restype = C.c_int
@@ -268,6 +269,12 @@ class HipTree:
         _check(self.L.nirrt_best_solution(self.h, C.byref(d), C.byref(i)))
         return d.value, i.value
 
+    def set_informed(self, c_min, x_center, C):
+        xc = np.zeros(3)
+        xc[: self.dim] = np.asarray(x_center, dtype=np.float64).ravel()[: self.dim]
+        Cm = _f64(np.asarray(C, dtype=np.float64).reshape(3, 3))
+        _check(self.L.nirrt_set_informed(self.h, float(c_min), _dp(xc), _dp(Cm)))
+
     # ---- whole iteration ----
     def step(self, node_rand, flags=0):
         q = _f64(node_rand)
@@ -312,3 +319,44 @@ def run_replay(trees, samples, flags=0, want_trace=False, device_ptr=None, iters
     a.kernel_ms = C.pointer(ms)
     _check(L.nirrt_run(handles, nt, C.byref(a)))
     return {"iters_done": done, "status": status, "kernel_ms": ms.value, "cost_trace": trace, "scan_elems": scan}
+
+
+def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=False):
+    """Device-resident loop with in-kernel sampling.  np_words / py_words: per-tree uint32 arrays of
+    raw MT19937 outputs (numpy legacy global stream / python `random`).  Returns dict with
+    iters_done, np_used, py_used (words consumed), status (0 | E_STREAM | E_CAPACITY), kernel_ms,
+    cost_trace, scan_elems."""
+    L = load()
+    nt = len(trees)
+    handles = (C.c_void_p * nt)(*[t.h for t in trees])
+    u32p = C.POINTER(C.c_uint32)
+    npw = [np.ascontiguousarray(w, dtype=np.uint32) for w in np_words]
+    np_ptrs = (u32p * nt)(*[w.ctypes.data_as(u32p) for w in npw])
+    n_np = np.array([len(w) for w in npw], dtype=np.int64)
+    a = RunArgs()
+    a.flags = int(flags)
+    a.iters = int(iters)
+    a.samples = None
+    a.np_words = C.cast(np_ptrs, C.POINTER(u32p))
+    a.n_np = _ip(n_np)
+    if py_words is not None:
+        pyw = [np.ascontiguousarray(w, dtype=np.uint32) for w in py_words]
+        py_ptrs = (u32p * nt)(*[w.ctypes.data_as(u32p) for w in pyw])
+        n_py = np.array([len(w) for w in pyw], dtype=np.int64)
+        a.py_words = C.cast(py_ptrs, C.POINTER(u32p))
+        a.n_py = _ip(n_py)
+    done = np.zeros(nt, dtype=np.int64)
+    np_used = np.zeros(nt, dtype=np.int64)
+    py_used = np.zeros(nt, dtype=np.int64)
+    status = np.zeros(nt, dtype=np.int32)
+    scan = np.zeros(nt, dtype=np.int64)
+    ms = C.c_double(0)
+    trace = np.zeros((nt, iters), dtype=np.float64) if want_trace else None
+    a.cost_trace = _dp(trace) if want_trace else None
+    a.np_used, a.py_used, a.iters_done = _ip(np_used), _ip(py_used), _ip(done)
+    a.status = status.ctypes.data_as(C.POINTER(C.c_int32))
+    a.kernel_ms = C.pointer(ms)
+    a.scan_elems = _ip(scan)
+    _check(L.nirrt_run(handles, nt, C.byref(a)))
+    return {"iters_done": done, "np_used": np_used, "py_used": py_used, "status": status, "kernel_ms": ms.value,
+            "cost_trace": trace, "scan_elems": scan}

@@ -4,6 +4,7 @@
 #include "nirrt_device.hpp"
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -186,6 +187,149 @@ __global__ __launch_bounds__(NT, 4) void k_run_replay(TreeDev *const *trees, Run
         if (t.status != 0) { k++; break; }
     }
     if (threadIdx.x == 0) a.iters_done[blockIdx.x] = k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// in-kernel sampling: consumes raw MT19937 32-bit outputs exactly like numpy's legacy RandomState
+// (random_sample: a = w>>5, b = w>>6, (a*2^26+b)/2^53; uniform(lo,hi) = lo + (hi-lo)*u) and CPython's
+// random.random() (same 53-bit construction), so the host generators can be advanced by the
+// reported word counts afterwards.
+// ------------------------------------------------------------------------------------------------
+struct WordStream {
+    const unsigned *w;
+    long long n, pos;
+    __device__ __forceinline__ bool has(long long k) const { return pos + k <= n; }
+    __device__ __forceinline__ double next_double()
+    {
+        unsigned a = w[pos] >> 5, b = w[pos + 1] >> 6;
+        pos += 2;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+};
+
+// SampleFree (rrt_base_2d.py:46-52 / rrt_base_3d.py:49-58); false = stream ran dry
+template <int D>
+__device__ __forceinline__ bool sample_free(const Lds<NT> &s, const TreeDev &t, WordStream &np, double *out)
+{
+    for (;;) {
+        if (!np.has(2 * D)) return false;
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            double lo = t.lo[k] + t.clearance, hi = t.hi[k] - t.clearance;
+            out[k] = lo + (hi - lo) * np.next_double();
+        }
+        if (!point_in_obs<D, NT>(s, out, t.clearance)) return true;
+    }
+}
+
+// SampleInformedSubset (irrt_star_2d.py:121-151 / irrt_star_3d.py:117-158).  The two matrix
+// products go through BLAS in the reference; the forms below are what OpenBLAS 0.3.29 (numpy 2.2.6
+// wheel, Haswell/Zen kernels) evaluates for these shapes (tests/test_host_sampling.py pins them on
+// the host): C.L -> RN(C[i][j]*r[j]);  2D (3,3)x(3,1) with x2 = 0 -> fma(a0,x0,a1*x1);
+// 3D (3,3)x(3,) -> fma(a2,x2,fma(a0,x0,a1*x1)).
+template <int D>
+__device__ __forceinline__ bool sample_informed(const Lds<NT> &s, const TreeDev &t, WordStream &np, WordStream &py,
+                                                double c_max, double *out)
+{
+    const double c_min = t.c_min;
+    double rad = c_max * c_max - c_min * c_min;
+    double eps = rad < 0 ? 1e-6 : 0.;
+    double r0 = c_max / 2.0;
+    double r1 = __builtin_sqrt(rad + eps) / 2.0;
+    double CL[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        CL[i][0] = t.CL_C[3 * i + 0] * r0;
+        CL[i][1] = t.CL_C[3 * i + 1] * r1;
+        CL[i][2] = t.CL_C[3 * i + 2] * r1;
+    }
+    for (;;) {
+        double xb[3];
+        if (D == 2) {
+            // SampleUnitBall: python random.uniform(-1, 1) twice until inside the open unit disk
+            for (;;) {
+                if (!py.has(4)) return false;
+                xb[0] = -1.0 + 2.0 * py.next_double();
+                xb[1] = -1.0 + 2.0 * py.next_double();
+                if (xb[0] * xb[0] + xb[1] * xb[1] < 1) break;
+            }
+            xb[2] = 0.;
+#pragma unroll
+            for (int i = 0; i < 2; i++) out[i] = __builtin_fma(CL[i][0], xb[0], CL[i][1] * xb[1]) + t.x_center[i];
+        } else {
+            // spherical coordinates with three numpy uniforms (not volume-uniform; reproduced as is)
+            if (!np.has(6)) return false;
+            const double PI = 3.141592653589793;
+            double rr = 0.0 + (1.0 - 0.0) * np.next_double();
+            double theta = 0.0 + (PI - 0.0) * np.next_double();
+            double phi = 0.0 + (2 * PI - 0.0) * np.next_double();
+            xb[0] = rr * sin(theta) * cos(phi);
+            xb[1] = rr * sin(theta) * sin(phi);
+            xb[2] = rr * cos(theta);
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                out[i] = __builtin_fma(CL[i][2], xb[2], __builtin_fma(CL[i][0], xb[0], CL[i][1] * xb[1])) + t.x_center[i];
+        }
+        // Utils.is_valid: inside the clearance-shrunk range and outside every inflated obstacle
+        if (point_in_range<D>(t, out) && !point_in_obs<D, NT>(s, out, t.clearance)) return true;
+    }
+}
+
+struct RunSampleDev {
+    unsigned flags;
+    int pad;
+    long long iters;
+    const unsigned *const *np_words;
+    const long long *n_np;
+    const unsigned *const *py_words;
+    const long long *n_py;
+    long long *np_used;
+    long long *py_used;
+    double *cost_trace;
+    long long *iters_done;
+    int *stop_code;   // per tree: 0 done, NIRRT_E_STREAM, NIRRT_E_CAPACITY
+};
+
+// persistent loop with in-kernel sampling (RRT*: SampleFree; IRRT*: informed once a solution exists)
+template <int D>
+__global__ __launch_bounds__(NT, 4) void k_run_sample(TreeDev *const *trees, RunSampleDev a)
+{
+    __shared__ Lds<NT> s;
+    const int b = blockIdx.x;
+    TreeDev &t = *trees[b];
+    stage_obstacles<NT>(s, t);
+    WordStream np = {a.np_words[b], a.n_np[b], 0};
+    WordStream py = {a.py_words ? a.py_words[b] : nullptr, a.py_words ? a.n_py[b] : 0, 0};
+    double *trace = a.cost_trace ? a.cost_trace + (long long)b * a.iters : nullptr;
+    const bool irrt = (a.flags & NIRRT_F_IRRT) != 0;
+    long long k = 0;
+    int stop = 0;
+    for (; k < a.iters; k++) {
+        double cb = __builtin_inf();
+        if (irrt || (a.flags & NIRRT_F_GOAL_SCAN)) cb = report_call<D>(&s, &t, a.flags);
+        if (threadIdx.x == 0) {
+            double q[3] = {0., 0., 0.};
+            long long np0 = np.pos, py0 = py.pos;
+            bool ok = (irrt && cb < __builtin_inf()) ? sample_informed<D>(s, t, np, py, cb, q) : sample_free<D>(s, t, np, q);
+            if (!ok) { np.pos = np0; py.pos = py0; }
+            s.bc_d[0] = q[0]; s.bc_d[1] = q[1]; s.bc_d[2] = q[2];
+            s.bc_i[0] = ok ? 0 : NIRRT_E_STREAM;
+        }
+        __syncthreads();
+        stop = s.bc_i[0];
+        double q0 = s.bc_d[0], q1 = s.bc_d[1], q2 = s.bc_d[2];
+        __syncthreads();
+        if (stop) break;
+        if (trace && threadIdx.x == 0) trace[k] = cb;
+        iteration_call<D>(&s, &t, q0, q1, q2, a.flags);
+        if (t.status != 0) { k++; stop = t.status; break; }
+    }
+    if (threadIdx.x == 0) {
+        a.iters_done[b] = k;
+        a.np_used[b] = np.pos;
+        a.py_used[b] = py.pos;
+        a.stop_code[b] = stop;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -647,6 +791,143 @@ extern "C" int nirrt_extend(nirrt_tree *t, int64_t nearest_idx, const double *no
     return do_step(t, node_new, 1, nearest_idx, flags, res);
 }
 
+extern "C" int nirrt_set_informed(nirrt_tree *t, double c_min, const double *x_center, const double *C)
+{
+    if (!t || !x_center || !C) return NIRRT_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    // patch the three fields in the device descriptor (the kernels own the rest of it)
+    t->host.c_min = c_min;
+    for (int k = 0; k < 3; k++) t->host.x_center[k] = k < t->dim ? x_center[k] : 0.;
+    for (int k = 0; k < 9; k++) t->host.CL_C[k] = C[k];
+    size_t off = offsetof(TreeDev, c_min);
+    HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, sizeof(TreeDev) - off, hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    return NIRRT_OK;
+}
+
+static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *a)
+{
+    nirrt_tree *t0 = trees[0];
+    const int D = t0->dim;
+    hipStream_t st = t0->stream;
+    if (!a->np_words || !a->n_np || !a->np_used || !a->py_used || !a->iters_done) {
+        g_err = "nirrt_run: sampling mode needs np_words, n_np, np_used, py_used, iters_done";
+        return NIRRT_E_ARG;
+    }
+    const bool need_py = (a->flags & NIRRT_F_IRRT) && D == 2;
+    if (need_py && (!a->py_words || !a->n_py)) { g_err = "nirrt_run: 2D IRRT* sampling needs py_words"; return NIRRT_E_ARG; }
+    std::vector<void *> to_free;
+    auto cleanup = [&]() { for (void *p : to_free) (void)hipFree(p); };
+#define HIPCHK_R(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+            cleanup();                                                                        \
+            return NIRRT_E_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+    auto dalloc = [&](size_t bytes, void **out) -> hipError_t {
+        hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+        if (e == hipSuccess) to_free.push_back(*out);
+        return e;
+    };
+    std::vector<TreeDev *> ptrs((size_t)n_trees);
+    std::vector<long long> scan0((size_t)n_trees, 0);
+    for (int i = 0; i < n_trees; i++) {
+        ptrs[(size_t)i] = trees[i]->dev;
+        TreeDev tmp;
+        HIPCHK_R(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
+        scan0[(size_t)i] = tmp.scan_elems;
+    }
+    // word streams -> device (one slab per generator) unless they already live there
+    std::vector<const unsigned *> npp((size_t)n_trees), pyp((size_t)n_trees, nullptr);
+    std::vector<long long> nnp((size_t)n_trees), npy((size_t)n_trees, 0);
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t *const *src = pass == 0 ? a->np_words : a->py_words;
+        const int64_t *cnt = pass == 0 ? a->n_np : a->n_py;
+        if (!src) continue;
+        std::vector<const unsigned *> &dst = pass == 0 ? npp : pyp;
+        std::vector<long long> &dn = pass == 0 ? nnp : npy;
+        size_t total = 0;
+        for (int i = 0; i < n_trees; i++) { dn[(size_t)i] = cnt[i]; total += (size_t)cnt[i]; }
+        if (a->inputs_on_device) {
+            for (int i = 0; i < n_trees; i++) dst[(size_t)i] = src[i];
+        } else {
+            unsigned *slab = nullptr;
+            HIPCHK_R(dalloc(sizeof(unsigned) * total, (void **)&slab));
+            size_t off = 0;
+            for (int i = 0; i < n_trees; i++) {
+                if (cnt[i] > 0) HIPCHK_R(hipMemcpyAsync(slab + off, src[i], sizeof(unsigned) * (size_t)cnt[i], hipMemcpyHostToDevice, st));
+                dst[(size_t)i] = slab + off;
+                off += (size_t)cnt[i];
+            }
+        }
+    }
+    TreeDev **d_ptrs = nullptr;
+    const unsigned **d_npp = nullptr, **d_pyp = nullptr;
+    long long *d_nnp = nullptr, *d_npy = nullptr, *d_npu = nullptr, *d_pyu = nullptr, *d_done = nullptr;
+    int *d_stop = nullptr;
+    double *d_trace = nullptr;
+    const size_t nt = (size_t)n_trees;
+    HIPCHK_R(dalloc(sizeof(void *) * nt, (void **)&d_ptrs));
+    HIPCHK_R(dalloc(sizeof(void *) * nt, (void **)&d_npp));
+    HIPCHK_R(dalloc(sizeof(void *) * nt, (void **)&d_pyp));
+    HIPCHK_R(dalloc(sizeof(long long) * nt, (void **)&d_nnp));
+    HIPCHK_R(dalloc(sizeof(long long) * nt, (void **)&d_npy));
+    HIPCHK_R(dalloc(sizeof(long long) * nt, (void **)&d_npu));
+    HIPCHK_R(dalloc(sizeof(long long) * nt, (void **)&d_pyu));
+    HIPCHK_R(dalloc(sizeof(long long) * nt, (void **)&d_done));
+    HIPCHK_R(dalloc(sizeof(int) * nt, (void **)&d_stop));
+    if (a->cost_trace) HIPCHK_R(dalloc(sizeof(double) * nt * (size_t)a->iters, (void **)&d_trace));
+    HIPCHK_R(hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(void *) * nt, hipMemcpyHostToDevice, st));
+    HIPCHK_R(hipMemcpyAsync(d_npp, npp.data(), sizeof(void *) * nt, hipMemcpyHostToDevice, st));
+    HIPCHK_R(hipMemcpyAsync(d_pyp, pyp.data(), sizeof(void *) * nt, hipMemcpyHostToDevice, st));
+    HIPCHK_R(hipMemcpyAsync(d_nnp, nnp.data(), sizeof(long long) * nt, hipMemcpyHostToDevice, st));
+    HIPCHK_R(hipMemcpyAsync(d_npy, npy.data(), sizeof(long long) * nt, hipMemcpyHostToDevice, st));
+    RunSampleDev rd;
+    rd.flags = a->flags; rd.pad = 0; rd.iters = a->iters;
+    rd.np_words = d_npp; rd.n_np = d_nnp; rd.py_words = a->py_words ? d_pyp : nullptr; rd.n_py = d_npy;
+    rd.np_used = d_npu; rd.py_used = d_pyu; rd.cost_trace = d_trace; rd.iters_done = d_done; rd.stop_code = d_stop;
+    hipEvent_t e0, e1;
+    HIPCHK_R(hipEventCreate(&e0));
+    HIPCHK_R(hipEventCreate(&e1));
+    HIPCHK_R(hipEventRecord(e0, st));
+    if (D == 2) hipLaunchKernelGGL(k_run_sample<2>, dim3(n_trees), dim3(NT), 0, st, (TreeDev *const *)d_ptrs, rd);
+    else hipLaunchKernelGGL(k_run_sample<3>, dim3(n_trees), dim3(NT), 0, st, (TreeDev *const *)d_ptrs, rd);
+    HIPCHK_R(hipEventRecord(e1, st));
+    HIPCHK_R(hipGetLastError());
+    HIPCHK_R(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIPCHK_R(hipEventElapsedTime(&ms, e0, e1));
+    if (a->kernel_ms) *a->kernel_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    std::vector<long long> done(nt), npu(nt), pyu(nt);
+    std::vector<int> stop(nt);
+    HIPCHK_R(hipMemcpy(done.data(), d_done, sizeof(long long) * nt, hipMemcpyDeviceToHost));
+    HIPCHK_R(hipMemcpy(npu.data(), d_npu, sizeof(long long) * nt, hipMemcpyDeviceToHost));
+    HIPCHK_R(hipMemcpy(pyu.data(), d_pyu, sizeof(long long) * nt, hipMemcpyDeviceToHost));
+    HIPCHK_R(hipMemcpy(stop.data(), d_stop, sizeof(int) * nt, hipMemcpyDeviceToHost));
+    if (a->cost_trace) HIPCHK_R(hipMemcpy(a->cost_trace, d_trace, sizeof(double) * nt * (size_t)a->iters, hipMemcpyDeviceToHost));
+    int rc_all = NIRRT_OK;
+    for (int i = 0; i < n_trees; i++) {
+        a->iters_done[i] = done[(size_t)i];
+        a->np_used[i] = npu[(size_t)i];
+        a->py_used[i] = pyu[(size_t)i];
+        if (a->status) a->status[i] = stop[(size_t)i];
+        if (a->scan_elems) {
+            TreeDev tmp;
+            HIPCHK_R(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
+            a->scan_elems[i] = tmp.scan_elems - scan0[(size_t)i];
+        }
+        if (stop[(size_t)i] == NIRRT_E_CAPACITY) rc_all = NIRRT_E_CAPACITY;
+    }
+    cleanup();
+    return rc_all;   // NIRRT_E_STREAM is reported per tree in status[] (the caller refills and resumes)
+#undef HIPCHK_R
+}
+
 extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *a)
 {
     if (!trees || n_trees <= 0 || !a || a->iters < 0) return NIRRT_E_ARG;
@@ -657,8 +938,9 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
             return NIRRT_E_ARG;
         }
     }
-    if (!a->samples) { g_err = "nirrt_run: in-kernel sampling not built in this version"; return NIRRT_E_ARG; }
     HIPCHK(hipSetDevice(t0->device));
+    for (int i = 1; i < n_trees; i++) HIPCHK(hipStreamSynchronize(trees[i]->stream));
+    if (!a->samples) return run_sampling(trees, n_trees, a);
     const int D = t0->dim;
     hipStream_t st = t0->stream;
     for (int i = 1; i < n_trees; i++) HIPCHK(hipStreamSynchronize(trees[i]->stream));
