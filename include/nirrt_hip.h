@@ -63,6 +63,8 @@ typedef struct nirrt_config {
 /* flags for nirrt_step / nirrt_extend / nirrt_run */
 #define NIRRT_F_IRRT 1u      /* IRRT*: InGoalRegion bookkeeping + best-solution report           */
 #define NIRRT_F_GOAL_SCAN 2u /* RRT* planning_random: search_goal_parent + path length each step */
+#define NIRRT_F_STOP_FIRST 4u /* nirrt_run: leave the loop right after the iteration that yields the first finite
+                                 best cost (phase 1 of planning_random, rrt_star_2d.py:230-232, irrt_star_2d.py:245-248) */
 
 /* What one loop body did (rrt_star_2d.py:37-55 / irrt_star_2d.py:51-73). */
 typedef struct nirrt_step_result {
@@ -149,9 +151,10 @@ int nirrt_extend(nirrt_tree *t, int64_t nearest_idx, const double *node_new, uin
  *                       py_words[i] : stream of python's `random` module    (n_py per tree)
  *                     On return np_used[i] / py_used[i] say how many words each tree consumed so the
  *                     host can advance its generators by exactly that much.
- * cost_trace (optional, (n_trees, iters) f64): per-iteration best cost -
- *   F_IRRT: c_best as used for sampling iteration k (irrt_star_2d.py:241: list entry k);
- *   F_GOAL_SCAN: path length after iteration k (rrt_star_2d.py:223-229).
+ * cost_trace (optional, (n_trees, iters) f64): entry k = best cost AFTER iteration k, which is what
+ *   planning_random's path_len_list holds at index k in both planners -
+ *   F_IRRT: find_best_path_solution (irrt_star_2d.py:239-241 after its [1:] shift);
+ *   F_GOAL_SCAN: get_path_len(extract_path(search_goal_parent())) (rrt_star_2d.py:223-229).
  * iters_done[i] < iters only if a word stream ran dry or a capacity was hit (status[i] != 0). */
 typedef struct nirrt_run_args {
     uint32_t flags;
@@ -173,6 +176,10 @@ typedef struct nirrt_run_args {
                             i.e. algorithmic bytes = scan_elems * dim * 8 */
 } nirrt_run_args;
 int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *args);
+
+/* debug aid: per-phase device tick counters of the loop body (zeros unless the library was built
+ * with -DNIRRT_PROFILE); out16 = int64[16] */
+int nirrt_debug_prof(nirrt_tree *t, int64_t *out16);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ SO_PATH = os.path.join(_HERE, "libnirrt_hip.so")
 
 F_IRRT = 1
 F_GOAL_SCAN = 2
+F_STOP_FIRST = 4
 
 E_ARG, E_HIP, E_CAPACITY, E_NODEVICE, E_STREAM = -1, -2, -3, -4, -5
 MAX_OBSTACLES = 64
@@ -22,7 +23,7 @@ EXPORTS = [
     "nirrt_last_error", "nirrt_device_count", "nirrt_create", "nirrt_destroy", "nirrt_reset", "nirrt_upload",
     "nirrt_download", "nirrt_num_vertices", "nirrt_nearest", "nirrt_collision_batch", "nirrt_points_in_obs",
     "nirrt_near", "nirrt_cost", "nirrt_search_goal_parent", "nirrt_best_solution", "nirrt_solutions",
-    "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed",
+    "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed", "nirrt_debug_prof",
 ]
 
 
@@ -92,6 +93,7 @@ def load():
     L.nirrt_extend.argtypes = [vp, C.c_int64, dp, C.c_uint32, C.POINTER(StepResult)]
     L.nirrt_run.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(RunArgs)]
     L.nirrt_set_informed.argtypes = [vp, C.c_double, dp, dp]
+    L.nirrt_debug_prof.argtypes = [vp, ip]
     for name in EXPORTS:
         if name != "nirrt_last_error":
             getattr(L, name).restype = C.c_int
@@ -268,6 +270,11 @@ class HipTree:
         d = C.c_double(0)
         _check(self.L.nirrt_best_solution(self.h, C.byref(d), C.byref(i)))
         return d.value, i.value
+
+    def debug_prof(self):
+        out = np.zeros(16, dtype=np.int64)
+        _check(self.L.nirrt_debug_prof(self.h, _ip(out)))
+        return out
 
     def set_informed(self, c_min, x_center, C):
         xc = np.zeros(3)

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libnirrt_hip.so")
-SOURCES = [os.path.join(CSRC, "nirrt_hip.hip")]
+SOURCES = [os.path.join(CSRC, "nirrt_hip.hip"), os.path.join(CSRC, "pointops.hip")]
 DEPS = SOURCES + [os.path.join(CSRC, "nirrt_device.hpp"),
                   os.path.join(os.path.dirname(HERE), "include", "nirrt_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
@@ -29,7 +29,8 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", SO] + SOURCES
+    extra = os.environ.get("NIRRT_EXTRA_FLAGS", "").split()
+    cmd = [hipcc] + FLAGS + extra + ["-o", SO] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -28,6 +28,20 @@
 #define ANC_MAX 3        // marked ancestors remembered per neighbour (more -> "overflow": always re-walk)
 #define WALK_R 4         // parent chains chased concurrently per lane
 
+// optional per-phase cycle accounting (build with -DNIRRT_PROFILE; scripts/perf_phases.py reads prof[])
+#ifdef NIRRT_PROFILE
+#define PROF_DECL long long prof_t0 = wall_clock64();
+#define PROF(slot)                                                     \
+    do {                                                               \
+        long long now_ = wall_clock64();                               \
+        if (threadIdx.x == 0) t.prof[slot] += now_ - prof_t0;          \
+        prof_t0 = now_;                                                \
+    } while (0)
+#else
+#define PROF_DECL
+#define PROF(slot)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // per-tree state in HBM
 // ------------------------------------------------------------------------------------------------
@@ -87,6 +101,7 @@ struct TreeDev {
     double c_min;
     double x_center[3];
     double CL_C[9];          // rotation-to-world matrix C, row-major 3x3
+    long long prof[16];      // NIRRT_PROFILE: wall_clock64 ticks (100 MHz) per phase
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -554,15 +569,32 @@ __device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, c
     const double2 *X = reinterpret_cast<const double2 *>(t.c[0]);
     const double2 *Y = reinterpret_cast<const double2 *>(t.c[1]);
     const double2 *Z = reinterpret_cast<const double2 *>(t.c[D - 1]);
-    for (int base = beg + 2 * lane; base < end; base += 128) {
-        double2 xv = X[base >> 1], yv = Y[base >> 1], zv;
+    for (int base = beg + 2 * lane; base < end; base += 256) {
+        // two 128-vertex chunks per trip; all 16-byte loads are issued before the first use
+        const int b1 = base + 128;
+        double2 xv = X[base >> 1], yv = Y[base >> 1], zv, xw, yw, zw;
         if (D == 3) zv = Z[base >> 1];
-        double da[3] = {q[0] - xv.x, q[1] - yv.x, D == 3 ? q[D - 1] - zv.x : 0.};
-        double db[3] = {q[0] - xv.y, q[1] - yv.y, D == 3 ? q[D - 1] - zv.y : 0.};
-        double va = dist2<D>(da);
-        double vb = base + 1 < end ? dist2<D>(db) : __builtin_inf();
-        if (va < m1) { m2 = m1; m1 = va; i1 = base; } else if (va < m2) m2 = va;
-        if (vb < m1) { m2 = m1; m1 = vb; i1 = base + 1; } else if (vb < m2) m2 = vb;
+        const bool two = b1 < end;
+        if (two) {
+            xw = X[b1 >> 1]; yw = Y[b1 >> 1];
+            if (D == 3) zw = Z[b1 >> 1];
+        }
+        {
+            double da[3] = {q[0] - xv.x, q[1] - yv.x, D == 3 ? q[D - 1] - zv.x : 0.};
+            double db[3] = {q[0] - xv.y, q[1] - yv.y, D == 3 ? q[D - 1] - zv.y : 0.};
+            double va = dist2<D>(da);
+            double vb = base + 1 < end ? dist2<D>(db) : __builtin_inf();
+            if (va < m1) { m2 = m1; m1 = va; i1 = base; } else if (va < m2) m2 = va;
+            if (vb < m1) { m2 = m1; m1 = vb; i1 = base + 1; } else if (vb < m2) m2 = vb;
+        }
+        if (two) {
+            double da[3] = {q[0] - xw.x, q[1] - yw.x, D == 3 ? q[D - 1] - zw.x : 0.};
+            double db[3] = {q[0] - xw.y, q[1] - yw.y, D == 3 ? q[D - 1] - zw.y : 0.};
+            double va = dist2<D>(da);
+            double vb = b1 + 1 < end ? dist2<D>(db) : __builtin_inf();
+            if (va < m1) { m2 = m1; m1 = va; i1 = b1; } else if (va < m2) m2 = va;
+            if (vb < m1) { m2 = m1; m1 = vb; i1 = b1 + 1; } else if (vb < m2) m2 = vb;
+        }
     }
     // wave: minimum (m1, i1) and the second-smallest value seen by the wave
     double wm = m1;
@@ -712,12 +744,10 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     const double2 *Z = reinterpret_cast<const double2 *>(t.c[D - 1]);
     const unsigned long long lt = (1ull << lane) - 1ull;
     int cnt = 0;  // wave-uniform
-    for (int cb = beg; cb < end; cb += 128) {
-        int base = cb + 2 * lane;
+    // one 128-vertex chunk: band-filtered hit test for this lane's two vertices + ordered staging
+    auto chunk = [&](int base, const double2 &xv, const double2 &yv, const double2 &zv) {
         bool ha = false, hb = false;
         if (base < end) {
-            double2 xv = X[base >> 1], yv = Y[base >> 1], zv;
-            if (D == 3) zv = Z[base >> 1];
             double da[3] = {node_new[0] - xv.x, node_new[1] - yv.x, D == 3 ? node_new[D - 1] - zv.x : 0.};
             double db[3] = {node_new[0] - xv.y, node_new[1] - yv.y, D == 3 ? node_new[D - 1] - zv.y : 0.};
             double va = dist2<D>(da), vb = dist2<D>(db);
@@ -735,6 +765,21 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
             if (hb) t.st_idx[beg + cnt + pre + (ha ? 1 : 0)] = base + 1;
             cnt += __popcll(ma) + __popcll(mb);
         }
+    };
+    for (int cb = beg; cb < end; cb += 256) {
+        // two chunks per trip; all 16-byte loads are issued before the first use
+        const int b0 = cb + 2 * lane, b1 = b0 + 128;
+        double2 x0 = {0., 0.}, y0 = {0., 0.}, z0 = {0., 0.}, x1 = {0., 0.}, y1 = {0., 0.}, z1 = {0., 0.};
+        if (b0 < end) {
+            x0 = X[b0 >> 1]; y0 = Y[b0 >> 1];
+            if (D == 3) z0 = Z[b0 >> 1];
+        }
+        if (b1 < end) {
+            x1 = X[b1 >> 1]; y1 = Y[b1 >> 1];
+            if (D == 3) z1 = Z[b1 >> 1];
+        }
+        chunk(b0, x0, y0, z0);
+        if (cb + 128 < end) chunk(b1, x1, y1, z1);   // wave-uniform
     }
     __syncthreads();
     if (lane == 0) s.wave_tot[w] = cnt;
@@ -745,7 +790,10 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     for (int i = 0; i < NW; i++) woff[i + 1] = woff[i] + s.wave_tot[i];
     const int kraw = woff[NW];
     const int per = ((n + NW * 128 - 1) / (NW * 128)) * 128;
-    // gather the staged hits (already ascending) into the candidate list
+    // gather the staged hits (already ascending) into the candidate list; their coordinates ride
+    // along in nr_c0 / nr_c1 / nr_dist (free until the walk phase) so the fan below needs no
+    // dependent index -> coordinate loads
+    double *cx = t.nr_c0, *cy = t.nr_c1, *cz = t.nr_dist;
     for (int a = tid; a < kraw; a += NT) {
         int ww = 0, offw = 0;
 #pragma unroll
@@ -754,40 +802,56 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
         int v = t.st_idx[ww * per + (a - offw)];
         t.nr_idx[a] = v;
         t.nr_flag[a] = (v == new_idx) ? 1 : 0;   // excluded like the colliding ones
+        cx[a] = t.c[0][v];
+        cy[a] = t.c[1][v];
+        if (D == 3) cz[a] = t.c[D - 1][v];
     }
     __syncthreads();
-    // fan of segment tests (node_new -> v_j) x obstacles, one (segment, obstacle) pair per lane
+    // fan of segment tests (node_new -> v_j) x obstacles
     const int M = s.n_round + s.n_box;
     if (M > 0) {
-        const int pairs = kraw * M;
-        for (int p = tid; p < pairs; p += NT) {
-            int j = p / M, o = p - j * M;
-            double vj[D];
-            load_vertex<D>(t, t.nr_idx[j], vj);
-            if (seg_obstacle<D, NT>(s, o, node_new, vj, clr)) t.nr_flag[j] = 1;
+        if (kraw < NT) {
+            // few segments: one (segment, obstacle) pair per lane
+            const int pairs = kraw * M;
+            for (int p = tid; p < pairs; p += NT) {
+                int j = p / M, o = p - j * M;
+                double vj[3] = {cx[j], cy[j], D == 3 ? cz[j] : 0.};
+                if (seg_obstacle<D, NT>(s, o, node_new, vj, clr)) t.nr_flag[j] = 1;
+            }
+        } else {
+            // many segments (informed sampling packs the Near ball): one segment per lane, obstacles from LDS
+            for (int j = tid; j < kraw; j += NT) {
+                double vj[3] = {cx[j], cy[j], D == 3 ? cz[j] : 0.};
+                if (seg_all<D, NT>(s, node_new, vj, clr)) t.nr_flag[j] = 1;
+            }
         }
     }
     __syncthreads();
-    // stable in-place filter
+    // stable in-place filter (index + coordinates)
     int k = 0;
     for (int base = 0; base < kraw; base += NT) {
         int a = base + tid;
         int vi = 0;
+        double vx = 0., vy = 0., vz = 0.;
         bool keep = false;
-        if (a < kraw) { vi = t.nr_idx[a]; keep = t.nr_flag[a] == 0; }
+        if (a < kraw) {
+            vi = t.nr_idx[a]; keep = t.nr_flag[a] == 0;
+            vx = cx[a]; vy = cy[a];
+            if (D == 3) vz = cz[a];
+        }
         int pos;
         int tot = block_compact<NT>(s, keep, pos);
-        if (keep) t.nr_idx[k + pos] = vi;
+        if (keep) {
+            t.nr_idx[k + pos] = vi; cx[k + pos] = vx; cy[k + pos] = vy;
+            if (D == 3) cz[k + pos] = vz;
+        }
         k += tot;
     }
     __syncthreads();
     // reference distances of the survivors + Near-set marks
     for (int a = tid; a < k; a += NT) {
         int vi = t.nr_idx[a];
-        double v[D], d[D];
-        load_vertex<D>(t, vi, v);
-#pragma unroll
-        for (int c = 0; c < D; c++) d[c] = node_new[c] - v[c];
+        double d[3] = {node_new[0] - cx[a], node_new[1] - cy[a], D == 3 ? node_new[D - 1] - cz[a] : 0.};
         t.nr_dist[a] = dist_scan<D>(d);
         t.aux[vi].mark = stamp;
         t.rank_of[vi] = a;
@@ -855,15 +919,31 @@ __device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double 
     if (t.sol_dirty) {   // uniform
         double bv = __builtin_inf();
         int bs = 0x7fffffff;
-        for (int q = tid; q < ns; q += NT) {
-            int idx = t.sol[q];
-            double v[D], d[D];
-            load_vertex<D>(t, idx, v);
+        for (int base = 0; base < ns; base += NT * WALK_R) {   // WALK_R chains in flight per lane
+            int idx[WALK_R], q[WALK_R];
+            double acc0[WALK_R], acc1[WALK_R], line[WALK_R];
 #pragma unroll
-            for (int k = 0; k < D; k++) d[k] = t.goal[k] - v[k];
-            double c = walk_cost<D>(t, idx) + hypot_py<D>(d);
-            t.sol_cost[q] = c;
-            if (c < bv) { bv = c; bs = q; }
+            for (int r = 0; r < WALK_R; r++) {
+                q[r] = base + r * NT + tid;
+                idx[r] = -1; acc0[r] = 0.; acc1[r] = 0.; line[r] = 0.;
+                if (q[r] < ns) {
+                    idx[r] = t.sol[q[r]];
+                    double v[D], d[D];
+                    load_vertex<D>(t, idx[r], v);
+#pragma unroll
+                    for (int k = 0; k < D; k++) d[k] = t.goal[k] - v[k];
+                    line[r] = hypot_py<D>(d);
+                }
+            }
+            walk_chains<D>(t, idx, acc0, acc1, nullptr, 0);
+#pragma unroll
+            for (int r = 0; r < WALK_R; r++) {
+                if (q[r] < ns) {
+                    double c = acc0[r] + line[r];
+                    t.sol_cost[q[r]] = c;
+                    if (c < bv || (c == bv && q[r] < bs)) { bv = c; bs = q[r]; }
+                }
+            }
         }
         block_argmin<NT>(s, bv, bs);
         if (bs == 0x7fffffff) bs = 0;
@@ -908,11 +988,24 @@ __device__ __forceinline__ void wg_goal_parent(Lds<NT> &s, TreeDev &t, int &gp, 
     if (t.gc_dirty) {
         double bv = __builtin_inf();
         int bq = 0x7fffffff;
-        for (int q = tid; q < ng; q += NT) {
-            double c = __builtin_inf();
-            if (!t.gc_col[q]) c = walk_cost<D>(t, t.gc_idx[q]) + t.gc_dist[q];
-            t.gc_cost[q] = c;
-            if (c < bv) { bv = c; bq = q; }
+        for (int base = 0; base < ng; base += NT * WALK_R) {
+            int idx[WALK_R], q[WALK_R];
+            double acc0[WALK_R], acc1[WALK_R];
+#pragma unroll
+            for (int r = 0; r < WALK_R; r++) {
+                q[r] = base + r * NT + tid;
+                idx[r] = -1; acc0[r] = 0.; acc1[r] = 0.;
+                if (q[r] < ng && !t.gc_col[q[r]]) idx[r] = t.gc_idx[q[r]];
+            }
+            walk_chains<D>(t, idx, acc0, acc1, nullptr, 0);
+#pragma unroll
+            for (int r = 0; r < WALK_R; r++) {
+                if (q[r] < ng) {
+                    double c = t.gc_col[q[r]] ? __builtin_inf() : acc0[r] + t.gc_dist[q[r]];
+                    t.gc_cost[q[r]] = c;
+                    if (c < bv || (c == bv && q[r] < bq)) { bv = c; bq = q[r]; }
+                }
+            }
         }
         block_argmin<NT>(s, bv, bq);
         if (bq == 0x7fffffff) bq = 0;  // every candidate collides: np.argmin of all-inf = 0
@@ -984,6 +1077,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
     int n = t.n;
     const int stamp = t.stamp + 1;   // published by thread 0 at the end of the iteration
     long long scanned = host_steer ? 0 : n;
+    PROF_DECL
     int ni;
     double node_new[D], nearest[D];
     if (host_steer) {
@@ -993,6 +1087,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         for (int k = 0; k < D; k++) node_new[k] = node_in[k];
     } else {
         ni = wg_nearest<D, NT>(s, t, n, node_in);
+        PROF(0);
         load_vertex<D>(t, ni, nearest);
         steer<D>(t, nearest, node_in, node_new);
     }
@@ -1002,6 +1097,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         res->node_new[0] = node_new[0]; res->node_new[1] = node_new[1]; res->node_new[2] = D == 3 ? node_new[D - 1] : 0.;
     }
     bool collided = wg_collision<D, NT>(s, nearest, node_new, clr);
+    PROF(1);
     int new_idx = -1;
     if (!collided) {
         double diff[D];
@@ -1033,12 +1129,14 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         }
         if (new_idx >= 0) {
             int k = wg_near<D, NT>(s, t, n, node_new, new_idx, stamp);
+            PROF(2);
             scanned += n;
             int reparented = 0, n_rewired = 0;
             if (k > 0) {
                 // parent-chain walks: slot j < k = neighbour j, slot k = `nearest`
                 wg_walk_neighbours<D, NT>(t, k, ni, node_new, stamp, 0, true);
                 __syncthreads();
+                PROF(3);
                 // choose_parent (rrt_star_2d.py:80-90)
                 double cand = __builtin_inf();
                 int cj = 0x7fffffff;
@@ -1072,6 +1170,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                         __syncthreads();
                     }
                 }
+                PROF(4);
                 // rewire (rrt_star_2d.py:92-99): sequential semantics.  All decisions up to and
                 // including the first "true" are exact with the costs in hand; after a re-parenting only
                 // neighbours that have the re-parented vertex among their (marked) ancestors change cost.
@@ -1107,6 +1206,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                     __syncthreads();
                 }
             }
+            PROF(5);
             if (inserted) wg_goal_candidate<D, NT>(s, t, new_idx, node_new);
             int in_goal = 0;
             if (flags & NIRRT_F_IRRT) {
@@ -1131,6 +1231,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
     } else if (res && tid == 0) {
         res->collided = 1;
     }
+    PROF(6);
     if (tid == 0) { t.stamp = stamp; t.scan_elems += scanned; }
     __syncthreads();
 }

@@ -152,7 +152,13 @@ __device__ __noinline__ double report_call(Lds<NT> *sp, TreeDev *tp, unsigned fl
 {
     double cb;
     int xb;
+#ifdef NIRRT_PROFILE
+    long long t0_ = wall_clock64();
+#endif
     wg_report<D, NT>(*sp, *tp, flags, cb, xb);
+#ifdef NIRRT_PROFILE
+    if (threadIdx.x == 0) tp->prof[7] += wall_clock64() - t0_;
+#endif
     return cb;
 }
 
@@ -180,9 +186,10 @@ __global__ __launch_bounds__(NT, 4) void k_run_replay(TreeDev *const *trees, Run
 #pragma unroll
         for (int c = 0; c < D; c++) q[c] = smp[k * D + c];
         iteration_call<D>(&s, &t, q[0], q[1], q[2], a.flags);
-        if (trace) {
+        if (trace || (a.flags & NIRRT_F_STOP_FIRST)) {
             double cb = report_call<D>(&s, &t, a.flags);
-            if (threadIdx.x == 0) trace[k] = cb;
+            if (trace && threadIdx.x == 0) trace[k] = cb;
+            if ((a.flags & NIRRT_F_STOP_FIRST) && cb < __builtin_inf()) { k++; break; }
         }
         if (t.status != 0) { k++; break; }
     }
@@ -302,11 +309,13 @@ __global__ __launch_bounds__(NT, 4) void k_run_sample(TreeDev *const *trees, Run
     WordStream py = {a.py_words ? a.py_words[b] : nullptr, a.py_words ? a.n_py[b] : 0, 0};
     double *trace = a.cost_trace ? a.cost_trace + (long long)b * a.iters : nullptr;
     const bool irrt = (a.flags & NIRRT_F_IRRT) != 0;
+    const bool reports = irrt || (a.flags & NIRRT_F_GOAL_SCAN);
     long long k = 0;
     int stop = 0;
+    // cb = best cost on the current tree: what IRRT* samples with at the top of the next iteration
+    // (irrt_star_2d.py:51-53) and what planning_random records after each iteration (:223-229, :241)
+    double cb = reports ? report_call<D>(&s, &t, a.flags) : __builtin_inf();
     for (; k < a.iters; k++) {
-        double cb = __builtin_inf();
-        if (irrt || (a.flags & NIRRT_F_GOAL_SCAN)) cb = report_call<D>(&s, &t, a.flags);
         if (threadIdx.x == 0) {
             double q[3] = {0., 0., 0.};
             long long np0 = np.pos, py0 = py.pos;
@@ -320,9 +329,11 @@ __global__ __launch_bounds__(NT, 4) void k_run_sample(TreeDev *const *trees, Run
         double q0 = s.bc_d[0], q1 = s.bc_d[1], q2 = s.bc_d[2];
         __syncthreads();
         if (stop) break;
-        if (trace && threadIdx.x == 0) trace[k] = cb;
         iteration_call<D>(&s, &t, q0, q1, q2, a.flags);
+        if (reports) cb = report_call<D>(&s, &t, a.flags);
+        if (trace && threadIdx.x == 0) trace[k] = cb;
         if (t.status != 0) { k++; stop = t.status; break; }
+        if ((a.flags & NIRRT_F_STOP_FIRST) && cb < __builtin_inf()) { k++; break; }
     }
     if (threadIdx.x == 0) {
         a.iters_done[b] = k;
@@ -926,6 +937,17 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
     cleanup();
     return rc_all;   // NIRRT_E_STREAM is reported per tree in status[] (the caller refills and resumes)
 #undef HIPCHK_R
+}
+
+/* debug: per-phase tick counters (all zero unless built with -DNIRRT_PROFILE) */
+extern "C" int nirrt_debug_prof(nirrt_tree *t, int64_t *out16)
+{
+    if (!t || !out16) return NIRRT_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    TreeDev tmp;
+    HIPCHK(hipMemcpy(&tmp, t->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 16; i++) out16[i] = tmp.prof[i];
+    return NIRRT_OK;
 }
 
 extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *a)

@@ -1,0 +1,151 @@
+// pointops.hip — PointNet++ point operators for the guidance sampler (gfx950), C ABI, raw device
+// pointers (torch tensors' data_ptr) + an explicit HIP stream.  Semantics follow the reference's
+// torch code (pointnet_pointnet2/models/pointnet2_utils.py): farthest_point_sample :65-86,
+// query_ball_point :89-109 (with square_distance :21-42), 3-NN of PointNetFeaturePropagation :295-299.
+// float32 arithmetic, -ffp-contract=off; the dot products of square_distance are a forward FMA chain.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FPS_NT 1024
+#define FPS_MAX_PER_THREAD 8   // N <= 8192
+
+// one workgroup per batch element; cloud in LDS, running min-distance in registers
+__global__ __launch_bounds__(FPS_NT) void k_fps(const float *__restrict__ xyz, int N, int S, const long long *__restrict__ start,
+                                               long long *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *px = reinterpret_cast<float *>(smem);
+    float *py = px + N;
+    float *pz = py + N;
+    float *rv = pz + N;                       // [16] wave maxima
+    int *ri = reinterpret_cast<int *>(rv + 16);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float *p = xyz + (size_t)b * N * 3;
+    for (int i = tid; i < N; i += FPS_NT) { px[i] = p[3 * i]; py[i] = p[3 * i + 1]; pz[i] = p[3 * i + 2]; }
+    float dist[FPS_MAX_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < FPS_MAX_PER_THREAD; j++) dist[j] = 1e10f;
+    int far = (int)start[b];
+    __syncthreads();
+    for (int s = 0; s < S; s++) {
+        if (tid == 0) out[(size_t)b * S + s] = far;
+        const float cx = px[far], cy = py[far], cz = pz[far];
+        float bv = -1.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < FPS_MAX_PER_THREAD; j++) {
+            int i = tid + j * FPS_NT;
+            if (i < N) {
+                float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
+                float d = dx * dx + dy * dy + dz * dz;
+                if (d < dist[j]) dist[j] = d;
+                if (dist[j] > bv) { bv = dist[j]; bi = i; }   // ascending i within the thread: first max kept
+            }
+        }
+        // argmax, lowest index on ties
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            float ov = __shfl_xor(bv, off);
+            int oi = __shfl_xor(bi, off);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { rv[w] = bv; ri[w] = bi; }
+        __syncthreads();
+        bv = rv[0]; bi = ri[0];
+#pragma unroll
+        for (int i = 1; i < FPS_NT / 64; i++) {
+            float ov = rv[i];
+            int oi = ri[i];
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        far = bi;
+    }
+}
+
+__device__ __forceinline__ float sqdist_ref(float qx, float qy, float qz, float sq, float x, float y, float z)
+{
+    // square_distance: -2*src.dst^T, += sum(src^2), += sum(dst^2)   (src = query)
+    float dot = __builtin_fmaf(qz, z, __builtin_fmaf(qy, y, qx * x));
+    float sp = x * x + y * y + z * z;
+    return (-2.f * dot + sq) + sp;
+}
+
+// one wave per query: first K indices (ascending) with sqrdist <= r2, padded with the first hit
+__global__ __launch_bounds__(256) void k_ball_query(const float *__restrict__ xyz, const float *__restrict__ new_xyz, int N, int S,
+                                                   int K, float r2, long long *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // global query id over B*S
+    const int b = (int)(q / S);
+    const float *p = xyz + (size_t)b * N * 3;
+    const float qx = new_xyz[q * 3], qy = new_xyz[q * 3 + 1], qz = new_xyz[q * 3 + 2];
+    const float sq = qx * qx + qy * qy + qz * qz;
+    long long *o = out + q * K;
+    int cnt = 0, first = -1;
+    for (int base = 0; base < N && cnt < K; base += 64) {
+        int i = base + lane;
+        bool hit = false;
+        if (i < N) hit = !(sqdist_ref(qx, qy, qz, sq, p[3 * i], p[3 * i + 1], p[3 * i + 2]) > r2);
+        unsigned long long m = __ballot(hit);
+        if (m) {
+            if (first < 0) first = base + __builtin_ctzll(m);
+            int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+            if (hit && pos < K) o[pos] = i;
+            cnt += __popcll(m);
+        }
+    }
+    if (cnt > K) cnt = K;
+    // reference pads with the first group member; an empty ball yields index N there (never happens:
+    // the query point itself is always a member) - we pad with 0 in that impossible case
+    if (first < 0) first = 0;
+    for (int k = cnt + lane; k < K; k += 64) o[k] = first;
+}
+
+// one thread per fine point: 3 nearest coarse points (distance ascending, index ascending on ties)
+__global__ __launch_bounds__(256) void k_three_nn(const float *__restrict__ xyz1, const float *__restrict__ xyz2, int N, int S,
+                                                 long long total, float *__restrict__ dist_out, long long *__restrict__ idx_out)
+{
+    long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const int b = (int)(g / N);
+    const float *c = xyz2 + (size_t)b * S * 3;
+    const float qx = xyz1[g * 3], qy = xyz1[g * 3 + 1], qz = xyz1[g * 3 + 2];
+    const float sq = qx * qx + qy * qy + qz * qz;
+    float d0 = 3.4e38f, d1 = 3.4e38f, d2 = 3.4e38f;
+    int i0 = 0, i1 = 0, i2 = 0;
+    for (int j = 0; j < S; j++) {
+        float d = sqdist_ref(qx, qy, qz, sq, c[3 * j], c[3 * j + 1], c[3 * j + 2]);
+        if (d < d0) { d2 = d1; i2 = i1; d1 = d0; i1 = i0; d0 = d; i0 = j; }
+        else if (d < d1) { d2 = d1; i2 = i1; d1 = d; i1 = j; }
+        else if (d < d2) { d2 = d; i2 = j; }
+    }
+    dist_out[g * 3] = d0; dist_out[g * 3 + 1] = d1; dist_out[g * 3 + 2] = d2;
+    idx_out[g * 3] = i0; idx_out[g * 3 + 1] = i1; idx_out[g * 3 + 2] = i2;
+}
+
+extern "C" int nirrt_pn2_fps(const float *xyz, int B, int N, int S, const int64_t *start, int64_t *out, void *stream)
+{
+    if (N > FPS_NT * FPS_MAX_PER_THREAD || N <= 0 || S <= 0) return -1;
+    size_t lds = sizeof(float) * 3 * (size_t)N + 16 * sizeof(float) + 16 * sizeof(int);
+    hipLaunchKernelGGL(k_fps, dim3(B), dim3(FPS_NT), lds, (hipStream_t)stream, xyz, N, S, (const long long *)start, (long long *)out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int nirrt_pn2_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, int K, float r2, int64_t *out,
+                                    void *stream)
+{
+    long long queries = (long long)B * S;
+    if (queries % 4 != 0) return -1;   // S is a multiple of 16 in this network
+    hipLaunchKernelGGL(k_ball_query, dim3((unsigned)(queries / 4)), dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, N, S, K, r2,
+                       (long long *)out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int nirrt_pn2_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S, float *dist, int64_t *idx, void *stream)
+{
+    long long total = (long long)B * N;
+    hipLaunchKernelGGL(k_three_nn, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xyz1, xyz2, N, S, total,
+                       dist, (long long *)idx);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -1,0 +1,3 @@
+"""Drop-in module: same import path and names as the reference's `path_planning_classes_3d/rrt_base_3d.py`, backed by libnirrt_hip.so.
+Put `nirrt_star_amd/dropin` first on sys.path."""
+from nirrt_star_amd.planners import RRTStar3D as RRTBase3D  # noqa: F401

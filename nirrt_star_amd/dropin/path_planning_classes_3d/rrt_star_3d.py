@@ -1,0 +1,4 @@
+"""Drop-in module: same import path and names as the reference's `path_planning_classes_3d/rrt_star_3d.py`, backed by libnirrt_hip.so.
+Put `nirrt_star_amd/dropin` first on sys.path."""
+from nirrt_star_amd.planners import RRTStar3D  # noqa: F401
+from nirrt_star_amd.planners import get_rrt_star_3d as get_path_planner  # noqa: F401

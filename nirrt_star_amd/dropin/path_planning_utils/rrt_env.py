@@ -1,0 +1,3 @@
+"""Drop-in module: same import path and names as the reference's `path_planning_utils/rrt_env.py`, backed by libnirrt_hip.so.
+Put `nirrt_star_amd/dropin` first on sys.path."""
+from nirrt_star_amd.env import Env  # noqa: F401

@@ -1,0 +1,112 @@
+"""PNGWrapper — point-cloud guidance adaptor around the PointNet++ net, reference interface:
+wrapper/pointnet_pointnet2/pointnet2_wrapper.py:9-63, pointnet2_wrapper_connect_bfs.py:13-240 and the
+wrapper_3d twins (3D: no z padding, 3D checkpoint path).
+
+    PNGWrapper(num_classes=2, root_dir='.', device='cuda')
+        .classify_path_points(pc f32 (N,2|3), start_mask f32 (N,), goal_mask f32 (N,)) -> (path_pred int (N,), path_score f32 (N,))
+        .generate_connected_path_points(pc, x_start, x_goal, env_dict, neighbor_radius, max_trial_attempts,
+                                        visualize=False, vis_folderpath="", token="") -> (bool, int, f32 (N,))
+"""
+from os.path import join
+
+import numpy as np
+import torch
+
+from .bfs_connect import bfs_point_cloud_visualization, get_boundary_mask, select_heuristic_boundary_point
+from .pointcloud import get_point_cloud_mask_around_points
+from .pointnet2 import get_model, pc_normalize
+
+
+def checkpoint_path(root_dir, dim):
+    tag = "pointnet2_%dd" % dim
+    return join(root_dir, "results/model_training/%s/checkpoints/best_%s.pth" % (tag, tag))
+
+
+def make_synthetic_checkpoint(path, seed=0, num_classes=2, calib_forwards=4, n_points=2048, dim=2):
+    """Seeded random-init weights + BatchNorm statistics calibrated by a few train-mode forwards on random
+    clouds, saved in the reference's checkpoint format (train_pointnet_pointnet2.py:266-272).  There are
+    no trained weights without network access; plain random init predicts an empty
+    class and the planner cannot sample from it."""
+    import os
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    model = get_model(num_classes)
+    model.train()
+    rs = np.random.RandomState(seed)
+    with torch.no_grad():
+        for _ in range(calib_forwards):
+            pc = rs.uniform(0, 224 if dim == 2 else 50, size=(n_points, 3)).astype(np.float32)
+            if dim == 2:
+                pc[:, 2] = 0
+            xyz = pc_normalize(pc)
+            s = (np.linalg.norm(pc - pc[0], axis=1) < 10).astype(np.float32)
+            gl = (np.linalg.norm(pc - pc[1], axis=1) < 10).astype(np.float32)
+            feat = np.stack([s, gl, 1 - ((s + gl) > 0).astype(np.float32)], axis=-1)
+            x = torch.from_numpy(np.concatenate([xyz, feat], axis=1).astype(np.float32)).permute(1, 0).unsqueeze(0)
+            model(x)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save({"epoch": 0, "class_avg_iou": 0.0, "model_state_dict": model.state_dict(), "optimizer_state_dict": {}}, path)
+    return path
+
+
+class PNGWrapper:
+    dim = 2
+
+    def __init__(self, num_classes=2, root_dir='.', device='cuda', model_filepath=None):
+        self.device = device
+        self.model = get_model(num_classes).to(device)
+        if model_filepath is None:
+            model_filepath = checkpoint_path(root_dir, self.dim)
+        # weights_only=False: reference checkpoints carry a numpy scalar ('class_avg_iou'), SURVEY Appendix B
+        checkpoint = torch.load(model_filepath, map_location=torch.device(device), weights_only=False)
+        self.model.load_state_dict(checkpoint['model_state_dict'])
+        self.model = self.model.eval().fold()
+        print("PointNet++ wrapper%s is initialized." % ("" if self.dim == 2 else " 3d"))
+
+    def classify_path_points(self, pc, start_mask, goal_mask):
+        with torch.no_grad():
+            n_points = pc.shape[0]
+            if pc.shape[1] == 2:
+                pc = np.concatenate((pc, np.zeros((n_points, 1)).astype(np.float32)), axis=1)
+            pc_xyz = torch.from_numpy(pc_normalize(pc)).to(self.device)
+            free_mask = 1 - (start_mask + goal_mask).astype(bool)
+            pc_features = torch.from_numpy(np.stack((start_mask, goal_mask, free_mask.astype(np.float32)), axis=-1)).to(self.device)
+            model_inputs = torch.cat([pc_xyz, pc_features], dim=1).permute(1, 0).unsqueeze(0)
+            seg_pred, _ = self.model(model_inputs.float())
+            seg = seg_pred.detach().to('cpu')
+            path_pred = np.argmax(seg.numpy(), 2)[0]
+            path_score = torch.softmax(seg, dim=-1)[0, :, 1].numpy()
+            return path_pred, path_score
+
+    def generate_connected_path_points(self, pc, x_start, x_goal, env_dict, neighbor_radius, max_trial_attempts,
+                                       visualize=False, vis_folderpath="", token=""):
+        """<= max_trial_attempts rounds of classify + BFS connectivity, re-seeding the start / goal masks at the
+        heuristic boundary point of the visited set, alternating start->goal and goal->start."""
+        has_path = False
+        path_pred_mask = np.zeros(len(pc)).astype(np.float32)
+        start_mask = get_point_cloud_mask_around_points(pc, x_start[np.newaxis].astype(np.float32), neighbor_radius)
+        goal_mask = get_point_cloud_mask_around_points(pc, x_goal[np.newaxis].astype(np.float32), neighbor_radius)
+        xs, xg = x_start.astype(np.float32), x_goal.astype(np.float32)
+        trial_i = -1
+        for trial_i in range(max_trial_attempts):
+            path_pred, _ = self.classify_path_points(pc, start_mask, goal_mask)
+            path_pred_mask = ((path_pred_mask + path_pred) > 0).astype(np.float32)
+            seeds = []
+            for a, b in ((xs, xg), (xg, xs)):
+                has_path, _, visited_mask = bfs_point_cloud_visualization(pc, path_pred_mask, a, b, neighbor_radius)
+                boundary_mask = get_boundary_mask(pc, visited_mask, 1 - path_pred_mask, neighbor_radius)
+                _, boundary_point, _ = select_heuristic_boundary_point(pc, boundary_mask, a, b)
+                if has_path:
+                    break
+                seeds.append(boundary_point)
+            if has_path:
+                break
+            nxt = []
+            for cur, bp in zip((start_mask, goal_mask), seeds):
+                nxt.append(cur if bp is None else get_point_cloud_mask_around_points(pc, bp, neighbor_radius))
+            start_mask, goal_mask = nxt
+        return has_path, trial_i + 1, path_pred_mask
+
+
+class PNGWrapper3D(PNGWrapper):
+    dim = 3

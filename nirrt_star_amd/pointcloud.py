@@ -1,0 +1,152 @@
+"""Guidance point clouds (reference: datasets/point_cloud_mask_utils.py, datasets_3d/point_cloud_mask_utils_3d.py).
+
+Same function names / arguments / RNG consumption (global numpy legacy generator) as the reference.
+The farthest-point down-sampling step is open3d's `farthest_point_down_sample` in the reference
+(un-vendored dependency, open3d 0.17): restated here from its published behaviour - greedy max-min
+squared distance starting at point 0, result returned in ORIGINAL index order - parity at this
+boundary is unpinned, so fixtures are defined downstream of the cloud.
+"""
+import math
+
+import numpy as np
+
+
+def farthest_point_down_sample(points, num_samples):
+    """open3d.geometry.PointCloud.farthest_point_down_sample restated (points (n, C) f64)."""
+    pts = np.asarray(points, dtype=np.float64)
+    n = len(pts)
+    if num_samples >= n:
+        return pts.copy()
+    sel = np.zeros(n, dtype=bool)
+    dist = np.full(n, np.inf)
+    far = 0
+    for _ in range(num_samples):
+        sel[far] = True
+        d = ((pts - pts[far]) ** 2).sum(axis=1)
+        np.minimum(dist, d, out=dist)
+        far = int(np.argmax(dist))
+    return pts[sel]
+
+
+def get_point_cloud_mask_around_points(point_cloud, points, neighbor_radius=3):
+    """point_cloud (n, C), points (m, C) -> bool (n,): strictly inside neighbor_radius of any point
+    (point_cloud_mask_utils.py:20-31)"""
+    diff = point_cloud[:, np.newaxis] - points
+    dist = np.linalg.norm(diff, axis=2)
+    return np.sum(dist < neighbor_radius, axis=1) > 0
+
+
+def _free_pixels_2d(point_cloud, binary_mask):
+    """keep points whose 4 surrounding pixels (clipped to the image) are all free"""
+    h, w = binary_mask.shape
+    pix = point_cloud.astype(int)
+    keep = np.ones(len(pix))
+    for dx in (0, 1):
+        for dy in (0, 1):
+            px = np.clip(pix[:, 0] + dx, 0, w - 1)
+            py = np.clip(pix[:, 1] + dy, 0, h - 1)
+            keep = keep * binary_mask[py, px]
+    return keep.nonzero()[0]
+
+
+def generate_rectangle_point_cloud(binary_mask, n_points, over_sample_scale=5):
+    """point_cloud_mask_utils.py:35-73 -> (n_points, 2)"""
+    h, w = binary_mask.shape
+    pc = np.random.uniform(low=[0, 0], high=[w, h], size=(n_points * over_sample_scale, 2))
+    pc = pc[_free_pixels_2d(pc, binary_mask)]
+    pc3 = np.concatenate([pc, np.zeros((pc.shape[0], 1))], axis=1)
+    return farthest_point_down_sample(pc3, n_points)[:, :2]
+
+
+def _rotation_to_world_2d(start_point, goal_point, L):
+    a1 = (goal_point - start_point) / L
+    a1 = np.concatenate([a1, np.array([0.])], axis=0)[:, np.newaxis]
+    e1 = np.array([[1.0], [0.0], [0.0]])
+    M = a1 @ e1.T
+    U, _, V_T = np.linalg.svd(M, True, True)
+    return U @ np.diag([1.0, 1.0, np.linalg.det(U) * np.linalg.det(V_T.T)]) @ V_T
+
+
+def ellipsoid_point_cloud_sampling(start_point, goal_point, max_min_ratio, binary_mask, n_points=1000, n_raw_samples=10000):
+    """point_cloud_mask_utils.py:104-174 -> (<= n_points, 2)"""
+    dx, dy = goal_point - start_point
+    c_min = math.hypot(dx, dy)
+    C = _rotation_to_world_2d(start_point, goal_point, c_min)
+    x_center = np.concatenate([(start_point + goal_point) / 2., np.array([0.])], axis=0)
+    c_max = c_min * max_min_ratio
+    eps = 1e-6 if c_max ** 2 - c_min ** 2 < 0 else 0
+    r = [c_max / 2.0, math.sqrt(c_max ** 2 - c_min ** 2 + eps) / 2.0, math.sqrt(c_max ** 2 - c_min ** 2 + eps) / 2.0]
+    L = np.diag(r)
+    samples = np.random.uniform(-1, 1, size=(n_raw_samples, 2))
+    samples = samples[np.linalg.norm(samples, axis=1) <= 1]
+    samples = np.concatenate([samples, np.zeros((len(samples), 1))], axis=1)
+    x_rand = np.dot(np.dot(C, L), samples.T).T + x_center
+    pc = x_rand[:, :2]
+    pc = pc[_free_pixels_2d(pc, binary_mask)]
+    h, w = binary_mask.shape
+    in_range = (0 <= pc[:, 0]) & (pc[:, 0] <= w) & (0 <= pc[:, 1]) & (pc[:, 1] <= h)
+    pc = pc[in_range]
+    if len(pc) > n_points:
+        pc3 = np.concatenate([pc, np.zeros((pc.shape[0], 1))], axis=1)
+        pc = farthest_point_down_sample(pc3, n_points)[:, :2]
+    return pc
+
+
+# ---------------------------------------------------------------------------------------------
+# 3D
+# ---------------------------------------------------------------------------------------------
+def _in_obstacles_3d(points, env, clearance):
+    p = np.asarray(points, dtype=np.float64)
+    inside = np.zeros(len(p), dtype=bool)
+    for bx, by, bz, br in np.asarray(env.obs_ball, dtype=np.float64).reshape(-1, 4):
+        rc = br + clearance
+        inside |= (p[:, 0] - bx) ** 2 + (p[:, 1] - by) ** 2 + (p[:, 2] - bz) ** 2 < rc ** 2
+    for x, y, z, w, h, d in np.asarray(env.obs_box, dtype=np.float64).reshape(-1, 6):
+        inside |= ((x - clearance <= p[:, 0]) & (p[:, 0] <= x + w + clearance) & (y - clearance <= p[:, 1]) &
+                   (p[:, 1] <= y + h + clearance) & (z - clearance <= p[:, 2]) & (p[:, 2] <= z + d + clearance))
+    return inside
+
+
+def generate_rectangle_point_cloud_3d(env, n_points, over_sample_scale=5, use_open3d=True, clearance=0):
+    """point_cloud_mask_utils_3d.py:83-113"""
+    pc = np.random.uniform(
+        low=(env.x_range[0] + clearance, env.y_range[0] + clearance, env.z_range[0] + clearance),
+        high=(env.x_range[1] - clearance, env.y_range[1] - clearance, env.z_range[1] - clearance),
+        size=(n_points * over_sample_scale, 3))
+    pc = pc[~_in_obstacles_3d(pc, env, clearance)]
+    if len(pc) > n_points:
+        pc = farthest_point_down_sample(pc, n_points)
+    return pc
+
+
+def _rotation_to_world_3d(x_start, x_goal, L):
+    a1 = (x_goal - x_start) / L
+    M = np.outer(a1, [1, 0, 0])
+    U, S, V = np.linalg.svd(M)
+    return U @ np.diag([1, 1, np.linalg.det(U) * np.linalg.det(V)]) @ V.T
+
+
+def ellipsoid_point_cloud_sampling_3d(start_point, goal_point, max_min_ratio, env, n_points=1000, n_raw_samples=10000,
+                                      clearance=0):
+    """point_cloud_mask_utils_3d.py:132-200"""
+    c_min = np.linalg.norm(goal_point - start_point)
+    C = _rotation_to_world_3d(start_point, goal_point, c_min)
+    x_center = (start_point + goal_point) / 2.
+    c_max = c_min * max_min_ratio
+    eps = 1e-6 if c_max ** 2 - c_min ** 2 < 0 else 0
+    r = np.zeros(3)
+    r[0] = c_max / 2
+    r[1] = r[2] = np.sqrt(c_max ** 2 - c_min ** 2 + eps) / 2
+    L = np.diag(r)
+    radius = np.random.uniform(0.0, 1.0, n_raw_samples)
+    theta = np.random.uniform(0, np.pi, n_raw_samples)
+    phi = np.random.uniform(0, 2 * np.pi, n_raw_samples)
+    samples = np.array([radius * np.sin(theta) * np.cos(phi), radius * np.sin(theta) * np.sin(phi), radius * np.cos(theta)]).T
+    pc = np.dot(np.dot(C, L), samples.T).T + x_center
+    in_range = ((env.x_range[0] + clearance <= pc[:, 0]) & (pc[:, 0] <= env.x_range[1] - clearance) &
+                (env.y_range[0] + clearance <= pc[:, 1]) & (pc[:, 1] <= env.y_range[1] - clearance) &
+                (env.z_range[0] + clearance <= pc[:, 2]) & (pc[:, 2] <= env.z_range[1] - clearance))
+    pc = pc[in_range & ~_in_obstacles_3d(pc, env, clearance)]
+    if len(pc) > n_points:
+        pc = farthest_point_down_sample(pc, n_points)
+    return pc

@@ -1,0 +1,189 @@
+"""PointNet++ MSG segmentation net for point-cloud guidance, forward only, PyTorch-ROCm.
+
+Architecture + state-dict layout of the reference (pointnet_pointnet2/models/pointnet2.py:7-42,
+pointnet2_utils.py:207-317) so its checkpoints load unchanged (240 tensors: sa{1-4}.conv_blocks.i.j,
+sa*.bn_blocks.i.j, fp{1-4}.mlp_convs.i / mlp_bns.i, conv1, bn1, conv2), but organised for inference
+on MI355X:
+
+  * at eval time every 1x1 conv + BatchNorm pair is folded into ONE weight/bias (`fold()`), so a
+    grouping MLP layer is a single GEMM (+bias+ReLU) over [C_in x K*S] columns - the rocBLAS/hipBLASLt
+    fp32 path, i.e. v_mfma_f32_* on gfx950;
+  * farthest point sampling, ball query and 3-NN search run as hand-written HIP kernels from
+    libnirrt_hip.so when the tensors are on the GPU (nirrt_star_amd/csrc/pointops.hip): FPS is one
+    persistent workgroup with the cloud in LDS instead of ~1360 dependent torch launches;
+    ball query is a first-K-in-index-order scan instead of an O(N log N) sort.
+    On CPU tensors (tests, fixtures) the same semantics run as plain torch ops.
+
+Semantics kept from the reference: FPS starts at torch.randint(0, N) drawn from the CPU generator
+(pointnet2_utils.py:77); ball query = first K indices in ascending order with squared distance
+<= r^2, padded with the first hit (:89-109); grouped features are [point feats, xyz - centre] (:247-250);
+3-NN inverse-distance weights with 1e-8 (:295-305).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pointops
+
+SA_SPECS = [  # npoint, radii, nsamples, in_channel, mlps   (pointnet2.py:11-14)
+    (1024, [0.05, 0.1], [16, 32], 6, [[16, 16, 32], [32, 32, 64]]),
+    (256, [0.1, 0.2], [16, 32], 32 + 64, [[64, 64, 128], [64, 96, 128]]),
+    (64, [0.2, 0.4], [16, 32], 128 + 128, [[128, 196, 256], [128, 196, 256]]),
+    (16, [0.4, 0.8], [16, 32], 256 + 256, [[256, 256, 512], [256, 384, 512]]),
+]
+FP_SPECS = [  # attribute, in_channel, mlp   (pointnet2.py:15-18)
+    ("fp4", 512 + 512 + 256 + 256, [256, 256]),
+    ("fp3", 128 + 128 + 256, [256, 256]),
+    ("fp2", 32 + 64 + 256, [256, 128]),
+    ("fp1", 128, [128, 128, 128]),
+]
+
+
+def _fold(conv, bn):
+    """(W, b) of conv followed by eval-mode BatchNorm as one affine map; W is (C_out, C_in)."""
+    w = conv.weight.reshape(conv.weight.shape[0], -1)
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return w * scale[:, None], (conv.bias - bn.running_mean) * scale + bn.bias
+
+
+class SetAbstractionMSG(nn.Module):
+    """FPS -> per radius: ball query, gather, shared MLP, max over the K group members."""
+
+    def __init__(self, npoint, radii, nsamples, in_channel, mlps):
+        super().__init__()
+        self.npoint, self.radii, self.nsamples = npoint, radii, nsamples
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        for widths in mlps:
+            convs, bns, c = nn.ModuleList(), nn.ModuleList(), in_channel + 3
+            for w in widths:
+                convs.append(nn.Conv2d(c, w, 1))
+                bns.append(nn.BatchNorm2d(w))
+                c = w
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+        self._folded = None
+
+    def fold(self):
+        self._folded = [[_fold(c, b) for c, b in zip(cs, bs)] for cs, bs in zip(self.conv_blocks, self.bn_blocks)]
+
+    def forward(self, xyz, feats, fps_start=None):
+        """xyz (B, N, 3), feats (B, N, C) -> new_xyz (B, S, 3), new_feats (B, S, sum C_out)"""
+        B, N, _ = xyz.shape
+        S = self.npoint
+        fps_idx = pointops.farthest_point_sample(xyz, S, fps_start)            # (B, S)
+        new_xyz = torch.gather(xyz, 1, fps_idx[..., None].expand(B, S, 3))
+        outs = []
+        for bi, (radius, K) in enumerate(zip(self.radii, self.nsamples)):
+            gidx = pointops.ball_query(radius, K, xyz, new_xyz)                # (B, S, K)
+            flat = gidx.reshape(B, S * K)
+            g_xyz = torch.gather(xyz, 1, flat[..., None].expand(B, S * K, 3)).view(B, S, K, 3) - new_xyz[:, :, None, :]
+            g_feat = torch.gather(feats, 1, flat[..., None].expand(B, S * K, feats.shape[-1])).view(B, S, K, -1)
+            x = torch.cat([g_feat, g_xyz], dim=-1)                             # (B, S, K, C_in) points first, then rel. xyz
+            if self._folded is not None and not self.training:
+                x = x.reshape(B * S * K, -1)
+                for w, b in self._folded[bi]:
+                    x = F.relu(torch.addmm(b, x, w.t()))                       # one GEMM per layer
+                x = x.view(B, S, K, -1).max(dim=2)[0]                          # (B, S, C_out)
+            else:
+                x = x.permute(0, 3, 2, 1)                                      # (B, C, K, S) like the reference
+                for conv, bn in zip(self.conv_blocks[bi], self.bn_blocks[bi]):
+                    x = F.relu(bn(conv(x)))
+                x = x.max(dim=2)[0].permute(0, 2, 1)
+            outs.append(x)
+        return new_xyz, torch.cat(outs, dim=-1), fps_idx
+
+
+class FeaturePropagation(nn.Module):
+    """3-NN inverse-distance interpolation from the coarse level + shared MLP."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        c = in_channel
+        for w in mlp:
+            self.mlp_convs.append(nn.Conv1d(c, w, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(w))
+            c = w
+        self._folded = None
+
+    def fold(self):
+        self._folded = [_fold(c, b) for c, b in zip(self.mlp_convs, self.mlp_bns)]
+
+    def forward(self, xyz1, xyz2, feats1, feats2):
+        """xyz1 (B, N, 3) fine, xyz2 (B, S, 3) coarse, feats1 (B, N, C1) | None, feats2 (B, S, C2) -> (B, N, C_out)"""
+        B, N, _ = xyz1.shape
+        S = xyz2.shape[1]
+        if S == 1:
+            interp = feats2.repeat(1, N, 1)
+        else:
+            d, idx = pointops.three_nn(xyz1, xyz2)                            # (B, N, 3) each
+            recip = 1.0 / (d + 1e-8)
+            wgt = recip / recip.sum(dim=2, keepdim=True)
+            nb = torch.gather(feats2, 1, idx.reshape(B, N * 3)[..., None].expand(B, N * 3, feats2.shape[-1])).view(B, N, 3, -1)
+            interp = (nb * wgt[..., None]).sum(dim=2)
+        x = interp if feats1 is None else torch.cat([feats1, interp], dim=-1)
+        if self._folded is not None and not self.training:
+            x = x.reshape(B * N, -1)
+            for w, b in self._folded:
+                x = F.relu(torch.addmm(b, x, w.t()))
+            return x.view(B, N, -1)
+        x = x.permute(0, 2, 1)
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            x = F.relu(bn(conv(x)))
+        return x.permute(0, 2, 1)
+
+
+class get_model(nn.Module):
+    """`get_model(num_classes).forward(points (B, 6, N)) -> (log_softmax (B, N, num_classes), l4 feats (B, 1024, 16))`"""
+
+    def __init__(self, num_classes):
+        super().__init__()
+        for i, spec in enumerate(SA_SPECS):
+            setattr(self, "sa%d" % (i + 1), SetAbstractionMSG(*spec))
+        for name, cin, mlp in FP_SPECS:
+            setattr(self, name, FeaturePropagation(cin, mlp))
+        self.conv1 = nn.Conv1d(128, 128, 1)
+        self.bn1 = nn.BatchNorm1d(128)
+        self.drop1 = nn.Dropout(0.5)
+        self.conv2 = nn.Conv1d(128, num_classes, 1)
+        self._head = None
+        self.last_fps = None
+
+    def fold(self):
+        """fold conv+BN pairs for inference (call after load_state_dict / eval)"""
+        for m in (self.sa1, self.sa2, self.sa3, self.sa4, self.fp1, self.fp2, self.fp3, self.fp4):
+            m.fold()
+        self._head = _fold(self.conv1, self.bn1)
+        return self
+
+    def forward(self, points, fps_starts=None):
+        feats0 = points.permute(0, 2, 1).contiguous()       # (B, N, 6)
+        xyz0 = feats0[:, :, :3].contiguous()
+        st = fps_starts or [None] * 4
+        xyz1, f1, i1 = self.sa1(xyz0, feats0, st[0])
+        xyz2, f2, i2 = self.sa2(xyz1, f1, st[1])
+        xyz3, f3, i3 = self.sa3(xyz2, f2, st[2])
+        xyz4, f4, i4 = self.sa4(xyz3, f3, st[3])
+        self.last_fps = (i1, i2, i3, i4)
+        f3 = self.fp4(xyz3, xyz4, f3, f4)
+        f2 = self.fp3(xyz2, xyz3, f2, f3)
+        f1 = self.fp2(xyz1, xyz2, f1, f2)
+        f0 = self.fp1(xyz0, xyz1, None, f1)                 # (B, N, 128)
+        if self._head is not None and not self.training:
+            B, N, _ = f0.shape
+            w, b = self._head
+            x = F.relu(torch.addmm(b, f0.reshape(B * N, -1), w.t()))
+            x = torch.addmm(self.conv2.bias, x, self.conv2.weight.reshape(self.conv2.weight.shape[0], -1).t()).view(B, N, -1)
+        else:
+            x = self.drop1(F.relu(self.bn1(self.conv1(f0.permute(0, 2, 1)))))
+            x = self.conv2(x).permute(0, 2, 1)
+        return F.log_softmax(x, dim=-1), f4.permute(0, 2, 1)
+
+
+def pc_normalize(pc):
+    """centroid + max-norm normalisation in the input dtype (pointnet2_utils.py:13-18)"""
+    import numpy as np
+    pc = pc - np.mean(pc, axis=0)
+    return pc / np.max(np.sqrt(np.sum(pc ** 2, axis=1)))

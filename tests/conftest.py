@@ -36,3 +36,29 @@ def make_oracle_tree(orc, g, iter_max=None):
     return orc.OracleTree(int(g["dim"]), int(iter_max if iter_max is not None else g["iter_max"]),
                           g["x_start"], g["x_goal"], float(g["step_len"]), float(g["search_radius"]),
                           float(g["clearance"]), g["env"])
+
+
+class FakePNG:
+    """Deterministic stand-in for the PointNet++ wrapper (same interface): a cloud point is a "path point"
+    iff it lies within `width` of the start-goal segment.  Used to pin the NIRRT* control flow (cloud
+    refresh rule, sampling mix, RNG consumption) against the reference independently of network weights."""
+
+    def __init__(self, x_start, x_goal, width=25.0):
+        self.a = np.asarray(x_start, dtype=np.float64)
+        self.b = np.asarray(x_goal, dtype=np.float64)
+        self.width = width
+        self.calls = 0
+
+    def classify_path_points(self, pc, start_mask, goal_mask):
+        self.calls += 1
+        p = np.asarray(pc, dtype=np.float64)
+        ab = self.b - self.a
+        t = np.clip(((p - self.a) @ ab) / (ab @ ab), 0, 1)
+        d = np.linalg.norm(p - (self.a + t[:, None] * ab), axis=1)
+        pred = (d < self.width).astype(np.int64)
+        return pred, (1.0 / (1.0 + d)).astype(np.float32)
+
+    def generate_connected_path_points(self, pc, x_start, x_goal, env_dict, neighbor_radius, max_trial_attempts,
+                                       visualize=False, vis_folderpath="", token=""):
+        pred, _ = self.classify_path_points(pc, None, None)
+        return True, 1, pred.astype(np.float32)

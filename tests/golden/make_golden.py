@@ -282,6 +282,113 @@ def run_planner(name, algo, dim, world_kind, world_seed, pair, iters, seed, trac
     print("   %s: n=%d path_len=%.6f  (%.1fs)" % (name, n, float(arrays["path_len"]), time.time() - t0))
 
 
+def nirrt_fixture(name, dim, connect, world_seed, iters, seed):
+    """L3: reference NIRRT*-PNG[(C)] whole run with a deterministic fake wrapper (tests/conftest.py FakePNG)
+    and OUR farthest-point restatement behind the open3d stub: pins update rule + sampling mix + RNG use."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    from conftest import FakePNG
+    if dim == 2:
+        from path_planning_classes.nirrt_star_png_2d import NIRRTStarPNG2D as P
+        from path_planning_classes.nirrt_star_png_c_2d import NIRRTStarPNGC2D as PC
+    else:
+        from path_planning_classes_3d.nirrt_star_png_3d import NIRRTStarPNG3D as P
+        from path_planning_classes_3d.nirrt_star_png_c_3d import NIRRTStarPNGC3D as PC
+    t0 = time.time()
+    pr, clearance = make_problem(dim, "b30", world_seed, 0)
+    w = FakePNG(pr["x_start"], pr["x_goal"], 25.0 if dim == 2 else 8.0)
+    common = [pr["x_start"], pr["x_goal"], STEP_LEN, pr["search_radius"], iters, pr["env_dict"], w]
+    tail = [clearance, 2048, 5, 0.5, 0.9]
+    if dim == 2:
+        common.append(pr["binary_mask"])
+    planner = (PC(*common, *tail, 5) if connect else P(*common, *tail))
+    samples = []
+    gen = planner.generate_random_node
+
+    def rec(*a, **k):
+        r = gen(*a, **k)
+        samples.append(np.array(r[0], dtype=np.float64))
+        return r
+
+    planner.generate_random_node = rec
+    np.random.seed(seed)
+    random.seed(seed)
+    with quiet():
+        planner.planning()
+    n = planner.num_vertices
+    path = np.array(planner.path, dtype=np.float64).reshape(-1, dim) if len(planner.path) else np.zeros((0, dim))
+    save(name, env=env_json(pr["env_dict"]), dim=np.array(dim), algo=np.array("nirrt_c" if connect else "nirrt"),
+         seed=np.array(seed), iter_max=np.array(iters), step_len=np.array(float(STEP_LEN)), clearance=np.array(float(clearance)),
+         search_radius=np.array(float(pr["search_radius"])), x_start=np.array(pr["x_start"], dtype=np.float64),
+         x_goal=np.array(pr["x_goal"], dtype=np.float64), n=np.array(n), vertices=planner.vertices[:n].copy(),
+         parents=planner.vertex_parents[:n].astype(np.int64), path=path, path_len=np.array(float(planner.get_path_len(planner.path))),
+         path_solutions=np.array(planner.path_solutions, dtype=np.int64), samples=np.array(samples),
+         png_calls=np.array(w.calls), binary_mask=(pr["binary_mask"].astype(np.uint8) if dim == 2 else np.zeros(0, np.uint8)))
+    print("   %s: n=%d path_len=%.4f png calls %d (%.1fs)" % (name, n, float(planner.get_path_len(planner.path)), w.calls, time.time() - t0))
+
+
+def pointnet2_fixture():
+    """L4: the reference PointNet++ (CPU, fp32) on a seeded cloud.  Weights = torch.manual_seed(seed) init
+    (regenerated by the test from the same seed - identical construction order) + the BatchNorm running
+    statistics saved here (calibrated by 4 train-mode forwards of the REFERENCE model)."""
+    import torch
+    from pointnet_pointnet2.models.pointnet2 import get_model as ref_get_model
+    from pointnet_pointnet2.models import pointnet2_utils as ref_utils
+    seed = 7
+    torch.manual_seed(seed)
+    model = ref_get_model(2)
+    rs = np.random.RandomState(seed)
+
+    def make_input(pc):
+        xyz = ref_utils.pc_normalize(pc)
+        s = (np.linalg.norm(pc - pc[0], axis=1) < 10).astype(np.float32)
+        g = (np.linalg.norm(pc - pc[1], axis=1) < 10).astype(np.float32)
+        feat = np.stack([s, g, 1 - ((s + g) > 0).astype(np.float32)], axis=-1)
+        return torch.from_numpy(np.concatenate([xyz, feat], axis=1).astype(np.float32)).permute(1, 0).unsqueeze(0)
+
+    model.train()
+    with torch.no_grad():
+        for _ in range(4):
+            pc = rs.uniform(0, 224, size=(2048, 3)).astype(np.float32)
+            pc[:, 2] = 0
+            model(make_input(pc))
+    model.eval()
+    bn = {k: v.numpy().copy() for k, v in model.state_dict().items() if "running_" in k}
+    # test cloud: a free-space cloud of world 0 (2D, z = 0), reference FPS starts recorded
+    ed = worlds.random_world_2d(0, "b30")
+    pr = worlds.problem_2d(ed, 0)
+    rs2 = np.random.RandomState(11)
+    cand = rs2.uniform(0, 224, size=(6000, 2))
+    free = pr["binary_mask"][np.clip(cand[:, 1].astype(int), 0, 223), np.clip(cand[:, 0].astype(int), 0, 223)] > 0
+    pc2 = cand[free][:2048].astype(np.float32)
+    pc = np.concatenate([pc2, np.zeros((2048, 1), np.float32)], axis=1)
+    xs, xg = np.array(pr["x_start"], np.float32), np.array(pr["x_goal"], np.float32)
+    s = (np.linalg.norm(pc2 - xs, axis=1) < 10).astype(np.float32)
+    g = (np.linalg.norm(pc2 - xg, axis=1) < 10).astype(np.float32)
+    feat = np.stack([s, g, 1 - ((s + g) > 0).astype(np.float32)], axis=-1)
+    x = torch.from_numpy(np.concatenate([ref_utils.pc_normalize(pc), feat], axis=1).astype(np.float32)).permute(1, 0).unsqueeze(0)
+    fps_log = []
+    orig = ref_utils.farthest_point_sample
+
+    def rec(xyz, npoint):
+        r = orig(xyz, npoint)
+        fps_log.append(r[0].numpy().copy())
+        return r
+
+    ref_utils.farthest_point_sample = rec
+    torch.manual_seed(123)
+    with torch.no_grad():
+        logp, l4 = model(x)
+    ref_utils.farthest_point_sample = orig
+    out = {"seed": np.array(seed), "input": x.numpy(), "logp": logp.numpy(), "l4": l4.numpy(), "pc": pc2,
+           "start_mask": s, "goal_mask": g}
+    for i, f in enumerate(fps_log):
+        out["fps%d" % i] = f.astype(np.int32)
+    for k, v in bn.items():
+        out["bn::" + k] = v
+    save("pointnet2_ref", **out)
+    print("   pointnet2_ref: predicted path points %d / 2048" % int((logp.numpy()[0].argmax(-1) == 1).sum()))
+
+
 JOBS = {
     "geom2d": geom2d,
     "geom3d": geom3d,
@@ -297,6 +404,10 @@ JOBS = {
     "random_rrt2d": lambda: run_planner("random_rrt2d", "rrt", 2, "ref2d", 4, 0, 5000, 1004, mode="random", iter_after_initial=300),
     "random_irrt2d": lambda: run_planner("random_irrt2d", "irrt", 2, "ref2d", 4, 0, 5000, 1004, mode="random", iter_after_initial=300),
     "random_rrt3d": lambda: run_planner("random_rrt3d", "rrt", 3, "ref3d", 3, 0, 5000, 1003, mode="random", iter_after_initial=300),
+    "pointnet2_ref": pointnet2_fixture,
+    "run_nirrt2d_1500": lambda: nirrt_fixture("run_nirrt2d_1500", 2, False, 9, 1500, 1009),
+    "run_nirrtc2d_1500": lambda: nirrt_fixture("run_nirrtc2d_1500", 2, True, 10, 1500, 1010),
+    "run_nirrt3d_1500": lambda: nirrt_fixture("run_nirrt3d_1500", 3, False, 4, 1500, 1004),
     "random_irrt3d": lambda: run_planner("random_irrt3d", "irrt", 3, "ref3d", 3, 0, 5000, 1003, mode="random", iter_after_initial=300),
 }
 

@@ -28,7 +28,18 @@ def install():
     sys.modules.setdefault("cv2", types.ModuleType("cv2"))
     if "open3d" not in sys.modules:
         o3d = types.ModuleType("open3d")
-        o3d.geometry = types.SimpleNamespace()
-        o3d.utility = types.SimpleNamespace()
+
+        class _PC:   # stand-in for open3d.geometry.PointCloud: FPS delegated to OUR restatement
+            def __init__(self):
+                self.points = None
+
+            def farthest_point_down_sample(self, num_samples):
+                from nirrt_star_amd.pointcloud import farthest_point_down_sample
+                out = _PC()
+                out.points = farthest_point_down_sample(self.points, num_samples)
+                return out
+
+        o3d.geometry = types.SimpleNamespace(PointCloud=_PC)
+        o3d.utility = types.SimpleNamespace(Vector3dVector=lambda a: a)
         sys.modules["open3d"] = o3d
     return REF

