@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — RRT*-family iterations/s while growing 50k-node trees on random_2d (BASELINE.json).
 
-One "step" = one pass of the hot path over one batch: B independent planning problems
-(224x224 world, 30 circle obstacles, clearance 3, step_len 10), each grown for `--iters`
-iterations (default 50 000) by the device-resident loop (one persistent workgroup per tree).
-N GPUs = N processes (torch.distributed / RCCL), each with its own B problems (weak scaling); the
-only collective is the barrier / max-time reduction of the timing protocol and a gather of the
-per-rank iteration counts.
+Workload (BASELINE.json configs[1]): `irrt_star random_2d, 50k iters`, batched on one MI355X:
+B independent planning problems (224x224 world, 30 circle obstacles, clearance 3, step_len 10), each
+planned for `--iters` iterations (default 50 000) by the device-resident loop - ONE persistent
+workgroup per tree; sampling (SampleFree, then informed once a solution exists), nearest, steer,
+collision, Near, choose-parent, rewire, goal bookkeeping and best-solution tracking all happen in the
+kernel.  `--algo rrt` runs plain RRT* on the same problems (uniform sampling, no solution tracking).
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     — HBM roofline of the persistent kernel: algorithmic bytes (vertices streamed by the
-                 nearest + Near passes x dim x 8 B, counted exactly inside the kernel) / HIP-event time
-  cpu_baseline — the oracle (oracle/nirrt_oracle.c, a C port of the reference loop) timed on this
-                 box's host cores on ONE of the same problems (bounded sample)
+One "step" = one pass of that loop over the whole batch (B x iters iterations), starting from fresh
+one-vertex trees.  Inputs (the raw MT19937 outputs of each problem's seeded numpy / python generators)
+are resident in HBM before the timed region.  N GPUs = N processes (torch.distributed / RCCL), each
+with its own B problems (weak scaling); the only collectives are the timing protocol's barrier /
+max-reduce and a gather of per-rank iteration counts.
+
+Prints ONE JSON line (rank 0): the driver's contract fields plus
+  roofline     — HBM roofline of the persistent kernel: algorithmic bytes (vertices streamed by the nearest
+                 + Near passes x dim x 8 B, counted exactly in the kernel) / HIP-event kernel time
+  cpu_baseline — the oracle (oracle/nirrt_oracle.c, C port of the reference loop incl. sampling) on this
+                 box's host, 1 core, on problem 0 of the same batch for a bounded time
+  time_to_first_solution — iterations / seconds until c_best first becomes finite (median over the batch)
 """
 import argparse
 import json
 import os
+import random
 import sys
 import time
 
@@ -26,7 +34,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.3 TB/s achievable)
-REF_CONTAINER_ITS = 153.0  # reference numpy path, 50k iters 2D, survey container - context only
+REF_PY = {"rrt": 153.0, "irrt": 43.0}  # reference numpy path in the survey container: context only
 
 
 def parse():
@@ -37,57 +45,43 @@ def parse():
     ap.add_argument("--trees", type=int, default=1024, help="problems per GPU per step")
     ap.add_argument("--iters", type=int, default=50000, help="planner iterations per problem (tree capacity)")
     ap.add_argument("--dim", type=int, default=2)
-    ap.add_argument("--algo", default="rrt", choices=["rrt"])
+    ap.add_argument("--algo", default="irrt", choices=["irrt", "rrt"])
     ap.add_argument("--world", default="b30")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--traffic-gb", type=float, default=None, help="HBM bytes per launch from a separate rocprofv3 --pmc run")
     return ap.parse_args()
 
 
 def make_problems(args, rank):
-    """B problems for this rank: world seeds are global problem ids, planner
-    seeds 1000+i drive SampleFree (rrt_base_2d.py:46-52) exactly like the reference would."""
+    """B problems for this rank: worlds 0..249 x 4 start/goal pairs = the 1000-problem evaluation set of
+    SURVEY.md §8d (wrapping around for larger batches); planner seed = 1000 + problem id."""
     from nirrt_star_amd import worlds
-    probs = []
-    cache = {}
+    probs, cache = [], {}
     for b in range(args.trees):
         pid = rank * args.trees + b
         if args.dim == 2:
-            if pid % 250 not in cache:
-                cache[pid % 250] = worlds.random_world_2d(pid % 250, args.world)
-            ed = cache[pid % 250]
-            pr = worlds.problem_2d(ed, (pid // 250) % 4)
+            w = pid % 250
+            if w not in cache:
+                cache[w] = worlds.random_world_2d(w, args.world)
+            pr = worlds.problem_2d(cache[w], (pid // 250) % 4)
             pr["clearance"] = 3
         else:
-            ed = worlds.random_world_3d(pid % 1000)
             np.random.seed(pid)
-            pr = worlds.problem_3d(ed)
+            pr = worlds.problem_3d(worlds.random_world_3d(pid % 1000))
             pr["clearance"] = 2
         pr["pid"] = pid
         probs.append(pr)
     return probs
 
 
-def sample_free_sequence(pr, dim, iters, seed, inside_fn):
-    """The node_rand sequence RRT*'s SampleFree produces for np.random.seed(seed): uniform draws in
-    the clearance-shrunk range, x then y [then z] per attempt, rejected while inside an inflated
-    obstacle.  Vectorised in blocks - the legacy stream is identical to scalar draws."""
-    rs = np.random.RandomState(seed)
-    c = pr["clearance"]
-    env = pr["env"]
-    lo = np.array([env.x_range[0] + c, env.y_range[0] + c] + ([env.z_range[0] + c] if dim == 3 else []), dtype=np.float64)
-    hi = np.array([env.x_range[1] - c, env.y_range[1] - c] + ([env.z_range[1] - c] if dim == 3 else []), dtype=np.float64)
-    out = np.zeros((iters, dim))
-    got = 0
-    while got < iters:
-        m = int((iters - got) * 1.6) + 64
-        u = rs.random_sample(m * dim).reshape(m, dim)
-        cand = lo + (hi - lo) * u
-        keep = cand[~inside_fn(cand)]
-        take = min(len(keep), iters - got)
-        out[got:got + take] = keep[:take]
-        got += take
-    return out
+def word_budgets(args):
+    D, it = args.dim, args.iters
+    if args.algo == "rrt":
+        return it * D * 2 * 2 + 4096, 0
+    if D == 2:
+        return it * 6 + 4096, it * 14 + 4096     # SampleFree until the first solution, then python-random unit disk
+    return it * 6 * 40 + 4096, 0                 # 3D informed sampling stays on the numpy stream
 
 
 def main():
@@ -104,18 +98,33 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from nirrt_star_amd import _hip, build
+    from nirrt_star_amd import _hip, build, sampling
     build.build()
 
     probs = make_problems(args, rank)
     D, B, iters = args.dim, args.trees, args.iters
-    trees = [_hip.HipTree(D, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"],
-                          device_id=local_rank) for pr in probs]
-    # inputs: pre-drawn SampleFree sequences, resident in HBM before the timed region
-    samples = np.zeros((B, iters, D))
-    for b, (pr, t) in enumerate(zip(probs, trees)):
-        samples[b] = sample_free_sequence(pr, D, iters, 1000 + pr["pid"], lambda p, t=t: t.points_in_obs(p)[0].astype(bool))
-    d_samples = torch.from_numpy(samples).to("cuda:%d" % local_rank)
+    flags = _hip.F_IRRT if args.algo == "irrt" else 0
+    trees = []
+    for pr in probs:
+        t = _hip.HipTree(D, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"],
+                         device_id=local_rank)
+        t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
+        trees.append(t)
+    # inputs: each problem's generator outputs (np.random.seed(s); random.seed(s)), resident in HBM
+    n_np, n_py = word_budgets(args)
+    h_np = np.empty((B, n_np), dtype=np.uint32)
+    h_py = np.empty((B, max(n_py, 1)), dtype=np.uint32)
+    for b, pr in enumerate(probs):
+        np.random.seed(1000 + pr["pid"])
+        random.seed(1000 + pr["pid"])
+        h_np[b] = sampling.peek_np_words(n_np)
+        if n_py:
+            h_py[b] = sampling.peek_py_words(n_py)
+    dev = "cuda:%d" % local_rank
+    d_np = torch.from_numpy(h_np.view(np.int32)).to(dev)
+    d_py = torch.from_numpy(h_py.view(np.int32)).to(dev)
+    np_tab = [(d_np.data_ptr() + 4 * n_np * b, n_np) for b in range(B)]
+    py_tab = [(d_py.data_ptr() + 4 * h_py.shape[1] * b, n_py) for b in range(B)] if n_py else None
     torch.cuda.synchronize()
 
     def barrier():
@@ -124,75 +133,103 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_step():
+    def one_step(want_trace=False):
         for t in trees:
             t.reset()
-        return _hip.run_replay(trees, None, flags=0, device_ptr=d_samples.data_ptr(), iters=iters)
+        return _hip.run_sampling(trees, iters, np_tab, py_tab, flags=flags, want_trace=want_trace, on_device=True)
 
     for _ in range(args.warmup):
         one_step()
-    kernel_ms, scan_elems, n_final = [], [], []
+    kernel_ms, scan_elems, done_iters = [], [], []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         r = one_step()
         kernel_ms.append(r["kernel_ms"])
         scan_elems.append(int(r["scan_elems"].sum()))
-        assert not r["status"].any() and (r["iters_done"] == iters).all()
+        done_iters.append(int(r["iters_done"].sum()))
     barrier()
     elapsed = time.perf_counter() - t0
     n_final = [t.n for t in trees]
+    n_sol = [len(trees[b].solutions) for b in range(0, B, max(1, B // 16))]
+    short = int((r["iters_done"] < iters).sum())
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([elapsed, float(sum(done_iters))], dtype=torch.float64, device="cuda")
     if world > 1:
+        tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed_max = float(tmax.item())
-    total_iters = world * args.steps * B * iters
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed_max, total_iters = float(tmax[0].item()), float(tot[1].item())
+    else:
+        elapsed_max, total_iters = elapsed, float(sum(done_iters))
     value = total_iters / elapsed_max
 
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
         alg_bytes = float(np.mean(scan_elems)) * D * 8.0
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        # time to first solution (untimed extra pass over a slice of the batch, with the per-iteration trace)
+        sub = list(range(0, B, max(1, B // 64)))
+        for b in sub:
+            trees[b].reset()
+        tr = _hip.run_sampling([trees[b] for b in sub], min(iters, 5000), [np_tab[b] for b in sub],
+                               [py_tab[b] for b in sub] if py_tab else None, flags=flags | _hip.F_GOAL_SCAN * (args.algo == "rrt"),
+                               want_trace=True, on_device=True)
+        first = np.array([int(np.argmax(np.isfinite(c))) + 1 if np.isfinite(c).any() else -1 for c in tr["cost_trace"]])
+        found = first[first > 0]
+        ttfs_it = float(np.median(found)) if len(found) else None
+        ttfs_s = (ttfs_it / min(iters, 5000)) * tr["kernel_ms"] * 1e-3 if ttfs_it else None   # resident loop, batch running concurrently
         out = {
-            "metric": "RRT* iters/sec (50k-node tree), random_2d" if D == 2 else "RRT* iters/sec (50k-node tree), random_3d",
+            "metric": "RRT* iters/sec (50k-node tree), random_%dd" % D,
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s_star random_%dd %s, %d problems/GPU x %d iters, device-resident batched loop"
-                                   % (args.algo, D, args.world, B, iters),
-                       "trees_per_gpu": B, "iters": iters, "dim": D, "step_len": 10, "obstacles": "30 circles r in [8,12]"
-                       if args.world == "b30" else args.world,
-                       "mean_final_vertices": float(np.mean(n_final)),
-                       "per_tree_iters_per_s": B * iters / (k_ms * 1e-3) / B},
+            "config": {"workload": "%s_star random_%dd (%s: 224x224, 30 circle obstacles), %d problems/GPU x %d iters, "
+                                   "device-resident batched loop with in-kernel sampling" % (args.algo, D, args.world, B, iters)
+                       if D == 2 else "%s_star random_3d, %d problems/GPU x %d iters" % (args.algo, B, iters),
+                       "trees_per_gpu": B, "iters": iters, "dim": D, "step_len": 10, "clearance": probs[0]["clearance"],
+                       "mean_final_vertices": float(np.mean(n_final)), "mean_solutions_per_tree": float(np.mean(n_sol)),
+                       "trees_stopped_early": short,
+                       "per_tree_iters_per_s": iters / (k_ms * 1e-3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_run_replay<%d>" % D, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
-            "reference_python_survey_container_its": REF_CONTAINER_ITS,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": args.traffic_gb * 1e9 if args.traffic_gb else None,
+                         "kernel": "k_run_sample<%d>" % D, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "time_to_first_solution": {"median_iterations": ttfs_it, "median_seconds_in_batch": ttfs_s,
+                                       "problems": len(sub), "solved_within_%d" % min(iters, 5000): int(len(found))},
+            "reference_python_survey_container_its": REF_PY[args.algo],
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, probs[0], samples[0])
+            out["cpu_baseline"] = cpu_baseline(args, probs[0], h_np[0], h_py[0] if n_py else None)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, pr, samples):
-    """The oracle (C port of the reference loop) on problem 0 of this very batch, 1 host core,
-    for at most --cpu-budget-s seconds (chunks of 2500 iterations)."""
+def cpu_baseline(args, pr, npw, pyw):
+    """The oracle (C port of the reference loop, incl. sampling and the reference's un-cached
+    find_best_path_solution) on problem 0 of this very batch: 1 host core, at most --cpu-budget-s."""
+    from nirrt_star_amd import sampling
     from oracle import oracle as orc
     orc.build()
     o = orc.OracleTree(args.dim, args.iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env_dict"])
-    done, t0 = 0, time.perf_counter()
+    frame = sampling.informed_frame(pr["x_start"], pr["x_goal"])
+    done, np_pos, py_pos, t0 = 0, 0, 0, time.perf_counter()
+    chunk = 1000
     while done < args.iters and time.perf_counter() - t0 < args.cpu_budget_s:
-        o.replay(samples[done:done + 2500], False)
-        done += 2500
+        r = o.run_sampling(min(chunk, args.iters - done), npw[np_pos:], pyw[py_pos:] if pyw is not None else None,
+                           irrt=args.algo == "irrt", frame=frame)
+        if r["iters_done"] == 0:
+            break
+        done += r["iters_done"]
+        np_pos += r["np_used"]
+        py_pos += r["py_used"]
     dt = time.perf_counter() - t0
-    done = min(done, args.iters)
     return {"value": done / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": "problem 0 of the batch, first %d of %d iterations (tree grown to %d vertices) in %.1f s; "
-                      "the CPU rate falls as the tree grows, so a truncated sample flatters the CPU" % (done, args.iters, o.n, dt)}
+            "sample": "problem 0 of the batch, first %d of %d iterations (tree grown to %d vertices, %d solutions) in %.1f s; "
+                      "the CPU rate falls as the tree grows, so a truncated sample flatters the CPU"
+                      % (done, args.iters, o.n, len(o.solutions), dt)}
 
 
 if __name__ == "__main__":

@@ -328,30 +328,38 @@ def run_replay(trees, samples, flags=0, want_trace=False, device_ptr=None, iters
     return {"iters_done": done, "status": status, "kernel_ms": ms.value, "cost_trace": trace, "scan_elems": scan}
 
 
-def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=False):
+def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=False, on_device=False):
     """Device-resident loop with in-kernel sampling.  np_words / py_words: per-tree uint32 arrays of
-    raw MT19937 outputs (numpy legacy global stream / python `random`).  Returns dict with
-    iters_done, np_used, py_used (words consumed), status (0 | E_STREAM | E_CAPACITY), kernel_ms,
-    cost_trace, scan_elems."""
+    raw MT19937 outputs (numpy legacy global stream / python `random`); with on_device=True they are
+    per-tree (device_address, n_words) pairs of buffers already resident in HBM (e.g. slices of a
+    torch.cuda tensor).  Returns dict with iters_done, np_used, py_used (words consumed), status
+    (0 | E_STREAM | E_CAPACITY), kernel_ms, cost_trace, scan_elems."""
     L = load()
     nt = len(trees)
     handles = (C.c_void_p * nt)(*[t.h for t in trees])
     u32p = C.POINTER(C.c_uint32)
-    npw = [np.ascontiguousarray(w, dtype=np.uint32) for w in np_words]
-    np_ptrs = (u32p * nt)(*[w.ctypes.data_as(u32p) for w in npw])
-    n_np = np.array([len(w) for w in npw], dtype=np.int64)
+    keep = []
+
+    def table(words):
+        if on_device:
+            ptrs = (u32p * nt)(*[C.cast(C.c_void_p(int(p)), u32p) for p, _ in words])
+            cnt = np.array([int(c) for _, c in words], dtype=np.int64)
+        else:
+            arrs = [np.ascontiguousarray(w, dtype=np.uint32) for w in words]
+            keep.append(arrs)
+            ptrs = (u32p * nt)(*[w.ctypes.data_as(u32p) for w in arrs])
+            cnt = np.array([len(w) for w in arrs], dtype=np.int64)
+        keep.append((ptrs, cnt))
+        return C.cast(ptrs, C.POINTER(u32p)), _ip(cnt)
+
     a = RunArgs()
     a.flags = int(flags)
+    a.inputs_on_device = 1 if on_device else 0
     a.iters = int(iters)
     a.samples = None
-    a.np_words = C.cast(np_ptrs, C.POINTER(u32p))
-    a.n_np = _ip(n_np)
+    a.np_words, a.n_np = table(np_words)
     if py_words is not None:
-        pyw = [np.ascontiguousarray(w, dtype=np.uint32) for w in py_words]
-        py_ptrs = (u32p * nt)(*[w.ctypes.data_as(u32p) for w in pyw])
-        n_py = np.array([len(w) for w in pyw], dtype=np.int64)
-        a.py_words = C.cast(py_ptrs, C.POINTER(u32p))
-        a.n_py = _ip(n_py)
+        a.py_words, a.n_py = table(py_words)
     done = np.zeros(nt, dtype=np.int64)
     np_used = np.zeros(nt, dtype=np.int64)
     py_used = np.zeros(nt, dtype=np.int64)

@@ -11,8 +11,11 @@
 //     which keeps the scans HBM-bound while every decision stays bit-identical to the reference.
 //     Reductions: wave64 __shfl_xor butterflies, then one LDS step across waves.
 //     Near hits are staged in index order with wave ballots (no atomics, no sort).
-//   * O(k) work (fan of segment tests, cost walks, choose-parent, rewire) is lane-parallel; walks
-//     chase one 16-byte {edge_len, parent, mark} record per hop.
+//   * O(k) work (fan of segment tests, choose-parent, rewire) is lane-parallel.
+//   * cost(v) is the reference's leaf->root sum (math.hypot per edge, added in that order).  It is kept
+//     EXACT in a per-vertex cache: a walk chases one 16-byte {edge_len, parent} record per hop, and a
+//     re-parented vertex has its whole subtree (child / sibling links) re-walked right away, so every
+//     cost the loop compares is the value the reference's un-cached cost() would return.
 //
 // Arithmetic: float64, compiled with -ffp-contract=off; per-call-site formulas of SURVEY.md App. A:
 //   np.hypot -> hypot_np()   math.hypot -> hypot_py<D>()   np.linalg.norm(axis) -> norm_axis<D>()
@@ -25,7 +28,6 @@
 
 #define MAX_OBS NIRRT_MAX_OBSTACLES
 #define SCAN_PAD 256     // extra elements allocated behind every per-vertex array (vector loads may overrun n)
-#define ANC_MAX 3        // marked ancestors remembered per neighbour (more -> "overflow": always re-walk)
 #define WALK_R 4         // parent chains chased concurrently per lane
 
 // optional per-phase cycle accounting (build with -DNIRRT_PROFILE; scripts/perf_phases.py reads prof[])
@@ -48,40 +50,40 @@
 struct __attribute__((aligned(16))) Aux {
     double elen;  // math.hypot(v - v_parent): the term cost() adds for this vertex (0 for the root)
     int parent;
-    int mark;     // == current iteration stamp  <=>  vertex is in the current Near set
+    int pad;
 };
 
 struct TreeDev {
     double *c[3];   // SoA coordinates x[cap], y[cap], z[cap]
     Aux *aux;       // aux[cap]
-    int *rank_of;   // rank in the current Near set (valid where aux.mark == stamp)
+    double *cost;   // cost[cap]: exact cost(v) of the CURRENT tree (see walk_chains / wg_recost_subtree)
+    int *first_child, *next_sib, *prev_sib;   // child lists (-1 = none); the root is nobody's child
+    int *bfs_q;     // scratch queue for subtree traversals
     int cap;
     int n;          // num_vertices
     int dim;
     int status;     // sticky NIRRT_E_* code
-    int stamp;      // iteration stamp for aux.mark (monotonic, never 0)
+    int stamp;      // iterations executed (diagnostic)
     int pad0;
     long long scan_elems;  // vertices streamed by nearest + Near passes (roofline accounting)
     // Near-set working arrays (capacity cap: a Near set can never exceed the tree)
     int *st_idx;     // ordered staging of scan hits, one region per wave segment
     int *nr_idx;     // neighbour vertex index, ascending
     int *nr_flag;    // segment (new -> neighbour) hits an obstacle
-    int *nr_anc;     // [4*j]: count (ANC_MAX+1 = overflow), [4*j+1..3]: ranks of marked ancestors
     double *nr_dist; // scan distance new <-> neighbour (np.hypot / axis norm)
-    double *nr_c0;   // cost(neighbour)
-    double *nr_c1;   // cost(new) if parent[new] were this neighbour
+    double *nr_c0;   // scratch: candidate x during the Near phase
+    double *nr_c1;   // scratch: candidate y during the Near phase
     // IRRT*: path_solutions (goal-parent indices, duplicates allowed) + cached costs
     int *sol;
-    double *sol_cost;
+    double *sol_line;   // Line(v, goal) of each solution vertex (static)
     int n_sol;
     int cap_sol;
-    int sol_dirty;   // some parent changed since sol_cost[] was computed
+    int sol_dirty;   // some parent changed since sol_best was computed
     int sol_best;    // argmin position in sol[] (first minimum), -1 if none
     double sol_best_cost;
     // RRT*: vertices within step_len of the goal (ascending index), distance, segment test result
     int *gc_idx;
     double *gc_dist;
-    double *gc_cost;
     unsigned char *gc_col;
     int n_gc;
     int gc_dirty;
@@ -632,21 +634,13 @@ __device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, c
     return gi;
 }
 
-// chase parent chains leaf -> root (RRTBase.cost).  Up to WALK_R chains per lane are walked
-// concurrently so that their dependent 16-byte loads overlap.
-//   idx[r] < 0: inactive slot.  acc0[r] += every edge; acc1[r] likewise (caller pre-loads e(new, idx)).
-//   If anc != nullptr: anc[r][0] = number of marked ancestors met (capped ANC_MAX+1), anc[r][1..] their ranks.
+// chase parent chains leaf -> root (RRTBase.cost, rrt_base_2d.py:54-61): acc = 0; acc += elen[v]; v = parent[v] ...
+// Up to WALK_R chains per lane are walked concurrently so that their dependent 16-byte loads overlap.
+// idx[r] <= 0: inactive slot (the root costs 0).
 template <int D>
-__device__ __forceinline__ void walk_chains(const TreeDev &t, int (&idx)[WALK_R], double (&acc0)[WALK_R],
-                                            double (&acc1)[WALK_R], int (*anc)[ANC_MAX + 1], int stamp)
+__device__ __forceinline__ void walk_chains(const TreeDev &t, int (&idx)[WALK_R], double (&acc)[WALK_R])
 {
-    bool first[WALK_R];
     int guard = t.cap + 1;
-#pragma unroll
-    for (int r = 0; r < WALK_R; r++) {
-        first[r] = true;
-        if (anc) anc[r][0] = 0;
-    }
     for (;;) {
         bool any = false;
 #pragma unroll
@@ -659,26 +653,14 @@ __device__ __forceinline__ void walk_chains(const TreeDev &t, int (&idx)[WALK_R]
 #pragma unroll
         for (int r = 0; r < WALK_R; r++) {
             if (idx[r] > 0) {
-                if (anc && !first[r] && a[r].mark == stamp) {
-                    int c = anc[r][0];
-                    if (c < ANC_MAX) {
-                        int rk = t.rank_of[idx[r]];
-#pragma unroll
-                        for (int cc = 0; cc < ANC_MAX; cc++)
-                            if (c == cc) anc[r][1 + cc] = rk;
-                    }
-                    anc[r][0] = c < ANC_MAX + 1 ? c + 1 : c;
-                }
-                first[r] = false;
-                acc0[r] += a[r].elen;
-                acc1[r] += a[r].elen;
+                acc[r] += a[r].elen;
                 idx[r] = a[r].parent;
             }
         }
     }
 }
 
-// single chain, plain cost
+// single chain
 template <int D>
 __device__ __forceinline__ double walk_cost(const TreeDev &t, int i)
 {
@@ -690,6 +672,65 @@ __device__ __forceinline__ double walk_cost(const TreeDev &t, int i)
         i = a.parent;
     }
     return acc;
+}
+
+// child-list maintenance (one thread)
+__device__ __forceinline__ void link_child(TreeDev &t, int v, int p)
+{
+    int f = t.first_child[p];
+    t.next_sib[v] = f;
+    t.prev_sib[v] = -1;
+    if (f >= 0) t.prev_sib[f] = v;
+    t.first_child[p] = v;
+}
+__device__ __forceinline__ void unlink_child(TreeDev &t, int v, int p)
+{
+    int nx = t.next_sib[v], pv = t.prev_sib[v];
+    if (pv >= 0) t.next_sib[pv] = nx; else t.first_child[p] = nx;
+    if (nx >= 0) t.prev_sib[nx] = pv;
+}
+
+// vertex v was just re-parented (aux[v] already updated, child lists already relinked): refresh the
+// exact cost of v and of every vertex below it.  Breadth-first over the child lists into bfs_q, then
+// one full leaf->root walk per collected vertex (WALK_R chains per lane).
+template <int D, int NT>
+__device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v)
+{
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid == 0) { t.bfs_q[0] = v; s.bc_i[4] = 1; }
+    __syncthreads();
+    int head = 0, tail = 1;
+    while (head < tail) {   // one BFS level per trip; uniform
+        for (int i = head + tid; i < tail; i += NT) {
+            int c = t.first_child[t.bfs_q[i]];
+            while (c >= 0) {
+                int pos = atomicAdd(&s.bc_i[4], 1);
+                t.bfs_q[pos] = c;
+                c = t.next_sib[c];
+            }
+        }
+        __syncthreads();
+        head = tail;
+        tail = s.bc_i[4];
+        __syncthreads();
+    }
+    for (int base = 0; base < tail; base += NT * WALK_R) {
+        int idx[WALK_R], who[WALK_R];
+        double acc[WALK_R];
+#pragma unroll
+        for (int r = 0; r < WALK_R; r++) {
+            int i = base + r * NT + tid;
+            who[r] = i < tail ? t.bfs_q[i] : -1;
+            idx[r] = who[r];
+            acc[r] = 0.;
+        }
+        walk_chains<D>(t, idx, acc);
+#pragma unroll
+        for (int r = 0; r < WALK_R; r++)
+            if (who[r] >= 0) t.cost[who[r]] = acc[r];
+    }
+    __syncthreads();
 }
 
 // steer (new_state).  2D: rrt_star_2d.py:67-78, device atan2/cos/sin; 3D: rrt_star_3d.py:67-78, IEEE only.
@@ -727,10 +768,9 @@ __device__ __forceinline__ bool wg_collision(const Lds<NT> &s, const double *a, 
 }
 
 // Near set of node_new on the current tree (find_near_neighbors, rrt_star_2d.py:125-144).
-// On return t.nr_idx[0..k) ascending, t.nr_dist[0..k) the reference scan distances, and every
-// member carries aux.mark = stamp, rank_of = its rank.  Returns k.
+// On return t.nr_idx[0..k) ascending and t.nr_dist[0..k) the reference scan distances.  Returns k.
 template <int D, int NT>
-__device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const double *node_new, int new_idx, int stamp)
+__device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const double *node_new, int new_idx)
 {
     constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
@@ -848,68 +888,18 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
         k += tot;
     }
     __syncthreads();
-    // reference distances of the survivors + Near-set marks
+    // reference distances of the survivors
     for (int a = tid; a < k; a += NT) {
-        int vi = t.nr_idx[a];
         double d[3] = {node_new[0] - cx[a], node_new[1] - cy[a], D == 3 ? node_new[D - 1] - cz[a] : 0.};
         t.nr_dist[a] = dist_scan<D>(d);
-        t.aux[vi].mark = stamp;
-        t.rank_of[vi] = a;
     }
     __syncthreads();
     return k;
 }
 
-// walk phase of one iteration: cost(j) and cost-of-new-via-j for every neighbour j < k, plus the
-// same for `extra` (the nearest vertex) stored at slot k.
-template <int D, int NT>
-__device__ __forceinline__ void wg_walk_neighbours(TreeDev &t, int k, int extra, const double *node_new, int stamp,
-                                                   int from_rank, bool with_c1)
-{
-    const int tid = threadIdx.x;
-    const int total = k + (extra >= 0 ? 1 : 0);
-    for (int base = from_rank; base < total; base += NT * WALK_R) {
-        int idx[WALK_R], slot[WALK_R];
-        double acc0[WALK_R], acc1[WALK_R];
-        int anc[WALK_R][ANC_MAX + 1];
-#pragma unroll
-        for (int r = 0; r < WALK_R; r++) {
-            int a = base + r * NT + tid;
-            slot[r] = a < total ? a : -1;
-            idx[r] = -1;
-            acc0[r] = 0.;
-            acc1[r] = 0.;
-            if (a < total) {
-                int vi = a < k ? t.nr_idx[a] : extra;
-                idx[r] = vi;
-                if (with_c1) {
-                    double v[D], d[D];
-                    load_vertex<D>(t, vi, v);
-#pragma unroll
-                    for (int c = 0; c < D; c++) d[c] = node_new[c] - v[c];
-                    acc1[r] = hypot_py<D>(d);
-                }
-            }
-        }
-        walk_chains<D>(t, idx, acc0, acc1, anc, stamp);
-#pragma unroll
-        for (int r = 0; r < WALK_R; r++) {
-            int a = slot[r];
-            if (a >= 0) {
-                t.nr_c0[a] = acc0[r];
-                if (with_c1) t.nr_c1[a] = acc1[r];
-                if (a < k) {
-                    t.nr_anc[4 * a] = anc[r][0];
-#pragma unroll
-                    for (int c = 0; c < ANC_MAX; c++) t.nr_anc[4 * a + 1 + c] = anc[r][1 + c];
-                }
-            }
-        }
-    }
-}
-
-// find_best_path_solution (irrt_star_2d.py:84-97) with exact caching: the per-solution costs only
-// change when some parent changed (sol_dirty); otherwise only solutions appended since are new.
+// find_best_path_solution (irrt_star_2d.py:84-97): argmin_s cost(sol[s]) + Line(v_s, goal), first minimum.
+// The costs come from the exact cache; the argmin is only redone when some parent changed (sol_dirty),
+// a solution appended in between competes with the standing minimum (strict <, so the first minimum stays).
 template <int D, int NT>
 __device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double &c_best, int &x_best)
 {
@@ -919,31 +909,9 @@ __device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double 
     if (t.sol_dirty) {   // uniform
         double bv = __builtin_inf();
         int bs = 0x7fffffff;
-        for (int base = 0; base < ns; base += NT * WALK_R) {   // WALK_R chains in flight per lane
-            int idx[WALK_R], q[WALK_R];
-            double acc0[WALK_R], acc1[WALK_R], line[WALK_R];
-#pragma unroll
-            for (int r = 0; r < WALK_R; r++) {
-                q[r] = base + r * NT + tid;
-                idx[r] = -1; acc0[r] = 0.; acc1[r] = 0.; line[r] = 0.;
-                if (q[r] < ns) {
-                    idx[r] = t.sol[q[r]];
-                    double v[D], d[D];
-                    load_vertex<D>(t, idx[r], v);
-#pragma unroll
-                    for (int k = 0; k < D; k++) d[k] = t.goal[k] - v[k];
-                    line[r] = hypot_py<D>(d);
-                }
-            }
-            walk_chains<D>(t, idx, acc0, acc1, nullptr, 0);
-#pragma unroll
-            for (int r = 0; r < WALK_R; r++) {
-                if (q[r] < ns) {
-                    double c = acc0[r] + line[r];
-                    t.sol_cost[q[r]] = c;
-                    if (c < bv || (c == bv && q[r] < bs)) { bv = c; bs = q[r]; }
-                }
-            }
+        for (int q = tid; q < ns; q += NT) {
+            double c = t.cost[t.sol[q]] + t.sol_line[q];
+            if (c < bv) { bv = c; bs = q; }
         }
         block_argmin<NT>(s, bv, bs);
         if (bs == 0x7fffffff) bs = 0;
@@ -954,21 +922,22 @@ __device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double 
     x_best = t.sol[t.sol_best];
 }
 
-// append a solution (InGoalRegion true) keeping the cache exact.  Uniform; thread 0 writes.
+// append a solution (InGoalRegion true).  Uniform; thread 0 writes.
 template <int D, int NT>
 __device__ __forceinline__ void wg_append_solution(Lds<NT> &s, TreeDev &t, int idx, const double *v)
 {
     if (threadIdx.x == 0) {
         if (t.n_sol < t.cap_sol) {
             int q = t.n_sol;
-            t.sol[q] = idx;
-            if (!t.sol_dirty) {
-                double d[D];
+            double d[D];
 #pragma unroll
-                for (int k = 0; k < D; k++) d[k] = t.goal[k] - v[k];
-                double c = walk_cost<D>(t, idx) + hypot_py<D>(d);
-                t.sol_cost[q] = c;
-                if (q == 0 || c < t.sol_best_cost) { t.sol_best = q; t.sol_best_cost = c; }  // first minimum stays
+            for (int k = 0; k < D; k++) d[k] = t.goal[k] - v[k];
+            double line = hypot_py<D>(d);
+            t.sol[q] = idx;
+            t.sol_line[q] = line;
+            if (!t.sol_dirty) {
+                double c = t.cost[idx] + line;
+                if (q == 0 || c < t.sol_best_cost) { t.sol_best = q; t.sol_best_cost = c; }
             }
             t.n_sol = q + 1;
         } else {
@@ -988,24 +957,9 @@ __device__ __forceinline__ void wg_goal_parent(Lds<NT> &s, TreeDev &t, int &gp, 
     if (t.gc_dirty) {
         double bv = __builtin_inf();
         int bq = 0x7fffffff;
-        for (int base = 0; base < ng; base += NT * WALK_R) {
-            int idx[WALK_R], q[WALK_R];
-            double acc0[WALK_R], acc1[WALK_R];
-#pragma unroll
-            for (int r = 0; r < WALK_R; r++) {
-                q[r] = base + r * NT + tid;
-                idx[r] = -1; acc0[r] = 0.; acc1[r] = 0.;
-                if (q[r] < ng && !t.gc_col[q[r]]) idx[r] = t.gc_idx[q[r]];
-            }
-            walk_chains<D>(t, idx, acc0, acc1, nullptr, 0);
-#pragma unroll
-            for (int r = 0; r < WALK_R; r++) {
-                if (q[r] < ng) {
-                    double c = t.gc_col[q[r]] ? __builtin_inf() : acc0[r] + t.gc_dist[q[r]];
-                    t.gc_cost[q[r]] = c;
-                    if (c < bv || (c == bv && q[r] < bq)) { bv = c; bq = q[r]; }
-                }
-            }
+        for (int q = tid; q < ng; q += NT) {
+            double c = t.gc_col[q] ? __builtin_inf() : t.cost[t.gc_idx[q]] + t.gc_dist[q];
+            if (c < bv) { bv = c; bq = q; }
         }
         block_argmin<NT>(s, bv, bq);
         if (bq == 0x7fffffff) bq = 0;  // every candidate collides: np.argmin of all-inf = 0
@@ -1034,8 +988,8 @@ __device__ __forceinline__ void wg_goal_parent(Lds<NT> &s, TreeDev &t, int &gp, 
     __syncthreads();
 }
 
-// bookkeeping when a vertex (idx, coordinates v) has just been appended: RRT* goal-candidate list.
-// Block-uniform control flow; `v` identical in all threads.
+// bookkeeping when a vertex (idx, coordinates v) joined the tree: RRT* goal-candidate list.
+// Block-uniform control flow; `v` identical in all threads; cost[idx] must be final.
 template <int D, int NT>
 __device__ __forceinline__ void wg_goal_candidate(Lds<NT> &s, TreeDev &t, int idx, const double *v)
 {
@@ -1051,10 +1005,8 @@ __device__ __forceinline__ void wg_goal_candidate(Lds<NT> &s, TreeDev &t, int id
             t.gc_idx[q] = idx;
             t.gc_dist[q] = h;
             t.gc_col[q] = col ? 1 : 0;
-            double c = __builtin_inf();
             if (!t.gc_dirty) {
-                if (!col) c = walk_cost<D>(t, idx) + h;
-                t.gc_cost[q] = c;
+                double c = col ? __builtin_inf() : t.cost[idx] + h;
                 if (q == 0 || c < t.gc_best_cost) { t.gc_best = q; t.gc_best_cost = c; }
             }
             t.n_gc = q + 1;
@@ -1075,7 +1027,6 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
     const int tid = threadIdx.x;
     const double clr = t.clearance;
     int n = t.n;
-    const int stamp = t.stamp + 1;   // published by thread 0 at the end of the iteration
     long long scanned = host_steer ? 0 : n;
     PROF_DECL
     int ni;
@@ -1119,8 +1070,10 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
 #pragma unroll
                 for (int k = 0; k < D; k++) t.c[k][new_idx] = node_new[k];
                 Aux a;
-                a.elen = edge_new; a.parent = ni; a.mark = 0;
+                a.elen = edge_new; a.parent = ni; a.pad = 0;
                 t.aux[new_idx] = a;
+                t.first_child[new_idx] = -1;
+                link_child(t, new_idx, ni);
                 t.n = n + 1;
             }
             n = n + 1;
@@ -1128,82 +1081,77 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
             __syncthreads();
         }
         if (new_idx >= 0) {
-            int k = wg_near<D, NT>(s, t, n, node_new, new_idx, stamp);
-            PROF(2);
+            int k = wg_near<D, NT>(s, t, n, node_new, new_idx);
             scanned += n;
+            PROF(2);
             int reparented = 0, n_rewired = 0;
+            // curr_node_new_cost (rrt_star_2d.py:45 "same point" / :51)
+            const double cost_ni = t.cost[ni];
+            const double curr = dup ? cost_ni : cost_ni + edge_new;
+            int best_parent = -1;
             if (k > 0) {
-                // parent-chain walks: slot j < k = neighbour j, slot k = `nearest`
-                wg_walk_neighbours<D, NT>(t, k, ni, node_new, stamp, 0, true);
-                __syncthreads();
-                PROF(3);
-                // choose_parent (rrt_star_2d.py:80-90)
+                // choose_parent (rrt_star_2d.py:80-90): argmin over the Near set of cost(j) + dist, first minimum
                 double cand = __builtin_inf();
                 int cj = 0x7fffffff;
                 for (int a = tid; a < k; a += NT) {
-                    double c = t.nr_c0[a] + t.nr_dist[a];
+                    double c = t.cost[t.nr_idx[a]] + t.nr_dist[a];
                     if (c < cand) { cand = c; cj = a; }
                 }
                 block_argmin<NT>(s, cand, cj);
-                // curr_node_new_cost (rrt_star_2d.py:45 same point / :51) and cost(new) with parent unchanged
-                const double c0n = t.nr_c0[k];
-                const double curr = dup ? c0n : c0n + edge_new;
-                double new_cost = dup ? c0n : t.nr_c1[k];
-                if (cand < curr) {
-                    reparented = 1;
-                    new_cost = t.nr_c1[cj];
-                    if (tid == 0) {
-                        int bj = t.nr_idx[cj];
-                        double v[D], d[D];
-                        load_vertex<D>(t, bj, v);
+                if (cand < curr) { reparented = 1; best_parent = t.nr_idx[cj]; }
+            }
+            PROF(3);
+            if (reparented) {
+                if (tid == 0) {
+                    double v[D], d[D];
+                    load_vertex<D>(t, best_parent, v);
 #pragma unroll
-                        for (int c = 0; c < D; c++) d[c] = node_new[c] - v[c];
-                        t.aux[new_idx].parent = bj;
-                        t.aux[new_idx].elen = hypot_py<D>(d);
-                        if (dup) { t.sol_dirty = 1; t.gc_dirty = 1; }
-                    }
-                    __syncthreads();
-                    if (dup) {
-                        // node_new is an existing vertex that just moved in the tree: every neighbour
-                        // below it changed cost -> re-walk before rewiring
-                        wg_walk_neighbours<D, NT>(t, k, -1, node_new, stamp, 0, false);
-                        __syncthreads();
-                    }
+                    for (int c = 0; c < D; c++) d[c] = node_new[c] - v[c];
+                    unlink_child(t, new_idx, t.aux[new_idx].parent);
+                    t.aux[new_idx].parent = best_parent;
+                    t.aux[new_idx].elen = hypot_py<D>(d);
+                    link_child(t, new_idx, best_parent);
+                    if (dup) { t.sol_dirty = 1; t.gc_dirty = 1; }
                 }
-                PROF(4);
-                // rewire (rrt_star_2d.py:92-99): sequential semantics.  All decisions up to and
-                // including the first "true" are exact with the costs in hand; after a re-parenting only
-                // neighbours that have the re-parented vertex among their (marked) ancestors change cost.
+                __syncthreads();
+            }
+            // cost(new): the fresh leaf is one walk; an existing vertex that moved (same-point case) takes its subtree along
+            if (dup) {
+                if (reparented) wg_recost_subtree<D, NT>(s, t, new_idx);
+            } else {
+                if (tid == 0) t.cost[new_idx] = walk_cost<D>(t, new_idx);
+                __syncthreads();
+            }
+            PROF(4);
+            if (k > 0) {
+                // rewire (rrt_star_2d.py:92-99): sequential semantics.  Decisions up to and including the first
+                // "true" are exact with the cached costs; the re-parented vertex's subtree is re-costed before
+                // the scan resumes, so later decisions see the updated costs exactly like the reference.
+                const double new_cost = t.cost[new_idx];
                 int start = 0;
                 while (start < k) {
                     int first = 0x7fffffff;
                     for (int a = start + tid; a < k; a += NT) {
-                        if (t.nr_c0[a] > new_cost + t.nr_dist[a]) { first = a; break; }
+                        if (t.cost[t.nr_idx[a]] > new_cost + t.nr_dist[a]) { first = a; break; }
                     }
                     first = block_min_int<NT>(s, first);
                     if (first == 0x7fffffff) break;
+                    const int vj = t.nr_idx[first];
                     if (tid == 0) {
-                        int vj = t.nr_idx[first];
                         double v[D], d[D];
                         load_vertex<D>(t, vj, v);
 #pragma unroll
                         for (int c = 0; c < D; c++) d[c] = v[c] - node_new[c];
+                        unlink_child(t, vj, t.aux[vj].parent);
                         t.aux[vj].parent = new_idx;
                         t.aux[vj].elen = hypot_py<D>(d);
+                        link_child(t, vj, new_idx);
                         t.sol_dirty = 1;
                         t.gc_dirty = 1;
                     }
                     n_rewired++;
                     start = first + 1;
-                    __syncthreads();
-                    // affected later neighbours: re-walk (plain cost; their ancestor lists stay valid supersets)
-                    for (int a = start + tid; a < k; a += NT) {
-                        int na = t.nr_anc[4 * a];
-                        bool hit = na > ANC_MAX;
-                        for (int c = 0; c < ANC_MAX; c++) hit = hit || (c < na && t.nr_anc[4 * a + 1 + c] == first);
-                        if (hit) t.nr_c0[a] = walk_cost<D>(t, t.nr_idx[a]);
-                    }
-                    __syncthreads();
+                    wg_recost_subtree<D, NT>(s, t, vj);
                 }
             }
             PROF(5);
@@ -1232,11 +1180,11 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         res->collided = 1;
     }
     PROF(6);
-    if (tid == 0) { t.stamp = stamp; t.scan_elems += scanned; }
+    if (tid == 0) { t.stamp = t.stamp + 1; t.scan_elems += scanned; }
     __syncthreads();
 }
 
-// end-of-iteration report shared by the step kernel and the persistent loop
+// end-of-iteration report shared by the step kernel and the persistent loops
 template <int D, int NT>
 __device__ __forceinline__ void wg_report(Lds<NT> &s, TreeDev &t, unsigned flags, double &cb, int &xb)
 {

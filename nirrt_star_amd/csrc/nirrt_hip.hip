@@ -28,8 +28,16 @@ __global__ __launch_bounds__(NT) void k_init(TreeDev *tp)
         t.sol_best_cost = __builtin_inf(); t.gc_best_cost = __builtin_inf();
     }
     __syncthreads();
-    // goal-candidate list over the current vertices, ascending (n == 1 after create/reset; n > 1 after upload)
+    // child lists + exact cost cache of the current tree (n == 1 after create/reset; n > 1 after upload)
     int n = t.n;
+    for (int i = threadIdx.x; i < n; i += NT) t.first_child[i] = -1;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int i = 1; i < n; i++) link_child(t, i, t.aux[i].parent);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += NT) t.cost[i] = walk_cost<D>(t, i);
+    __syncthreads();
+    // goal-candidate list over the current vertices, ascending
     for (int i = 0; i < n; i++) {  // uniform loop; cheap for n == 1, acceptable for test uploads
         double v[D];
         load_vertex<D>(t, i, v);
@@ -85,10 +93,8 @@ __global__ __launch_bounds__(NT) void k_near(TreeDev *tp, double q0, double q1, 
     TreeDev &t = *tp;
     stage_obstacles<NT>(s, t);
     double q[3] = {q0, q1, q2};
-    const int stamp = t.stamp + 1;
-    __syncthreads();
-    int k = wg_near<D, NT>(s, t, t.n, q, new_idx, stamp);   // result left in t.nr_idx[0..k)
-    if (threadIdx.x == 0) { *out_k = k; t.stamp = stamp; }
+    int k = wg_near<D, NT>(s, t, t.n, q, new_idx);   // result left in t.nr_idx[0..k)
+    if (threadIdx.x == 0) *out_k = k;
 }
 
 template <int D>
@@ -439,8 +445,9 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     TreeDev &h = t->host;
-    void *bufs[] = {h.c[0], h.c[1], h.c[2], h.aux, h.rank_of, h.st_idx, h.nr_idx, h.nr_flag, h.nr_anc, h.nr_dist,
-                    h.nr_c0, h.nr_c1, h.sol, h.sol_cost, h.gc_idx, h.gc_dist, h.gc_cost, h.gc_col, t->near_r};
+    void *bufs[] = {h.c[0], h.c[1], h.c[2], h.aux, h.cost, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.st_idx,
+                    h.nr_idx, h.nr_flag, h.nr_dist, h.nr_c0, h.nr_c1, h.sol, h.sol_line, h.gc_idx, h.gc_dist, h.gc_col,
+                    t->near_r};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (t->dev) (void)hipFree(t->dev);
@@ -517,11 +524,14 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         HIPCHK_T(hipMemset(h.c[k], 0, sizeof(double) * np));
     }
     HIPCHK_T(hipMalloc(&h.aux, sizeof(Aux) * np));
-    HIPCHK_T(hipMalloc(&h.rank_of, sizeof(int) * np));
+    HIPCHK_T(hipMalloc(&h.cost, sizeof(double) * np));
+    HIPCHK_T(hipMalloc(&h.first_child, sizeof(int) * np));
+    HIPCHK_T(hipMalloc(&h.next_sib, sizeof(int) * np));
+    HIPCHK_T(hipMalloc(&h.prev_sib, sizeof(int) * np));
+    HIPCHK_T(hipMalloc(&h.bfs_q, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.st_idx, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.nr_idx, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.nr_flag, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.nr_anc, sizeof(int) * 4 * np));
     HIPCHK_T(hipMalloc(&h.nr_dist, sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.nr_c0, sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.nr_c1, sizeof(double) * np));
@@ -529,10 +539,9 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     h.dim = D;
     h.cap_sol = t->cap;
     HIPCHK_T(hipMalloc(&h.sol, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.sol_cost, sizeof(double) * np));
+    HIPCHK_T(hipMalloc(&h.sol_line, sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.gc_idx, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.gc_dist, sizeof(double) * np));
-    HIPCHK_T(hipMalloc(&h.gc_cost, sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.gc_col, np));
     HIPCHK_T(hipMalloc(&t->near_r, sizeof(double) * (size_t)(t->cap + 1)));
     HIPCHK_T(hipMalloc(&t->dev, sizeof(TreeDev)));
@@ -606,7 +615,7 @@ extern "C" int nirrt_upload(nirrt_tree *t, int64_t n, const double *vertices, co
         for (int k = 0; k < D; k++) d[k] = vertices[i * D + k] - vertices[parents[i] * D + k];
         ax[(size_t)i].elen = i == 0 ? 0. : host_hypot_py(D, d);
         ax[(size_t)i].parent = (int)parents[i];
-        ax[(size_t)i].mark = 0;
+        ax[(size_t)i].pad = 0;
     }
     HIPCHK(hipMemcpy(t->host.aux, ax.data(), sizeof(Aux) * (size_t)n, hipMemcpyHostToDevice));
     t->host.n = (int)n;

@@ -71,6 +71,10 @@ def lib():
         L.orc_path_len.argtypes = [C.c_void_p, C.c_int64]
         L.orc_step.argtypes = [C.c_void_p, dp, C.c_int, C.POINTER(StepResult)]
         L.orc_replay.argtypes = [C.c_void_p, dp, C.c_int64, C.c_int]
+        u32 = C.POINTER(C.c_uint32)
+        L.orc_run_sampling.restype = C.c_int64
+        L.orc_run_sampling.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, u32, C.c_int64, u32, C.c_int64,
+                                       C.c_double, dp, dp, dp, ip, ip]
         for f in ("orc_is_collision",):
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [C.c_void_p, dp, dp]
@@ -231,3 +235,19 @@ class OracleTree:
     def replay(self, samples, irrt=False):
         s = np.ascontiguousarray(samples, dtype=np.float64)
         self.L.orc_replay(self.h, _dp(s), len(s), int(irrt))
+
+    def run_sampling(self, iters, np_words, py_words=None, irrt=False, goal_scan=False, stop_first=False, frame=None, want_trace=False):
+        """whole loop incl. sampling from raw MT19937 word streams -> dict(iters_done, np_used, py_used, cost_trace)"""
+        u32 = C.POINTER(C.c_uint32)
+        npw = np.ascontiguousarray(np_words, dtype=np.uint32)
+        pyw = np.ascontiguousarray(py_words if py_words is not None else np.zeros(0), dtype=np.uint32)
+        c_min, xc, Cm = frame if frame is not None else (0.0, np.zeros(3), np.eye(3))
+        xc3 = np.zeros(3)
+        xc3[: self.dim] = np.asarray(xc, dtype=np.float64).ravel()[: self.dim]
+        Cm = np.ascontiguousarray(np.asarray(Cm, dtype=np.float64).reshape(3, 3))
+        trace = np.zeros(iters, dtype=np.float64) if want_trace else None
+        npu, pyu = C.c_int64(0), C.c_int64(0)
+        done = self.L.orc_run_sampling(self.h, int(irrt), int(goal_scan), int(stop_first), int(iters), npw.ctypes.data_as(u32), len(npw),
+                                       pyw.ctypes.data_as(u32), len(pyw), float(c_min), _dp(xc3), _dp(Cm),
+                                       _dp(trace) if want_trace else None, C.byref(npu), C.byref(pyu))
+        return {"iters_done": int(done), "np_used": npu.value, "py_used": pyu.value, "cost_trace": trace}
