@@ -29,6 +29,8 @@
 #define MAX_OBS NIRRT_MAX_OBSTACLES
 #define SCAN_PAD 256     // extra elements allocated behind every per-vertex array (vector loads may overrun n)
 #define WALK_R 4         // parent chains chased concurrently per lane
+#define SCAN_U 4         // 128-vertex chunks a wave loads per scan trip (16-byte loads issued back to back)
+#define CHAIN_MAX 512    // LDS slots for the new->root edge-length sequence (deeper chains fall back to global walks)
 
 // optional per-phase cycle accounting (build with -DNIRRT_PROFILE; scripts/perf_phases.py reads prof[])
 #ifdef NIRRT_PROFILE
@@ -68,6 +70,7 @@ struct TreeDev {
     long long scan_elems;  // vertices streamed by nearest + Near passes (roofline accounting)
     // Near-set working arrays (capacity cap: a Near set can never exceed the tree)
     int *st_idx;     // ordered staging of scan hits, one region per wave segment
+    double *st_c[3]; // coordinates of the staged hits (captured while they are in registers)
     int *nr_idx;     // neighbour vertex index, ascending
     int *nr_flag;    // segment (new -> neighbour) hits an obstacle
     double *nr_dist; // scan distance new <-> neighbour (np.hypot / axis norm)
@@ -115,12 +118,17 @@ struct Lds {
     int n_round, n_box;
     double rnd[MAX_OBS][4];
     double box[MAX_OBS][6];
+    double aabb[2 * MAX_OBS][6];   // clearance-inflated bounds lo[3], hi[3] per obstacle (round first, then boxes)
     double red_val[NW];
     double red_val2[NW];
     int red_idx[NW];
     int wave_tot[NW];
     double bc_d[8];
     int bc_i[8];
+    // edge lengths along the chain new -> root of the current iteration (every vertex re-costed in this
+    // iteration hangs below `new`, so its walk ends with exactly this sequence)
+    int chain_len;          // entries valid in chainE, or -1 if the chain is longer than CHAIN_MAX
+    double chainE[CHAIN_MAX];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -389,6 +397,17 @@ __device__ __forceinline__ bool seg_obstacle(const Lds<NT> &s, int o, const doub
     return seg_box_3d(a, b, s.box[o], clr);
 }
 
+// the AABB prefilter alone (same arithmetic as the first lines of the seg_* tests above)
+template <int D, int NT>
+__device__ __forceinline__ bool seg_aabb_pass(const Lds<NT> &s, int o, const double *l0, const double *l1)
+{
+    // l0 / l1 = per-axis min / max of the segment end points; bounds precomputed by stage_obstacles
+    bool pass = true;
+#pragma unroll
+    for (int k = 0; k < D; k++) pass = pass && (l0[k] <= s.aabb[o][3 + k]) && (l1[k] >= s.aabb[o][k]);
+    return pass;
+}
+
 // whole segment test by ONE lane (lane-parallel fans over many segments)
 template <int D, int NT>
 __device__ __forceinline__ bool seg_all(const Lds<NT> &s, const double *a, const double *b, double clr)
@@ -447,6 +466,18 @@ __device__ __forceinline__ void stage_obstacles(Lds<NT> &s, const TreeDev &t)
     if (tid == 0) { s.n_round = t.n_round; s.n_box = t.n_box; }
     for (int i = tid; i < t.n_round * 4; i += NT) s.rnd[i / 4][i % 4] = t.rnd[i / 4][i % 4];
     for (int i = tid; i < t.n_box * 6; i += NT) s.box[i / 6][i % 6] = t.box[i / 6][i % 6];
+    // the prefilter bounds exactly as the reference forms them: c - r - clr, c + r + clr / x - clr, x + w + clr
+    const double clr = t.clearance;
+    for (int i = tid; i < t.n_round * 3; i += NT) {
+        int o = i / 3, k = i % 3;
+        s.aabb[o][k] = t.rnd[o][k] - t.rnd[o][3] - clr;
+        s.aabb[o][3 + k] = t.rnd[o][k] + t.rnd[o][3] + clr;
+    }
+    for (int i = tid; i < t.n_box * 3; i += NT) {
+        int o = i / 3, k = i % 3;
+        s.aabb[t.n_round + o][k] = t.box[o][k] - clr;
+        s.aabb[t.n_round + o][3 + k] = t.box[o][k] + t.box[o][3 + k] + clr;
+    }
     __syncthreads();
 }
 
@@ -571,31 +602,29 @@ __device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, c
     const double2 *X = reinterpret_cast<const double2 *>(t.c[0]);
     const double2 *Y = reinterpret_cast<const double2 *>(t.c[1]);
     const double2 *Z = reinterpret_cast<const double2 *>(t.c[D - 1]);
-    for (int base = beg + 2 * lane; base < end; base += 256) {
-        // two 128-vertex chunks per trip; all 16-byte loads are issued before the first use
-        const int b1 = base + 128;
-        double2 xv = X[base >> 1], yv = Y[base >> 1], zv, xw, yw, zw;
-        if (D == 3) zv = Z[base >> 1];
-        const bool two = b1 < end;
-        if (two) {
-            xw = X[b1 >> 1]; yw = Y[b1 >> 1];
-            if (D == 3) zw = Z[b1 >> 1];
+    for (int base = beg + 2 * lane; base < end; base += 128 * SCAN_U) {
+        // SCAN_U 128-vertex chunks per trip; all 16-byte loads are issued before the first use so that
+        // each wave keeps SCAN_U * D KiB in flight
+        double2 xv[SCAN_U], yv[SCAN_U], zv[SCAN_U];
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++) {
+            const int bu = base + 128 * u;
+            if (bu < end) {
+                xv[u] = X[bu >> 1]; yv[u] = Y[bu >> 1];
+                if (D == 3) zv[u] = Z[bu >> 1];
+            }
         }
-        {
-            double da[3] = {q[0] - xv.x, q[1] - yv.x, D == 3 ? q[D - 1] - zv.x : 0.};
-            double db[3] = {q[0] - xv.y, q[1] - yv.y, D == 3 ? q[D - 1] - zv.y : 0.};
-            double va = dist2<D>(da);
-            double vb = base + 1 < end ? dist2<D>(db) : __builtin_inf();
-            if (va < m1) { m2 = m1; m1 = va; i1 = base; } else if (va < m2) m2 = va;
-            if (vb < m1) { m2 = m1; m1 = vb; i1 = base + 1; } else if (vb < m2) m2 = vb;
-        }
-        if (two) {
-            double da[3] = {q[0] - xw.x, q[1] - yw.x, D == 3 ? q[D - 1] - zw.x : 0.};
-            double db[3] = {q[0] - xw.y, q[1] - yw.y, D == 3 ? q[D - 1] - zw.y : 0.};
-            double va = dist2<D>(da);
-            double vb = b1 + 1 < end ? dist2<D>(db) : __builtin_inf();
-            if (va < m1) { m2 = m1; m1 = va; i1 = b1; } else if (va < m2) m2 = va;
-            if (vb < m1) { m2 = m1; m1 = vb; i1 = b1 + 1; } else if (vb < m2) m2 = vb;
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++) {
+            const int bu = base + 128 * u;
+            if (bu < end) {
+                double da[3] = {q[0] - xv[u].x, q[1] - yv[u].x, D == 3 ? q[D - 1] - zv[u].x : 0.};
+                double db[3] = {q[0] - xv[u].y, q[1] - yv[u].y, D == 3 ? q[D - 1] - zv[u].y : 0.};
+                double va = dist2<D>(da);
+                double vb = bu + 1 < end ? dist2<D>(db) : __builtin_inf();
+                if (va < m1) { m2 = m1; m1 = va; i1 = bu; } else if (va < m2) m2 = va;
+                if (vb < m1) { m2 = m1; m1 = vb; i1 = bu + 1; } else if (vb < m2) m2 = vb;
+            }
         }
     }
     // wave: minimum (m1, i1) and the second-smallest value seen by the wave
@@ -636,23 +665,24 @@ __device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, c
 
 // chase parent chains leaf -> root (RRTBase.cost, rrt_base_2d.py:54-61): acc = 0; acc += elen[v]; v = parent[v] ...
 // Up to WALK_R chains per lane are walked concurrently so that their dependent 16-byte loads overlap.
-// idx[r] <= 0: inactive slot (the root costs 0).
+// idx[r] <= 0: inactive slot (the root costs 0).  A chain stops early when it reaches `stop_at` (> 0):
+// the caller then continues the very same left-to-right sum with the cached tail of that vertex.
 template <int D>
-__device__ __forceinline__ void walk_chains(const TreeDev &t, int (&idx)[WALK_R], double (&acc)[WALK_R])
+__device__ __forceinline__ void walk_chains(const TreeDev &t, int (&idx)[WALK_R], double (&acc)[WALK_R], int stop_at)
 {
     int guard = t.cap + 1;
     for (;;) {
         bool any = false;
 #pragma unroll
-        for (int r = 0; r < WALK_R; r++) any = any || idx[r] > 0;
+        for (int r = 0; r < WALK_R; r++) any = any || (idx[r] > 0 && idx[r] != stop_at);
         if (!any || guard-- <= 0) break;
         Aux a[WALK_R];
 #pragma unroll
         for (int r = 0; r < WALK_R; r++)
-            if (idx[r] > 0) a[r] = t.aux[idx[r]];
+            if (idx[r] > 0 && idx[r] != stop_at) a[r] = t.aux[idx[r]];
 #pragma unroll
         for (int r = 0; r < WALK_R; r++) {
-            if (idx[r] > 0) {
+            if (idx[r] > 0 && idx[r] != stop_at) {
                 acc[r] += a[r].elen;
                 idx[r] = a[r].parent;
             }
@@ -692,9 +722,12 @@ __device__ __forceinline__ void unlink_child(TreeDev &t, int v, int p)
 
 // vertex v was just re-parented (aux[v] already updated, child lists already relinked): refresh the
 // exact cost of v and of every vertex below it.  Breadth-first over the child lists into bfs_q, then
-// one full leaf->root walk per collected vertex (WALK_R chains per lane).
+// one leaf->root walk per collected vertex (WALK_R chains per lane).  Every such walk passes through
+// `through` (= new_idx, the vertex they were all just hung under): it is chased in memory only up to
+// there and finished from s.chainE, the edge-length sequence through -> root recorded this iteration
+// - the same additions in the same order as a full walk.
 template <int D, int NT>
-__device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v)
+__device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v, int through)
 {
     const int tid = threadIdx.x;
     __syncthreads();
@@ -725,12 +758,43 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v)
             idx[r] = who[r];
             acc[r] = 0.;
         }
-        walk_chains<D>(t, idx, acc);
+        const int clen = s.chain_len;
+        const int stop_at = clen >= 0 ? through : -1;
+        walk_chains<D>(t, idx, acc, stop_at);
+        if (clen >= 0) {
+#pragma unroll
+            for (int r = 0; r < WALK_R; r++) {
+                if (who[r] >= 0 && idx[r] == through)
+                    for (int i = 0; i < clen; i++) acc[r] += s.chainE[i];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < WALK_R; r++)
             if (who[r] >= 0) t.cost[who[r]] = acc[r];
     }
     __syncthreads();
+}
+
+// record the edge-length sequence new_idx -> root in LDS and return cost(new_idx) (thread 0 walks; uniform result)
+template <int D, int NT>
+__device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeDev &t, int new_idx)
+{
+    if (threadIdx.x == 0) {
+        double acc = 0.;
+        int i = new_idx, len = 0, guard = t.cap + 1;
+        while (i > 0 && guard-- > 0) {
+            Aux a = t.aux[i];
+            acc += a.elen;
+            if (len < CHAIN_MAX) s.chainE[len] = a.elen;
+            len++;
+            i = a.parent;
+        }
+        s.chain_len = len <= CHAIN_MAX ? len : -1;
+        s.bc_d[6] = acc;
+    }
+    __syncthreads();
+    double c = s.bc_d[6];
+    return c;
 }
 
 // steer (new_state).  2D: rrt_star_2d.py:67-78, device atan2/cos/sin; 3D: rrt_star_3d.py:67-78, IEEE only.
@@ -784,6 +848,7 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     const double2 *Z = reinterpret_cast<const double2 *>(t.c[D - 1]);
     const unsigned long long lt = (1ull << lane) - 1ull;
     int cnt = 0;  // wave-uniform
+    PROF_DECL
     // one 128-vertex chunk: band-filtered hit test for this lane's two vertices + ordered staging
     auto chunk = [&](int base, const double2 &xv, const double2 &yv, const double2 &zv) {
         bool ha = false, hb = false;
@@ -806,22 +871,24 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
             cnt += __popcll(ma) + __popcll(mb);
         }
     };
-    for (int cb = beg; cb < end; cb += 256) {
-        // two chunks per trip; all 16-byte loads are issued before the first use
-        const int b0 = cb + 2 * lane, b1 = b0 + 128;
-        double2 x0 = {0., 0.}, y0 = {0., 0.}, z0 = {0., 0.}, x1 = {0., 0.}, y1 = {0., 0.}, z1 = {0., 0.};
-        if (b0 < end) {
-            x0 = X[b0 >> 1]; y0 = Y[b0 >> 1];
-            if (D == 3) z0 = Z[b0 >> 1];
+    for (int cb = beg; cb < end; cb += 128 * SCAN_U) {
+        // SCAN_U chunks per trip; all 16-byte loads are issued before the first use
+        double2 xv[SCAN_U], yv[SCAN_U], zv[SCAN_U];
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++) {
+            const int bu = cb + 128 * u + 2 * lane;
+            xv[u] = make_double2(0., 0.); yv[u] = xv[u]; zv[u] = xv[u];
+            if (bu < end) {
+                xv[u] = X[bu >> 1]; yv[u] = Y[bu >> 1];
+                if (D == 3) zv[u] = Z[bu >> 1];
+            }
         }
-        if (b1 < end) {
-            x1 = X[b1 >> 1]; y1 = Y[b1 >> 1];
-            if (D == 3) z1 = Z[b1 >> 1];
-        }
-        chunk(b0, x0, y0, z0);
-        if (cb + 128 < end) chunk(b1, x1, y1, z1);   // wave-uniform
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++)
+            if (cb + 128 * u < end) chunk(cb + 128 * u + 2 * lane, xv[u], yv[u], zv[u]);   // wave-uniform
     }
     __syncthreads();
+    PROF(8);
     if (lane == 0) s.wave_tot[w] = cnt;
     __syncthreads();
     int woff[NW + 1];
@@ -830,70 +897,73 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     for (int i = 0; i < NW; i++) woff[i + 1] = woff[i] + s.wave_tot[i];
     const int kraw = woff[NW];
     const int per = ((n + NW * 128 - 1) / (NW * 128)) * 128;
-    // gather the staged hits (already ascending) into the candidate list; their coordinates ride
-    // along in nr_c0 / nr_c1 / nr_dist (free until the walk phase) so the fan below needs no
-    // dependent index -> coordinate loads
-    double *cx = t.nr_c0, *cy = t.nr_c1, *cz = t.nr_dist;
+    // Pass A - gather the staged hits (already ascending): index, coordinates (kept in nr_c0/nr_c1/st scratch
+    // for pass B), reference distance, and the AABB prefilter against every obstacle.  (segment, obstacle)
+    // pairs that survive the prefilter are queued so that the expensive exact tests run densely packed.
+    double *cx = t.nr_c0, *cy = t.nr_c1, *cz = t.st_c[0];
+    int *pairq = t.bfs_q;
+    const int pair_cap = t.cap;
+    const int M = s.n_round + s.n_box;
+    if (tid == 0) s.bc_i[5] = 0;
+    __syncthreads();
     for (int a = tid; a < kraw; a += NT) {
         int ww = 0, offw = 0;
 #pragma unroll
         for (int i = 1; i < NW; i++)
             if (a >= woff[i]) { ww = i; offw = woff[i]; }
-        int v = t.st_idx[ww * per + (a - offw)];
+        const int v = t.st_idx[ww * per + (a - offw)];
+        double vj[3] = {t.c[0][v], t.c[1][v], D == 3 ? t.c[D - 1][v] : 0.};
+        double d[3] = {node_new[0] - vj[0], node_new[1] - vj[1], D == 3 ? node_new[D - 1] - vj[2] : 0.};
         t.nr_idx[a] = v;
         t.nr_flag[a] = (v == new_idx) ? 1 : 0;   // excluded like the colliding ones
-        cx[a] = t.c[0][v];
-        cy[a] = t.c[1][v];
-        if (D == 3) cz[a] = t.c[D - 1][v];
-    }
-    __syncthreads();
-    // fan of segment tests (node_new -> v_j) x obstacles
-    const int M = s.n_round + s.n_box;
-    if (M > 0) {
-        if (kraw < NT) {
-            // few segments: one (segment, obstacle) pair per lane
-            const int pairs = kraw * M;
-            for (int p = tid; p < pairs; p += NT) {
-                int j = p / M, o = p - j * M;
-                double vj[3] = {cx[j], cy[j], D == 3 ? cz[j] : 0.};
-                if (seg_obstacle<D, NT>(s, o, node_new, vj, clr)) t.nr_flag[j] = 1;
-            }
-        } else {
-            // many segments (informed sampling packs the Near ball): one segment per lane, obstacles from LDS
-            for (int j = tid; j < kraw; j += NT) {
-                double vj[3] = {cx[j], cy[j], D == 3 ? cz[j] : 0.};
-                if (seg_all<D, NT>(s, node_new, vj, clr)) t.nr_flag[j] = 1;
+        t.nr_dist[a] = dist_scan<D>(d);
+        cx[a] = vj[0]; cy[a] = vj[1];
+        if (D == 3) cz[a] = vj[2];
+        double l0[3], l1[3];
+#pragma unroll
+        for (int c = 0; c < D; c++) { l0[c] = fmin(node_new[c], vj[c]); l1[c] = fmax(node_new[c], vj[c]); }
+        for (int o = 0; o < M; o++) {
+            if (seg_aabb_pass<D, NT>(s, o, l0, l1)) {
+                int pos = atomicAdd(&s.bc_i[5], 1);
+                if (pos < pair_cap) pairq[pos] = a * MAX_OBS * 2 + o;
             }
         }
     }
     __syncthreads();
-    // stable in-place filter (index + coordinates)
+    PROF(9);
+    // Pass B - exact segment tests for the queued pairs (node_new -> v_j vs obstacle o)
+    const int npairs = s.bc_i[5];
+    if (npairs <= pair_cap) {
+        for (int p = tid; p < npairs; p += NT) {
+            int code = pairq[p];
+            int j = code / (MAX_OBS * 2), o = code - j * (MAX_OBS * 2);
+            double vj[3] = {cx[j], cy[j], D == 3 ? cz[j] : 0.};
+            if (seg_obstacle<D, NT>(s, o, node_new, vj, clr)) t.nr_flag[j] = 1;
+        }
+    } else {
+        // pair queue overflow (cannot happen unless almost every obstacle overlaps every segment): direct loop
+        for (int j = tid; j < kraw; j += NT) {
+            double vj[3] = {cx[j], cy[j], D == 3 ? cz[j] : 0.};
+            if (seg_all<D, NT>(s, node_new, vj, clr)) t.nr_flag[j] = 1;
+        }
+    }
+    __syncthreads();
+    PROF(10);
+    // Pass C - stable in-place filter (index + distance)
     int k = 0;
     for (int base = 0; base < kraw; base += NT) {
         int a = base + tid;
         int vi = 0;
-        double vx = 0., vy = 0., vz = 0.;
+        double vd = 0.;
         bool keep = false;
-        if (a < kraw) {
-            vi = t.nr_idx[a]; keep = t.nr_flag[a] == 0;
-            vx = cx[a]; vy = cy[a];
-            if (D == 3) vz = cz[a];
-        }
+        if (a < kraw) { vi = t.nr_idx[a]; vd = t.nr_dist[a]; keep = t.nr_flag[a] == 0; }
         int pos;
         int tot = block_compact<NT>(s, keep, pos);
-        if (keep) {
-            t.nr_idx[k + pos] = vi; cx[k + pos] = vx; cy[k + pos] = vy;
-            if (D == 3) cz[k + pos] = vz;
-        }
+        if (keep) { t.nr_idx[k + pos] = vi; t.nr_dist[k + pos] = vd; }
         k += tot;
     }
     __syncthreads();
-    // reference distances of the survivors
-    for (int a = tid; a < k; a += NT) {
-        double d[3] = {node_new[0] - cx[a], node_new[1] - cy[a], D == 3 ? node_new[D - 1] - cz[a] : 0.};
-        t.nr_dist[a] = dist_scan<D>(d);
-    }
-    __syncthreads();
+    PROF(11);
     return k;
 }
 
@@ -1115,19 +1185,22 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 }
                 __syncthreads();
             }
-            // cost(new): the fresh leaf is one walk; an existing vertex that moved (same-point case) takes its subtree along
-            if (dup) {
-                if (reparented) wg_recost_subtree<D, NT>(s, t, new_idx);
-            } else {
-                if (tid == 0) t.cost[new_idx] = walk_cost<D>(t, new_idx);
-                __syncthreads();
+            // cost(new) = the one long pointer chase of the iteration; its edge lengths stay in LDS for the
+            // re-costing below.  An existing vertex that moved (same-point case) takes its subtree along.
+            double new_cost = cost_ni;
+            if (k > 0 || !dup) {
+                new_cost = wg_chain_of_new<D, NT>(s, t, new_idx);
+                if (dup) {
+                    if (reparented) wg_recost_subtree<D, NT>(s, t, new_idx, new_idx);
+                } else {
+                    if (tid == 0) t.cost[new_idx] = new_cost;
+                }
             }
             PROF(4);
             if (k > 0) {
                 // rewire (rrt_star_2d.py:92-99): sequential semantics.  Decisions up to and including the first
                 // "true" are exact with the cached costs; the re-parented vertex's subtree is re-costed before
                 // the scan resumes, so later decisions see the updated costs exactly like the reference.
-                const double new_cost = t.cost[new_idx];
                 int start = 0;
                 while (start < k) {
                     int first = 0x7fffffff;
@@ -1151,7 +1224,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                     }
                     n_rewired++;
                     start = first + 1;
-                    wg_recost_subtree<D, NT>(s, t, vj);
+                    wg_recost_subtree<D, NT>(s, t, vj, new_idx);
                 }
             }
             PROF(5);

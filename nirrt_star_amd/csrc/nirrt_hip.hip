@@ -16,10 +16,14 @@
 // ------------------------------------------------------------------------------------------------
 #define NT 256   // 4 wave64 = one wave per SIMD; several trees share a CU
 
+// The workgroup's LDS working set lives at file scope so that the (non-inlined) loop-body function
+// addresses it as LDS (ds_* instructions) instead of through a generic pointer.
+__shared__ Lds<NT> g_lds;
+
 template <int D>
 __global__ __launch_bounds__(NT) void k_init(TreeDev *tp)
 {
-    __shared__ Lds<NT> s;
+    Lds<NT> &s = g_lds;
     TreeDev &t = *tp;
     stage_obstacles<NT>(s, t);
     if (threadIdx.x == 0) {
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(NT) void k_init(TreeDev *tp)
 template <int D>
 __global__ __launch_bounds__(NT) void k_nearest(TreeDev *tp, double q0, double q1, double q2, int *out_idx)
 {
-    __shared__ Lds<NT> s;
+    Lds<NT> &s = g_lds;
     TreeDev &t = *tp;
     double q[3] = {q0, q1, q2};
     int bi = wg_nearest<D, NT>(s, t, t.n, q);
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(NT) void k_nearest(TreeDev *tp, double q0, double q
 template <int D>
 __global__ __launch_bounds__(NT) void k_collision_batch(TreeDev *tp, long long n_seg, const double *seg, unsigned char *out)
 {
-    __shared__ Lds<NT> s;
+    Lds<NT> &s = g_lds;
     TreeDev &t = *tp;
     stage_obstacles<NT>(s, t);
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n_seg; i += (long long)gridDim.x * NT) {
@@ -73,7 +77,7 @@ template <int D>
 __global__ __launch_bounds__(NT) void k_points(TreeDev *tp, long long n, const double *pts, unsigned char *inside,
                                                unsigned char *valid)
 {
-    __shared__ Lds<NT> s;
+    Lds<NT> &s = g_lds;
     TreeDev &t = *tp;
     stage_obstacles<NT>(s, t);
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(NT) void k_points(TreeDev *tp, long long n, const d
 template <int D>
 __global__ __launch_bounds__(NT) void k_near(TreeDev *tp, double q0, double q1, double q2, int new_idx, int *out_k)
 {
-    __shared__ Lds<NT> s;
+    Lds<NT> &s = g_lds;
     TreeDev &t = *tp;
     stage_obstacles<NT>(s, t);
     double q[3] = {q0, q1, q2};
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(NT) void k_cost(TreeDev *tp, long long n_idx, const
 template <int D>
 __global__ __launch_bounds__(NT) void k_goal_parent(TreeDev *tp, int *out_idx, double *out_len)
 {
-    __shared__ Lds<NT> s;
+    Lds<NT> &s = g_lds;
     TreeDev &t = *tp;
     int gp;
     double len;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(NT) void k_goal_parent(TreeDev *tp, int *out_idx, d
 template <int D>
 __global__ __launch_bounds__(NT) void k_best_solution(TreeDev *tp, int *out_idx, double *out_c)
 {
-    __shared__ Lds<NT> s;
+    Lds<NT> &s = g_lds;
     TreeDev &t = *tp;
     double cb;
     int xb;
@@ -131,7 +135,7 @@ template <int D>
 __global__ __launch_bounds__(NT, 4) void k_step(TreeDev *tp, double q0, double q1, double q2, int host_steer, int nearest_in,
                                              unsigned flags, nirrt_step_result *res)
 {
-    __shared__ Lds<NT> s;
+    Lds<NT> &s = g_lds;
     TreeDev &t = *tp;
     stage_obstacles<NT>(s, t);
     double q[3] = {q0, q1, q2};
@@ -147,21 +151,21 @@ __global__ __launch_bounds__(NT, 4) void k_step(TreeDev *tp, double q0, double q
 // The persistent loops call the loop body through a real function call: inlined into the loop the
 // compiler hoists the tree descriptor into registers across iterations and spills.
 template <int D>
-__device__ __noinline__ void iteration_call(Lds<NT> *sp, TreeDev *tp, double q0, double q1, double q2, unsigned flags)
+__device__ __noinline__ void iteration_call(TreeDev *tp, double q0, double q1, double q2, unsigned flags)
 {
     double q[3] = {q0, q1, q2};
-    wg_iteration<D, NT>(*sp, *tp, q, false, 0, flags, nullptr);
+    wg_iteration<D, NT>(g_lds, *tp, q, false, 0, flags, nullptr);
 }
 
 template <int D>
-__device__ __noinline__ double report_call(Lds<NT> *sp, TreeDev *tp, unsigned flags)
+__device__ __noinline__ double report_call(TreeDev *tp, unsigned flags)
 {
     double cb;
     int xb;
 #ifdef NIRRT_PROFILE
     long long t0_ = wall_clock64();
 #endif
-    wg_report<D, NT>(*sp, *tp, flags, cb, xb);
+    wg_report<D, NT>(g_lds, *tp, flags, cb, xb);
 #ifdef NIRRT_PROFILE
     if (threadIdx.x == 0) tp->prof[7] += wall_clock64() - t0_;
 #endif
@@ -181,7 +185,7 @@ struct RunDev {
 template <int D>
 __global__ __launch_bounds__(NT, 4) void k_run_replay(TreeDev *const *trees, RunDev a)
 {
-    __shared__ Lds<NT> s;
+    Lds<NT> &s = g_lds;
     TreeDev &t = *trees[blockIdx.x];
     stage_obstacles<NT>(s, t);
     const double *smp = a.samples + (long long)blockIdx.x * a.iters * D;
@@ -191,9 +195,9 @@ __global__ __launch_bounds__(NT, 4) void k_run_replay(TreeDev *const *trees, Run
         double q[3] = {0., 0., 0.};
 #pragma unroll
         for (int c = 0; c < D; c++) q[c] = smp[k * D + c];
-        iteration_call<D>(&s, &t, q[0], q[1], q[2], a.flags);
+        iteration_call<D>(&t, q[0], q[1], q[2], a.flags);
         if (trace || (a.flags & NIRRT_F_STOP_FIRST)) {
-            double cb = report_call<D>(&s, &t, a.flags);
+            double cb = report_call<D>(&t, a.flags);
             if (trace && threadIdx.x == 0) trace[k] = cb;
             if ((a.flags & NIRRT_F_STOP_FIRST) && cb < __builtin_inf()) { k++; break; }
         }
@@ -307,7 +311,7 @@ struct RunSampleDev {
 template <int D>
 __global__ __launch_bounds__(NT, 4) void k_run_sample(TreeDev *const *trees, RunSampleDev a)
 {
-    __shared__ Lds<NT> s;
+    Lds<NT> &s = g_lds;
     const int b = blockIdx.x;
     TreeDev &t = *trees[b];
     stage_obstacles<NT>(s, t);
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(NT, 4) void k_run_sample(TreeDev *const *trees, Run
     int stop = 0;
     // cb = best cost on the current tree: what IRRT* samples with at the top of the next iteration
     // (irrt_star_2d.py:51-53) and what planning_random records after each iteration (:223-229, :241)
-    double cb = reports ? report_call<D>(&s, &t, a.flags) : __builtin_inf();
+    double cb = reports ? report_call<D>(&t, a.flags) : __builtin_inf();
     for (; k < a.iters; k++) {
         if (threadIdx.x == 0) {
             double q[3] = {0., 0., 0.};
@@ -335,8 +339,8 @@ __global__ __launch_bounds__(NT, 4) void k_run_sample(TreeDev *const *trees, Run
         double q0 = s.bc_d[0], q1 = s.bc_d[1], q2 = s.bc_d[2];
         __syncthreads();
         if (stop) break;
-        iteration_call<D>(&s, &t, q0, q1, q2, a.flags);
-        if (reports) cb = report_call<D>(&s, &t, a.flags);
+        iteration_call<D>(&t, q0, q1, q2, a.flags);
+        if (reports) cb = report_call<D>(&t, a.flags);
         if (trace && threadIdx.x == 0) trace[k] = cb;
         if (t.status != 0) { k++; stop = t.status; break; }
         if ((a.flags & NIRRT_F_STOP_FIRST) && cb < __builtin_inf()) { k++; break; }
@@ -445,7 +449,7 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     TreeDev &h = t->host;
-    void *bufs[] = {h.c[0], h.c[1], h.c[2], h.aux, h.cost, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.st_idx,
+    void *bufs[] = {h.st_c[0], h.st_c[1], h.st_c[2], h.c[0], h.c[1], h.c[2], h.aux, h.cost, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.st_idx,
                     h.nr_idx, h.nr_flag, h.nr_dist, h.nr_c0, h.nr_c1, h.sol, h.sol_line, h.gc_idx, h.gc_dist, h.gc_col,
                     t->near_r};
     for (void *b : bufs)
@@ -523,6 +527,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         HIPCHK_T(hipMalloc(&h.c[k], sizeof(double) * np));
         HIPCHK_T(hipMemset(h.c[k], 0, sizeof(double) * np));
     }
+    for (int k = 0; k < D; k++) HIPCHK_T(hipMalloc(&h.st_c[k], sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.aux, sizeof(Aux) * np));
     HIPCHK_T(hipMalloc(&h.cost, sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.first_child, sizeof(int) * np));
