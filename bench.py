@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--world", default="b30")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
-    ap.add_argument("--traffic-gb", type=float, default=None, help="HBM bytes per launch from a separate rocprofv3 --pmc run")
+    ap.add_argument("--traffic-gb", type=float, default=None,
+                    help="HBM GB per launch from a separate rocprofv3 --pmc run (default: profiles/r01_traffic.json if it has this config)")
     return ap.parse_args()
 
 
@@ -193,7 +194,7 @@ def main():
                        "per_tree_iters_per_s": iters / (k_ms * 1e-3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": args.traffic_gb * 1e9 if args.traffic_gb else None,
+                         "traffic": measured_traffic(args),
                          "kernel": "k_run_sample<%d>" % D, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "time_to_first_solution": {"median_iterations": ttfs_it, "median_seconds_in_batch": ttfs_s,
                                        "problems": len(sub), "solved_within_%d" % min(iters, 5000): int(len(found))},
@@ -205,6 +206,19 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(args):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (collected separately, as the
+    profiling guide prescribes); None for configurations that were not profiled."""
+    if args.traffic_gb:
+        return args.traffic_gb * 1e9
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            tab = json.load(f)
+        return tab["%s_%dd_%dx%d" % (args.algo, args.dim, args.trees, args.iters)]["traffic_bytes"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(args, pr, npw, pyw):

@@ -1,0 +1,167 @@
+"""Evaluation of a set of independent planning problems sharded over GPUs (the
+reference's single-process counterpart is eval_planning_2d.py:83-136).
+
+Problems (env x start/goal pairs) share nothing, so the partitioning is static round-robin
+`problem i -> rank i mod world_size`, one process per GPU, no collective on the data path; each rank
+plans its problems in batches (one persistent launch per batch, one workgroup per problem) with the
+`planning_random(iter_after_initial)` protocol, and ONE gather of fixed-size result records
+(RCCL over xGMI when the ranks own GPUs; gloo in the CPU tests) ends the run.
+
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m nirrt_star_amd.eval_sharded \
+        --problem random_2d --planner irrt_star --iter_after_initial 3000
+"""
+import argparse
+import json
+import os
+import random
+import time
+
+import numpy as np
+
+CHECKPOINTS = list(range(0, 3001, 250))   # cost recorded at +0, +250, ... +3000 iterations after the first solution
+RECORD_LEN = 4 + len(CHECKPOINTS)         # problem_id, first_solution_iter, n_vertices, total_iters, costs...
+
+
+def shard_indices(n_problems, rank, world_size):
+    return list(range(rank, n_problems, world_size))
+
+
+def gather_records(local, world_size, rank, device="cpu"):
+    """local: (m, RECORD_LEN) float64 -> rank 0 gets every rank's records sorted by problem id (None elsewhere).
+    Shards differ in length by at most one, so each is padded to the common maximum with id = -1 rows."""
+    import torch
+    import torch.distributed as dist
+    local = np.asarray(local, dtype=np.float64).reshape(-1, RECORD_LEN)
+    if world_size == 1:
+        return local[np.argsort(local[:, 0])]
+    m = torch.tensor([len(local)], dtype=torch.int64, device=device)
+    mx = m.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    pad = np.full((int(mx.item()), RECORD_LEN), -1.0)
+    pad[: len(local)] = local
+    t = torch.from_numpy(pad).to(device)
+    out = [torch.empty_like(t) for _ in range(world_size)] if rank == 0 else None
+    dist.gather(t, out, dst=0)
+    if rank != 0:
+        return None
+    allr = torch.cat(out).cpu().numpy()
+    allr = allr[allr[:, 0] >= 0]
+    return allr[np.argsort(allr[:, 0])]
+
+
+def make_record(pid, trace, n_vertices):
+    """trace: best cost after each iteration (inf before the first solution)"""
+    rec = np.full(RECORD_LEN, np.inf)
+    rec[0] = pid
+    fin = np.isfinite(trace)
+    rec[1] = int(np.argmax(fin)) + 1 if fin.any() else -1
+    rec[2] = n_vertices
+    rec[3] = len(trace)
+    if fin.any():
+        k0 = int(rec[1]) - 1
+        for j, c in enumerate(CHECKPOINTS):
+            if k0 + c < len(trace):
+                rec[4 + j] = trace[k0 + c]
+    return rec
+
+
+def plan_batch(problems, pids, args, device_id):
+    """planning_random for a batch of problems in two persistent launches (until-first-solution, then
+    iter_after_initial more).  Each problem uses its own seeded generator pair (1000 + problem id)."""
+    from . import _hip, sampling
+    dim = 2 if args.problem == "random_2d" else 3
+    irrt = args.planner == "irrt_star"
+    flags = _hip.F_IRRT if irrt else _hip.F_GOAL_SCAN
+    cap = args.iter_max + args.iter_after_initial
+    trees, npw, pyw = [], [], []
+    for pr, pid in zip(problems, pids):
+        t = _hip.HipTree(dim, cap, pr["x_start"], pr["x_goal"], args.step_len, pr["search_radius"], args.clearance, pr["env"],
+                         device_id=device_id)
+        t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
+        trees.append(t)
+        rs = np.random.RandomState(1000 + pid)
+        npw.append(rs.randint(0, 1 << 32, size=cap * (6 if dim == 2 else 240) + 4096, dtype=np.uint32))
+        if dim == 2 and irrt:
+            n = cap * 16 + 4096
+            bits = random.Random(1000 + pid).getrandbits(32 * n)
+            pyw.append(np.frombuffer(bits.to_bytes(4 * n, "little"), dtype="<u4").astype(np.uint32))
+    use_py = bool(pyw)
+    r1 = _hip.run_sampling(trees, args.iter_max, npw, pyw if use_py else None, flags=flags | _hip.F_STOP_FIRST, want_trace=True)
+    traces = [r1["cost_trace"][i, : r1["iters_done"][i]] for i in range(len(trees))]
+    solved = [i for i in range(len(trees)) if len(traces[i]) and np.isfinite(traces[i][-1])]
+    if solved and args.iter_after_initial > 0:
+        r2 = _hip.run_sampling([trees[i] for i in solved], args.iter_after_initial,
+                               [npw[i][r1["np_used"][i]:] for i in solved],
+                               [pyw[i][r1["py_used"][i]:] for i in solved] if use_py else None, flags=flags, want_trace=True)
+        for j, i in enumerate(solved):
+            traces[i] = np.concatenate([traces[i], r2["cost_trace"][j, : r2["iters_done"][j]]])
+    recs = [make_record(pid, tr, t.n) for pid, tr, t in zip(pids, traces, trees)]
+    for t in trees:
+        t.close()
+    return recs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--problem", default="random_2d", choices=["random_2d", "random_3d"])
+    ap.add_argument("--planner", default="irrt_star", choices=["rrt_star", "irrt_star"])
+    ap.add_argument("--iter_max", type=int, default=50000)
+    ap.add_argument("--iter_after_initial", type=int, default=3000)
+    ap.add_argument("--step_len", type=float, default=10)
+    ap.add_argument("--clearance", type=float, default=None)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--max_problems", type=int, default=None)
+    ap.add_argument("--out", default="results/evaluation/sharded_result.json")
+    args = ap.parse_args()
+    if args.clearance is None:
+        args.clearance = 3 if args.problem == "random_2d" else 2
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("eval_sharded needs MI355X GPUs (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from . import problems as P
+    if args.problem == "random_2d":
+        cfgs = P.get_random_2d_env_configs()
+        get = P.get_random_2d_problem_input
+    else:
+        cfgs = P.get_random_3d_env_configs()
+        get = P.get_random_3d_problem_input
+    if args.max_problems:
+        cfgs = cfgs[: args.max_problems]
+    mine = shard_indices(len(cfgs), rank, world)
+    t0 = time.time()
+    recs = []
+    for b0 in range(0, len(mine), args.batch):
+        ids = mine[b0:b0 + args.batch]
+        probs = []
+        for i in ids:
+            if args.problem == "random_3d":
+                np.random.seed(i)   # gamma estimate consumes the global generator
+            probs.append(get(cfgs[i]))
+        recs += plan_batch(probs, ids, args, local_rank)
+    allr = gather_records(np.array(recs).reshape(-1, RECORD_LEN), world, rank, device="cuda")
+    if rank == 0:
+        solved = allr[allr[:, 1] > 0]
+        summary = {"problems": int(len(allr)), "solved": int(len(solved)), "world_size": world,
+                   "median_first_solution_iter": float(np.median(solved[:, 1])) if len(solved) else None,
+                   "mean_cost_at": {str(c): float(np.mean(solved[:, 4 + j][np.isfinite(solved[:, 4 + j])]))
+                                    for j, c in enumerate(CHECKPOINTS) if len(solved) and np.isfinite(solved[:, 4 + j]).any()},
+                   "seconds": time.time() - t0}
+        os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+        with open(args.out, "w") as f:
+            json.dump({"summary": summary, "records": allr.tolist()}, f)
+        print(json.dumps(summary))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

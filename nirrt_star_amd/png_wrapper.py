@@ -44,6 +44,23 @@ def make_synthetic_checkpoint(path, seed=0, num_classes=2, calib_forwards=4, n_p
             feat = np.stack([s, gl, 1 - ((s + gl) > 0).astype(np.float32)], axis=-1)
             x = torch.from_numpy(np.concatenate([xyz, feat], axis=1).astype(np.float32)).permute(1, 0).unsqueeze(0)
             model(x)
+    # un-trained weights put (almost) every point in one class and the planner cannot sample from an empty
+    # prediction (the reference crashes in np.random.randint(0, 0), nirrt_star_png_2d.py:130): shift the class-1
+    # bias so that about a third of the calibration points are labelled "path"
+    model.eval()
+    gaps = []
+    with torch.no_grad():
+        for _ in range(2):
+            pc = rs.uniform(0, 224 if dim == 2 else 50, size=(n_points, 3)).astype(np.float32)
+            if dim == 2:
+                pc[:, 2] = 0
+            s = (np.linalg.norm(pc - pc[0], axis=1) < 10).astype(np.float32)
+            gl = (np.linalg.norm(pc - pc[1], axis=1) < 10).astype(np.float32)
+            feat = np.stack([s, gl, 1 - ((s + gl) > 0).astype(np.float32)], axis=-1)
+            x = torch.from_numpy(np.concatenate([pc_normalize(pc), feat], axis=1).astype(np.float32)).permute(1, 0).unsqueeze(0)
+            logp, _ = model(x)
+            gaps.append((logp[0, :, 1] - logp[0, :, 0]).numpy())
+        model.conv2.bias[1] -= float(np.percentile(np.concatenate(gaps), 65))
     os.makedirs(os.path.dirname(path), exist_ok=True)
     torch.save({"epoch": 0, "class_avg_iou": 0.0, "model_state_dict": model.state_dict(), "optimizer_state_dict": {}}, path)
     return path

@@ -145,3 +145,22 @@ def test_get_path_planner_factories_and_dropin_paths():
         assert pu.compute_gamma_rrt_star(pr["binary_mask"]) == pr["search_radius"]
     finally:
         sys.path.remove(drop)
+
+
+def test_sharded_eval_batch_matches_planner_class():
+    """eval_sharded.plan_batch (many problems per persistent launch) == planning_random of the planner class"""
+    from types import SimpleNamespace as NS
+    from nirrt_star_amd import eval_sharded as es, planners, worlds
+    args = NS(problem="random_2d", planner="irrt_star", iter_max=4000, iter_after_initial=250, step_len=10, clearance=3)
+    ed = [worlds.random_world_2d(i, "ref2d") for i in range(3)]
+    probs = [worlds.problem_2d(e, 0) for e in ed]
+    pids = [5, 6, 7]
+    recs = es.plan_batch(probs, pids, args, 0)
+    for pr, pid, rec in zip(probs, pids, recs):
+        p = planners.IRRTStar2D(pr["x_start"], pr["x_goal"], 10, pr["search_radius"], 4250, pr["env"], 3)
+        np.random.seed(1000 + pid)
+        random.seed(1000 + pid)
+        lst = np.array(p.planning_random(250))
+        first = int(np.argmax(np.isfinite(lst))) + 1
+        assert rec[0] == pid and rec[1] == first and rec[2] == p.num_vertices and rec[3] == len(lst)
+        assert abs(rec[4] - lst[first - 1]) <= 1e-9 and abs(rec[5] - lst[first - 1 + 250]) <= 1e-9
