@@ -5,6 +5,7 @@
 // float32 arithmetic, -ffp-contract=off; the dot products of square_distance are a forward FMA chain.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #define FPS_NT 1024
 #define FPS_MAX_PER_THREAD 8   // N <= 8192
@@ -148,4 +149,83 @@ extern "C" int nirrt_pn2_three_nn(const float *xyz1, const float *xyz2, int B, i
     hipLaunchKernelGGL(k_three_nn, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xyz1, xyz2, N, S, total,
                        dist, (long long *)idx);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// float64 farthest-point down-sampling of the guidance cloud (the reference calls open3d's
+// PointCloud.farthest_point_down_sample, datasets/point_cloud_mask_utils.py:69-72,170-173): start at
+// point 0, greedy max-min squared distance, first maximum on ties; the caller keeps the selected points
+// in their original order.  One workgroup, running min-distances in registers, cloud read from L2.
+// ------------------------------------------------------------------------------------------------
+#define FPS64_MAX_PER_THREAD 16   // N <= 16384
+
+__global__ __launch_bounds__(FPS_NT) void k_fps_f64(const double *__restrict__ x, const double *__restrict__ y,
+                                                   const double *__restrict__ z, int N, int S, unsigned char *__restrict__ sel)
+{
+    __shared__ double rv[FPS_NT / 64];
+    __shared__ int ri[FPS_NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double dist[FPS64_MAX_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < FPS64_MAX_PER_THREAD; j++) dist[j] = __builtin_inf();
+    for (int i = tid; i < N; i += FPS_NT) sel[i] = 0;
+    int far = 0;
+    __syncthreads();
+    for (int s = 0; s < S; s++) {
+        if (tid == 0) sel[far] = 1;
+        const double cx = x[far], cy = y[far], cz = z[far];
+        double bv = -1.;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < FPS64_MAX_PER_THREAD; j++) {
+            int i = tid + j * FPS_NT;
+            if (i < N) {
+                double dx = x[i] - cx, dy = y[i] - cy, dz = z[i] - cz;
+                double d = dx * dx + dy * dy + dz * dz;
+                if (d < dist[j]) dist[j] = d;
+                if (dist[j] > bv) { bv = dist[j]; bi = i; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            double ov = __shfl_xor(bv, off);
+            int oi = __shfl_xor(bi, off);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { rv[w] = bv; ri[w] = bi; }
+        __syncthreads();
+        bv = rv[0]; bi = ri[0];
+#pragma unroll
+        for (int i = 1; i < FPS_NT / 64; i++) {
+            double ov = rv[i];
+            int oi = ri[i];
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        far = bi;
+    }
+}
+
+// host pointers in / out: pts (N,3) row-major f64, sel (N,) bytes (1 = kept)
+extern "C" int nirrt_fps_f64(const double *pts, int N, int num_samples, unsigned char *sel, int device_id)
+{
+    if (!pts || !sel || N <= 0 || num_samples <= 0 || N > FPS_NT * FPS64_MAX_PER_THREAD) return -1;
+    if (hipSetDevice(device_id) != hipSuccess) return -4;
+    double *d = nullptr;
+    unsigned char *ds = nullptr;
+    if (hipMalloc(&d, sizeof(double) * 3 * (size_t)N) != hipSuccess) return -2;
+    if (hipMalloc(&ds, (size_t)N) != hipSuccess) { (void)hipFree(d); return -2; }
+    double *h = (double *)malloc(sizeof(double) * 3 * (size_t)N);
+    for (int i = 0; i < N; i++) { h[i] = pts[3 * i]; h[N + i] = pts[3 * i + 1]; h[2 * (size_t)N + i] = pts[3 * i + 2]; }
+    int rc = 0;
+    if (hipMemcpy(d, h, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice) != hipSuccess) rc = -2;
+    if (!rc) {
+        hipLaunchKernelGGL(k_fps_f64, dim3(1), dim3(FPS_NT), 0, 0, (const double *)d, (const double *)(d + N), (const double *)(d + 2 * (size_t)N),
+                           N, num_samples, ds);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(sel, ds, (size_t)N, hipMemcpyDeviceToHost) != hipSuccess) rc = -2;
+    }
+    free(h);
+    (void)hipFree(d);
+    (void)hipFree(ds);
+    return rc;
 }

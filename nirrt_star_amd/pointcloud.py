@@ -12,11 +12,25 @@ import numpy as np
 
 
 def farthest_point_down_sample(points, num_samples):
-    """open3d.geometry.PointCloud.farthest_point_down_sample restated (points (n, C) f64)."""
-    pts = np.asarray(points, dtype=np.float64)
+    """open3d.geometry.PointCloud.farthest_point_down_sample restated (points (n, 3) f64): greedy max-min
+    squared distance from point 0, first maximum on ties, survivors in original order.  Runs as a HIP kernel
+    (csrc/pointops.hip k_fps_f64, same float64 arithmetic) when a GPU is visible; the numpy loop below is the
+    host implementation used where there is no device (fixture generation, CPU tests)."""
+    pts = np.ascontiguousarray(points, dtype=np.float64)
     n = len(pts)
     if num_samples >= n:
         return pts.copy()
+    from . import _hip
+    if pts.shape[1] == 3 and n <= 16384 and _hip.device_count() > 0:
+        import ctypes as C
+        L = _hip.load()
+        sel8 = np.zeros(n, dtype=np.uint8)
+        L.nirrt_fps_f64.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.nirrt_fps_f64.restype = C.c_int
+        rc = L.nirrt_fps_f64(pts.ctypes.data, n, int(num_samples), sel8.ctypes.data, 0)
+        if rc != 0:
+            raise _hip.NirrtError("nirrt_fps_f64 failed (%d)" % rc)
+        return pts[sel8.astype(bool)]
     sel = np.zeros(n, dtype=bool)
     dist = np.full(n, np.inf)
     far = 0

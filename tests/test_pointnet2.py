@@ -87,3 +87,22 @@ def test_gpu_pointops_equal_cpu_semantics():
     db, ib = pointops.three_nn(xyz.cuda(), new.cuda())
     assert (ia == ib.cpu()).float().mean() > 0.999
     assert torch.allclose(da, db.cpu(), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_cloud_downsampling_equals_host_restatement():
+    """k_fps_f64 == the numpy restatement of open3d's farthest_point_down_sample (same float64 arithmetic)"""
+    from nirrt_star_amd import pointcloud
+    rng = np.random.default_rng(5)
+    for n, s in ((9000, 2048), (3000, 2048), (2500, 100)):
+        pts = np.concatenate([rng.uniform(0, 224, size=(n, 2)), np.zeros((n, 1))], axis=1)
+        got = pointcloud.farthest_point_down_sample(pts, s)            # HIP (a device is visible)
+        sel = np.zeros(n, dtype=bool)
+        dist = np.full(n, np.inf)
+        far = 0
+        for _ in range(s):
+            sel[far] = True
+            d = ((pts - pts[far]) ** 2).sum(axis=1)
+            np.minimum(dist, d, out=dist)
+            far = int(np.argmax(dist))
+        assert np.array_equal(got, pts[sel])
