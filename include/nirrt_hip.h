@@ -34,6 +34,7 @@ extern "C" {
 #define NIRRT_E_CAPACITY (-3) /* tree / Near-set / obstacle / solution capacity hit    */
 #define NIRRT_E_NODEVICE (-4) /* no gfx950 device visible                              */
 #define NIRRT_E_STREAM (-5)   /* random-word stream exhausted inside nirrt_run         */
+#define NIRRT_E_CLOUD (-6)    /* nirrt_run + NIRRT_F_PNG: guidance cloud refresh due (not an error) */
 
 #define NIRRT_MAX_OBSTACLES 64 /* per kind (round / box) */
 #define NIRRT_NEAR_CAPACITY 0 /* unlimited: Near-set scratch is sized like the tree */
@@ -63,6 +64,7 @@ typedef struct nirrt_config {
 /* flags for nirrt_step / nirrt_extend / nirrt_run */
 #define NIRRT_F_IRRT 1u      /* IRRT*: InGoalRegion bookkeeping + best-solution report           */
 #define NIRRT_F_GOAL_SCAN 2u /* RRT* planning_random: search_goal_parent + path length each step */
+#define NIRRT_F_PNG 8u        /* nirrt_run: NIRRT* sampling policy (nirrt_star_png_2d.py:99-130) with the cloud of nirrt_set_cloud */
 #define NIRRT_F_STOP_FIRST 4u /* nirrt_run: leave the loop right after the iteration that yields the first finite
                                  best cost (phase 1 of planning_random, rrt_star_2d.py:230-232, irrt_star_2d.py:245-248) */
 
@@ -127,6 +129,12 @@ int nirrt_solutions(nirrt_tree *t, int64_t *n_sol, int64_t *out, int64_t cap);
  * the caller exactly like the reference (math.hypot, numpy SVD): c_min, x_center (dim), C (3x3 row-major).
  * Only needed before nirrt_run with in-kernel IRRT* sampling. */
 int nirrt_set_informed(nirrt_tree *t, double c_min, const double *x_center, const double *C);
+
+/* NIRRT* guidance state for nirrt_run + NIRRT_F_PNG: the predicted path points `self.path_point_cloud_pred`
+ * ((n, dim) f64), pc_sample_rate, pc_update_cost_ratio and c_update (nirrt_star_png_2d.py:56-63,99-130).  The
+ * kernel returns status NIRRT_E_CLOUD as soon as c_best < ratio * c_update: the caller runs
+ * update_point_cloud (PointNet++), calls nirrt_set_cloud again with c_update = c_best and resumes. */
+int nirrt_set_cloud(nirrt_tree *t, int64_t n, const double *pts, double sample_rate, double update_cost_ratio, double c_update);
 
 /* ---- one whole iteration --------------------------------------------------------------------- */
 /* Loop body of RRTStar2D.planning (rrt_star_2d.py:37-55) / IRRTStar2D.planning

@@ -15,15 +15,16 @@ SO_PATH = os.path.join(_HERE, "libnirrt_hip.so")
 F_IRRT = 1
 F_GOAL_SCAN = 2
 F_STOP_FIRST = 4
+F_PNG = 8
 
-E_ARG, E_HIP, E_CAPACITY, E_NODEVICE, E_STREAM = -1, -2, -3, -4, -5
+E_ARG, E_HIP, E_CAPACITY, E_NODEVICE, E_STREAM, E_CLOUD = -1, -2, -3, -4, -5, -6
 MAX_OBSTACLES = 64
 
 EXPORTS = [
     "nirrt_last_error", "nirrt_device_count", "nirrt_create", "nirrt_destroy", "nirrt_reset", "nirrt_upload",
     "nirrt_download", "nirrt_num_vertices", "nirrt_nearest", "nirrt_collision_batch", "nirrt_points_in_obs",
     "nirrt_near", "nirrt_cost", "nirrt_search_goal_parent", "nirrt_best_solution", "nirrt_solutions",
-    "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed", "nirrt_debug_prof",
+    "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed", "nirrt_debug_prof", "nirrt_set_cloud",
 ]
 
 
@@ -94,6 +95,7 @@ def load():
     L.nirrt_run.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(RunArgs)]
     L.nirrt_set_informed.argtypes = [vp, C.c_double, dp, dp]
     L.nirrt_debug_prof.argtypes = [vp, ip]
+    L.nirrt_set_cloud.argtypes = [vp, C.c_int64, dp, C.c_double, C.c_double, C.c_double]
     for name in EXPORTS:
         if name != "nirrt_last_error":
             getattr(L, name).restype = C.c_int
@@ -270,6 +272,11 @@ class HipTree:
         d = C.c_double(0)
         _check(self.L.nirrt_best_solution(self.h, C.byref(d), C.byref(i)))
         return d.value, i.value
+
+    def set_cloud(self, pts, sample_rate, update_cost_ratio, c_update):
+        pts = _f64(pts).reshape(-1, self.dim)
+        _check(self.L.nirrt_set_cloud(self.h, len(pts), _dp(pts) if len(pts) else None, float(sample_rate),
+                                      float(update_cost_ratio), float(c_update)))
 
     def debug_prof(self):
         out = np.zeros(16, dtype=np.int64)

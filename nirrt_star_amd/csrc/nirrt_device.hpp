@@ -107,6 +107,13 @@ struct TreeDev {
     double x_center[3];
     double CL_C[9];          // rotation-to-world matrix C, row-major 3x3
     long long prof[16];      // NIRRT_PROFILE: wall_clock64 ticks (100 MHz) per phase
+    // NIRRT* point-cloud guidance (nirrt_star_png_2d.py:99-130): predicted path points + policy scalars
+    const double *pc;        // (pc_n, dim) row-major
+    int pc_n;
+    int pad2;
+    double pc_rate;          // pc_sample_rate
+    double pc_ratio;         // pc_update_cost_ratio
+    double c_update;         // best cost at the last cloud refresh (inf before the first solution)
 };
 
 // ------------------------------------------------------------------------------------------------

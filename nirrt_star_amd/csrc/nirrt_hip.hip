@@ -292,6 +292,26 @@ __device__ __forceinline__ bool sample_informed(const Lds<NT> &s, const TreeDev 
     }
 }
 
+// SamplePointCloud (nirrt_star_png_2d.py:129-130): np.random.randint(0, m) of the legacy generator = masked
+// rejection on single 32-bit outputs (rng = m-1; no draw when rng == 0)
+template <int D>
+__device__ __forceinline__ int sample_cloud(const TreeDev &t, WordStream &np, double *out)
+{
+    const unsigned rng = (unsigned)(t.pc_n - 1);
+    unsigned idx = 0;
+    if (rng != 0) {
+        unsigned mask = rng;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        do {
+            if (!np.has(1)) return 0;
+            idx = np.w[np.pos++] & mask;
+        } while (idx > rng);
+    }
+#pragma unroll
+    for (int k = 0; k < D; k++) out[k] = t.pc[(size_t)idx * D + k];
+    return 1;
+}
+
 struct RunSampleDev {
     unsigned flags;
     int pad;
@@ -319,6 +339,7 @@ __global__ __launch_bounds__(NT, 4) void k_run_sample(TreeDev *const *trees, Run
     WordStream py = {a.py_words ? a.py_words[b] : nullptr, a.py_words ? a.n_py[b] : 0, 0};
     double *trace = a.cost_trace ? a.cost_trace + (long long)b * a.iters : nullptr;
     const bool irrt = (a.flags & NIRRT_F_IRRT) != 0;
+    const bool png = (a.flags & NIRRT_F_PNG) != 0;
     const bool reports = irrt || (a.flags & NIRRT_F_GOAL_SCAN);
     long long k = 0;
     int stop = 0;
@@ -326,13 +347,29 @@ __global__ __launch_bounds__(NT, 4) void k_run_sample(TreeDev *const *trees, Run
     // (irrt_star_2d.py:51-53) and what planning_random records after each iteration (:223-229, :241)
     double cb = reports ? report_call<D>(&t, a.flags) : __builtin_inf();
     for (; k < a.iters; k++) {
+        // NIRRT*: the guidance cloud is refreshed by the host (PointNet++) once the best cost has dropped below
+        // pc_update_cost_ratio * c_update (nirrt_star_png_2d.py:114-116) -> hand control back before sampling
+        if (png && cb < t.pc_ratio * t.c_update) { stop = NIRRT_E_CLOUD; break; }
         if (threadIdx.x == 0) {
             double q[3] = {0., 0., 0.};
             long long np0 = np.pos, py0 = py.pos;
-            bool ok = (irrt && cb < __builtin_inf()) ? sample_informed<D>(s, t, np, py, cb, q) : sample_free<D>(s, t, np, q);
+            int ok = 1, code = NIRRT_E_STREAM;
+            bool from_cloud = false;
+            if (png) {
+                if (!np.has(2)) ok = 0;
+                else from_cloud = np.next_double() < t.pc_rate;     // np.random.random() < pc_sample_rate
+            }
+            if (ok) {
+                if (from_cloud) {
+                    if (t.pc_n <= 0) { ok = 0; code = NIRRT_E_ARG; }   // empty prediction: the reference raises in randint(0, 0)
+                    else ok = sample_cloud<D>(t, np, q);
+                } else {
+                    ok = (irrt && cb < __builtin_inf()) ? sample_informed<D>(s, t, np, py, cb, q) : sample_free<D>(s, t, np, q);
+                }
+            }
             if (!ok) { np.pos = np0; py.pos = py0; }
             s.bc_d[0] = q[0]; s.bc_d[1] = q[1]; s.bc_d[2] = q[2];
-            s.bc_i[0] = ok ? 0 : NIRRT_E_STREAM;
+            s.bc_i[0] = ok ? 0 : code;
         }
         __syncthreads();
         stop = s.bc_i[0];
@@ -411,6 +448,7 @@ struct nirrt_tree {
     double *near_r;  // device table
     Scratch *scratch;      // pinned host memory
     Scratch *scratch_dev;  // device alias of the same memory
+    double *pc_dev;        // guidance cloud (nirrt_set_cloud)
 };
 
 extern "C" const char *nirrt_last_error(void) { return g_err.c_str(); }
@@ -454,6 +492,7 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
                     t->near_r};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    if (t->pc_dev) (void)hipFree(t->pc_dev);
     if (t->dev) (void)hipFree(t->dev);
     if (t->scratch) (void)hipHostFree(t->scratch);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -508,7 +547,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     t->cap = (int)(cfg->iter_max + 1);
     t->device = cfg->device_id;
     t->stream = nullptr;
-    t->dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr;
+    t->dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->pc_dev = nullptr;
     const int D = t->dim;
     auto fail = [&](int rc) { nirrt_destroy(t); return rc; };
 #define HIPCHK_T(expr)                                                                        \
@@ -585,6 +624,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     }
     h.c_min = 0.;
     for (int k = 0; k < 9; k++) h.CL_C[k] = (k % 4 == 0) ? 1. : 0.;
+    h.pc = nullptr; h.pc_n = 0; h.pad2 = 0; h.pc_rate = 0.; h.pc_ratio = 0.; h.c_update = std::numeric_limits<double>::infinity();
     int rc = nirrt_reset(t);
     if (rc) return fail(rc);
     *out = t;
@@ -825,6 +865,28 @@ extern "C" int nirrt_set_informed(nirrt_tree *t, double c_min, const double *x_c
     for (int k = 0; k < 3; k++) t->host.x_center[k] = k < t->dim ? x_center[k] : 0.;
     for (int k = 0; k < 9; k++) t->host.CL_C[k] = C[k];
     size_t off = offsetof(TreeDev, c_min);
+    HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, sizeof(TreeDev) - off, hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    return NIRRT_OK;
+}
+
+extern "C" int nirrt_set_cloud(nirrt_tree *t, int64_t n, const double *pts, double sample_rate, double update_cost_ratio,
+                               double c_update)
+{
+    if (!t || n < 0 || (n > 0 && !pts)) return NIRRT_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    if (t->pc_dev) { (void)hipFree(t->pc_dev); t->pc_dev = nullptr; }
+    if (n > 0) {
+        HIPCHK(hipMalloc(&t->pc_dev, sizeof(double) * (size_t)n * t->dim));
+        HIPCHK(hipMemcpy(t->pc_dev, pts, sizeof(double) * (size_t)n * t->dim, hipMemcpyHostToDevice));
+    }
+    t->host.pc = t->pc_dev;
+    t->host.pc_n = (int)n;
+    t->host.pad2 = 0;
+    t->host.pc_rate = sample_rate;
+    t->host.pc_ratio = update_cost_ratio;
+    t->host.c_update = c_update;
+    size_t off = offsetof(TreeDev, pc);
     HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, sizeof(TreeDev) - off, hipMemcpyHostToDevice, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     return NIRRT_OK;

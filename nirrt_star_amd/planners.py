@@ -13,10 +13,10 @@ Where the loop runs (``mode``):
       kernel; sampling happens in the kernel from the raw MT19937 outputs of the process-global
       numpy / python generators, which are then advanced by exactly what was consumed
       (nirrt_star_amd/sampling.py) - `np.random.seed(s); random.seed(s)` therefore mean what they
-      mean for the reference.
+      mean for the reference.  NIRRT* runs the same way: its sampling policy (cloud / informed / free) is in
+      the kernel too, which returns to the host only when the guidance cloud is due for a PointNet++ refresh.
   "step": host Python loop; sampling with the reference's own numpy / random calls, one fused HIP
-      kernel per iteration (nearest -> steer -> ... -> rewire).  NIRRT* always uses this mode because
-      its sampler calls PointNet++ between iterations.
+      kernel per iteration (nearest -> steer -> ... -> rewire).
   "exact": like "step" but nearest and the rest are two launches with new_state() evaluated on the
       host by glibc in between: 2D vertices bit-identical to the reference (3D already is).
 """
@@ -186,6 +186,11 @@ class _HipPlanner:
             st = int(res["status"][0])
             if st == _hip.E_CAPACITY:
                 raise IndexError("tree capacity (1+iter_max vertices) exceeded")   # the reference raises IndexError here too
+            if st == _hip.E_ARG:
+                raise ValueError("high <= 0")   # empty predicted cloud: np.random.randint(0, 0) in the reference
+            if st == _hip.E_CLOUD:
+                self._refresh_cloud_on_device()
+                continue
             if st == 0 and d < left:   # STOP_FIRST fired
                 break
             if d == 0 and st == _hip.E_STREAM and len(npw) > (1 << 24):
@@ -440,7 +445,9 @@ class IRRTStar3D(_IRRTStar):
 # Neural Informed RRT* (point-cloud guidance)
 # ================================================================================================
 class _NIRRTStarPNG(_IRRTStar):
-    default_mode = "step"   # the sampler calls PointNet++ between iterations
+    # "resident": the loop runs in the persistent kernel (sampling policy included) and returns to the host only
+    # when the guidance cloud is due for a refresh (PointNet++), O(10) times per run
+    default_mode = "resident"
     connect = False
 
     def _png_init(self, png_wrapper, binary_mask, pc_n_points, pc_over_sample_scale, pc_sample_rate, pc_update_cost_ratio,
@@ -457,12 +464,22 @@ class _NIRRTStarPNG(_IRRTStar):
         self.path_point_cloud_pred = None
         self.path_point_cloud_other = None
         self.num_png_calls = 0
-        if self.mode == "resident":
-            self.mode = "step"
+        self._c_update = np.inf
         self._irrt_init()
 
     def init_pc(self):
         self.update_point_cloud(cmax=np.inf, cmin=None)
+
+    def _push_cloud(self):
+        pc = self.path_point_cloud_pred if self.path_point_cloud_pred is not None else np.zeros((0, self.dim))
+        self.tree.set_cloud(pc, self.pc_sample_rate, self.pc_update_cost_ratio, self._c_update)
+
+    def _refresh_cloud_on_device(self):
+        """the kernel stopped because c_best < pc_update_cost_ratio * c_update (nirrt_star_png_2d.py:114-116)"""
+        c_best, _ = self.tree.best_solution()
+        self.update_point_cloud(c_best, self._frame[0])
+        self._c_update = c_best
+        self._push_cloud()
 
     def SamplePointCloud(self):
         return self.path_point_cloud_pred[np.random.randint(0, len(self.path_point_cloud_pred))]
@@ -518,14 +535,20 @@ class _NIRRTStarPNG(_IRRTStar):
         self.init_pc()
         c_best = np.inf
         c_update = c_best
-        self._begin_host_loop()
-        for k in range(self.iter_max):
-            if k % _PRINT_EVERY == 0:
-                print(k)
-            node_rand, c_update = self.generate_random_node(c_best, c_update=c_update)
-            r = self._one_step(node_rand, _hip.F_IRRT)
-            c_best = float(r.c_best)
-        self._sync()
+        if self.mode == "resident":
+            self._c_update = np.inf
+            self._push_cloud()
+            print(0)
+            self._resident(self.iter_max, _hip.F_IRRT | _hip.F_PNG)
+        else:
+            self._begin_host_loop()
+            for k in range(self.iter_max):
+                if k % _PRINT_EVERY == 0:
+                    print(k)
+                node_rand, c_update = self.generate_random_node(c_best, c_update=c_update)
+                r = self._one_step(node_rand, _hip.F_IRRT)
+                c_best = float(r.c_best)
+            self._sync()
         self.path_solutions = [int(v) for v in self.tree.solutions]
         if len(self.path_solutions) > 0:
             c_best, x_best = self.find_best_path_solution()
@@ -538,6 +561,12 @@ class _NIRRTStarPNG(_IRRTStar):
     def planning_random(self, iter_after_initial):
         """nirrt_star_png_2d.py:247-335"""
         self.init_pc()
+        if self.mode == "resident":
+            self._c_update = np.inf
+            self._push_cloud()
+            lst = self._planning_random(iter_after_initial, _hip.F_IRRT | _hip.F_PNG)
+            self.path_solutions = [int(v) for v in self.tree.solutions]
+            return lst
         self._begin_host_loop()
         lst, c_best, c_update = [], np.inf, np.inf
         for k in range(self.iter_max):

@@ -65,3 +65,27 @@ def test_blas_forms_of_informed_sampling_on_this_box():
 def _fma(a, b, c):
     from fractions import Fraction
     return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+
+def test_randint_is_masked_rejection_on_single_words():
+    """np.random.randint(0, m) of the legacy generator == mask-and-reject on 32-bit outputs (what the kernel's
+    SamplePointCloud emulates)"""
+    np.random.seed(5)
+    w = sampling.peek_np_words(40000)
+    pos = 0
+    for m in [1, 2, 3, 7, 8, 9, 700, 1023, 1024, 1025, 2048] * 40:
+        exp = np.random.randint(0, m)
+        rng = m - 1
+        got = 0
+        if rng:
+            mask = rng
+            for sft in (1, 2, 4, 8, 16):
+                mask |= mask >> sft
+            while True:
+                got = int(w[pos]) & mask
+                pos += 1
+                if got <= rng:
+                    break
+        assert got == exp
+    # interleaved with doubles like the NIRRT* sampler does
+    assert np.random.random() == sampling.words_to_doubles(w[pos:pos + 2])[0]

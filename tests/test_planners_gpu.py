@@ -114,12 +114,19 @@ def test_nirrt_control_flow_with_fake_wrapper(name):
         cls = planners.NIRRTStarPNGC2D if connect else planners.NIRRTStarPNG2D
     else:
         cls = planners.NIRRTStarPNGC3D if connect else planners.NIRRTStarPNG3D
-    p = cls(*common, *tail, 5, mode="exact") if connect else cls(*common, *tail, mode="exact")
-    _seed(g)
-    p.planning()
-    assert w.calls == int(g["png_calls"])
-    _check_tree(p, g, exact=True)
-    assert np.array_equal(np.array(p.path_solutions), g["path_solutions"])
+    for mode in ("exact", "resident"):
+        w.calls = 0
+        p = cls(*common, *tail, 5, mode=mode) if connect else cls(*common, *tail, mode=mode)
+        _seed(g)
+        p.planning()
+        assert w.calls == int(g["png_calls"]), mode
+        _check_tree(p, g, exact=(mode == "exact"))
+        assert np.array_equal(np.array(p.path_solutions), g["path_solutions"])
+        tail_rng = (np.random.random_sample(), random.random())
+        if mode == "exact":
+            ref_tail = tail_rng
+        else:
+            assert tail_rng == ref_tail   # both modes leave the global generators in the same state
 
 
 def test_get_path_planner_factories_and_dropin_paths():
