@@ -64,6 +64,54 @@ __global__ __launch_bounds__(FPS_NT) void k_fps(const float *__restrict__ xyz, i
     }
 }
 
+// single-wave variant for N <= 64*PPL: every lane keeps PPL points and their running min-distances in
+// registers, so a step is pure VALU + one wave64 butterfly (no barrier); the LDS copy only serves the
+// centroid lookup.  Same arithmetic and tie-breaking as k_fps.
+template <int PPL>
+__global__ __launch_bounds__(64) void k_fps_wave(const float *__restrict__ xyz, int N, int S, const long long *__restrict__ start,
+                                                long long *__restrict__ out)
+{
+    __shared__ float lp[64 * PPL * 3];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float *p = xyz + (size_t)b * N * 3;
+    float px[PPL], py[PPL], pz[PPL], dist[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; j++) {
+        int i = lane + 64 * j;
+        px[j] = py[j] = pz[j] = 0.f;
+        dist[j] = 1e10f;
+        if (i < N) {
+            px[j] = p[3 * i]; py[j] = p[3 * i + 1]; pz[j] = p[3 * i + 2];
+            lp[3 * i] = px[j]; lp[3 * i + 1] = py[j]; lp[3 * i + 2] = pz[j];
+        }
+    }
+    __syncthreads();
+    int far = (int)start[b];
+    for (int s = 0; s < S; s++) {
+        if (lane == 0) out[(size_t)b * S + s] = far;
+        const float cx = lp[3 * far], cy = lp[3 * far + 1], cz = lp[3 * far + 2];
+        float bv = -1.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            int i = lane + 64 * j;
+            if (i < N) {
+                float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+                float d = dx * dx + dy * dy + dz * dz;
+                if (d < dist[j]) dist[j] = d;
+                if (dist[j] > bv) { bv = dist[j]; bi = i; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            float ov = __shfl_xor(bv, off);
+            int oi = __shfl_xor(bi, off);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        far = bi;
+    }
+}
+
 __device__ __forceinline__ float sqdist_ref(float qx, float qy, float qz, float sq, float x, float y, float z)
 {
     // square_distance: -2*src.dst^T, += sum(src^2), += sum(dst^2)   (src = query)
@@ -128,8 +176,17 @@ __global__ __launch_bounds__(256) void k_three_nn(const float *__restrict__ xyz1
 extern "C" int nirrt_pn2_fps(const float *xyz, int B, int N, int S, const int64_t *start, int64_t *out, void *stream)
 {
     if (N > FPS_NT * FPS_MAX_PER_THREAD || N <= 0 || S <= 0) return -1;
-    size_t lds = sizeof(float) * 3 * (size_t)N + 16 * sizeof(float) + 16 * sizeof(int);
-    hipLaunchKernelGGL(k_fps, dim3(B), dim3(FPS_NT), lds, (hipStream_t)stream, xyz, N, S, (const long long *)start, (long long *)out);
+    hipStream_t st = (hipStream_t)stream;
+    const long long *sp = (const long long *)start;
+    long long *op = (long long *)out;
+    if (N <= 64) hipLaunchKernelGGL(k_fps_wave<1>, dim3(B), dim3(64), 0, st, xyz, N, S, sp, op);
+    else if (N <= 256) hipLaunchKernelGGL(k_fps_wave<4>, dim3(B), dim3(64), 0, st, xyz, N, S, sp, op);
+    else if (N <= 1024) hipLaunchKernelGGL(k_fps_wave<16>, dim3(B), dim3(64), 0, st, xyz, N, S, sp, op);
+    else if (N <= 2048) hipLaunchKernelGGL(k_fps_wave<32>, dim3(B), dim3(64), 0, st, xyz, N, S, sp, op);
+    else {
+        size_t lds = sizeof(float) * 3 * (size_t)N + 16 * sizeof(float) + 16 * sizeof(int);
+        hipLaunchKernelGGL(k_fps, dim3(B), dim3(FPS_NT), lds, st, xyz, N, S, sp, op);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

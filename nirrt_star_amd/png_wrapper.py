@@ -90,9 +90,8 @@ class PNGWrapper:
             pc_features = torch.from_numpy(np.stack((start_mask, goal_mask, free_mask.astype(np.float32)), axis=-1)).to(self.device)
             model_inputs = torch.cat([pc_xyz, pc_features], dim=1).permute(1, 0).unsqueeze(0)
             seg_pred, _ = self.model(model_inputs.float())
-            seg = seg_pred.detach().to('cpu')
-            path_pred = np.argmax(seg.numpy(), 2)[0]
-            path_score = torch.softmax(seg, dim=-1)[0, :, 1].numpy()
+            path_pred = np.argmax(seg_pred.detach().to('cpu').numpy(), 2)[0]
+            path_score = torch.softmax(seg_pred, dim=-1)[0, :, 1].detach().to('cpu').numpy()   # on the device, like the reference
             return path_pred, path_score
 
     def generate_connected_path_points(self, pc, x_start, x_goal, env_dict, neighbor_radius, max_trial_attempts,
