@@ -180,8 +180,11 @@ typedef struct nirrt_run_args {
     int64_t *iters_done;
     int32_t *status;
     double *kernel_ms;   /* optional: device time of the persistent kernel (hipEvent) */
-    int64_t *scan_elems; /* optional (n_trees,): vertices streamed by the nearest + Near passes of this call,
-                            i.e. algorithmic bytes = scan_elems * dim * 8 */
+    int64_t *scan_elems; /* optional (n_trees,): vertices actually streamed by the O(n) passes of this call (the Near
+                            pass of iteration k also answers iteration k+1's nearest query, so a pass counts once) */
+    int64_t *alg_elems;  /* optional (n_trees,): vertices the reference algorithm scans for the same iterations - n per
+                            nearest_neighbor + n per find_near_neighbors - i.e. algorithmic bytes = alg_elems * dim * 8
+                            (B_iter = 2*n*D*8) */
 } nirrt_run_args;
 int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *args);
 

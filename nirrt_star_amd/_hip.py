@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libnirrt_hip.so")
+SO_PATH = os.environ.get("NIRRT_HIP_SO") or os.path.join(_HERE, "libnirrt_hip.so")   # env override: A/B builds
 
 F_IRRT = 1
 F_GOAL_SCAN = 2
@@ -57,7 +57,7 @@ class RunArgs(C.Structure):
                 ("cost_trace", C.POINTER(C.c_double)), ("np_used", C.POINTER(C.c_int64)),
                 ("py_used", C.POINTER(C.c_int64)), ("iters_done", C.POINTER(C.c_int64)),
                 ("status", C.POINTER(C.c_int32)), ("kernel_ms", C.POINTER(C.c_double)),
-                ("scan_elems", C.POINTER(C.c_int64))]
+                ("scan_elems", C.POINTER(C.c_int64)), ("alg_elems", C.POINTER(C.c_int64))]
 
 
 _lib = None
@@ -326,13 +326,16 @@ def run_replay(trees, samples, flags=0, want_trace=False, device_ptr=None, iters
         a.inputs_on_device = 1
         a.samples = C.cast(C.c_void_p(int(device_ptr)), C.POINTER(C.c_double))
     scan = np.zeros(nt, dtype=np.int64)
+    alg = np.zeros(nt, dtype=np.int64)
     a.scan_elems = _ip(scan)
+    a.alg_elems = _ip(alg)
     a.cost_trace = _dp(trace) if want_trace else None
     a.iters_done = _ip(done)
     a.status = status.ctypes.data_as(C.POINTER(C.c_int32))
     a.kernel_ms = C.pointer(ms)
     _check(L.nirrt_run(handles, nt, C.byref(a)))
-    return {"iters_done": done, "status": status, "kernel_ms": ms.value, "cost_trace": trace, "scan_elems": scan}
+    return {"iters_done": done, "status": status, "kernel_ms": ms.value, "cost_trace": trace, "scan_elems": scan,
+            "alg_elems": alg}
 
 
 def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=False, on_device=False):
@@ -372,13 +375,15 @@ def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=Fals
     py_used = np.zeros(nt, dtype=np.int64)
     status = np.zeros(nt, dtype=np.int32)
     scan = np.zeros(nt, dtype=np.int64)
+    alg = np.zeros(nt, dtype=np.int64)
     ms = C.c_double(0)
     trace = np.zeros((nt, iters), dtype=np.float64) if want_trace else None
     a.cost_trace = _dp(trace) if want_trace else None
+    a.alg_elems = _ip(alg)
     a.np_used, a.py_used, a.iters_done = _ip(np_used), _ip(py_used), _ip(done)
     a.status = status.ctypes.data_as(C.POINTER(C.c_int32))
     a.kernel_ms = C.pointer(ms)
     a.scan_elems = _ip(scan)
     _check(L.nirrt_run(handles, nt, C.byref(a)))
     return {"iters_done": done, "np_used": np_used, "py_used": py_used, "status": status, "kernel_ms": ms.value,
-            "cost_trace": trace, "scan_elems": scan}
+            "cost_trace": trace, "scan_elems": scan, "alg_elems": alg}

@@ -55,10 +55,17 @@ struct __attribute__((aligned(16))) Aux {
     int pad;
 };
 
+// random-access twin of a vertex: one 32-byte record (half a 64-byte sector) holds everything the O(k) phases
+// need about a Near candidate - coordinates and the exact cost(v) - so a candidate costs ONE sector read
+struct __attribute__((aligned(32))) VRec {
+    double x, y, z;
+    double cost;   // exact cost(v) of the CURRENT tree (see walk_chains / wg_recost_subtree)
+};
+
 struct TreeDev {
-    double *c[3];   // SoA coordinates x[cap], y[cap], z[cap]
+    double *c[3];   // SoA coordinates x[cap], y[cap], z[cap] (streamed by the O(n) scans)
     Aux *aux;       // aux[cap]
-    double *cost;   // cost[cap]: exact cost(v) of the CURRENT tree (see walk_chains / wg_recost_subtree)
+    VRec *vrec;     // vrec[cap]: coordinates + exact cost for random access
     int *first_child, *next_sib, *prev_sib;   // child lists (-1 = none); the root is nobody's child
     int *bfs_q;     // scratch queue for subtree traversals
     int cap;
@@ -67,13 +74,15 @@ struct TreeDev {
     int status;     // sticky NIRRT_E_* code
     int stamp;      // iterations executed (diagnostic)
     int pad0;
-    long long scan_elems;  // vertices streamed by nearest + Near passes (roofline accounting)
+    long long scan_elems;  // vertices actually streamed by the O(n) passes (fused passes count once)
+    long long alg_elems;   // vertices the reference algorithm scans: n per nearest_neighbor + n per find_near_neighbors
     // Near-set working arrays (capacity cap: a Near set can never exceed the tree)
     int *st_idx;     // ordered staging of scan hits, one region per wave segment
     double *st_c[3]; // coordinates of the staged hits (captured while they are in registers)
     int *nr_idx;     // neighbour vertex index, ascending
     int *nr_flag;    // segment (new -> neighbour) hits an obstacle
     double *nr_dist; // scan distance new <-> neighbour (np.hypot / axis norm)
+    double *nr_cost; // cost(neighbour), kept current through the rewire rounds
     double *nr_c0;   // scratch: candidate x during the Near phase
     double *nr_c1;   // scratch: candidate y during the Near phase
     // IRRT*: path_solutions (goal-parent indices, duplicates allowed) + cached costs
@@ -594,6 +603,49 @@ __device__ __noinline__ int wg_nearest_exact(Lds<NT> &s, const TreeDev &t, int n
     return bi;
 }
 
+// workgroup reduction of the per-lane (smallest d2, its index, second-smallest d2) triples of a nearest scan;
+// falls back to the reference-formula scan when the runner-up is inside the guard band of the minimum
+template <int D, int NT>
+__device__ __forceinline__ int wg_nearest_finish(Lds<NT> &s, const TreeDev &t, int n, const double *q, double m1, int i1, double m2)
+{
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // wave: minimum (m1, i1) and the second-smallest value seen by the wave
+    double wm = m1;
+    int wi = i1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double ov = __shfl_xor(wm, off);
+        int oi = __shfl_xor(wi, off);
+        if (ov < wm || (ov == wm && oi < wi)) { wm = ov; wi = oi; }
+    }
+    double ws = (i1 == wi) ? m2 : m1;  // this lane's best that is NOT the wave winner
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double ov = __shfl_xor(ws, off);
+        ws = ov < ws ? ov : ws;
+    }
+    __syncthreads();
+    if (lane == 0) { s.red_val[w] = wm; s.red_idx[w] = wi; s.red_val2[w] = ws; }
+    __syncthreads();
+    double g1 = s.red_val[0];
+    int gi = s.red_idx[0], gw = 0;
+#pragma unroll
+    for (int i = 1; i < NW; i++) {
+        double ov = s.red_val[i];
+        int oi = s.red_idx[i];
+        if (ov < g1 || (ov == g1 && oi < gi)) { g1 = ov; gi = oi; gw = i; }
+    }
+    double g2 = __builtin_inf();
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        double c = (i == gw) ? s.red_val2[i] : s.red_val[i];
+        g2 = c < g2 ? c : g2;
+    }
+    if (g2 <= g1 * BAND_HI) return wg_nearest_exact<D, NT>(s, t, n, q);  // uniform branch (rare)
+    return gi;
+}
+
 // nearest_neighbor: argmin_i dist(q, v_i), lowest index on ties (np.argmin).
 // Squared distances decide; if a second vertex lies within the guard band of the minimum the
 // reference formula decides instead (wg_nearest_exact).
@@ -634,40 +686,7 @@ __device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, c
             }
         }
     }
-    // wave: minimum (m1, i1) and the second-smallest value seen by the wave
-    double wm = m1;
-    int wi = i1;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double ov = __shfl_xor(wm, off);
-        int oi = __shfl_xor(wi, off);
-        if (ov < wm || (ov == wm && oi < wi)) { wm = ov; wi = oi; }
-    }
-    double ws = (i1 == wi) ? m2 : m1;  // this lane's best that is NOT the wave winner
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double ov = __shfl_xor(ws, off);
-        ws = ov < ws ? ov : ws;
-    }
-    __syncthreads();
-    if (lane == 0) { s.red_val[w] = wm; s.red_idx[w] = wi; s.red_val2[w] = ws; }
-    __syncthreads();
-    double g1 = s.red_val[0];
-    int gi = s.red_idx[0], gw = 0;
-#pragma unroll
-    for (int i = 1; i < NW; i++) {
-        double ov = s.red_val[i];
-        int oi = s.red_idx[i];
-        if (ov < g1 || (ov == g1 && oi < gi)) { g1 = ov; gi = oi; gw = i; }
-    }
-    double g2 = __builtin_inf();
-#pragma unroll
-    for (int i = 0; i < NW; i++) {
-        double c = (i == gw) ? s.red_val2[i] : s.red_val[i];
-        g2 = c < g2 ? c : g2;
-    }
-    if (g2 <= g1 * BAND_HI) return wg_nearest_exact<D, NT>(s, t, n, q);  // uniform branch (rare)
-    return gi;
+    return wg_nearest_finish<D, NT>(s, t, n, q, m1, i1, m2);
 }
 
 // chase parent chains leaf -> root (RRTBase.cost, rrt_base_2d.py:54-61): acc = 0; acc += elen[v]; v = parent[v] ...
@@ -734,8 +753,10 @@ __device__ __forceinline__ void unlink_child(TreeDev &t, int v, int p)
 // there and finished from s.chainE, the edge-length sequence through -> root recorded this iteration
 // - the same additions in the same order as a full walk.
 template <int D, int NT>
-__device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v, int through)
+__device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v, int through, int k_near = 0)
 {
+    // k_near > 0: the current Near list t.nr_idx[0..k_near) (ascending) mirrors costs in t.nr_cost; members that
+    // are re-costed here are patched there too (binary search), so the rewire scan never re-reads scattered records
     const int tid = threadIdx.x;
     __syncthreads();
     if (tid == 0) { t.bfs_q[0] = v; s.bc_i[4] = 1; }
@@ -776,8 +797,19 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v,
             }
         }
 #pragma unroll
-        for (int r = 0; r < WALK_R; r++)
-            if (who[r] >= 0) t.cost[who[r]] = acc[r];
+        for (int r = 0; r < WALK_R; r++) {
+            if (who[r] >= 0) {
+                t.vrec[who[r]].cost = acc[r];
+                if (k_near > 0) {
+                    int lo = 0, hi = k_near;
+                    while (lo < hi) {
+                        int mid = (lo + hi) >> 1;
+                        if (t.nr_idx[mid] < who[r]) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo < k_near && t.nr_idx[lo] == who[r]) t.nr_cost[lo] = acc[r];
+                }
+            }
+        }
     }
     __syncthreads();
 }
@@ -841,7 +873,8 @@ __device__ __forceinline__ bool wg_collision(const Lds<NT> &s, const double *a, 
 // Near set of node_new on the current tree (find_near_neighbors, rrt_star_2d.py:125-144).
 // On return t.nr_idx[0..k) ascending and t.nr_dist[0..k) the reference scan distances.  Returns k.
 template <int D, int NT>
-__device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const double *node_new, int new_idx)
+__device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const double *node_new, int new_idx,
+                                       const double *q2 = nullptr, int *ni2 = nullptr)
 {
     constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
@@ -855,11 +888,24 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     const double2 *Z = reinterpret_cast<const double2 *>(t.c[D - 1]);
     const unsigned long long lt = (1ull << lane) - 1ull;
     int cnt = 0;  // wave-uniform
+    // the same pass can serve the NEXT iteration's nearest query (q2): vertices never move and this scan already
+    // covers the vertex just appended, so argmin_i |q2 - v_i| over [0, n) is exactly what nearest_neighbor will need
+    const bool fuse = q2 != nullptr;
+    double m1 = __builtin_inf(), m2 = __builtin_inf();
+    int i1 = 0x7fffffff;
     PROF_DECL
     // one 128-vertex chunk: band-filtered hit test for this lane's two vertices + ordered staging
     auto chunk = [&](int base, const double2 &xv, const double2 &yv, const double2 &zv) {
         bool ha = false, hb = false;
         if (base < end) {
+            if (fuse) {
+                double ea[3] = {q2[0] - xv.x, q2[1] - yv.x, D == 3 ? q2[D - 1] - zv.x : 0.};
+                double eb[3] = {q2[0] - xv.y, q2[1] - yv.y, D == 3 ? q2[D - 1] - zv.y : 0.};
+                double wa = dist2<D>(ea);
+                double wb = base + 1 < end ? dist2<D>(eb) : __builtin_inf();
+                if (wa < m1) { m2 = m1; m1 = wa; i1 = base; } else if (wa < m2) m2 = wa;
+                if (wb < m1) { m2 = m1; m1 = wb; i1 = base + 1; } else if (wb < m2) m2 = wb;
+            }
             double da[3] = {node_new[0] - xv.x, node_new[1] - yv.x, D == 3 ? node_new[D - 1] - zv.x : 0.};
             double db[3] = {node_new[0] - xv.y, node_new[1] - yv.y, D == 3 ? node_new[D - 1] - zv.y : 0.};
             double va = dist2<D>(da), vb = dist2<D>(db);
@@ -894,6 +940,7 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
         for (int u = 0; u < SCAN_U; u++)
             if (cb + 128 * u < end) chunk(cb + 128 * u + 2 * lane, xv[u], yv[u], zv[u]);   // wave-uniform
     }
+    if (fuse) *ni2 = wg_nearest_finish<D, NT>(s, t, n, q2, m1, i1, m2);
     __syncthreads();
     PROF(8);
     if (lane == 0) s.wave_tot[w] = cnt;
@@ -919,7 +966,9 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
         for (int i = 1; i < NW; i++)
             if (a >= woff[i]) { ww = i; offw = woff[i]; }
         const int v = t.st_idx[ww * per + (a - offw)];
-        double vj[3] = {t.c[0][v], t.c[1][v], D == 3 ? t.c[D - 1][v] : 0.};
+        const VRec vr = t.vrec[v];
+        double vj[3] = {vr.x, vr.y, vr.z};
+        t.nr_cost[a] = vr.cost;
         double d[3] = {node_new[0] - vj[0], node_new[1] - vj[1], D == 3 ? node_new[D - 1] - vj[2] : 0.};
         t.nr_idx[a] = v;
         t.nr_flag[a] = (v == new_idx) ? 1 : 0;   // excluded like the colliding ones
@@ -961,12 +1010,12 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     for (int base = 0; base < kraw; base += NT) {
         int a = base + tid;
         int vi = 0;
-        double vd = 0.;
+        double vd = 0., vc = 0.;
         bool keep = false;
-        if (a < kraw) { vi = t.nr_idx[a]; vd = t.nr_dist[a]; keep = t.nr_flag[a] == 0; }
+        if (a < kraw) { vi = t.nr_idx[a]; vd = t.nr_dist[a]; vc = t.nr_cost[a]; keep = t.nr_flag[a] == 0; }
         int pos;
         int tot = block_compact<NT>(s, keep, pos);
-        if (keep) { t.nr_idx[k + pos] = vi; t.nr_dist[k + pos] = vd; }
+        if (keep) { t.nr_idx[k + pos] = vi; t.nr_dist[k + pos] = vd; t.nr_cost[k + pos] = vc; }
         k += tot;
     }
     __syncthreads();
@@ -987,7 +1036,7 @@ __device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double 
         double bv = __builtin_inf();
         int bs = 0x7fffffff;
         for (int q = tid; q < ns; q += NT) {
-            double c = t.cost[t.sol[q]] + t.sol_line[q];
+            double c = t.vrec[t.sol[q]].cost + t.sol_line[q];
             if (c < bv) { bv = c; bs = q; }
         }
         block_argmin<NT>(s, bv, bs);
@@ -1013,7 +1062,7 @@ __device__ __forceinline__ void wg_append_solution(Lds<NT> &s, TreeDev &t, int i
             t.sol[q] = idx;
             t.sol_line[q] = line;
             if (!t.sol_dirty) {
-                double c = t.cost[idx] + line;
+                double c = t.vrec[idx].cost + line;
                 if (q == 0 || c < t.sol_best_cost) { t.sol_best = q; t.sol_best_cost = c; }
             }
             t.n_sol = q + 1;
@@ -1035,7 +1084,7 @@ __device__ __forceinline__ void wg_goal_parent(Lds<NT> &s, TreeDev &t, int &gp, 
         double bv = __builtin_inf();
         int bq = 0x7fffffff;
         for (int q = tid; q < ng; q += NT) {
-            double c = t.gc_col[q] ? __builtin_inf() : t.cost[t.gc_idx[q]] + t.gc_dist[q];
+            double c = t.gc_col[q] ? __builtin_inf() : t.vrec[t.gc_idx[q]].cost + t.gc_dist[q];
             if (c < bv) { bv = c; bq = q; }
         }
         block_argmin<NT>(s, bv, bq);
@@ -1083,7 +1132,7 @@ __device__ __forceinline__ void wg_goal_candidate(Lds<NT> &s, TreeDev &t, int id
             t.gc_dist[q] = h;
             t.gc_col[q] = col ? 1 : 0;
             if (!t.gc_dirty) {
-                double c = col ? __builtin_inf() : t.cost[idx] + h;
+                double c = col ? __builtin_inf() : t.vrec[idx].cost + h;
                 if (q == 0 || c < t.gc_best_cost) { t.gc_best = q; t.gc_best_cost = c; }
             }
             t.n_gc = q + 1;
@@ -1099,12 +1148,17 @@ __device__ __forceinline__ void wg_goal_candidate(Lds<NT> &s, TreeDev &t, int id
 // ------------------------------------------------------------------------------------------------
 template <int D, int NT>
 __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const double *node_in, bool host_steer,
-                                             int nearest_in, unsigned flags, nirrt_step_result *res)
+                                             int nearest_in, unsigned flags, nirrt_step_result *res,
+                                             int pref_ni = -1, const double *q_next = nullptr)
 {
+    // pref_ni >= 0: nearest_neighbor(node_in) already known from the previous iteration's fused Near scan.
+    // q_next != nullptr: the next iteration's node_rand; if this iteration runs a Near scan its nearest index is
+    // left in s.bc_i[6] (else -1) for the caller to pass back as pref_ni.
     const int tid = threadIdx.x;
     const double clr = t.clearance;
     int n = t.n;
     long long scanned = host_steer ? 0 : n;
+    long long alg = scanned;
     PROF_DECL
     int ni;
     double node_new[D], nearest[D];
@@ -1114,11 +1168,13 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
 #pragma unroll
         for (int k = 0; k < D; k++) node_new[k] = node_in[k];
     } else {
-        ni = wg_nearest<D, NT>(s, t, n, node_in);
+        if (pref_ni >= 0) { ni = pref_ni; scanned = 0; }
+        else ni = wg_nearest<D, NT>(s, t, n, node_in);
         PROF(0);
         load_vertex<D>(t, ni, nearest);
         steer<D>(t, nearest, node_in, node_new);
     }
+    int next_ni = -1;
     if (res && tid == 0) {
         res->collided = 0; res->inserted = 0; res->nearest_idx = ni; res->new_idx = -1; res->n_near = 0;
         res->reparented = 0; res->n_rewired = 0; res->in_goal = 0; res->status = 0; res->reserved = 0;
@@ -1149,6 +1205,9 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 Aux a;
                 a.elen = edge_new; a.parent = ni; a.pad = 0;
                 t.aux[new_idx] = a;
+                VRec vr;
+                vr.x = node_new[0]; vr.y = node_new[1]; vr.z = D == 3 ? node_new[D - 1] : 0.; vr.cost = 0.;
+                t.vrec[new_idx] = vr;
                 t.first_child[new_idx] = -1;
                 link_child(t, new_idx, ni);
                 t.n = n + 1;
@@ -1158,12 +1217,13 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
             __syncthreads();
         }
         if (new_idx >= 0) {
-            int k = wg_near<D, NT>(s, t, n, node_new, new_idx);
+            int k = wg_near<D, NT>(s, t, n, node_new, new_idx, q_next, &next_ni);
             scanned += n;
+            alg += n;
             PROF(2);
             int reparented = 0, n_rewired = 0;
             // curr_node_new_cost (rrt_star_2d.py:45 "same point" / :51)
-            const double cost_ni = t.cost[ni];
+            const double cost_ni = t.vrec[ni].cost;
             const double curr = dup ? cost_ni : cost_ni + edge_new;
             int best_parent = -1;
             if (k > 0) {
@@ -1171,7 +1231,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 double cand = __builtin_inf();
                 int cj = 0x7fffffff;
                 for (int a = tid; a < k; a += NT) {
-                    double c = t.cost[t.nr_idx[a]] + t.nr_dist[a];
+                    double c = t.nr_cost[a] + t.nr_dist[a];
                     if (c < cand) { cand = c; cj = a; }
                 }
                 block_argmin<NT>(s, cand, cj);
@@ -1198,9 +1258,9 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
             if (k > 0 || !dup) {
                 new_cost = wg_chain_of_new<D, NT>(s, t, new_idx);
                 if (dup) {
-                    if (reparented) wg_recost_subtree<D, NT>(s, t, new_idx, new_idx);
+                    if (reparented) wg_recost_subtree<D, NT>(s, t, new_idx, new_idx, k);
                 } else {
-                    if (tid == 0) t.cost[new_idx] = new_cost;
+                    if (tid == 0) t.vrec[new_idx].cost = new_cost;
                 }
             }
             PROF(4);
@@ -1212,7 +1272,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 while (start < k) {
                     int first = 0x7fffffff;
                     for (int a = start + tid; a < k; a += NT) {
-                        if (t.cost[t.nr_idx[a]] > new_cost + t.nr_dist[a]) { first = a; break; }
+                        if (t.nr_cost[a] > new_cost + t.nr_dist[a]) { first = a; break; }
                     }
                     first = block_min_int<NT>(s, first);
                     if (first == 0x7fffffff) break;
@@ -1231,7 +1291,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                     }
                     n_rewired++;
                     start = first + 1;
-                    wg_recost_subtree<D, NT>(s, t, vj, new_idx);
+                    wg_recost_subtree<D, NT>(s, t, vj, new_idx, k);
                 }
             }
             PROF(5);
@@ -1260,7 +1320,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         res->collided = 1;
     }
     PROF(6);
-    if (tid == 0) { t.stamp = t.stamp + 1; t.scan_elems += scanned; }
+    if (tid == 0) { t.stamp = t.stamp + 1; t.scan_elems += scanned; t.alg_elems += alg; s.bc_i[6] = next_ni; }
     __syncthreads();
 }
 

@@ -39,7 +39,12 @@ __global__ __launch_bounds__(NT) void k_init(TreeDev *tp)
     if (threadIdx.x == 0)
         for (int i = 1; i < n; i++) link_child(t, i, t.aux[i].parent);
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += NT) t.cost[i] = walk_cost<D>(t, i);
+    for (int i = threadIdx.x; i < n; i += NT) {
+        VRec vr;
+        vr.x = t.c[0][i]; vr.y = t.c[1][i]; vr.z = D == 3 ? t.c[D - 1][i] : 0.;
+        vr.cost = walk_cost<D>(t, i);
+        t.vrec[i] = vr;
+    }
     __syncthreads();
     // goal-candidate list over the current vertices, ascending
     for (int i = 0; i < n; i++) {  // uniform loop; cheap for n == 1, acceptable for test uploads
@@ -151,10 +156,13 @@ __global__ __launch_bounds__(NT, 4) void k_step(TreeDev *tp, double q0, double q
 // The persistent loops call the loop body through a real function call: inlined into the loop the
 // compiler hoists the tree descriptor into registers across iterations and spills.
 template <int D>
-__device__ __noinline__ void iteration_call(TreeDev *tp, double q0, double q1, double q2, unsigned flags)
+__device__ __noinline__ int iteration_call(TreeDev *tp, double q0, double q1, double q2, unsigned flags, int pref_ni,
+                                           int has_next, double n0, double n1, double n2)
 {
     double q[3] = {q0, q1, q2};
-    wg_iteration<D, NT>(g_lds, *tp, q, false, 0, flags, nullptr);
+    double qn[3] = {n0, n1, n2};
+    wg_iteration<D, NT>(g_lds, *tp, q, false, 0, flags, nullptr, pref_ni, has_next ? qn : nullptr);
+    return g_lds.bc_i[6];   // nearest index of the next sample if this iteration's Near scan ran, else -1
 }
 
 template <int D>
@@ -191,11 +199,17 @@ __global__ __launch_bounds__(NT, 4) void k_run_replay(TreeDev *const *trees, Run
     const double *smp = a.samples + (long long)blockIdx.x * a.iters * D;
     double *trace = a.cost_trace ? a.cost_trace + (long long)blockIdx.x * a.iters : nullptr;
     long long k = 0;
+    int pref = -1;
     for (; k < a.iters; k++) {
-        double q[3] = {0., 0., 0.};
+        double q[3] = {0., 0., 0.}, qn[3] = {0., 0., 0.};
+        const int has_next = k + 1 < a.iters;
 #pragma unroll
-        for (int c = 0; c < D; c++) q[c] = smp[k * D + c];
-        iteration_call<D>(&t, q[0], q[1], q[2], a.flags);
+        for (int c = 0; c < D; c++) {
+            q[c] = smp[k * D + c];
+            if (has_next) qn[c] = smp[(k + 1) * D + c];
+        }
+        // the Near scan of this iteration also answers the next iteration's nearest query (one pass per iteration)
+        pref = iteration_call<D>(&t, q[0], q[1], q[2], a.flags, pref, has_next, qn[0], qn[1], qn[2]);
         if (trace || (a.flags & NIRRT_F_STOP_FIRST)) {
             double cb = report_call<D>(&t, a.flags);
             if (trace && threadIdx.x == 0) trace[k] = cb;
@@ -346,12 +360,12 @@ __global__ __launch_bounds__(NT, 4) void k_run_sample(TreeDev *const *trees, Run
     // cb = best cost on the current tree: what IRRT* samples with at the top of the next iteration
     // (irrt_star_2d.py:51-53) and what planning_random records after each iteration (:223-229, :241)
     double cb = reports ? report_call<D>(&t, a.flags) : __builtin_inf();
-    for (; k < a.iters; k++) {
-        // NIRRT*: the guidance cloud is refreshed by the host (PointNet++) once the best cost has dropped below
-        // pc_update_cost_ratio * c_update (nirrt_star_png_2d.py:114-116) -> hand control back before sampling
-        if (png && cb < t.pc_ratio * t.c_update) { stop = NIRRT_E_CLOUD; break; }
+
+    // draw node_rand for the coming iteration with the reference's policy (thread 0), broadcast through LDS.
+    // returns 0 or a stop code; on failure the stream positions are left where they were.
+    auto draw = [&](double cbest, double *q) -> int {
         if (threadIdx.x == 0) {
-            double q[3] = {0., 0., 0.};
+            double v[3] = {0., 0., 0.};
             long long np0 = np.pos, py0 = py.pos;
             int ok = 1, code = NIRRT_E_STREAM;
             bool from_cloud = false;
@@ -362,25 +376,58 @@ __global__ __launch_bounds__(NT, 4) void k_run_sample(TreeDev *const *trees, Run
             if (ok) {
                 if (from_cloud) {
                     if (t.pc_n <= 0) { ok = 0; code = NIRRT_E_ARG; }   // empty prediction: the reference raises in randint(0, 0)
-                    else ok = sample_cloud<D>(t, np, q);
+                    else ok = sample_cloud<D>(t, np, v);
                 } else {
-                    ok = (irrt && cb < __builtin_inf()) ? sample_informed<D>(s, t, np, py, cb, q) : sample_free<D>(s, t, np, q);
+                    ok = (irrt && cbest < __builtin_inf()) ? sample_informed<D>(s, t, np, py, cbest, v) : sample_free<D>(s, t, np, v);
                 }
             }
             if (!ok) { np.pos = np0; py.pos = py0; }
-            s.bc_d[0] = q[0]; s.bc_d[1] = q[1]; s.bc_d[2] = q[2];
+            s.bc_d[0] = v[0]; s.bc_d[1] = v[1]; s.bc_d[2] = v[2];
             s.bc_i[0] = ok ? 0 : code;
         }
         __syncthreads();
-        stop = s.bc_i[0];
-        double q0 = s.bc_d[0], q1 = s.bc_d[1], q2 = s.bc_d[2];
+        int rc = s.bc_i[0];
+        q[0] = s.bc_d[0]; q[1] = s.bc_d[1]; q[2] = s.bc_d[2];
         __syncthreads();
-        if (stop) break;
-        iteration_call<D>(&t, q0, q1, q2, a.flags);
-        if (reports) cb = report_call<D>(&t, a.flags);
-        if (trace && threadIdx.x == 0) trace[k] = cb;
-        if (t.status != 0) { k++; stop = t.status; break; }
-        if ((a.flags & NIRRT_F_STOP_FIRST) && cb < __builtin_inf()) { k++; break; }
+        return rc;
+    };
+
+    // Software pipeline: the sample of iteration k+1 is drawn BEFORE iteration k runs, with the best cost known at
+    // that point, so that iteration k's Near scan can also answer iteration k+1's nearest query.  Tree operations
+    // never touch the generators, so the early draw consumes exactly the words the reference's draw would - unless
+    // iteration k changes the best cost (or ends the run): then the draw is undone (stream positions restored) and
+    // repeated with the new value, and the prefetched nearest index is dropped.
+    double q[3], qn[3] = {0., 0., 0.};
+    bool have_q = false, spec = false;
+    int pref = -1;
+    long long sp_np = 0, sp_py = 0;
+    for (; k < a.iters; k++) {
+        if (!have_q) {
+            // NIRRT*: the guidance cloud is refreshed by the host (PointNet++) once the best cost has dropped below
+            // pc_update_cost_ratio * c_update (nirrt_star_png_2d.py:114-116) -> hand control back before sampling
+            if (png && cb < t.pc_ratio * t.c_update) { stop = NIRRT_E_CLOUD; break; }
+            stop = draw(cb, q);
+            if (stop) break;
+            pref = -1;
+        }
+        have_q = false;
+        // speculative draw for iteration k+1 (thread 0 owns the stream state)
+        spec = false;
+        if (k + 1 < a.iters) {
+            sp_np = np.pos; sp_py = py.pos;
+            spec = draw(cb, qn) == 0;
+        }
+        pref = iteration_call<D>(&t, q[0], q[1], q[2], a.flags, pref, spec ? 1 : 0, qn[0], qn[1], qn[2]);
+        const double cb_new = reports ? report_call<D>(&t, a.flags) : cb;
+        if (trace && threadIdx.x == 0) trace[k] = cb_new;
+        bool leave = false;
+        if (t.status != 0) { stop = t.status; leave = true; }
+        else if ((a.flags & NIRRT_F_STOP_FIRST) && cb_new < __builtin_inf()) leave = true;
+        const bool keep = spec && !leave && cb_new == cb && !(png && cb_new < t.pc_ratio * t.c_update);
+        if (spec && !keep) { np.pos = sp_np; py.pos = sp_py; pref = -1; }   // undo the early draw (only thread 0's copy matters)
+        cb = cb_new;
+        if (leave) { k++; break; }
+        if (keep) { q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2]; have_q = true; }
     }
     if (threadIdx.x == 0) {
         a.iters_done[b] = k;
@@ -487,7 +534,7 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     TreeDev &h = t->host;
-    void *bufs[] = {h.st_c[0], h.st_c[1], h.st_c[2], h.c[0], h.c[1], h.c[2], h.aux, h.cost, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.st_idx,
+    void *bufs[] = {h.st_c[0], h.st_c[1], h.st_c[2], h.c[0], h.c[1], h.c[2], h.aux, h.vrec, h.nr_cost, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.st_idx,
                     h.nr_idx, h.nr_flag, h.nr_dist, h.nr_c0, h.nr_c1, h.sol, h.sol_line, h.gc_idx, h.gc_dist, h.gc_col,
                     t->near_r};
     for (void *b : bufs)
@@ -513,6 +560,7 @@ extern "C" int nirrt_reset(nirrt_tree *t)
     t->host.status = 0;
     t->host.stamp = 0;
     t->host.scan_elems = 0;
+    t->host.alg_elems = 0;
     int rc = push_desc(t);
     if (rc) return rc;
     DISPATCH_DIM(t, k_init, 1, t->dev);
@@ -568,7 +616,8 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     }
     for (int k = 0; k < D; k++) HIPCHK_T(hipMalloc(&h.st_c[k], sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.aux, sizeof(Aux) * np));
-    HIPCHK_T(hipMalloc(&h.cost, sizeof(double) * np));
+    HIPCHK_T(hipMalloc(&h.vrec, sizeof(VRec) * np));
+    HIPCHK_T(hipMalloc(&h.nr_cost, sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.first_child, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.next_sib, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.prev_sib, sizeof(int) * np));
@@ -920,12 +969,13 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         return e;
     };
     std::vector<TreeDev *> ptrs((size_t)n_trees);
-    std::vector<long long> scan0((size_t)n_trees, 0);
+    std::vector<long long> scan0((size_t)n_trees, 0), alg0((size_t)n_trees, 0);
     for (int i = 0; i < n_trees; i++) {
         ptrs[(size_t)i] = trees[i]->dev;
         TreeDev tmp;
         HIPCHK_R(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
         scan0[(size_t)i] = tmp.scan_elems;
+        alg0[(size_t)i] = tmp.alg_elems;
     }
     // word streams -> device (one slab per generator) unless they already live there
     std::vector<const unsigned *> npp((size_t)n_trees), pyp((size_t)n_trees, nullptr);
@@ -1003,10 +1053,11 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         a->np_used[i] = npu[(size_t)i];
         a->py_used[i] = pyu[(size_t)i];
         if (a->status) a->status[i] = stop[(size_t)i];
-        if (a->scan_elems) {
+        if (a->scan_elems || a->alg_elems) {
             TreeDev tmp;
             HIPCHK_R(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
-            a->scan_elems[i] = tmp.scan_elems - scan0[(size_t)i];
+            if (a->scan_elems) a->scan_elems[i] = tmp.scan_elems - scan0[(size_t)i];
+            if (a->alg_elems) a->alg_elems[i] = tmp.alg_elems - alg0[(size_t)i];
         }
         if (stop[(size_t)i] == NIRRT_E_CAPACITY) rc_all = NIRRT_E_CAPACITY;
     }
@@ -1049,11 +1100,12 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
     long long *d_done = nullptr;
     size_t sbytes = sizeof(double) * (size_t)n_trees * (size_t)a->iters * D;
     HIPCHK(hipMalloc(&d_ptrs, sizeof(TreeDev *) * (size_t)n_trees));
-    std::vector<long long> scan0((size_t)n_trees, 0);
+    std::vector<long long> scan0((size_t)n_trees, 0), alg0((size_t)n_trees, 0);
     for (int i = 0; i < n_trees; i++) {
         TreeDev tmp;
         HIPCHK(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
         scan0[(size_t)i] = tmp.scan_elems;
+        alg0[(size_t)i] = tmp.alg_elems;
     }
     if (a->inputs_on_device) d_samples = const_cast<double *>(a->samples);
     else HIPCHK(hipMalloc(&d_samples, sbytes ? sbytes : 8));
@@ -1090,6 +1142,7 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
         HIPCHK(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
         if (a->status) a->status[i] = tmp.status;
         if (a->scan_elems) a->scan_elems[i] = tmp.scan_elems - scan0[(size_t)i];
+        if (a->alg_elems) a->alg_elems[i] = tmp.alg_elems - alg0[(size_t)i];
         if (tmp.status) rc_all = tmp.status;
     }
     (void)hipFree(d_ptrs);
