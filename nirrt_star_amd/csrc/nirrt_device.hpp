@@ -63,7 +63,9 @@ struct __attribute__((aligned(32))) VRec {
 };
 
 struct TreeDev {
-    double *c[3];   // SoA coordinates x[cap], y[cap], z[cap] (streamed by the O(n) scans)
+    double *c[3];   // SoA coordinates x[cap], y[cap], z[cap] (exact values; streamed only by the fallback scans)
+    float *cf[3];   // float32 twins of c[]: what the O(n) filter scans stream (4 B per coordinate)
+    double cmax;    // max |coordinate| over the range box and every vertex stored so far (float32 rounding bound)
     Aux *aux;       // aux[cap]
     VRec *vrec;     // vrec[cap]: coordinates + exact cost for random access
     int *first_child, *next_sib, *prev_sib;   // child lists (-1 = none); the root is nobody's child
@@ -646,11 +648,11 @@ __device__ __forceinline__ int wg_nearest_finish(Lds<NT> &s, const TreeDev &t, i
     return gi;
 }
 
-// nearest_neighbor: argmin_i dist(q, v_i), lowest index on ties (np.argmin).
+// float64 nearest scan (fallback of the float32 filter scan below).
 // Squared distances decide; if a second vertex lies within the guard band of the minimum the
 // reference formula decides instead (wg_nearest_exact).
 template <int D, int NT>
-__device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, const double *q)
+__device__ __noinline__ int wg_nearest64(Lds<NT> &s, const TreeDev &t, int n, const double *q)
 {
     constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -687,6 +689,165 @@ __device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, c
         }
     }
     return wg_nearest_finish<D, NT>(s, t, n, q, m1, i1, m2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// float32 filter scans.  The O(n) passes stream the float32 twins of the coordinates (half the bytes, twice the
+// VALU rate of float64) and decide with a RIGOROUS error bound; only vertices whose float32 squared distance is
+// within that bound of a decision threshold are re-decided from the float64 coordinates with the float64 logic
+// (guard band + reference formula).  Every decision therefore equals the float64 path's decision.
+//
+// Bound: with e = f32_eps >= |float(x) - x| for every coordinate, u = 2^-24, d = true distance:
+//   |d2_f32 - d2| <= 4.01 e sqrt(D) d + 6 u d^2 + D (2.1 e + u d)^2  <=  E(d2) := 8 e sqrt(D d2) + 2e-6 d2 + 64 e^2
+// ------------------------------------------------------------------------------------------------
+// e for one scan: covers the stored vertices (cmax) and the query point(s) of that scan
+__device__ __forceinline__ double f32_eps_for(const TreeDev &t, const double *q, int D, const double *q2 = nullptr)
+{
+    double m = t.cmax;
+    for (int k = 0; k < D; k++) {
+        m = fmax(m, fabs(q[k]));
+        if (q2) m = fmax(m, fabs(q2[k]));
+    }
+    return 0x1p-24 * 1.01 * m;
+}
+template <int D>
+__device__ __forceinline__ double f32_err(double e, double d2)
+{
+    return 8.0 * e * __builtin_sqrt((double)D * d2) + 2e-6 * d2 + 64.0 * e * e;
+}
+__device__ __forceinline__ float f32_down(double z)   // largest float <= z (z > 0), or -1 if z <= 0
+{
+    if (!(z > 0.0)) return -1.f;
+    float f = (float)z;
+    if ((double)f > z) f = __uint_as_float(__float_as_uint(f) - 1u);
+    return f;
+}
+__device__ __forceinline__ float f32_up(double z)     // smallest float >= z (z >= 0)
+{
+    float f = (float)z;
+    if ((double)f < z) f = __uint_as_float(__float_as_uint(f) + 1u);
+    return f;
+}
+// |y - z| <= E(y) with E(y) = a sqrt(y) + b y + c  =>  y in [f32_lower(z), f32_upper(z)]  (y true d2, z float32 d2)
+template <int D>
+__device__ __forceinline__ double f32_upper(double e, double z)
+{
+    const double a = 8.0 * e * __builtin_sqrt((double)D), b = 2e-6, c = 64.0 * e * e;
+    double r = (a + __builtin_sqrt(a * a + 4.0 * (1.0 - b) * (z + c))) / (2.0 * (1.0 - b));
+    return r * r * (1.0 + 1e-12);
+}
+template <int D>
+__device__ __forceinline__ double f32_lower(double e, double z)
+{
+    const double a = 8.0 * e * __builtin_sqrt((double)D), b = 2e-6, c = 64.0 * e * e;
+    if (!(z > c)) return 0.0;
+    double r = (-a + __builtin_sqrt(a * a + 4.0 * (1.0 + b) * (z - c))) / (2.0 * (1.0 + b));
+    return r <= 0.0 ? 0.0 : r * r * (1.0 - 1e-12);
+}
+
+template <int NT>
+__device__ __forceinline__ void wave_segment256(int n, int &beg, int &end, int &per)
+{
+    constexpr int NW = NT / 64;
+    per = ((n + NW * 256 - 1) / (NW * 256)) * 256;
+    int w = threadIdx.x >> 6;
+    beg = w * per;
+    end = beg + per < n ? beg + per : n;
+    if (beg > n) beg = n;
+}
+
+template <int D>
+__device__ __forceinline__ float dist2f(float ax, float ay, float az)
+{
+    float s = ax * ax + ay * ay;
+    if (D == 3) s = s + az * az;
+    return s;
+}
+
+// workgroup reduction of per-lane float32 (min d2, its index, second-smallest d2); returns the winner's index or
+// -1 when the runner-up is too close to call in float32 (caller falls back to the float64 scan)
+template <int D, int NT>
+__device__ __forceinline__ int wg_nearest_finish32(Lds<NT> &s, double e, float m1, int i1, float m2)
+{
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float wm = m1;
+    int wi = i1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float ov = __shfl_xor(wm, off);
+        int oi = __shfl_xor(wi, off);
+        if (ov < wm || (ov == wm && oi < wi)) { wm = ov; wi = oi; }
+    }
+    float ws = (i1 == wi) ? m2 : m1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float ov = __shfl_xor(ws, off);
+        ws = ov < ws ? ov : ws;
+    }
+    __syncthreads();
+    if (lane == 0) { s.red_val[w] = wm; s.red_idx[w] = wi; s.red_val2[w] = ws; }
+    __syncthreads();
+    double g1 = s.red_val[0];
+    int gi = s.red_idx[0], gw = 0;
+#pragma unroll
+    for (int i = 1; i < NW; i++) {
+        double ov = s.red_val[i];
+        int oi = s.red_idx[i];
+        if (ov < g1 || (ov == g1 && oi < gi)) { g1 = ov; gi = oi; gw = i; }
+    }
+    double g2 = __builtin_inf();
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        double c = (i == gw) ? s.red_val2[i] : s.red_val[i];
+        g2 = c < g2 ? c : g2;
+    }
+    // unambiguous iff every other vertex is provably farther (by more than the float64 path's own tie band)
+    const bool clear = g2 == __builtin_inf() || f32_upper<D>(e, g1) < f32_lower<D>(e, g2) * BAND_LO;
+    return clear ? gi : -1;
+}
+
+// nearest_neighbor: argmin_i dist(q, v_i), lowest index on ties (np.argmin)
+template <int D, int NT>
+__device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, const double *q)
+{
+    const int lane = threadIdx.x & 63;
+    int beg, end, per;
+    wave_segment256<NT>(n, beg, end, per);
+    const float qx = (float)q[0], qy = (float)q[1], qz = D == 3 ? (float)q[D - 1] : 0.f;
+    float m1 = __builtin_inff(), m2 = __builtin_inff();
+    int i1 = 0x7fffffff;
+    const float4 *X = reinterpret_cast<const float4 *>(t.cf[0]);
+    const float4 *Y = reinterpret_cast<const float4 *>(t.cf[1]);
+    const float4 *Z = reinterpret_cast<const float4 *>(t.cf[D - 1]);
+    for (int base = beg + 4 * lane; base < end; base += 256 * SCAN_U) {
+        float4 xv[SCAN_U], yv[SCAN_U], zv[SCAN_U];
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++) {
+            const int bu = base + 256 * u;
+            if (bu < end) {
+                xv[u] = X[bu >> 2]; yv[u] = Y[bu >> 2];
+                if (D == 3) zv[u] = Z[bu >> 2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++) {
+            const int bu = base + 256 * u;
+            if (bu < end) {
+                const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+                const float ys[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+                const float zs[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float v = bu + e < end ? dist2f<D>(qx - xs[e], qy - ys[e], D == 3 ? qz - zs[e] : 0.f) : __builtin_inff();
+                    if (v < m1) { m2 = m1; m1 = v; i1 = bu + e; } else if (v < m2) m2 = v;
+                }
+            }
+        }
+    }
+    int gi = wg_nearest_finish32<D, NT>(s, f32_eps_for(t, q, D), m1, i1, m2);
+    if (gi < 0) gi = wg_nearest64<D, NT>(s, t, n, q);   // uniform (rare)
+    return gi;
 }
 
 // chase parent chains leaf -> root (RRTBase.cost, rrt_base_2d.py:54-61): acc = 0; acc += elen[v]; v = parent[v] ...
@@ -881,66 +1042,87 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     const double r = t.near_r[n];
     const double r2 = r * r, r2lo = r2 * BAND_LO, r2hi = r2 * BAND_HI;
     const double clr = t.clearance;
-    int beg, end;
-    wave_segment<NT>(n, beg, end);
-    const double2 *X = reinterpret_cast<const double2 *>(t.c[0]);
-    const double2 *Y = reinterpret_cast<const double2 *>(t.c[1]);
-    const double2 *Z = reinterpret_cast<const double2 *>(t.c[D - 1]);
+    int beg, end, per;
+    wave_segment256<NT>(n, beg, end, per);
+    const float4 *X = reinterpret_cast<const float4 *>(t.cf[0]);
+    const float4 *Y = reinterpret_cast<const float4 *>(t.cf[1]);
+    const float4 *Z = reinterpret_cast<const float4 *>(t.cf[D - 1]);
     const unsigned long long lt = (1ull << lane) - 1ull;
     int cnt = 0;  // wave-uniform
+    // float32 thresholds of the filter: z <= lo_f => certainly d2 <= r2lo (inside); z > hi_f => certainly d2 > r2hi
+    // (outside); anything between is re-decided from the float64 coordinates with the float64 logic
+    const double e32 = f32_eps_for(t, node_new, D, q2);
+    const float lo_f = f32_down(r2lo - f32_err<D>(e32, r2lo)), hi_f = f32_up(r2hi + f32_err<D>(e32, r2hi));
+    const float nx = (float)node_new[0], ny = (float)node_new[1], nz = D == 3 ? (float)node_new[D - 1] : 0.f;
     // the same pass can serve the NEXT iteration's nearest query (q2): vertices never move and this scan already
     // covers the vertex just appended, so argmin_i |q2 - v_i| over [0, n) is exactly what nearest_neighbor will need
     const bool fuse = q2 != nullptr;
-    double m1 = __builtin_inf(), m2 = __builtin_inf();
+    const float qx = fuse ? (float)q2[0] : 0.f, qy = fuse ? (float)q2[1] : 0.f, qz = (fuse && D == 3) ? (float)q2[D - 1] : 0.f;
+    float m1 = __builtin_inff(), m2 = __builtin_inff();
     int i1 = 0x7fffffff;
     PROF_DECL
-    // one 128-vertex chunk: band-filtered hit test for this lane's two vertices + ordered staging
-    auto chunk = [&](int base, const double2 &xv, const double2 &yv, const double2 &zv) {
-        bool ha = false, hb = false;
-        if (base < end) {
-            if (fuse) {
-                double ea[3] = {q2[0] - xv.x, q2[1] - yv.x, D == 3 ? q2[D - 1] - zv.x : 0.};
-                double eb[3] = {q2[0] - xv.y, q2[1] - yv.y, D == 3 ? q2[D - 1] - zv.y : 0.};
-                double wa = dist2<D>(ea);
-                double wb = base + 1 < end ? dist2<D>(eb) : __builtin_inf();
-                if (wa < m1) { m2 = m1; m1 = wa; i1 = base; } else if (wa < m2) m2 = wa;
-                if (wb < m1) { m2 = m1; m1 = wb; i1 = base + 1; } else if (wb < m2) m2 = wb;
-            }
-            double da[3] = {node_new[0] - xv.x, node_new[1] - yv.x, D == 3 ? node_new[D - 1] - zv.x : 0.};
-            double db[3] = {node_new[0] - xv.y, node_new[1] - yv.y, D == 3 ? node_new[D - 1] - zv.y : 0.};
-            double va = dist2<D>(da), vb = dist2<D>(db);
-            ha = va <= r2lo;
-            if (!ha && va <= r2hi) ha = dist_scan<D>(da) <= r;   // inside the guard band: reference formula
-            if (base + 1 < end) {
-                hb = vb <= r2lo;
-                if (!hb && vb <= r2hi) hb = dist_scan<D>(db) <= r;
+    // exact (float64) Near membership of one vertex: the float64 guard-band logic
+    auto exact_hit = [&](int i) -> bool {
+        double d[3] = {node_new[0] - t.c[0][i], node_new[1] - t.c[1][i], D == 3 ? node_new[D - 1] - t.c[D - 1][i] : 0.};
+        double v = dist2<D>(d);
+        if (v <= r2lo) return true;
+        if (v > r2hi) return false;
+        return dist_scan<D>(d) <= r;
+    };
+    // one 256-vertex chunk: filter test for this lane's four vertices + ordered staging
+    auto chunk = [&](int base, const float4 &xv, const float4 &yv, const float4 &zv) {
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
+        const float zs[4] = {zv.x, zv.y, zv.z, zv.w};
+        bool h[4] = {false, false, false, false};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = base + e;
+            if (i < end) {
+                if (fuse) {
+                    float wv = dist2f<D>(qx - xs[e], qy - ys[e], D == 3 ? qz - zs[e] : 0.f);
+                    if (wv < m1) { m2 = m1; m1 = wv; i1 = i; } else if (wv < m2) m2 = wv;
+                }
+                float v = dist2f<D>(nx - xs[e], ny - ys[e], D == 3 ? nz - zs[e] : 0.f);
+                h[e] = v <= lo_f;
+                if (!h[e] && v <= hi_f) h[e] = exact_hit(i);   // inside the float32 error band: float64 decides
             }
         }
-        unsigned long long ma = __ballot(ha), mb = __ballot(hb);
-        if (ma | mb) {
-            int pre = __popcll(ma & lt) + __popcll(mb & lt);
-            if (ha) t.st_idx[beg + cnt + pre] = base;
-            if (hb) t.st_idx[beg + cnt + pre + (ha ? 1 : 0)] = base + 1;
-            cnt += __popcll(ma) + __popcll(mb);
+        unsigned long long mk[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) mk[e] = __ballot(h[e]);
+        if (mk[0] | mk[1] | mk[2] | mk[3]) {
+            int pos = beg + cnt;
+#pragma unroll
+            for (int e = 0; e < 4; e++) pos += __popcll(mk[e] & lt);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (h[e]) { t.st_idx[pos] = base + e; pos++; }
+            }
+            cnt += __popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3]);
         }
     };
-    for (int cb = beg; cb < end; cb += 128 * SCAN_U) {
+    for (int cb = beg; cb < end; cb += 256 * SCAN_U) {
         // SCAN_U chunks per trip; all 16-byte loads are issued before the first use
-        double2 xv[SCAN_U], yv[SCAN_U], zv[SCAN_U];
+        float4 xv[SCAN_U], yv[SCAN_U], zv[SCAN_U];
 #pragma unroll
         for (int u = 0; u < SCAN_U; u++) {
-            const int bu = cb + 128 * u + 2 * lane;
-            xv[u] = make_double2(0., 0.); yv[u] = xv[u]; zv[u] = xv[u];
+            const int bu = cb + 256 * u + 4 * lane;
+            xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); yv[u] = xv[u]; zv[u] = xv[u];
             if (bu < end) {
-                xv[u] = X[bu >> 1]; yv[u] = Y[bu >> 1];
-                if (D == 3) zv[u] = Z[bu >> 1];
+                xv[u] = X[bu >> 2]; yv[u] = Y[bu >> 2];
+                if (D == 3) zv[u] = Z[bu >> 2];
             }
         }
 #pragma unroll
         for (int u = 0; u < SCAN_U; u++)
-            if (cb + 128 * u < end) chunk(cb + 128 * u + 2 * lane, xv[u], yv[u], zv[u]);   // wave-uniform
+            if (cb + 256 * u < end) chunk(cb + 256 * u + 4 * lane, xv[u], yv[u], zv[u]);   // wave-uniform
     }
-    if (fuse) *ni2 = wg_nearest_finish<D, NT>(s, t, n, q2, m1, i1, m2);
+    if (fuse) {
+        int gi = wg_nearest_finish32<D, NT>(s, e32, m1, i1, m2);
+        if (gi < 0) gi = wg_nearest64<D, NT>(s, t, n, q2);   // uniform (rare)
+        *ni2 = gi;
+    }
     __syncthreads();
     PROF(8);
     if (lane == 0) s.wave_tot[w] = cnt;
@@ -950,7 +1132,6 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
 #pragma unroll
     for (int i = 0; i < NW; i++) woff[i + 1] = woff[i] + s.wave_tot[i];
     const int kraw = woff[NW];
-    const int per = ((n + NW * 128 - 1) / (NW * 128)) * 128;
     // Pass A - gather the staged hits (already ascending): index, coordinates (kept in nr_c0/nr_c1/st scratch
     // for pass B), reference distance, and the AABB prefilter against every obstacle.  (segment, obstacle)
     // pairs that survive the prefilter are queued so that the expensive exact tests run densely packed.
@@ -1200,8 +1381,14 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         } else {
             new_idx = n;
             if (tid == 0) {
+                double cm = t.cmax;
 #pragma unroll
-                for (int k = 0; k < D; k++) t.c[k][new_idx] = node_new[k];
+                for (int k = 0; k < D; k++) {
+                    t.c[k][new_idx] = node_new[k];
+                    t.cf[k][new_idx] = (float)node_new[k];
+                    cm = fmax(cm, fabs(node_new[k]));
+                }
+                t.cmax = cm;
                 Aux a;
                 a.elen = edge_new; a.parent = ni; a.pad = 0;
                 t.aux[new_idx] = a;

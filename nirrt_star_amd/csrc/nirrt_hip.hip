@@ -39,7 +39,15 @@ __global__ __launch_bounds__(NT) void k_init(TreeDev *tp)
     if (threadIdx.x == 0)
         for (int i = 1; i < n; i++) link_child(t, i, t.aux[i].parent);
     __syncthreads();
+    if (threadIdx.x == 0) {   // uploaded vertices may lie outside the range box
+        double cm = t.cmax;
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < D; k++) cm = fmax(cm, fabs(t.c[k][i]));
+        t.cmax = cm;
+    }
     for (int i = threadIdx.x; i < n; i += NT) {
+#pragma unroll
+        for (int k = 0; k < D; k++) t.cf[k][i] = (float)t.c[k][i];
         VRec vr;
         vr.x = t.c[0][i]; vr.y = t.c[1][i]; vr.z = D == 3 ? t.c[D - 1][i] : 0.;
         vr.cost = walk_cost<D>(t, i);
@@ -534,7 +542,7 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     TreeDev &h = t->host;
-    void *bufs[] = {h.st_c[0], h.st_c[1], h.st_c[2], h.c[0], h.c[1], h.c[2], h.aux, h.vrec, h.nr_cost, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.st_idx,
+    void *bufs[] = {h.cf[0], h.cf[1], h.cf[2], h.st_c[0], h.st_c[1], h.st_c[2], h.c[0], h.c[1], h.c[2], h.aux, h.vrec, h.nr_cost, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.st_idx,
                     h.nr_idx, h.nr_flag, h.nr_dist, h.nr_c0, h.nr_c1, h.sol, h.sol_line, h.gc_idx, h.gc_dist, h.gc_col,
                     t->near_r};
     for (void *b : bufs)
@@ -615,6 +623,15 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         HIPCHK_T(hipMemset(h.c[k], 0, sizeof(double) * np));
     }
     for (int k = 0; k < D; k++) HIPCHK_T(hipMalloc(&h.st_c[k], sizeof(double) * np));
+    for (int k = 0; k < D; k++) {
+        HIPCHK_T(hipMalloc(&h.cf[k], sizeof(float) * np));
+        HIPCHK_T(hipMemset(h.cf[k], 0, sizeof(float) * np));
+    }
+    {
+        double cmax = 0.;
+        for (int k = 0; k < D; k++) cmax = std::fmax(cmax, std::fmax(std::fabs(cfg->range_lo[k]), std::fabs(cfg->range_hi[k])));
+        h.cmax = cmax;
+    }
     HIPCHK_T(hipMalloc(&h.aux, sizeof(Aux) * np));
     HIPCHK_T(hipMalloc(&h.vrec, sizeof(VRec) * np));
     HIPCHK_T(hipMalloc(&h.nr_cost, sizeof(double) * np));
