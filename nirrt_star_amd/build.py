@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libnirrt_hip.so")
 SOURCES = [os.path.join(CSRC, "nirrt_hip.hip"), os.path.join(CSRC, "pointops.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "nirrt_device.hpp"),
+DEPS = SOURCES + [os.path.join(CSRC, "nirrt_device.hpp"), os.path.join(CSRC, "nirrt_kernels.inc"),
                   os.path.join(os.path.dirname(HERE), "include", "nirrt_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 

@@ -3,6 +3,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
 #include "nirrt_device.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -12,183 +13,8 @@
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------
-// kernels: one workgroup (NT threads) per tree
+// launch-argument structs shared by both kernel variants
 // ------------------------------------------------------------------------------------------------
-#define NT 256   // 4 wave64 = one wave per SIMD; several trees share a CU
-
-// The workgroup's LDS working set lives at file scope so that the (non-inlined) loop-body function
-// addresses it as LDS (ds_* instructions) instead of through a generic pointer.
-__shared__ Lds<NT> g_lds;
-
-template <int D>
-__global__ __launch_bounds__(NT) void k_init(TreeDev *tp)
-{
-    Lds<NT> &s = g_lds;
-    TreeDev &t = *tp;
-    stage_obstacles<NT>(s, t);
-    if (threadIdx.x == 0) {
-        t.n_gc = 0; t.n_sol = 0; t.status = 0;
-        t.sol_dirty = 1; t.gc_dirty = 1; t.sol_best = -1; t.gc_best = -1;
-        t.sol_best_cost = __builtin_inf(); t.gc_best_cost = __builtin_inf();
-    }
-    __syncthreads();
-    // child lists + exact cost cache of the current tree (n == 1 after create/reset; n > 1 after upload)
-    int n = t.n;
-    for (int i = threadIdx.x; i < n; i += NT) t.first_child[i] = -1;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        for (int i = 1; i < n; i++) link_child(t, i, t.aux[i].parent);
-    __syncthreads();
-    if (threadIdx.x == 0) {   // uploaded vertices may lie outside the range box
-        double cm = t.cmax;
-        for (int i = 0; i < n; i++)
-            for (int k = 0; k < D; k++) cm = fmax(cm, fabs(t.c[k][i]));
-        t.cmax = cm;
-    }
-    for (int i = threadIdx.x; i < n; i += NT) {
-#pragma unroll
-        for (int k = 0; k < D; k++) t.cf[k][i] = (float)t.c[k][i];
-        VRec vr;
-        vr.x = t.c[0][i]; vr.y = t.c[1][i]; vr.z = D == 3 ? t.c[D - 1][i] : 0.;
-        vr.cost = walk_cost<D>(t, i);
-        t.vrec[i] = vr;
-    }
-    __syncthreads();
-    // goal-candidate list over the current vertices, ascending
-    for (int i = 0; i < n; i++) {  // uniform loop; cheap for n == 1, acceptable for test uploads
-        double v[D];
-        load_vertex<D>(t, i, v);
-        wg_goal_candidate<D, NT>(s, t, i, v);
-    }
-}
-
-template <int D>
-__global__ __launch_bounds__(NT) void k_nearest(TreeDev *tp, double q0, double q1, double q2, int *out_idx)
-{
-    Lds<NT> &s = g_lds;
-    TreeDev &t = *tp;
-    double q[3] = {q0, q1, q2};
-    int bi = wg_nearest<D, NT>(s, t, t.n, q);
-    if (threadIdx.x == 0) *out_idx = bi;
-}
-
-template <int D>
-__global__ __launch_bounds__(NT) void k_collision_batch(TreeDev *tp, long long n_seg, const double *seg, unsigned char *out)
-{
-    Lds<NT> &s = g_lds;
-    TreeDev &t = *tp;
-    stage_obstacles<NT>(s, t);
-    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n_seg; i += (long long)gridDim.x * NT) {
-        double a[D], b[D];
-#pragma unroll
-        for (int k = 0; k < D; k++) { a[k] = seg[i * 2 * D + k]; b[k] = seg[i * 2 * D + D + k]; }
-        out[i] = seg_all<D, NT>(s, a, b, t.clearance) ? 1 : 0;
-    }
-}
-
-template <int D>
-__global__ __launch_bounds__(NT) void k_points(TreeDev *tp, long long n, const double *pts, unsigned char *inside,
-                                               unsigned char *valid)
-{
-    Lds<NT> &s = g_lds;
-    TreeDev &t = *tp;
-    stage_obstacles<NT>(s, t);
-    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
-        double p[D];
-#pragma unroll
-        for (int k = 0; k < D; k++) p[k] = pts[i * D + k];
-        bool in = point_in_obs<D, NT>(s, p, t.clearance);
-        if (inside) inside[i] = in ? 1 : 0;
-        if (valid) valid[i] = (point_in_range<D>(t, p) && !in) ? 1 : 0;
-    }
-}
-
-template <int D>
-__global__ __launch_bounds__(NT) void k_near(TreeDev *tp, double q0, double q1, double q2, int new_idx, int *out_k)
-{
-    Lds<NT> &s = g_lds;
-    TreeDev &t = *tp;
-    stage_obstacles<NT>(s, t);
-    double q[3] = {q0, q1, q2};
-    int k = wg_near<D, NT>(s, t, t.n, q, new_idx);   // result left in t.nr_idx[0..k)
-    if (threadIdx.x == 0) *out_k = k;
-}
-
-template <int D>
-__global__ __launch_bounds__(NT) void k_cost(TreeDev *tp, long long n_idx, const long long *idx, double *out)
-{
-    TreeDev &t = *tp;
-    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n_idx; i += (long long)gridDim.x * NT)
-        out[i] = walk_cost<D>(t, (int)idx[i]);
-}
-
-template <int D>
-__global__ __launch_bounds__(NT) void k_goal_parent(TreeDev *tp, int *out_idx, double *out_len)
-{
-    Lds<NT> &s = g_lds;
-    TreeDev &t = *tp;
-    int gp;
-    double len;
-    wg_goal_parent<D, NT>(s, t, gp, len);
-    if (threadIdx.x == 0) { *out_idx = gp; *out_len = len; }
-}
-
-template <int D>
-__global__ __launch_bounds__(NT) void k_best_solution(TreeDev *tp, int *out_idx, double *out_c)
-{
-    Lds<NT> &s = g_lds;
-    TreeDev &t = *tp;
-    double cb;
-    int xb;
-    wg_best_solution<D, NT>(s, t, cb, xb);
-    if (threadIdx.x == 0) { *out_idx = xb; *out_c = cb; }
-}
-
-template <int D>
-__global__ __launch_bounds__(NT, 4) void k_step(TreeDev *tp, double q0, double q1, double q2, int host_steer, int nearest_in,
-                                             unsigned flags, nirrt_step_result *res)
-{
-    Lds<NT> &s = g_lds;
-    TreeDev &t = *tp;
-    stage_obstacles<NT>(s, t);
-    double q[3] = {q0, q1, q2};
-    wg_iteration<D, NT>(s, t, q, host_steer != 0, nearest_in, flags, res);
-    double cb;
-    int xb;
-    wg_report<D, NT>(s, t, flags, cb, xb);
-    if (threadIdx.x == 0) {
-        res->c_best = cb; res->x_best = xb; res->n_solutions = t.n_sol; res->n = t.n; res->status = t.status;
-    }
-}
-
-// The persistent loops call the loop body through a real function call: inlined into the loop the
-// compiler hoists the tree descriptor into registers across iterations and spills.
-template <int D>
-__device__ __noinline__ int iteration_call(TreeDev *tp, double q0, double q1, double q2, unsigned flags, int pref_ni,
-                                           int has_next, double n0, double n1, double n2)
-{
-    double q[3] = {q0, q1, q2};
-    double qn[3] = {n0, n1, n2};
-    wg_iteration<D, NT>(g_lds, *tp, q, false, 0, flags, nullptr, pref_ni, has_next ? qn : nullptr);
-    return g_lds.bc_i[6];   // nearest index of the next sample if this iteration's Near scan ran, else -1
-}
-
-template <int D>
-__device__ __noinline__ double report_call(TreeDev *tp, unsigned flags)
-{
-    double cb;
-    int xb;
-#ifdef NIRRT_PROFILE
-    long long t0_ = wall_clock64();
-#endif
-    wg_report<D, NT>(g_lds, *tp, flags, cb, xb);
-#ifdef NIRRT_PROFILE
-    if (threadIdx.x == 0) tp->prof[7] += wall_clock64() - t0_;
-#endif
-    return cb;
-}
-
-// persistent loop, replayed samples: block b owns trees[b]
 struct RunDev {
     unsigned flags;
     int pad;
@@ -198,42 +24,6 @@ struct RunDev {
     long long *iters_done;  // (n_trees,)
 };
 
-template <int D>
-__global__ __launch_bounds__(NT, 4) void k_run_replay(TreeDev *const *trees, RunDev a)
-{
-    Lds<NT> &s = g_lds;
-    TreeDev &t = *trees[blockIdx.x];
-    stage_obstacles<NT>(s, t);
-    const double *smp = a.samples + (long long)blockIdx.x * a.iters * D;
-    double *trace = a.cost_trace ? a.cost_trace + (long long)blockIdx.x * a.iters : nullptr;
-    long long k = 0;
-    int pref = -1;
-    for (; k < a.iters; k++) {
-        double q[3] = {0., 0., 0.}, qn[3] = {0., 0., 0.};
-        const int has_next = k + 1 < a.iters;
-#pragma unroll
-        for (int c = 0; c < D; c++) {
-            q[c] = smp[k * D + c];
-            if (has_next) qn[c] = smp[(k + 1) * D + c];
-        }
-        // the Near scan of this iteration also answers the next iteration's nearest query (one pass per iteration)
-        pref = iteration_call<D>(&t, q[0], q[1], q[2], a.flags, pref, has_next, qn[0], qn[1], qn[2]);
-        if (trace || (a.flags & NIRRT_F_STOP_FIRST)) {
-            double cb = report_call<D>(&t, a.flags);
-            if (trace && threadIdx.x == 0) trace[k] = cb;
-            if ((a.flags & NIRRT_F_STOP_FIRST) && cb < __builtin_inf()) { k++; break; }
-        }
-        if (t.status != 0) { k++; break; }
-    }
-    if (threadIdx.x == 0) a.iters_done[blockIdx.x] = k;
-}
-
-// ------------------------------------------------------------------------------------------------
-// in-kernel sampling: consumes raw MT19937 32-bit outputs exactly like numpy's legacy RandomState
-// (random_sample: a = w>>5, b = w>>6, (a*2^26+b)/2^53; uniform(lo,hi) = lo + (hi-lo)*u) and CPython's
-// random.random() (same 53-bit construction), so the host generators can be advanced by the
-// reported word counts afterwards.
-// ------------------------------------------------------------------------------------------------
 struct WordStream {
     const unsigned *w;
     long long n, pos;
@@ -245,94 +35,6 @@ struct WordStream {
         return (a * 67108864.0 + b) / 9007199254740992.0;
     }
 };
-
-// SampleFree (rrt_base_2d.py:46-52 / rrt_base_3d.py:49-58); false = stream ran dry
-template <int D>
-__device__ __forceinline__ bool sample_free(const Lds<NT> &s, const TreeDev &t, WordStream &np, double *out)
-{
-    for (;;) {
-        if (!np.has(2 * D)) return false;
-#pragma unroll
-        for (int k = 0; k < D; k++) {
-            double lo = t.lo[k] + t.clearance, hi = t.hi[k] - t.clearance;
-            out[k] = lo + (hi - lo) * np.next_double();
-        }
-        if (!point_in_obs<D, NT>(s, out, t.clearance)) return true;
-    }
-}
-
-// SampleInformedSubset (irrt_star_2d.py:121-151 / irrt_star_3d.py:117-158).  The two matrix
-// products go through BLAS in the reference; the forms below are what OpenBLAS 0.3.29 (numpy 2.2.6
-// wheel, Haswell/Zen kernels) evaluates for these shapes (tests/test_host_sampling.py pins them on
-// the host): C.L -> RN(C[i][j]*r[j]);  2D (3,3)x(3,1) with x2 = 0 -> fma(a0,x0,a1*x1);
-// 3D (3,3)x(3,) -> fma(a2,x2,fma(a0,x0,a1*x1)).
-template <int D>
-__device__ __forceinline__ bool sample_informed(const Lds<NT> &s, const TreeDev &t, WordStream &np, WordStream &py,
-                                                double c_max, double *out)
-{
-    const double c_min = t.c_min;
-    double rad = c_max * c_max - c_min * c_min;
-    double eps = rad < 0 ? 1e-6 : 0.;
-    double r0 = c_max / 2.0;
-    double r1 = __builtin_sqrt(rad + eps) / 2.0;
-    double CL[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        CL[i][0] = t.CL_C[3 * i + 0] * r0;
-        CL[i][1] = t.CL_C[3 * i + 1] * r1;
-        CL[i][2] = t.CL_C[3 * i + 2] * r1;
-    }
-    for (;;) {
-        double xb[3];
-        if (D == 2) {
-            // SampleUnitBall: python random.uniform(-1, 1) twice until inside the open unit disk
-            for (;;) {
-                if (!py.has(4)) return false;
-                xb[0] = -1.0 + 2.0 * py.next_double();
-                xb[1] = -1.0 + 2.0 * py.next_double();
-                if (xb[0] * xb[0] + xb[1] * xb[1] < 1) break;
-            }
-            xb[2] = 0.;
-#pragma unroll
-            for (int i = 0; i < 2; i++) out[i] = __builtin_fma(CL[i][0], xb[0], CL[i][1] * xb[1]) + t.x_center[i];
-        } else {
-            // spherical coordinates with three numpy uniforms (not volume-uniform; reproduced as is)
-            if (!np.has(6)) return false;
-            const double PI = 3.141592653589793;
-            double rr = 0.0 + (1.0 - 0.0) * np.next_double();
-            double theta = 0.0 + (PI - 0.0) * np.next_double();
-            double phi = 0.0 + (2 * PI - 0.0) * np.next_double();
-            xb[0] = rr * sin(theta) * cos(phi);
-            xb[1] = rr * sin(theta) * sin(phi);
-            xb[2] = rr * cos(theta);
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-                out[i] = __builtin_fma(CL[i][2], xb[2], __builtin_fma(CL[i][0], xb[0], CL[i][1] * xb[1])) + t.x_center[i];
-        }
-        // Utils.is_valid: inside the clearance-shrunk range and outside every inflated obstacle
-        if (point_in_range<D>(t, out) && !point_in_obs<D, NT>(s, out, t.clearance)) return true;
-    }
-}
-
-// SamplePointCloud (nirrt_star_png_2d.py:129-130): np.random.randint(0, m) of the legacy generator = masked
-// rejection on single 32-bit outputs (rng = m-1; no draw when rng == 0)
-template <int D>
-__device__ __forceinline__ int sample_cloud(const TreeDev &t, WordStream &np, double *out)
-{
-    const unsigned rng = (unsigned)(t.pc_n - 1);
-    unsigned idx = 0;
-    if (rng != 0) {
-        unsigned mask = rng;
-        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-        do {
-            if (!np.has(1)) return 0;
-            idx = np.w[np.pos++] & mask;
-        } while (idx > rng);
-    }
-#pragma unroll
-    for (int k = 0; k < D; k++) out[k] = t.pc[(size_t)idx * D + k];
-    return 1;
-}
 
 struct RunSampleDev {
     unsigned flags;
@@ -349,101 +51,23 @@ struct RunSampleDev {
     int *stop_code;   // per tree: 0 done, NIRRT_E_STREAM, NIRRT_E_CAPACITY
 };
 
-// persistent loop with in-kernel sampling (RRT*: SampleFree; IRRT*: informed once a solution exists)
-template <int D>
-__global__ __launch_bounds__(NT, 4) void k_run_sample(TreeDev *const *trees, RunSampleDev a)
-{
-    Lds<NT> &s = g_lds;
-    const int b = blockIdx.x;
-    TreeDev &t = *trees[b];
-    stage_obstacles<NT>(s, t);
-    WordStream np = {a.np_words[b], a.n_np[b], 0};
-    WordStream py = {a.py_words ? a.py_words[b] : nullptr, a.py_words ? a.n_py[b] : 0, 0};
-    double *trace = a.cost_trace ? a.cost_trace + (long long)b * a.iters : nullptr;
-    const bool irrt = (a.flags & NIRRT_F_IRRT) != 0;
-    const bool png = (a.flags & NIRRT_F_PNG) != 0;
-    const bool reports = irrt || (a.flags & NIRRT_F_GOAL_SCAN);
-    long long k = 0;
-    int stop = 0;
-    // cb = best cost on the current tree: what IRRT* samples with at the top of the next iteration
-    // (irrt_star_2d.py:51-53) and what planning_random records after each iteration (:223-229, :241)
-    double cb = reports ? report_call<D>(&t, a.flags) : __builtin_inf();
-
-    // draw node_rand for the coming iteration with the reference's policy (thread 0), broadcast through LDS.
-    // returns 0 or a stop code; on failure the stream positions are left where they were.
-    auto draw = [&](double cbest, double *q) -> int {
-        if (threadIdx.x == 0) {
-            double v[3] = {0., 0., 0.};
-            long long np0 = np.pos, py0 = py.pos;
-            int ok = 1, code = NIRRT_E_STREAM;
-            bool from_cloud = false;
-            if (png) {
-                if (!np.has(2)) ok = 0;
-                else from_cloud = np.next_double() < t.pc_rate;     // np.random.random() < pc_sample_rate
-            }
-            if (ok) {
-                if (from_cloud) {
-                    if (t.pc_n <= 0) { ok = 0; code = NIRRT_E_ARG; }   // empty prediction: the reference raises in randint(0, 0)
-                    else ok = sample_cloud<D>(t, np, v);
-                } else {
-                    ok = (irrt && cbest < __builtin_inf()) ? sample_informed<D>(s, t, np, py, cbest, v) : sample_free<D>(s, t, np, v);
-                }
-            }
-            if (!ok) { np.pos = np0; py.pos = py0; }
-            s.bc_d[0] = v[0]; s.bc_d[1] = v[1]; s.bc_d[2] = v[2];
-            s.bc_i[0] = ok ? 0 : code;
-        }
-        __syncthreads();
-        int rc = s.bc_i[0];
-        q[0] = s.bc_d[0]; q[1] = s.bc_d[1]; q[2] = s.bc_d[2];
-        __syncthreads();
-        return rc;
-    };
-
-    // Software pipeline: the sample of iteration k+1 is drawn BEFORE iteration k runs, with the best cost known at
-    // that point, so that iteration k's Near scan can also answer iteration k+1's nearest query.  Tree operations
-    // never touch the generators, so the early draw consumes exactly the words the reference's draw would - unless
-    // iteration k changes the best cost (or ends the run): then the draw is undone (stream positions restored) and
-    // repeated with the new value, and the prefetched nearest index is dropped.
-    double q[3], qn[3] = {0., 0., 0.};
-    bool have_q = false, spec = false;
-    int pref = -1;
-    long long sp_np = 0, sp_py = 0;
-    for (; k < a.iters; k++) {
-        if (!have_q) {
-            // NIRRT*: the guidance cloud is refreshed by the host (PointNet++) once the best cost has dropped below
-            // pc_update_cost_ratio * c_update (nirrt_star_png_2d.py:114-116) -> hand control back before sampling
-            if (png && cb < t.pc_ratio * t.c_update) { stop = NIRRT_E_CLOUD; break; }
-            stop = draw(cb, q);
-            if (stop) break;
-            pref = -1;
-        }
-        have_q = false;
-        // speculative draw for iteration k+1 (thread 0 owns the stream state)
-        spec = false;
-        if (k + 1 < a.iters) {
-            sp_np = np.pos; sp_py = py.pos;
-            spec = draw(cb, qn) == 0;
-        }
-        pref = iteration_call<D>(&t, q[0], q[1], q[2], a.flags, pref, spec ? 1 : 0, qn[0], qn[1], qn[2]);
-        const double cb_new = reports ? report_call<D>(&t, a.flags) : cb;
-        if (trace && threadIdx.x == 0) trace[k] = cb_new;
-        bool leave = false;
-        if (t.status != 0) { stop = t.status; leave = true; }
-        else if ((a.flags & NIRRT_F_STOP_FIRST) && cb_new < __builtin_inf()) leave = true;
-        const bool keep = spec && !leave && cb_new == cb && !(png && cb_new < t.pc_ratio * t.c_update);
-        if (spec && !keep) { np.pos = sp_np; py.pos = sp_py; pref = -1; }   // undo the early draw (only thread 0's copy matters)
-        cb = cb_new;
-        if (leave) { k++; break; }
-        if (keep) { q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2]; have_q = true; }
-    }
-    if (threadIdx.x == 0) {
-        a.iters_done[b] = k;
-        a.np_used[b] = np.pos;
-        a.py_used[b] = py.pos;
-        a.stop_code[b] = stop;
-    }
+// Two instantiations of every kernel: the workgroup size that is best for a batch (one wave per SIMD per tree, four
+// trees per CU: their latency phases overlap each other's streaming) is not the best for a single tree (all 16 waves
+// of a CU on one tree: measured 1.4x faster for one 50k-iteration IRRT* problem, 1.5-2.3x slower for 1024 of them).
+#define NT 256
+namespace narrow {
+#include "nirrt_kernels.inc"
 }
+#undef NT
+#define NT 1024
+namespace wide {
+#include "nirrt_kernels.inc"
+}
+#undef NT
+#define NT_NARROW 256
+#define NT_WIDE 1024
+#define WIDE_MAX_TREES 96   // nirrt_run: batches up to this many trees use the wide kernels ...
+#define WIDE_MIN_VERTICES 16000   // ... once the trees are (or will grow) this big; small trees sync cheaper with 4 waves
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -504,6 +128,7 @@ struct nirrt_tree {
     Scratch *scratch;      // pinned host memory
     Scratch *scratch_dev;  // device alias of the same memory
     double *pc_dev;        // guidance cloud (nirrt_set_cloud)
+    long long last_n;      // num_vertices as of the last call that reported it (kernel-variant choice only)
 };
 
 extern "C" const char *nirrt_last_error(void) { return g_err.c_str(); }
@@ -519,8 +144,19 @@ extern "C" int nirrt_device_count(int *count)
 
 #define DISPATCH_DIM(t, KERNEL, grid, ...)                                                     \
     do {                                                                                       \
-        if ((t)->dim == 2) hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(NT), 0, (t)->stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL(KERNEL<3>, dim3(grid), dim3(NT), 0, (t)->stream, __VA_ARGS__); \
+        if ((t)->dim == 2) hipLaunchKernelGGL(wide::KERNEL<2>, dim3(grid), dim3(NT_WIDE), 0, (t)->stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(wide::KERNEL<3>, dim3(grid), dim3(NT_WIDE), 0, (t)->stream, __VA_ARGS__); \
+    } while (0)
+
+#define DISPATCH_BY_SIZE(t, KERNEL, ...)                                                        \
+    do {                                                                                       \
+        if ((t)->last_n >= WIDE_MIN_VERTICES) {                                                \
+            if ((t)->dim == 2) hipLaunchKernelGGL(wide::KERNEL<2>, dim3(1), dim3(NT_WIDE), 0, (t)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL(wide::KERNEL<3>, dim3(1), dim3(NT_WIDE), 0, (t)->stream, __VA_ARGS__); \
+        } else {                                                                               \
+            if ((t)->dim == 2) hipLaunchKernelGGL(narrow::KERNEL<2>, dim3(1), dim3(NT_NARROW), 0, (t)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL(narrow::KERNEL<3>, dim3(1), dim3(NT_NARROW), 0, (t)->stream, __VA_ARGS__); \
+        }                                                                                      \
     } while (0)
 
 static int sync_check(nirrt_tree *t)
@@ -563,6 +199,7 @@ extern "C" int nirrt_reset(nirrt_tree *t)
         HIPCHK(hipMemcpyAsync(t->host.c[k], &t->cfg.x_start[k], sizeof(double), hipMemcpyHostToDevice, t->stream));
     HIPCHK(hipMemsetAsync(t->host.aux, 0, sizeof(Aux) * (size_t)(t->cap + SCAN_PAD), t->stream));  // parent 0, elen 0, mark 0
     t->host.n = 1;
+    t->last_n = 1;
     t->host.n_sol = 0;
     t->host.n_gc = 0;
     t->host.status = 0;
@@ -730,6 +367,7 @@ extern "C" int nirrt_upload(nirrt_tree *t, int64_t n, const double *vertices, co
     }
     HIPCHK(hipMemcpy(t->host.aux, ax.data(), sizeof(Aux) * (size_t)n, hipMemcpyHostToDevice));
     t->host.n = (int)n;
+    t->last_n = n;
     t->host.n_sol = 0;
     t->host.n_gc = 0;
     t->host.status = 0;
@@ -766,7 +404,7 @@ extern "C" int nirrt_nearest(nirrt_tree *t, const double *q, int64_t *idx)
 {
     if (!t || !q || !idx) return NIRRT_E_ARG;
     HIPCHK(hipSetDevice(t->device));
-    DISPATCH_DIM(t, k_nearest, 1, t->dev, q[0], q[1], t->dim == 3 ? q[2] : 0., &t->scratch_dev->i[0]);
+    DISPATCH_BY_SIZE(t, k_nearest, t->dev, q[0], q[1], t->dim == 3 ? q[2] : 0., &t->scratch_dev->i[0]);
     int rc = sync_check(t);
     if (rc) return rc;
     *idx = t->scratch->i[0];
@@ -775,7 +413,7 @@ extern "C" int nirrt_nearest(nirrt_tree *t, const double *q, int64_t *idx)
 
 static int grid_for(long long n)
 {
-    long long g = (n + NT - 1) / NT;
+    long long g = (n + NT_WIDE - 1) / NT_WIDE;
     if (g < 1) g = 1;
     if (g > 2048) g = 2048;
     return (int)g;
@@ -902,11 +540,12 @@ static int do_step(nirrt_tree *t, const double *p, int host_steer, int64_t neare
 {
     if (!t || !p || !res) return NIRRT_E_ARG;
     HIPCHK(hipSetDevice(t->device));
-    DISPATCH_DIM(t, k_step, 1, t->dev, p[0], p[1], t->dim == 3 ? p[2] : 0., host_steer, (int)nearest_idx, (unsigned)flags,
-                 &t->scratch_dev->step);
+    DISPATCH_BY_SIZE(t, k_step, t->dev, p[0], p[1], t->dim == 3 ? p[2] : 0., host_steer, (int)nearest_idx, (unsigned)flags,
+                     &t->scratch_dev->step);
     int rc = sync_check(t);
     if (rc) return rc;
     *res = t->scratch->step;
+    t->last_n = res->n;
     if (res->status) { g_err = "capacity exceeded inside step"; return res->status; }
     return NIRRT_OK;
 }
@@ -1047,8 +686,16 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
     HIPCHK_R(hipEventCreate(&e0));
     HIPCHK_R(hipEventCreate(&e1));
     HIPCHK_R(hipEventRecord(e0, st));
-    if (D == 2) hipLaunchKernelGGL(k_run_sample<2>, dim3(n_trees), dim3(NT), 0, st, (TreeDev *const *)d_ptrs, rd);
-    else hipLaunchKernelGGL(k_run_sample<3>, dim3(n_trees), dim3(NT), 0, st, (TreeDev *const *)d_ptrs, rd);
+    long long n_hi = 0;
+    for (int i = 0; i < n_trees; i++) n_hi = std::max(n_hi, trees[i]->last_n);
+    const bool use_wide = n_trees <= WIDE_MAX_TREES && n_hi + a->iters >= WIDE_MIN_VERTICES;
+    if (use_wide) {
+        if (D == 2) hipLaunchKernelGGL(wide::k_run_sample<2>, dim3(n_trees), dim3(NT_WIDE), 0, st, (TreeDev *const *)d_ptrs, rd);
+        else hipLaunchKernelGGL(wide::k_run_sample<3>, dim3(n_trees), dim3(NT_WIDE), 0, st, (TreeDev *const *)d_ptrs, rd);
+    } else {
+        if (D == 2) hipLaunchKernelGGL(narrow::k_run_sample<2>, dim3(n_trees), dim3(NT_NARROW), 0, st, (TreeDev *const *)d_ptrs, rd);
+        else hipLaunchKernelGGL(narrow::k_run_sample<3>, dim3(n_trees), dim3(NT_NARROW), 0, st, (TreeDev *const *)d_ptrs, rd);
+    }
     HIPCHK_R(hipEventRecord(e1, st));
     HIPCHK_R(hipGetLastError());
     HIPCHK_R(hipStreamSynchronize(st));
@@ -1070,11 +717,12 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         a->np_used[i] = npu[(size_t)i];
         a->py_used[i] = pyu[(size_t)i];
         if (a->status) a->status[i] = stop[(size_t)i];
-        if (a->scan_elems || a->alg_elems) {
+        {
             TreeDev tmp;
             HIPCHK_R(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
             if (a->scan_elems) a->scan_elems[i] = tmp.scan_elems - scan0[(size_t)i];
             if (a->alg_elems) a->alg_elems[i] = tmp.alg_elems - alg0[(size_t)i];
+            trees[i]->last_n = tmp.n;
         }
         if (stop[(size_t)i] == NIRRT_E_CAPACITY) rc_all = NIRRT_E_CAPACITY;
     }
@@ -1136,8 +784,16 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, st));
-    if (D == 2) hipLaunchKernelGGL(k_run_replay<2>, dim3(n_trees), dim3(NT), 0, st, (TreeDev *const *)d_ptrs, rd);
-    else hipLaunchKernelGGL(k_run_replay<3>, dim3(n_trees), dim3(NT), 0, st, (TreeDev *const *)d_ptrs, rd);
+    long long n_hi = 0;
+    for (int i = 0; i < n_trees; i++) n_hi = std::max(n_hi, trees[i]->last_n);
+    const bool use_wide = n_trees <= WIDE_MAX_TREES && n_hi + a->iters >= WIDE_MIN_VERTICES;
+    if (use_wide) {
+        if (D == 2) hipLaunchKernelGGL(wide::k_run_replay<2>, dim3(n_trees), dim3(NT_WIDE), 0, st, (TreeDev *const *)d_ptrs, rd);
+        else hipLaunchKernelGGL(wide::k_run_replay<3>, dim3(n_trees), dim3(NT_WIDE), 0, st, (TreeDev *const *)d_ptrs, rd);
+    } else {
+        if (D == 2) hipLaunchKernelGGL(narrow::k_run_replay<2>, dim3(n_trees), dim3(NT_NARROW), 0, st, (TreeDev *const *)d_ptrs, rd);
+        else hipLaunchKernelGGL(narrow::k_run_replay<3>, dim3(n_trees), dim3(NT_NARROW), 0, st, (TreeDev *const *)d_ptrs, rd);
+    }
     HIPCHK(hipEventRecord(e1, st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
@@ -1158,6 +814,7 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
         TreeDev tmp;
         HIPCHK(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
         if (a->status) a->status[i] = tmp.status;
+        trees[i]->last_n = tmp.n;
         if (a->scan_elems) a->scan_elems[i] = tmp.scan_elems - scan0[(size_t)i];
         if (a->alg_elems) a->alg_elems[i] = tmp.alg_elems - alg0[(size_t)i];
         if (tmp.status) rc_all = tmp.status;
