@@ -1,0 +1,151 @@
+"""GPU parity at BASELINE.json's full size (50 000 iterations, 50k-vertex trees) through properties that do not
+need a 50k-iteration reference run: brute-force numpy checks of the filtered scans on the big tree, structural
+invariants of the tree, cache-vs-walk cost consistency, batch (narrow) vs single (wide) kernel agreement,
+plus ONE full oracle comparison (3D RRT*, bit-exact)."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ITERS = 50000
+
+
+def _problem(dim, seed):
+    from nirrt_star_amd import worlds
+    if dim == 2:
+        pr = worlds.problem_2d(worlds.random_world_2d(seed, "b30"), 0)
+        pr["clearance"] = 3
+    else:
+        np.random.seed(seed)
+        pr = worlds.problem_3d(worlds.random_world_3d(seed))
+        pr["clearance"] = 2
+    return pr
+
+
+def _grow(dim, seed, flags, n_copies=1):
+    from nirrt_star_amd import _hip, sampling
+    pr = _problem(dim, seed)
+    trees = []
+    for _ in range(n_copies):
+        t = _hip.HipTree(dim, ITERS, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"])
+        t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
+        trees.append(t)
+    np.random.seed(1000 + seed)
+    random.seed(1000 + seed)
+    irrt = bool(flags & _hip.F_IRRT)
+    npw = sampling.peek_np_words(ITERS * (6 if dim == 2 else (240 if irrt else 24)) + 4096)
+    pyw = sampling.peek_py_words(ITERS * 20 + 4096) if (dim == 2 and irrt) else None
+    return pr, trees, npw, pyw
+
+
+@pytest.fixture(scope="module")
+def big_irrt2d():
+    from nirrt_star_amd import _hip
+    pr, (t,), npw, pyw = _grow(2, 11, _hip.F_IRRT)
+    res = _hip.run_sampling([t], ITERS, [npw], [pyw], flags=_hip.F_IRRT, want_trace=True)   # 1 tree -> wide kernels
+    assert res["iters_done"][0] == ITERS and res["status"][0] == 0
+    v, p = t.download()
+    yield pr, t, v, p, res, npw, pyw
+    t.close()
+
+
+def test_tree_invariants_at_50k(big_irrt2d):
+    pr, t, v, p, res, _, _ = big_irrt2d
+    n = len(v)
+    assert 45000 < n <= ITERS + 1
+    assert p[0] == 0 and np.all(p[1:] >= 0) and np.all(p[1:] < n) and np.all(p[1:] != np.arange(1, n))
+    # acyclic: depth by pointer doubling reaches the root for every vertex
+    anc = p.copy()
+    for _ in range(18):
+        anc = anc[anc]
+    assert np.all(anc == 0)
+    # every tree edge is collision-free and no longer than step_len (extension <= step_len, rewire <= r <= step_len)
+    seg = np.stack([v[1:], v[p[1:]]], axis=1)
+    assert not t.collision_batch(seg).any()
+    assert np.max(np.hypot(*(v[1:] - v[p[1:]]).T)) <= 10.0 + 1e-9
+    # all vertices valid (in the clearance-shrunk range, outside inflated obstacles)
+    ins, val = t.points_in_obs(v[1:])
+    assert not ins.any() and val.all()
+    # best cost is non-increasing once found
+    tr = res["cost_trace"][0]
+    fin = tr[np.isfinite(tr)]
+    assert len(fin) > 40000 and np.all(np.diff(fin) <= 1e-12)
+
+
+def test_cached_costs_equal_walked_costs_at_50k(big_irrt2d):
+    """the kernel's exact cost cache (what choose_parent / rewire / best-solution compare) vs fresh leaf->root walks"""
+    import math
+    pr, t, v, p, res, _, _ = big_irrt2d
+    sol = t.solutions
+    assert len(sol) > 100
+    walked = t.cost(sol)                                       # nirrt_cost = pointer-chasing walk
+    line = np.array([math.hypot(*(np.asarray(pr["x_goal"], dtype=float) - v[s])) for s in sol])
+    tot = walked + line
+    c_best, x_best = t.best_solution()                         # served from the cache
+    assert c_best == tot.min() and x_best == sol[int(np.argmin(tot))]
+    assert c_best == res["cost_trace"][0, -1]
+    # and the walks themselves equal a host re-computation with math.hypot in leaf->root order
+    for s in sol[:: max(1, len(sol) // 25)]:
+        c, i = 0.0, int(s)
+        while i != 0:
+            c += math.hypot(*(v[i] - v[p[i]]))
+            i = int(p[i])
+        assert c == walked[list(sol).index(s)]
+
+
+def test_filtered_scans_equal_brute_force_at_50k(big_irrt2d):
+    """float32-filtered nearest / Near on the 50k-vertex tree vs numpy with the reference formulas"""
+    pr, t, v, p, _, _, _ = big_irrt2d
+    n = len(v)
+    rng = np.random.default_rng(3)
+    qs = rng.uniform(3, 221, size=(400, 2))
+    qs[:50] = v[rng.integers(0, n, 50)]                                  # exact hits (distance 0)
+    qs[50:100] = v[rng.integers(0, n, 50)] + rng.normal(scale=1e-7, size=(50, 2))   # float32-indistinguishable neighbours
+    qs[100:150] = 0.5 * (v[rng.integers(0, n, 50)] + v[rng.integers(0, n, 50)])     # near-ties between two vertices
+    for q in qs:
+        d = np.hypot(q[0] - v[:, 0], q[1] - v[:, 1])
+        assert t.nearest(q) == int(np.argmin(d))
+    import math
+    r = min(pr["search_radius"] * math.sqrt(math.log(n) / n), 10)
+    for q in qs[:120]:
+        d = np.hypot(q[0] - v[:, 0], q[1] - v[:, 1])
+        cand = np.where(d <= r)[0]
+        if len(cand):
+            col = t.collision_batch(np.stack([np.repeat(q[None], len(cand), 0), v[cand]], axis=1)).astype(bool)
+            cand = cand[~col]
+        assert np.array_equal(t.near(q, n), cand)
+
+
+def test_batch_kernels_equal_single_tree_kernels_at_50k(big_irrt2d):
+    """narrow (256-thread, many trees) and wide (1024-thread, one tree) instantiations: same seeds -> same tree"""
+    from nirrt_star_amd import _hip
+    pr, t_wide, v, p, res_w, npw, pyw = big_irrt2d
+    n_copies = 100                                             # > WIDE_MAX_TREES -> narrow kernels
+    _, trees, _, _ = _grow(2, 11, _hip.F_IRRT, n_copies)
+    res = _hip.run_sampling(trees, ITERS, [npw] * n_copies, [pyw] * n_copies, flags=_hip.F_IRRT)
+    assert (res["iters_done"] == ITERS).all() and not res["status"].any()
+    assert (res["np_used"] == res_w["np_used"][0]).all() and (res["py_used"] == res_w["py_used"][0]).all()
+    for t in (trees[0], trees[57], trees[-1]):
+        v2, p2 = t.download()
+        assert np.array_equal(p2, p) and np.array_equal(v2, v)
+        assert np.array_equal(t.solutions, t_wide.solutions)
+    for t in trees:
+        t.close()
+
+
+def test_rrt3d_50k_bit_exact_against_oracle(oracle):
+    """one full-size oracle comparison: 3D RRT* needs only IEEE ops on the device, so it must be bit-identical"""
+    from nirrt_star_amd import _hip
+    from oracle import oracle as orc
+    pr, (t,), npw, _ = _grow(3, 5, 0)
+    res = _hip.run_sampling([t], ITERS, [npw], None, flags=0)
+    assert res["iters_done"][0] == ITERS
+    o = orc.OracleTree(3, ITERS, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], 2, pr["env_dict"])
+    ro = o.run_sampling(ITERS, npw)
+    assert ro["iters_done"] == ITERS and ro["np_used"] == int(res["np_used"][0])
+    v, p = t.download()
+    assert np.array_equal(p, o.parents) and np.array_equal(v, o.vertices)
+    t.close()
+    o.close()
