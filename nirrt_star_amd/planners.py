@@ -233,10 +233,12 @@ class _Utils:
 # RRT*
 # ================================================================================================
 class _RRTStar(_HipPlanner):
+    _extra_flags = 0   # NRRT*: F_PNG
+
     def planning(self, visualize=False):
         """rrt_star_2d.py:32-65"""
         if self.mode == "resident":
-            self._resident(self.iter_max, 0)
+            self._resident(self.iter_max, self._extra_flags)
         else:
             self._begin_host_loop()
             for k in range(self.iter_max):
@@ -256,7 +258,7 @@ class _RRTStar(_HipPlanner):
     def planning_random(self, iter_after_initial):
         """rrt_star_2d.py:198-268: until the first finite path length (<= iter_max iterations), then
         exactly iter_after_initial more; entry j = path length after j+1 iterations."""
-        return self._planning_random(iter_after_initial, _hip.F_GOAL_SCAN)
+        return self._planning_random(iter_after_initial, _hip.F_GOAL_SCAN | self._extra_flags)
 
     def planning_block_gap(self, path_len_threshold):
         """rrt_star_2d.py:159-196 (host loop; stops when the path gets shorter than the threshold)"""
@@ -645,6 +647,112 @@ class NIRRTStarPNGC3D(_NIRRTStarPNG):
 
 
 # ================================================================================================
+# Neural RRT* (point-cloud guidance without the informed set): path_planning_classes{,_3d}/nrrt_star_png{,_c}_*.py
+# ================================================================================================
+class _NRRTStarPNG(_RRTStar):
+    """RRT* whose sampler draws from the PointNet++-predicted cloud with probability pc_sample_rate
+    (nrrt_star_png_2d.py:52-59); the cloud is computed once (init_pc) and never refreshed."""
+    _extra_flags = _hip.F_PNG
+    connect = False
+
+    def _nrrt_init(self, png_wrapper, binary_mask, pc_n_points, pc_over_sample_scale, pc_sample_rate, env_dict=None,
+                   connect_max_trial_attempts=None):
+        self.png_wrapper = png_wrapper
+        self.binary_mask = binary_mask
+        self.pc_n_points = pc_n_points
+        self.pc_over_sample_scale = pc_over_sample_scale
+        self.pc_sample_rate = pc_sample_rate
+        self.pc_neighbor_radius = self.step_len
+        self.env_dict = env_dict
+        self.connect_max_trial_attempts = connect_max_trial_attempts
+        self.path_point_cloud_pred = None
+
+    def init_pc(self):
+        self.update_point_cloud()
+        pc = self.path_point_cloud_pred if self.path_point_cloud_pred is not None else np.zeros((0, self.dim))
+        self.tree.set_cloud(pc, self.pc_sample_rate, 0.0, np.inf)   # ratio 0: the kernel never asks for a refresh
+
+    def update_point_cloud(self):
+        from . import pointcloud as pcu
+        if self.pc_sample_rate == 0:
+            self.path_point_cloud_pred = None
+            return
+        if self.dim == 2:
+            pc = pcu.generate_rectangle_point_cloud(self.binary_mask, self.pc_n_points, self.pc_over_sample_scale)
+        else:
+            pc = pcu.generate_rectangle_point_cloud_3d(self.env, self.pc_n_points, over_sample_scale=self.pc_over_sample_scale)
+        if self.connect:
+            _, _, path_pred = self.png_wrapper.generate_connected_path_points(
+                pc.astype(np.float32), self.x_start, self.x_goal, self.env_dict, neighbor_radius=self.pc_neighbor_radius,
+                max_trial_attempts=self.connect_max_trial_attempts)
+        else:
+            sm = pcu.get_point_cloud_mask_around_points(pc, self.x_start[np.newaxis, :], self.pc_neighbor_radius)
+            gm = pcu.get_point_cloud_mask_around_points(pc, self.x_goal[np.newaxis, :], self.pc_neighbor_radius)
+            path_pred, _ = self.png_wrapper.classify_path_points(pc.astype(np.float32), sm.astype(np.float32), gm.astype(np.float32))
+        self.path_point_cloud_pred = pc[np.asarray(path_pred).nonzero()[0]]
+
+    def SamplePointCloud(self):
+        return self.path_point_cloud_pred[np.random.randint(0, len(self.path_point_cloud_pred))]
+
+    def generate_random_node(self, *a, **k):
+        if np.random.random() < self.pc_sample_rate:
+            return self.SamplePointCloud()
+        return self.SampleFree()
+
+    def planning(self, visualize=False):
+        self.init_pc()
+        _RRTStar.planning(self, visualize)
+
+    def planning_random(self, iter_after_initial):
+        self.init_pc()
+        return _RRTStar.planning_random(self, iter_after_initial)
+
+    def planning_block_gap(self, path_len_threshold):
+        self.init_pc()
+        return _RRTStar.planning_block_gap(self, path_len_threshold)
+
+
+class NRRTStarPNG2D(_NRRTStarPNG):
+    dim = 2
+
+    def __init__(self, x_start, x_goal, step_len, search_radius, iter_max, env_dict, png_wrapper, binary_mask, clearance,
+                 pc_n_points, pc_over_sample_scale, pc_sample_rate, mode=None, device_id=0):
+        self._base_init(x_start, x_goal, step_len, search_radius, iter_max, Env(env_dict), clearance, "NRRT*-PNG 2D", mode, device_id)
+        self._nrrt_init(png_wrapper, binary_mask, pc_n_points, pc_over_sample_scale, pc_sample_rate, env_dict)
+
+
+class NRRTStarPNGC2D(_NRRTStarPNG):
+    dim = 2
+    connect = True
+
+    def __init__(self, x_start, x_goal, step_len, search_radius, iter_max, env_dict, png_wrapper_connect, binary_mask, clearance,
+                 pc_n_points, pc_over_sample_scale, pc_sample_rate, connect_max_trial_attempts, mode=None, device_id=0):
+        self._base_init(x_start, x_goal, step_len, search_radius, iter_max, Env(env_dict), clearance, "NRRT*-PNG(C) 2D", mode, device_id)
+        self._nrrt_init(png_wrapper_connect, binary_mask, pc_n_points, pc_over_sample_scale, pc_sample_rate, env_dict,
+                        connect_max_trial_attempts)
+
+
+class NRRTStarPNG3D(_NRRTStarPNG):
+    dim = 3
+
+    def __init__(self, x_start, x_goal, step_len, search_radius, iter_max, env_dict, png_wrapper, clearance,
+                 pc_n_points, pc_over_sample_scale, pc_sample_rate, mode=None, device_id=0):
+        self._base_init(x_start, x_goal, step_len, search_radius, iter_max, Env3D(env_dict), clearance, "NRRT*-PNG 3D", mode, device_id)
+        self._nrrt_init(png_wrapper, None, pc_n_points, pc_over_sample_scale, pc_sample_rate, env_dict)
+
+
+class NRRTStarPNGC3D(_NRRTStarPNG):
+    dim = 3
+    connect = True
+
+    def __init__(self, x_start, x_goal, step_len, search_radius, iter_max, env_dict, png_wrapper_connect, clearance,
+                 pc_n_points, pc_over_sample_scale, pc_sample_rate, connect_max_trial_attempts, mode=None, device_id=0):
+        self._base_init(x_start, x_goal, step_len, search_radius, iter_max, Env3D(env_dict), clearance, "NRRT*-PNG(C) 3D", mode, device_id)
+        self._nrrt_init(png_wrapper_connect, None, pc_n_points, pc_over_sample_scale, pc_sample_rate, env_dict,
+                        connect_max_trial_attempts)
+
+
+# ================================================================================================
 # get_path_planner factories (same signature as every reference planner module)
 # ================================================================================================
 def get_rrt_star_2d(args, problem, neural_wrapper=None):
@@ -691,3 +799,27 @@ def get_nirrt_star_png_c_3d(args, problem, neural_wrapper):
                            problem["env_dict"], neural_wrapper, args.clearance, args.pc_n_points,
                            args.pc_over_sample_scale, args.pc_sample_rate, args.pc_update_cost_ratio,
                            args.connect_max_trial_attempts)
+
+
+def get_nrrt_star_png_2d(args, problem, neural_wrapper):
+    return NRRTStarPNG2D(problem["x_start"], problem["x_goal"], args.step_len, problem["search_radius"], args.iter_max,
+                         problem["env_dict"], neural_wrapper, problem["binary_mask"], args.clearance, args.pc_n_points,
+                         args.pc_over_sample_scale, args.pc_sample_rate)
+
+
+def get_nrrt_star_png_c_2d(args, problem, neural_wrapper):
+    return NRRTStarPNGC2D(problem["x_start"], problem["x_goal"], args.step_len, problem["search_radius"], args.iter_max,
+                          problem["env_dict"], neural_wrapper, problem["binary_mask"], args.clearance, args.pc_n_points,
+                          args.pc_over_sample_scale, args.pc_sample_rate, args.connect_max_trial_attempts)
+
+
+def get_nrrt_star_png_3d(args, problem, neural_wrapper):
+    return NRRTStarPNG3D(problem["x_start"], problem["x_goal"], args.step_len, problem["search_radius"], args.iter_max,
+                         problem["env_dict"], neural_wrapper, args.clearance, args.pc_n_points, args.pc_over_sample_scale,
+                         args.pc_sample_rate)
+
+
+def get_nrrt_star_png_c_3d(args, problem, neural_wrapper):
+    return NRRTStarPNGC3D(problem["x_start"], problem["x_goal"], args.step_len, problem["search_radius"], args.iter_max,
+                          problem["env_dict"], neural_wrapper, args.clearance, args.pc_n_points, args.pc_over_sample_scale,
+                          args.pc_sample_rate, args.connect_max_trial_attempts)

@@ -21,7 +21,7 @@ import numpy as np  # noqa: E402
 
 def arg_parse():
     p = argparse.ArgumentParser()
-    p.add_argument('-p', '--path_planner', default='rrt_star', help='rrt_star, irrt_star, nirrt_star')
+    p.add_argument('-p', '--path_planner', default='rrt_star', help='rrt_star, irrt_star, nrrt_star, nirrt_star')
     p.add_argument('-n', '--neural_net', default='none', help='none, pointnet2')
     p.add_argument('-c', '--connect', default='none', help='none, bfs')
     p.add_argument('--device', default='cuda')
@@ -45,7 +45,7 @@ def main():
     dim = "2d" if args.problem == "random_2d" else "3d"
     name = args.path_planner
     if args.neural_net != 'none':
-        assert name == 'nirrt_star'
+        assert name in ('nirrt_star', 'nrrt_star')
         name += '_png'
         if args.connect == 'bfs':
             name += '_c'

@@ -326,6 +326,35 @@ def nirrt_fixture(name, dim, connect, world_seed, iters, seed):
     print("   %s: n=%d path_len=%.4f png calls %d (%.1fs)" % (name, n, float(planner.get_path_len(planner.path)), w.calls, time.time() - t0))
 
 
+def nrrt_fixture(name, dim, world_seed, iters, seed):
+    """NRRT*-PNG (RRT* + cloud sampling, no informed set) whole run with the fake wrapper (see nirrt_fixture)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    from conftest import FakePNG
+    if dim == 2:
+        from path_planning_classes.nrrt_star_png_2d import NRRTStarPNG2D as P
+    else:
+        from path_planning_classes_3d.nrrt_star_png_3d import NRRTStarPNG3D as P
+    pr, clearance = make_problem(dim, "b30", world_seed, 0)
+    w = FakePNG(pr["x_start"], pr["x_goal"], 25.0 if dim == 2 else 8.0)
+    common = [pr["x_start"], pr["x_goal"], STEP_LEN, pr["search_radius"], iters, pr["env_dict"], w]
+    if dim == 2:
+        common.append(pr["binary_mask"])
+    planner = P(*common, clearance, 2048, 5, 0.5)
+    np.random.seed(seed)
+    random.seed(seed)
+    with quiet():
+        planner.planning()
+    n = planner.num_vertices
+    path = np.array(planner.path, dtype=np.float64).reshape(-1, dim) if len(planner.path) else np.zeros((0, dim))
+    save(name, env=env_json(pr["env_dict"]), dim=np.array(dim), algo=np.array("nrrt"), seed=np.array(seed), iter_max=np.array(iters),
+         step_len=np.array(float(STEP_LEN)), clearance=np.array(float(clearance)), search_radius=np.array(float(pr["search_radius"])),
+         x_start=np.array(pr["x_start"], dtype=np.float64), x_goal=np.array(pr["x_goal"], dtype=np.float64), n=np.array(n),
+         vertices=planner.vertices[:n].copy(), parents=planner.vertex_parents[:n].astype(np.int64), path=path,
+         path_len=np.array(float(planner.get_path_len(planner.path))), png_calls=np.array(w.calls),
+         binary_mask=(pr["binary_mask"].astype(np.uint8) if dim == 2 else np.zeros(0, np.uint8)))
+    print("   %s: n=%d path_len=%.4f png calls %d" % (name, n, float(planner.get_path_len(planner.path)), w.calls))
+
+
 def pointnet2_fixture():
     """L4: the reference PointNet++ (CPU, fp32) on a seeded cloud.  Weights = torch.manual_seed(seed) init
     (regenerated by the test from the same seed - identical construction order) + the BatchNorm running
@@ -408,6 +437,8 @@ JOBS = {
     "run_nirrt2d_1500": lambda: nirrt_fixture("run_nirrt2d_1500", 2, False, 9, 1500, 1009),
     "run_nirrtc2d_1500": lambda: nirrt_fixture("run_nirrtc2d_1500", 2, True, 10, 1500, 1010),
     "run_nirrt3d_1500": lambda: nirrt_fixture("run_nirrt3d_1500", 3, False, 4, 1500, 1004),
+    "run_nrrt2d_1500": lambda: nrrt_fixture("run_nrrt2d_1500", 2, 12, 1500, 1012),
+    "run_nrrt3d_1500": lambda: nrrt_fixture("run_nrrt3d_1500", 3, 6, 1500, 1006),
     "random_irrt3d": lambda: run_planner("random_irrt3d", "irrt", 3, "ref3d", 3, 0, 5000, 1003, mode="random", iter_after_initial=300),
 }
 

@@ -171,3 +171,22 @@ def test_sharded_eval_batch_matches_planner_class():
         first = int(np.argmax(np.isfinite(lst))) + 1
         assert rec[0] == pid and rec[1] == first and rec[2] == p.num_vertices and rec[3] == len(lst)
         assert abs(rec[4] - lst[first - 1]) <= 1e-9 and abs(rec[5] - lst[first - 1 + 250]) <= 1e-9
+
+
+@pytest.mark.parametrize("name", ["run_nrrt2d_1500", "run_nrrt3d_1500"])
+def test_nrrt_png_against_reference_run(name):
+    """NRRT*-PNG: RRT* + point-cloud sampling, resident and host-loop modes"""
+    from nirrt_star_amd import planners
+    g = load_golden(name)
+    dim = int(g["dim"])
+    for mode in ("exact", "resident"):
+        w = FakePNG(g["x_start"], g["x_goal"], 25.0 if dim == 2 else 8.0)
+        common = [tuple(g["x_start"]), tuple(g["x_goal"]), 10, float(g["search_radius"]), int(g["iter_max"]), g["env"], w]
+        if dim == 2:
+            common.append(g["binary_mask"].astype(np.float64))
+        cls = planners.NRRTStarPNG2D if dim == 2 else planners.NRRTStarPNG3D
+        p = cls(*common, int(g["clearance"]), 2048, 5, 0.5, mode=mode)
+        _seed(g)
+        p.planning()
+        assert w.calls == int(g["png_calls"]) == 1
+        _check_tree(p, g, exact=(mode == "exact" or dim == 3))
