@@ -64,20 +64,54 @@ __global__ __launch_bounds__(FPS_NT) void k_fps(const float *__restrict__ xyz, i
     }
 }
 
-// single-wave variant for N <= 64*PPL: every lane keeps PPL points and their running min-distances in
-// registers, so a step is pure VALU + one wave64 butterfly (no barrier); the LDS copy only serves the
-// centroid lookup.  Same arithmetic and tie-breaking as k_fps.
-template <int PPL>
-__global__ __launch_bounds__(64) void k_fps_wave(const float *__restrict__ xyz, int N, int S, const long long *__restrict__ start,
-                                                long long *__restrict__ out)
+// wave64 max of a 64-bit key without LDS traffic: four DPP steps (quad swaps, half-row and row mirrors)
+// leave every 16-lane row holding its maximum, v_readlane pulls the four row maxima into scalars
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long k)
 {
-    __shared__ float lp[64 * PPL * 3];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+    unsigned ol = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+    unsigned oh = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+    unsigned long long o = ((unsigned long long)oh << 32) | ol;
+    return o > k ? o : k;
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+{
+    k = dpp_max_step<0xB1>(k);    // quad_perm [1,0,3,2]
+    k = dpp_max_step<0x4E>(k);    // quad_perm [2,3,0,1]
+    k = dpp_max_step<0x141>(k);   // row_half_mirror
+    k = dpp_max_step<0x140>(k);   // row_mirror
+    unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+    unsigned long long r = 0;
+#pragma unroll
+    for (int row = 0; row < 4; row++) {
+        unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, row * 16) << 32) |
+                               (unsigned)__builtin_amdgcn_readlane((int)lo, row * 16);
+        r = o > r ? o : r;
+    }
+    return r;
+}
+
+// register-resident variant for N <= 64*NW*PPL: every lane keeps PPL points and their running
+// min-distances in registers, so a step is VALU work + a DPP wave reduction of the packed key
+// (distance bits, ~index): distances are non-negative, so their bit patterns order like the values
+// and the complemented index makes the lowest index win ties, as in k_fps.  NW > 1 waves exchange
+// their maxima through double-buffered LDS slots: one barrier per step.  The LDS copy of the cloud
+// only serves the centroid lookup.  Same arithmetic and tie-breaking as k_fps.
+template <int PPL, int NW>
+__global__ __launch_bounds__(64 * NW) void k_fps_wave(const float *__restrict__ xyz, int N, int S, const long long *__restrict__ start,
+                                                     long long *__restrict__ out)
+{
+    constexpr int NT = 64 * NW;
+    __shared__ float lp[NT * PPL * 3];
+    __shared__ unsigned long long slot[2][NW];
+    const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
     const float *p = xyz + (size_t)b * N * 3;
     float px[PPL], py[PPL], pz[PPL], dist[PPL];
 #pragma unroll
     for (int j = 0; j < PPL; j++) {
-        int i = lane + 64 * j;
+        int i = tid + NT * j;
         px[j] = py[j] = pz[j] = 0.f;
         dist[j] = 1e10f;
         if (i < N) {
@@ -88,13 +122,13 @@ __global__ __launch_bounds__(64) void k_fps_wave(const float *__restrict__ xyz, 
     __syncthreads();
     int far = (int)start[b];
     for (int s = 0; s < S; s++) {
-        if (lane == 0) out[(size_t)b * S + s] = far;
+        if (tid == 0) out[(size_t)b * S + s] = far;
         const float cx = lp[3 * far], cy = lp[3 * far + 1], cz = lp[3 * far + 2];
         float bv = -1.f;
         int bi = 0x7fffffff;
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
-            int i = lane + 64 * j;
+            int i = tid + NT * j;
             if (i < N) {
                 float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
                 float d = dx * dx + dy * dy + dz * dz;
@@ -102,13 +136,18 @@ __global__ __launch_bounds__(64) void k_fps_wave(const float *__restrict__ xyz, 
                 if (dist[j] > bv) { bv = dist[j]; bi = i; }
             }
         }
+        unsigned long long key = bv < 0.f ? 0ull : (((unsigned long long)__float_as_uint(bv) << 32) | (unsigned)~bi);
+        key = wave_max_u64(key);
+        if (NW > 1) {
+            if ((tid & 63) == 0) slot[s & 1][w] = key;
+            __syncthreads();
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            float ov = __shfl_xor(bv, off);
-            int oi = __shfl_xor(bi, off);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            for (int i = 0; i < NW; i++) {
+                unsigned long long o = slot[s & 1][i];
+                key = o > key ? o : key;
+            }
         }
-        far = bi;
+        far = (int)~(unsigned)key;
     }
 }
 
@@ -151,24 +190,38 @@ __global__ __launch_bounds__(256) void k_ball_query(const float *__restrict__ xy
     for (int k = cnt + lane; k < K; k += 64) o[k] = first;
 }
 
-// one thread per fine point: 3 nearest coarse points (distance ascending, index ascending on ties)
-__global__ __launch_bounds__(256) void k_three_nn(const float *__restrict__ xyz1, const float *__restrict__ xyz2, int N, int S,
-                                                 long long total, float *__restrict__ dist_out, long long *__restrict__ idx_out)
+// one thread per fine point: 3 nearest coarse points (distance ascending, index ascending on ties).
+// 64-thread workgroups, grid (ceil(N/64), B); the coarse cloud is staged through LDS in chunks and read back as wave-uniform
+// broadcasts, so the scan is VALU-bound instead of waiting on one global load per candidate.
+#define NN_CHUNK 1024
+__global__ __launch_bounds__(64) void k_three_nn(const float *__restrict__ xyz1, const float *__restrict__ xyz2, int N, int S,
+                                                long long total, float *__restrict__ dist_out, long long *__restrict__ idx_out)
 {
-    long long g = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (g >= total) return;
-    const int b = (int)(g / N);
+    __shared__ float cs[NN_CHUNK * 3];
+    const int b = blockIdx.y, loc = blockIdx.x * 64 + threadIdx.x;
+    const long long g = (long long)b * N + loc;
     const float *c = xyz2 + (size_t)b * S * 3;
-    const float qx = xyz1[g * 3], qy = xyz1[g * 3 + 1], qz = xyz1[g * 3 + 2];
+    const bool live = loc < N && g < total;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (live) { qx = xyz1[g * 3]; qy = xyz1[g * 3 + 1]; qz = xyz1[g * 3 + 2]; }
     const float sq = qx * qx + qy * qy + qz * qz;
     float d0 = 3.4e38f, d1 = 3.4e38f, d2 = 3.4e38f;
     int i0 = 0, i1 = 0, i2 = 0;
-    for (int j = 0; j < S; j++) {
-        float d = sqdist_ref(qx, qy, qz, sq, c[3 * j], c[3 * j + 1], c[3 * j + 2]);
-        if (d < d0) { d2 = d1; i2 = i1; d1 = d0; i1 = i0; d0 = d; i0 = j; }
-        else if (d < d1) { d2 = d1; i2 = i1; d1 = d; i1 = j; }
-        else if (d < d2) { d2 = d; i2 = j; }
+    for (int base = 0; base < S; base += NN_CHUNK) {
+        const int m = min(NN_CHUNK, S - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < 3 * m; k += 64) cs[k] = c[3 * base + k];
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < m; j++) {
+            float d = sqdist_ref(qx, qy, qz, sq, cs[3 * j], cs[3 * j + 1], cs[3 * j + 2]);
+            int jj = base + j;
+            if (d < d0) { d2 = d1; i2 = i1; d1 = d0; i1 = i0; d0 = d; i0 = jj; }
+            else if (d < d1) { d2 = d1; i2 = i1; d1 = d; i1 = jj; }
+            else if (d < d2) { d2 = d; i2 = jj; }
+        }
     }
+    if (!live) return;
     dist_out[g * 3] = d0; dist_out[g * 3 + 1] = d1; dist_out[g * 3 + 2] = d2;
     idx_out[g * 3] = i0; idx_out[g * 3 + 1] = i1; idx_out[g * 3 + 2] = i2;
 }
@@ -179,10 +232,10 @@ extern "C" int nirrt_pn2_fps(const float *xyz, int B, int N, int S, const int64_
     hipStream_t st = (hipStream_t)stream;
     const long long *sp = (const long long *)start;
     long long *op = (long long *)out;
-    if (N <= 64) hipLaunchKernelGGL(k_fps_wave<1>, dim3(B), dim3(64), 0, st, xyz, N, S, sp, op);
-    else if (N <= 256) hipLaunchKernelGGL(k_fps_wave<4>, dim3(B), dim3(64), 0, st, xyz, N, S, sp, op);
-    else if (N <= 1024) hipLaunchKernelGGL(k_fps_wave<16>, dim3(B), dim3(64), 0, st, xyz, N, S, sp, op);
-    else if (N <= 2048) hipLaunchKernelGGL(k_fps_wave<32>, dim3(B), dim3(64), 0, st, xyz, N, S, sp, op);
+    if (N <= 64) hipLaunchKernelGGL((k_fps_wave<1, 1>), dim3(B), dim3(64), 0, st, xyz, N, S, sp, op);
+    else if (N <= 256) hipLaunchKernelGGL((k_fps_wave<4, 1>), dim3(B), dim3(64), 0, st, xyz, N, S, sp, op);
+    else if (N <= 1024) hipLaunchKernelGGL((k_fps_wave<4, 4>), dim3(B), dim3(256), 0, st, xyz, N, S, sp, op);
+    else if (N <= 2048) hipLaunchKernelGGL((k_fps_wave<8, 4>), dim3(B), dim3(256), 0, st, xyz, N, S, sp, op);
     else {
         size_t lds = sizeof(float) * 3 * (size_t)N + 16 * sizeof(float) + 16 * sizeof(int);
         hipLaunchKernelGGL(k_fps, dim3(B), dim3(FPS_NT), lds, st, xyz, N, S, sp, op);
@@ -203,8 +256,8 @@ extern "C" int nirrt_pn2_ball_query(const float *xyz, const float *new_xyz, int 
 extern "C" int nirrt_pn2_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S, float *dist, int64_t *idx, void *stream)
 {
     long long total = (long long)B * N;
-    hipLaunchKernelGGL(k_three_nn, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xyz1, xyz2, N, S, total,
-                       dist, (long long *)idx);
+    hipLaunchKernelGGL(k_three_nn, dim3((unsigned)((N + 63) / 64), (unsigned)B), dim3(64), 0, (hipStream_t)stream, xyz1, xyz2, N, S,
+                       total, dist, (long long *)idx);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

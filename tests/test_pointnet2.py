@@ -90,6 +90,25 @@ def test_gpu_pointops_equal_cpu_semantics():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,s", [(40, 16), (64, 16), (200, 64), (256, 64), (1000, 256), (1024, 256), (2048, 1024), (5000, 512)])
+def test_gpu_fps_every_kernel_variant(n, s):
+    """each (points-per-lane, waves) instantiation of k_fps_wave and the LDS k_fps pick the reference's indices"""
+    from nirrt_star_amd import pointops
+    torch.manual_seed(n)
+    xyz = torch.rand(3, n, 3)
+    xyz[1, : n // 2] = xyz[1, n // 2: 2 * (n // 2)]        # duplicated points: ties resolved to the lowest index
+    start = torch.tensor([0, n - 1, n // 3])
+    a = pointops.farthest_point_sample(xyz, s, start)
+    b = pointops.farthest_point_sample(xyz.cuda(), s, start).cpu()
+    assert torch.equal(a, b)
+    new = torch.gather(xyz, 1, a[..., None].expand(3, s, 3))
+    da, ia = pointops.three_nn(xyz, new)
+    db, ib = pointops.three_nn(xyz.cuda(), new.cuda())
+    assert (ia == ib.cpu()).float().mean() > 0.99
+    assert torch.allclose(da, db.cpu(), atol=1e-6)
+
+
+@pytest.mark.gpu
 def test_gpu_cloud_downsampling_equals_host_restatement():
     """k_fps_f64 == the numpy restatement of open3d's farthest_point_down_sample (same float64 arithmetic)"""
     from nirrt_star_amd import pointcloud
