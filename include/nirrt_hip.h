@@ -189,8 +189,8 @@ typedef struct nirrt_run_args {
 int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *args);
 
 /* debug aid: per-phase device tick counters of the loop body (zeros unless the library was built
- * with -DNIRRT_PROFILE); out16 = int64[16] */
-int nirrt_debug_prof(nirrt_tree *t, int64_t *out16);
+ * with -DNIRRT_PROFILE); out24 = int64[24] */
+int nirrt_debug_prof(nirrt_tree *t, int64_t *out24);
 
 #ifdef __cplusplus
 }

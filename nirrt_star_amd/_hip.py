@@ -279,7 +279,7 @@ class HipTree:
                                       float(update_cost_ratio), float(c_update)))
 
     def debug_prof(self):
-        out = np.zeros(16, dtype=np.int64)
+        out = np.zeros(24, dtype=np.int64)
         _check(self.L.nirrt_debug_prof(self.h, _ip(out)))
         return out
 

@@ -30,7 +30,18 @@
 #define SCAN_PAD 256     // extra elements allocated behind every per-vertex array (vector loads may overrun n)
 #define WALK_R 4         // parent chains chased concurrently per lane
 #define SCAN_U 4         // 128-vertex chunks a wave loads per scan trip (16-byte loads issued back to back)
+#ifndef CHAIN_MAX
 #define CHAIN_MAX 512    // LDS slots for the new->root edge-length sequence (deeper chains fall back to global walks)
+#endif
+#define GRID_MIN_VERTICES 2048   // smaller trees are scanned whole
+#define GRID_REBUILD_EVERY 1024  // vertices appended behind the cell-ordered part before it is rebuilt
+#define GRID_RG_MAX 96           // slot ranges per query (rows of cells + tail); larger boxes fall back to whole scans
+#ifndef GRID_BM_WORDS
+#define GRID_BM_WORDS 2048       // LDS hit bitmap: 65 536 vertices per ordering window
+#endif
+#define GRID_U 4                 // slots per lane and trip of a grid visit
+#define GRID_N 1u                // range serves the Near query
+#define GRID_Q 2u                // range serves the nearest query
 
 // optional per-phase cycle accounting (build with -DNIRRT_PROFILE; scripts/perf_phases.py reads prof[])
 #ifdef NIRRT_PROFILE
@@ -38,7 +49,7 @@
 #define PROF(slot)                                                     \
     do {                                                               \
         long long now_ = wall_clock64();                               \
-        if (threadIdx.x == 0) t.prof[slot] += now_ - prof_t0;          \
+        if (threadIdx.x == 0) const_cast<TreeDev &>(t).prof[slot] += now_ - prof_t0; \
         prof_t0 = now_;                                                \
     } while (0)
 #else
@@ -117,7 +128,7 @@ struct TreeDev {
     double c_min;
     double x_center[3];
     double CL_C[9];          // rotation-to-world matrix C, row-major 3x3
-    long long prof[16];      // NIRRT_PROFILE: wall_clock64 ticks (100 MHz) per phase
+    long long prof[24];      // NIRRT_PROFILE: wall_clock64 ticks (100 MHz) per phase
     // NIRRT* point-cloud guidance (nirrt_star_png_2d.py:99-130): predicted path points + policy scalars
     const double *pc;        // (pc_n, dim) row-major
     int pc_n;
@@ -125,6 +136,20 @@ struct TreeDev {
     double pc_rate;          // pc_sample_rate
     double pc_ratio;         // pc_update_cost_ratio
     double c_update;         // best cost at the last cloud refresh (inf before the first solution)
+    // uniform-grid index over the float32 twins (see "uniform-grid index" below)
+    float4 *g_rec;           // {x, y, z, bits(vertex index)}: [0, g_ns) ordered by cell, [g_ns, n) in insertion order
+    int *g_start;            // g_start[c] .. g_start[c+1]: slots of cell c inside [0, g_ns); g_ncell + 1 entries
+    int *g_cnt;              // rebuild scratch: per-cell counters
+    int *g_rank;             // rebuild scratch: rank of vertex i inside its cell
+    int g_ns;                // vertices covered by the cell-ordered part (0: index not built yet)
+    int g_G;                 // cells per axis
+    int g_ncell;             // g_G ^ dim
+    int g_min;               // smallest tree that gets indexed (GRID_MIN_VERTICES; env NIRRT_GRID_MIN)
+    int g_every;             // rebuild interval in vertices (GRID_REBUILD_EVERY; env NIRRT_GRID_REBUILD)
+    int pad3;
+    double g_rho;            // running estimate of the nearest-vertex distance of the samples (first box of a nearest query)
+    double g_inv_h[3];       // cells per unit length, per axis
+    double g_margin[3];      // slack added to every query box (covers the float32 rounding of the twins)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -147,6 +172,12 @@ struct Lds {
     // iteration hangs below `new`, so its walk ends with exactly this sequence)
     int chain_len;          // entries valid in chainE, or -1 if the chain is longer than CHAIN_MAX
     double chainE[CHAIN_MAX];
+    // grid queries: slot ranges of g_rec to visit (rows of cells + the unsorted tail) and the hit bitmap
+    int rg_n, hit_cnt;
+    int ob_n;                     // obstacles whose inflated box meets the Near ball's box (wg_near)
+    short ob_list[2 * MAX_OBS];
+    int rg_beg[GRID_RG_MAX], rg_len[GRID_RG_MAX], rg_flag[GRID_RG_MAX];
+    unsigned bm[GRID_BM_WORDS];   // one bit per vertex of a 32*GRID_BM_WORDS window; all-zero between uses
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -482,6 +513,7 @@ __device__ __forceinline__ void stage_obstacles(Lds<NT> &s, const TreeDev &t)
 {
     int tid = threadIdx.x;
     if (tid == 0) { s.n_round = t.n_round; s.n_box = t.n_box; }
+    for (int i = tid; i < GRID_BM_WORDS; i += NT) s.bm[i] = 0u;
     for (int i = tid; i < t.n_round * 4; i += NT) s.rnd[i / 4][i % 4] = t.rnd[i / 4][i % 4];
     for (int i = tid; i < t.n_box * 6; i += NT) s.box[i / 6][i % 6] = t.box[i / 6][i % 6];
     // the prefilter bounds exactly as the reference forms them: c - r - clr, c + r + clr / x - clr, x + w + clr
@@ -767,7 +799,7 @@ __device__ __forceinline__ float dist2f(float ax, float ay, float az)
 // workgroup reduction of per-lane float32 (min d2, its index, second-smallest d2); returns the winner's index or
 // -1 when the runner-up is too close to call in float32 (caller falls back to the float64 scan)
 template <int D, int NT>
-__device__ __forceinline__ int wg_nearest_finish32(Lds<NT> &s, double e, float m1, int i1, float m2)
+__device__ __forceinline__ int wg_nearest_finish32(Lds<NT> &s, double e, float m1, int i1, float m2, double *g1_out = nullptr)
 {
     constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -802,14 +834,15 @@ __device__ __forceinline__ int wg_nearest_finish32(Lds<NT> &s, double e, float m
         double c = (i == gw) ? s.red_val2[i] : s.red_val[i];
         g2 = c < g2 ? c : g2;
     }
+    if (g1_out) *g1_out = g1;
     // unambiguous iff every other vertex is provably farther (by more than the float64 path's own tie band)
     const bool clear = g2 == __builtin_inf() || f32_upper<D>(e, g1) < f32_lower<D>(e, g2) * BAND_LO;
     return clear ? gi : -1;
 }
 
-// nearest_neighbor: argmin_i dist(q, v_i), lowest index on ties (np.argmin)
+// nearest_neighbor by a whole float32 scan: argmin_i dist(q, v_i), lowest index on ties (np.argmin)
 template <int D, int NT>
-__device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, const double *q)
+__device__ __forceinline__ int wg_nearest_scan(Lds<NT> &s, const TreeDev &t, int n, const double *q)
 {
     const int lane = threadIdx.x & 63;
     int beg, end, per;
@@ -848,6 +881,353 @@ __device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, c
     int gi = wg_nearest_finish32<D, NT>(s, f32_eps_for(t, q, D), m1, i1, m2);
     if (gi < 0) gi = wg_nearest64<D, NT>(s, t, n, q);   // uniform (rare)
     return gi;
+}
+
+// ------------------------------------------------------------------------------------------------
+// uniform-grid index.  The reference scans every vertex for nearest_neighbor and find_near_neighbors; the
+// answers only depend on the vertices inside a small ball around the query, so large trees keep their float32
+// twins ordered by cell of a G^D grid over the range box (g_rec[0, g_ns), rebuilt by a counting sort every
+// GRID_REBUILD_EVERY insertions) followed by the not yet ordered tail g_rec[g_ns, n).  A query visits the rows
+// of cells (contiguous slot ranges) that intersect its box plus the tail, with exactly the filter arithmetic
+// of the whole scans: float32 squared distances with rigorous error bounds, float64 / reference formula inside
+// the bands.  Completeness: cell(x) is monotone in x per axis and computed from the twin, whose distance to the
+// exact coordinate is far below g_margin, so every vertex within `rad` of p (per axis) lies in a cell of
+// grid_box(p, rad).  Near hits are put in ascending vertex order through an LDS bitmap (the reference's
+// np.where order, which choose_parent's first-minimum and the sequential rewire depend on).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int grid_cell_axis(const TreeDev &t, int k, double x)
+{
+    const double a = (x - t.lo[k]) * t.g_inv_h[k];
+    const int G = t.g_G;
+    return a <= 0.0 ? 0 : (a >= (double)G ? G - 1 : (int)a);
+}
+
+template <int D>
+__device__ __forceinline__ void grid_box(const TreeDev &t, const double *p, double rad, int (&c0)[3], int (&c1)[3])
+{
+    c0[2] = 0; c1[2] = 0;
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        c0[k] = grid_cell_axis(t, k, p[k] - rad - t.g_margin[k]);
+        c1[k] = grid_cell_axis(t, k, p[k] + rad + t.g_margin[k]);
+    }
+}
+
+__device__ __forceinline__ int grid_rows(const int (&c0)[3], const int (&c1)[3])
+{
+    return (c1[1] - c0[1] + 1) * (c1[2] - c0[2] + 1);
+}
+
+// exclusive prefix sum over the workgroup (thread order); returns the total
+template <int NT>
+__device__ __forceinline__ int block_excl_scan(Lds<NT> &s, int v, int &off)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) s.wave_tot[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; i++) {
+        int c = s.wave_tot[i];
+        if (i < w) base += c;
+        tot += c;
+    }
+    off = base + inc - v;
+    return tot;
+}
+
+// counting sort of the twins of vertices [0, n) by cell.  The order inside a cell is whatever the atomics
+// produce; no result depends on it (minima are reduced as (value, index) pairs, hits are re-ordered by index).
+template <int D, int NT>
+__device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeDev &t, int n)
+{
+    const int tid = threadIdx.x, nc = t.g_ncell, G = t.g_G;
+    for (int c = tid; c < nc; c += NT) t.g_cnt[c] = 0;
+    __syncthreads();
+    auto cell_of = [&](int i) -> int {
+        int c = grid_cell_axis(t, 0, (double)t.cf[0][i]) + G * grid_cell_axis(t, 1, (double)t.cf[1][i]);
+        if (D == 3) c += G * G * grid_cell_axis(t, 2, (double)t.cf[D - 1][i]);
+        return c;
+    };
+    for (int i = tid; i < n; i += NT) t.g_rank[i] = atomicAdd(&t.g_cnt[cell_of(i)], 1);
+    __syncthreads();
+    const int per = (nc + NT - 1) / NT, b = tid * per;
+    int sum = 0;
+    for (int j = 0; j < per; j++)
+        if (b + j < nc) sum += t.g_cnt[b + j];
+    int run;
+    block_excl_scan<NT>(s, sum, run);
+    for (int j = 0; j < per; j++) {
+        if (b + j < nc) {
+            int c = t.g_cnt[b + j];
+            t.g_start[b + j] = run;
+            run += c;
+        }
+    }
+    if (tid == 0) t.g_start[nc] = n;
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        const int pos = t.g_start[cell_of(i)] + t.g_rank[i];
+        t.g_rec[pos] = make_float4(t.cf[0][i], t.cf[1][i], D == 3 ? t.cf[D - 1][i] : 0.f, __int_as_float(i));
+    }
+    if (tid == 0) t.g_ns = n;
+    __syncthreads();
+}
+
+// Near set of pn (radius r, may be null) and / or nearest vertex of q (may be null) through the grid.
+// Near hits end up ascending in t.st_idx[0, kraw); returns kraw.  *ni = nearest index of q.
+// `scanned` = slots visited.
+template <int D, int NT>
+__device__ __forceinline__ int wg_grid_query(Lds<NT> &s, const TreeDev &t, int n, const double *pn, double r, const double *q,
+                                             int *ni, long long &scanned)
+{
+    const int tid = threadIdx.x, lane = tid & 63, G = t.g_G;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int ns = t.g_ns;
+    const bool wantN = pn != nullptr, wantQ = q != nullptr;
+    const double r2 = r * r, r2lo = r2 * BAND_LO, r2hi = r2 * BAND_HI;
+    const double e32 = f32_eps_for(t, wantN ? pn : q, D, wantN ? q : nullptr);
+    const float lo_f = wantN ? f32_down(r2lo - f32_err<D>(e32, r2lo)) : -1.f;
+    const float hi_f = wantN ? f32_up(r2hi + f32_err<D>(e32, r2hi)) : -1.f;
+    const float nx = wantN ? (float)pn[0] : 0.f, ny = wantN ? (float)pn[1] : 0.f, nz = (wantN && D == 3) ? (float)pn[D - 1] : 0.f;
+    const float qx = wantQ ? (float)q[0] : 0.f, qy = wantQ ? (float)q[1] : 0.f, qz = (wantQ && D == 3) ? (float)q[D - 1] : 0.f;
+    auto exact_hit = [&](int i) -> bool {
+        double d[3] = {pn[0] - t.c[0][i], pn[1] - t.c[1][i], D == 3 ? pn[D - 1] - t.c[D - 1][i] : 0.};
+        double v = dist2<D>(d);
+        if (v <= r2lo) return true;
+        if (v > r2hi) return false;
+        return dist_scan<D>(d) <= r;
+    };
+    // row `row` of box (c0, c1) -> slot range.  ball != nullptr: only the cells of the row that the ball (ball, rad)
+    // can reach are kept (the corner cells of the box are dropped)
+    auto put_row = [&](int slot, const int (&c0)[3], const int (&c1)[3], int row, int flag, const double *ball, double rad) {
+        const int ny_ = c1[1] - c0[1] + 1;
+        const int cy = c0[1] + row % ny_, cz = c0[2] + row / ny_;
+        int x0 = c0[0], x1 = c1[0];
+        bool empty = false;
+        if (ball) {
+            // distance from the ball centre to the row's slab in y (and z); border cells extend to infinity
+            double rem = (rad + t.g_margin[0]) * (rad + t.g_margin[0]);
+#pragma unroll
+            for (int k = 1; k < D; k++) {
+                const int ck = k == 1 ? cy : cz;
+                const double h = 1.0 / t.g_inv_h[k];
+                const double a = ck == 0 ? -__builtin_inf() : t.lo[k] + ck * h;
+                const double b = ck == G - 1 ? __builtin_inf() : t.lo[k] + (ck + 1) * h;
+                double dk = fmax(fmax(a - ball[k], ball[k] - b), 0.0) - t.g_margin[k];
+                if (dk > 0.0) rem -= dk * dk;
+            }
+            if (rem < 0.0) empty = true;
+            else {
+                const double w = __builtin_sqrt(rem) + t.g_margin[0];
+                x0 = max(x0, grid_cell_axis(t, 0, ball[0] - w));
+                x1 = min(x1, grid_cell_axis(t, 0, ball[0] + w));
+                if (x1 < x0) empty = true;
+            }
+        }
+        const int base = (cz * G + cy) * G;
+        int b = 0, e = 0;
+        if (!empty) { b = t.g_start[base + x0]; e = t.g_start[base + x1 + 1]; }
+        s.rg_beg[slot] = b; s.rg_len[slot] = e - b; s.rg_flag[slot] = flag;
+    };
+    int nb0[3] = {0, 0, 0}, nb1[3] = {0, 0, 0}, qb0[3] = {0, 0, 0}, qb1[3] = {0, 0, 0};
+    int rowsN = 0, rowsQ = 0;
+    if (wantN) { grid_box<D>(t, pn, r, nb0, nb1); rowsN = grid_rows(nb0, nb1); }
+    if (wantQ) {
+        // first guess: the cells within 1.5x the typical nearest distance seen so far (the cell of q itself at first)
+        grid_box<D>(t, q, 1.5 * t.g_rho, qb0, qb1);
+        rowsQ = grid_rows(qb0, qb1);
+    }
+    int result_ni = -1;
+    bool brute_q = false;
+    if (rowsN + rowsQ + 1 > GRID_RG_MAX) {
+        // a box that large is not worth indexing (never the case for the Near radius of a tree this size)
+        if (wantN) return -1;   // caller scans whole
+        brute_q = true;
+    }
+    float m1 = __builtin_inff(), m2 = __builtin_inff();
+    int i1 = 0x7fffffff;
+    int kraw = 0;
+    scanned = 0;
+    PROF_DECL
+    // one visit of the ranges in s.rg_*; uniform trip counts.  GRID_U slots per lane and trip: all their 16-byte
+    // loads are issued before the first use
+    auto visit = [&]() {
+        const int R = s.rg_n;
+        int total = 0;
+        for (int i = 0; i < R; i++) total += s.rg_len[i];
+        scanned += total;
+        for (int f0 = 0; f0 < total; f0 += NT * GRID_U) {
+            float4 rec[GRID_U];
+            unsigned flag[GRID_U];
+#pragma unroll
+            for (int u = 0; u < GRID_U; u++) {
+                int off = f0 + u * NT + tid;
+                rec[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                flag[u] = 0u;
+                if (off < total) {
+                    int rr = 0, len = s.rg_len[0];
+                    while (off >= len) { off -= len; rr++; len = s.rg_len[rr]; }
+                    rec[u] = t.g_rec[s.rg_beg[rr] + off];
+                    flag[u] = (unsigned)s.rg_flag[rr];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GRID_U; u++) {
+                if (f0 + u * NT < total) {   // uniform
+                    const int id = __float_as_int(rec[u].w);
+                    if (flag[u] & GRID_Q) {
+                        float wv = dist2f<D>(qx - rec[u].x, qy - rec[u].y, D == 3 ? qz - rec[u].z : 0.f);
+                        if (wv < m1 || (wv == m1 && id < i1)) { m2 = m1; m1 = wv; i1 = id; } else if (wv < m2) m2 = wv;
+                    }
+                    bool hit = false;
+                    if (flag[u] & GRID_N) {
+                        float v = dist2f<D>(nx - rec[u].x, ny - rec[u].y, D == 3 ? nz - rec[u].z : 0.f);
+                        hit = v <= lo_f;
+                        if (!hit && v <= hi_f) hit = exact_hit(id);
+                    }
+                    const unsigned long long mk = __ballot(hit);
+                    if (mk) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&s.hit_cnt, __popcll(mk));
+                        base = __shfl(base, 0);
+                        if (hit) t.bfs_q[base + __popcll(mk & lt)] = id;
+                    }
+                }
+            }
+        }
+    };
+    if (!(brute_q && !wantN)) {
+        __syncthreads();
+        if (tid < rowsN) put_row(tid, nb0, nb1, tid, GRID_N, pn, r);
+        else if (!brute_q && tid < rowsN + rowsQ) put_row(tid, qb0, qb1, tid - rowsN, GRID_Q, nullptr, 0.);
+        if (tid == 0) {
+            const int R = rowsN + (brute_q ? 0 : rowsQ);
+            s.rg_beg[R] = ns; s.rg_len[R] = n - ns;
+            s.rg_flag[R] = (wantN ? GRID_N : 0u) | ((wantQ && !brute_q) ? GRID_Q : 0u);
+            s.rg_n = R + 1;
+            s.hit_cnt = 0;
+        }
+        __syncthreads();
+        visit();
+    }
+    PROF(13);
+    if (wantQ && !brute_q) {
+        // widen the box until it provably contains the nearest vertex: nothing found -> one more ring of cells (twice),
+        // something found -> the box of the ball through the float32 winner's upper distance bound (then final)
+        double ring = 0.;
+        for (int pass = 0;; pass++) {   // uniform
+            double g1;
+            int gi = wg_nearest_finish32<D, NT>(s, e32, m1, i1, m2, &g1);
+            int eb0[3], eb1[3];
+            if (g1 == __builtin_inf()) {
+                if (pass >= 2) { brute_q = true; break; }
+                double h = 0.;
+#pragma unroll
+                for (int k = 0; k < D; k++) h = fmax(h, 1.0 / t.g_inv_h[k]);
+                ring += h;
+                grid_box<D>(t, q, ring, eb0, eb1);
+            } else {
+                // every vertex that could beat the float32 winner lies within sqrt(upper bound of its true d2) of q
+                const double rad = __builtin_sqrt(f32_upper<D>(e32, g1)) * (1.0 + 1e-9);
+                grid_box<D>(t, q, rad, eb0, eb1);
+                bool covered = true;
+#pragma unroll
+                for (int k = 0; k < D; k++) covered = covered && eb0[k] >= qb0[k] && eb1[k] <= qb1[k];
+                if (covered) {
+                    if (gi < 0) brute_q = true; else result_ni = gi;
+                    if (tid == 0) {   // statistics only: no decision depends on it
+                        TreeDev &tw = const_cast<TreeDev &>(t);
+                        tw.g_rho = 0.875 * tw.g_rho + 0.125 * __builtin_sqrt(g1);
+                    }
+                    break;
+                }
+            }
+            const int rowsE = grid_rows(eb0, eb1);
+            if (rowsE + 1 > GRID_RG_MAX || pass >= 3) { brute_q = true; break; }
+            // another visit: the enlarged box + tail, nearest only (a fresh reduction: a vertex seen twice would look
+            // like its own runner-up)
+            __syncthreads();
+            if (tid < rowsE) put_row(tid, eb0, eb1, tid, GRID_Q, nullptr, 0.);
+            if (tid == 0) {
+                s.rg_beg[rowsE] = ns; s.rg_len[rowsE] = n - ns; s.rg_flag[rowsE] = GRID_Q;
+                s.rg_n = rowsE + 1;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 3; k++) { qb0[k] = eb0[k]; qb1[k] = eb1[k]; }
+            m1 = __builtin_inff(); m2 = __builtin_inff(); i1 = 0x7fffffff;
+            visit();
+        }
+    }
+    __syncthreads();
+    PROF(14);
+    if (wantN) {
+        // ascending order through the bitmap, one 65 536-vertex window at a time
+        kraw = s.hit_cnt;
+        int kout = 0;
+        for (int wb = 0; wb < n && kout < kraw; wb += 32 * GRID_BM_WORDS) {
+            for (int a = tid; a < kraw; a += NT) {
+                const unsigned id = (unsigned)(t.bfs_q[a] - wb);
+                if (id < 32u * GRID_BM_WORDS) atomicOr(&s.bm[id >> 5], 1u << (id & 31u));
+            }
+            __syncthreads();
+            const int left = n - wb;
+            const int nw = left >= 32 * GRID_BM_WORDS ? GRID_BM_WORDS : (left + 31) >> 5;
+            const int per = (nw + NT - 1) / NT, b = tid * per;
+            int cnt = 0;
+            for (int j = 0; j < per; j++)
+                if (b + j < nw) cnt += __popc(s.bm[b + j]);
+            int off;
+            const int tot = block_excl_scan<NT>(s, cnt, off);
+            int o = kout + off;
+            for (int j = 0; j < per; j++) {
+                if (b + j < nw) {
+                    unsigned m = s.bm[b + j];
+                    if (m) {
+                        s.bm[b + j] = 0u;
+                        while (m) {
+                            t.st_idx[o++] = wb + ((b + j) << 5) + __builtin_ctz(m);
+                            m &= m - 1u;
+                        }
+                    }
+                }
+            }
+            kout += tot;
+            __syncthreads();
+        }
+    }
+    PROF(15);
+    if (wantQ) {
+        if (brute_q) {
+            result_ni = wg_nearest_scan<D, NT>(s, t, n, q);   // uniform (rare)
+            scanned += n;
+        }
+        *ni = result_ni;
+    }
+    return kraw;
+}
+
+// nearest_neighbor: argmin_i dist(q, v_i), lowest index on ties (np.argmin)
+template <int D, int NT>
+__device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, const double *q, long long *scanned = nullptr)
+{
+    if (t.g_ns > 0) {
+        int ni = -1;
+        long long sc = 0;
+        wg_grid_query<D, NT>(s, t, n, nullptr, 0., q, &ni, sc);
+        if (scanned) *scanned = sc;
+        return ni;
+    }
+    if (scanned) *scanned = n;
+    return wg_nearest_scan<D, NT>(s, t, n, q);
 }
 
 // chase parent chains leaf -> root (RRTBase.cost, rrt_base_2d.py:54-61): acc = 0; acc += elen[v]; v = parent[v] ...
@@ -1035,7 +1415,7 @@ __device__ __forceinline__ bool wg_collision(const Lds<NT> &s, const double *a, 
 // On return t.nr_idx[0..k) ascending and t.nr_dist[0..k) the reference scan distances.  Returns k.
 template <int D, int NT>
 __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const double *node_new, int new_idx,
-                                       const double *q2 = nullptr, int *ni2 = nullptr)
+                                       const double *q2 = nullptr, int *ni2 = nullptr, long long *scanned = nullptr)
 {
     constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
@@ -1044,94 +1424,107 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     const double clr = t.clearance;
     int beg, end, per;
     wave_segment256<NT>(n, beg, end, per);
-    const float4 *X = reinterpret_cast<const float4 *>(t.cf[0]);
-    const float4 *Y = reinterpret_cast<const float4 *>(t.cf[1]);
-    const float4 *Z = reinterpret_cast<const float4 *>(t.cf[D - 1]);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int cnt = 0;  // wave-uniform
-    // float32 thresholds of the filter: z <= lo_f => certainly d2 <= r2lo (inside); z > hi_f => certainly d2 > r2hi
-    // (outside); anything between is re-decided from the float64 coordinates with the float64 logic
-    const double e32 = f32_eps_for(t, node_new, D, q2);
-    const float lo_f = f32_down(r2lo - f32_err<D>(e32, r2lo)), hi_f = f32_up(r2hi + f32_err<D>(e32, r2hi));
-    const float nx = (float)node_new[0], ny = (float)node_new[1], nz = D == 3 ? (float)node_new[D - 1] : 0.f;
-    // the same pass can serve the NEXT iteration's nearest query (q2): vertices never move and this scan already
-    // covers the vertex just appended, so argmin_i |q2 - v_i| over [0, n) is exactly what nearest_neighbor will need
-    const bool fuse = q2 != nullptr;
-    const float qx = fuse ? (float)q2[0] : 0.f, qy = fuse ? (float)q2[1] : 0.f, qz = (fuse && D == 3) ? (float)q2[D - 1] : 0.f;
-    float m1 = __builtin_inff(), m2 = __builtin_inff();
-    int i1 = 0x7fffffff;
+    int woff[NW + 1];
+#pragma unroll
+    for (int i = 0; i <= NW; i++) woff[i] = 0;
+    int kgrid = -1;
     PROF_DECL
-    // exact (float64) Near membership of one vertex: the float64 guard-band logic
-    auto exact_hit = [&](int i) -> bool {
-        double d[3] = {node_new[0] - t.c[0][i], node_new[1] - t.c[1][i], D == 3 ? node_new[D - 1] - t.c[D - 1][i] : 0.};
-        double v = dist2<D>(d);
-        if (v <= r2lo) return true;
-        if (v > r2hi) return false;
-        return dist_scan<D>(d) <= r;
-    };
-    // one 256-vertex chunk: filter test for this lane's four vertices + ordered staging
-    auto chunk = [&](int base, const float4 &xv, const float4 &yv, const float4 &zv) {
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
-        const float zs[4] = {zv.x, zv.y, zv.z, zv.w};
-        bool h[4] = {false, false, false, false};
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int i = base + e;
-            if (i < end) {
-                if (fuse) {
-                    float wv = dist2f<D>(qx - xs[e], qy - ys[e], D == 3 ? qz - zs[e] : 0.f);
-                    if (wv < m1) { m2 = m1; m1 = wv; i1 = i; } else if (wv < m2) m2 = wv;
-                }
-                float v = dist2f<D>(nx - xs[e], ny - ys[e], D == 3 ? nz - zs[e] : 0.f);
-                h[e] = v <= lo_f;
-                if (!h[e] && v <= hi_f) h[e] = exact_hit(i);   // inside the float32 error band: float64 decides
-            }
-        }
-        unsigned long long mk[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) mk[e] = __ballot(h[e]);
-        if (mk[0] | mk[1] | mk[2] | mk[3]) {
-            int pos = beg + cnt;
-#pragma unroll
-            for (int e = 0; e < 4; e++) pos += __popcll(mk[e] & lt);
+    if (t.g_ns > 0) {   // uniform: large tree, indexed
+        long long sc = 0;
+        kgrid = wg_grid_query<D, NT>(s, t, n, node_new, r, q2, ni2, sc);
+        if (kgrid >= 0 && scanned) *scanned = sc;
+        PROF(8);
+    }
+    if (kgrid < 0) {
+        if (scanned) *scanned = n;
+        const float4 *X = reinterpret_cast<const float4 *>(t.cf[0]);
+        const float4 *Y = reinterpret_cast<const float4 *>(t.cf[1]);
+        const float4 *Z = reinterpret_cast<const float4 *>(t.cf[D - 1]);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int cnt = 0;  // wave-uniform
+        // float32 thresholds of the filter: z <= lo_f => certainly d2 <= r2lo (inside); z > hi_f => certainly d2 > r2hi
+        // (outside); anything between is re-decided from the float64 coordinates with the float64 logic
+        const double e32 = f32_eps_for(t, node_new, D, q2);
+        const float lo_f = f32_down(r2lo - f32_err<D>(e32, r2lo)), hi_f = f32_up(r2hi + f32_err<D>(e32, r2hi));
+        const float nx = (float)node_new[0], ny = (float)node_new[1], nz = D == 3 ? (float)node_new[D - 1] : 0.f;
+        // the same pass can serve the NEXT iteration's nearest query (q2): vertices never move and this scan already
+        // covers the vertex just appended, so argmin_i |q2 - v_i| over [0, n) is exactly what nearest_neighbor will need
+        const bool fuse = q2 != nullptr;
+        const float qx = fuse ? (float)q2[0] : 0.f, qy = fuse ? (float)q2[1] : 0.f, qz = (fuse && D == 3) ? (float)q2[D - 1] : 0.f;
+        float m1 = __builtin_inff(), m2 = __builtin_inff();
+        int i1 = 0x7fffffff;
+        // exact (float64) Near membership of one vertex: the float64 guard-band logic
+        auto exact_hit = [&](int i) -> bool {
+            double d[3] = {node_new[0] - t.c[0][i], node_new[1] - t.c[1][i], D == 3 ? node_new[D - 1] - t.c[D - 1][i] : 0.};
+            double v = dist2<D>(d);
+            if (v <= r2lo) return true;
+            if (v > r2hi) return false;
+            return dist_scan<D>(d) <= r;
+        };
+        // one 256-vertex chunk: filter test for this lane's four vertices + ordered staging
+        auto chunk = [&](int base, const float4 &xv, const float4 &yv, const float4 &zv) {
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
+            const float zs[4] = {zv.x, zv.y, zv.z, zv.w};
+            bool h[4] = {false, false, false, false};
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                if (h[e]) { t.st_idx[pos] = base + e; pos++; }
+                const int i = base + e;
+                if (i < end) {
+                    if (fuse) {
+                        float wv = dist2f<D>(qx - xs[e], qy - ys[e], D == 3 ? qz - zs[e] : 0.f);
+                        if (wv < m1) { m2 = m1; m1 = wv; i1 = i; } else if (wv < m2) m2 = wv;
+                    }
+                    float v = dist2f<D>(nx - xs[e], ny - ys[e], D == 3 ? nz - zs[e] : 0.f);
+                    h[e] = v <= lo_f;
+                    if (!h[e] && v <= hi_f) h[e] = exact_hit(i);   // inside the float32 error band: float64 decides
+                }
             }
-            cnt += __popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3]);
-        }
-    };
-    for (int cb = beg; cb < end; cb += 256 * SCAN_U) {
-        // SCAN_U chunks per trip; all 16-byte loads are issued before the first use
-        float4 xv[SCAN_U], yv[SCAN_U], zv[SCAN_U];
+            unsigned long long mk[4];
 #pragma unroll
-        for (int u = 0; u < SCAN_U; u++) {
-            const int bu = cb + 256 * u + 4 * lane;
-            xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); yv[u] = xv[u]; zv[u] = xv[u];
-            if (bu < end) {
-                xv[u] = X[bu >> 2]; yv[u] = Y[bu >> 2];
-                if (D == 3) zv[u] = Z[bu >> 2];
+            for (int e = 0; e < 4; e++) mk[e] = __ballot(h[e]);
+            if (mk[0] | mk[1] | mk[2] | mk[3]) {
+                int pos = beg + cnt;
+#pragma unroll
+                for (int e = 0; e < 4; e++) pos += __popcll(mk[e] & lt);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (h[e]) { t.st_idx[pos] = base + e; pos++; }
+                }
+                cnt += __popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3]);
             }
+        };
+        for (int cb = beg; cb < end; cb += 256 * SCAN_U) {
+            // SCAN_U chunks per trip; all 16-byte loads are issued before the first use
+            float4 xv[SCAN_U], yv[SCAN_U], zv[SCAN_U];
+#pragma unroll
+            for (int u = 0; u < SCAN_U; u++) {
+                const int bu = cb + 256 * u + 4 * lane;
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); yv[u] = xv[u]; zv[u] = xv[u];
+                if (bu < end) {
+                    xv[u] = X[bu >> 2]; yv[u] = Y[bu >> 2];
+                    if (D == 3) zv[u] = Z[bu >> 2];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SCAN_U; u++)
+                if (cb + 256 * u < end) chunk(cb + 256 * u + 4 * lane, xv[u], yv[u], zv[u]);   // wave-uniform
         }
+        if (fuse) {
+            int gi = wg_nearest_finish32<D, NT>(s, e32, m1, i1, m2);
+            if (gi < 0) gi = wg_nearest64<D, NT>(s, t, n, q2);   // uniform (rare)
+            *ni2 = gi;
+        }
+        __syncthreads();
+        PROF(8);
+        if (lane == 0) s.wave_tot[w] = cnt;
+        __syncthreads();
+        woff[0] = 0;
 #pragma unroll
-        for (int u = 0; u < SCAN_U; u++)
-            if (cb + 256 * u < end) chunk(cb + 256 * u + 4 * lane, xv[u], yv[u], zv[u]);   // wave-uniform
+        for (int i = 0; i < NW; i++) woff[i + 1] = woff[i] + s.wave_tot[i];
     }
-    if (fuse) {
-        int gi = wg_nearest_finish32<D, NT>(s, e32, m1, i1, m2);
-        if (gi < 0) gi = wg_nearest64<D, NT>(s, t, n, q2);   // uniform (rare)
-        *ni2 = gi;
-    }
-    __syncthreads();
-    PROF(8);
-    if (lane == 0) s.wave_tot[w] = cnt;
-    __syncthreads();
-    int woff[NW + 1];
-    woff[0] = 0;
-#pragma unroll
-    for (int i = 0; i < NW; i++) woff[i + 1] = woff[i] + s.wave_tot[i];
-    const int kraw = woff[NW];
+    const bool contig = kgrid >= 0;
+    const int kraw = contig ? kgrid : woff[NW];
     // Pass A - gather the staged hits (already ascending): index, coordinates (kept in nr_c0/nr_c1/st scratch
     // for pass B), reference distance, and the AABB prefilter against every obstacle.  (segment, obstacle)
     // pairs that survive the prefilter are queued so that the expensive exact tests run densely packed.
@@ -1139,14 +1532,25 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     int *pairq = t.bfs_q;
     const int pair_cap = t.cap;
     const int M = s.n_round + s.n_box;
-    if (tid == 0) s.bc_i[5] = 0;
+    if (tid == 0) { s.bc_i[5] = 0; s.ob_n = 0; }
     __syncthreads();
+    // obstacles whose inflated box meets the box of the Near ball: a segment new -> v_j (|v_j - new| <= r per axis)
+    // can only pass the prefilter of those.  Same comparisons as seg_aabb_pass, on a superset of every segment's box.
+    for (int o = tid; o < M; o += NT) {
+        const double rb = r * (1.0 + 1e-9);
+        double l0[3], l1[3];
+#pragma unroll
+        for (int c = 0; c < D; c++) { l0[c] = node_new[c] - rb; l1[c] = node_new[c] + rb; }
+        if (seg_aabb_pass<D, NT>(s, o, l0, l1)) s.ob_list[atomicAdd(&s.ob_n, 1)] = (short)o;
+    }
+    __syncthreads();
+    const int n_ob = s.ob_n;
     for (int a = tid; a < kraw; a += NT) {
         int ww = 0, offw = 0;
 #pragma unroll
         for (int i = 1; i < NW; i++)
             if (a >= woff[i]) { ww = i; offw = woff[i]; }
-        const int v = t.st_idx[ww * per + (a - offw)];
+        const int v = contig ? t.st_idx[a] : t.st_idx[ww * per + (a - offw)];
         const VRec vr = t.vrec[v];
         double vj[3] = {vr.x, vr.y, vr.z};
         t.nr_cost[a] = vr.cost;
@@ -1159,7 +1563,8 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
         double l0[3], l1[3];
 #pragma unroll
         for (int c = 0; c < D; c++) { l0[c] = fmin(node_new[c], vj[c]); l1[c] = fmax(node_new[c], vj[c]); }
-        for (int o = 0; o < M; o++) {
+        for (int j = 0; j < n_ob; j++) {
+            const int o = s.ob_list[j];
             if (seg_aabb_pass<D, NT>(s, o, l0, l1)) {
                 int pos = atomicAdd(&s.bc_i[5], 1);
                 if (pos < pair_cap) pairq[pos] = a * MAX_OBS * 2 + o;
@@ -1338,9 +1743,12 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
     const int tid = threadIdx.x;
     const double clr = t.clearance;
     int n = t.n;
-    long long scanned = host_steer ? 0 : n;
-    long long alg = scanned;
+    long long scanned = 0;
+    long long alg = host_steer ? 0 : n;
     PROF_DECL
+    // keep the cell-ordered part of the grid index within GRID_REBUILD_EVERY vertices of the tree
+    if (n >= t.g_min && n - t.g_ns >= t.g_every) wg_grid_rebuild<D, NT>(s, t, n);   // uniform
+    PROF(12);
     int ni;
     double node_new[D], nearest[D];
     if (host_steer) {
@@ -1349,8 +1757,8 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
 #pragma unroll
         for (int k = 0; k < D; k++) node_new[k] = node_in[k];
     } else {
-        if (pref_ni >= 0) { ni = pref_ni; scanned = 0; }
-        else ni = wg_nearest<D, NT>(s, t, n, node_in);
+        if (pref_ni >= 0) ni = pref_ni;
+        else ni = wg_nearest<D, NT>(s, t, n, node_in, &scanned);
         PROF(0);
         load_vertex<D>(t, ni, nearest);
         steer<D>(t, nearest, node_in, node_new);
@@ -1388,6 +1796,8 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                     t.cf[k][new_idx] = (float)node_new[k];
                     cm = fmax(cm, fabs(node_new[k]));
                 }
+                t.g_rec[new_idx] = make_float4((float)node_new[0], (float)node_new[1], D == 3 ? (float)node_new[D - 1] : 0.f,
+                                               __int_as_float(new_idx));
                 t.cmax = cm;
                 Aux a;
                 a.elen = edge_new; a.parent = ni; a.pad = 0;
@@ -1404,8 +1814,9 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
             __syncthreads();
         }
         if (new_idx >= 0) {
-            int k = wg_near<D, NT>(s, t, n, node_new, new_idx, q_next, &next_ni);
-            scanned += n;
+            long long sc_near = 0;
+            int k = wg_near<D, NT>(s, t, n, node_new, new_idx, q_next, &next_ni, &sc_near);
+            scanned += sc_near;
             alg += n;
             PROF(2);
             int reparented = 0, n_rewired = 0;

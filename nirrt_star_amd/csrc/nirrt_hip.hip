@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -54,7 +55,10 @@ struct RunSampleDev {
 // Two instantiations of every kernel: the workgroup size that is best for a batch (one wave per SIMD per tree, four
 // trees per CU: their latency phases overlap each other's streaming) is not the best for a single tree (all 16 waves
 // of a CU on one tree: measured 1.4x faster for one 50k-iteration IRRT* problem, 1.5-2.3x slower for 1024 of them).
-#define NT 256
+#ifndef NIRRT_NT_NARROW
+#define NIRRT_NT_NARROW 256
+#endif
+#define NT NIRRT_NT_NARROW
 namespace narrow {
 #include "nirrt_kernels.inc"
 }
@@ -64,7 +68,7 @@ namespace wide {
 #include "nirrt_kernels.inc"
 }
 #undef NT
-#define NT_NARROW 256
+#define NT_NARROW NIRRT_NT_NARROW
 #define NT_WIDE 1024
 #define WIDE_MAX_TREES 96   // nirrt_run: batches up to this many trees use the wide kernels ...
 #define WIDE_MIN_VERTICES 16000   // ... once the trees are (or will grow) this big; small trees sync cheaper with 4 waves
@@ -180,7 +184,7 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     TreeDev &h = t->host;
     void *bufs[] = {h.cf[0], h.cf[1], h.cf[2], h.st_c[0], h.st_c[1], h.st_c[2], h.c[0], h.c[1], h.c[2], h.aux, h.vrec, h.nr_cost, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.st_idx,
                     h.nr_idx, h.nr_flag, h.nr_dist, h.nr_c0, h.nr_c1, h.sol, h.sol_line, h.gc_idx, h.gc_dist, h.gc_col,
-                    t->near_r};
+                    h.g_rec, h.g_start, h.g_cnt, h.g_rank, t->near_r};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (t->pc_dev) (void)hipFree(t->pc_dev);
@@ -291,6 +295,26 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     HIPCHK_T(hipMalloc(&h.gc_dist, sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.gc_col, np));
     HIPCHK_T(hipMalloc(&t->near_r, sizeof(double) * (size_t)(t->cap + 1)));
+    // uniform-grid index: 64^2 / 16^3 cells over the range box
+    h.g_G = D == 2 ? 64 : 16;
+    if (const char *e = std::getenv("NIRRT_GRID_G")) h.g_G = std::min(D == 2 ? 256 : 40, std::max(1, std::atoi(e)));
+    h.g_ncell = D == 2 ? h.g_G * h.g_G : h.g_G * h.g_G * h.g_G;
+    h.g_ns = 0;
+    h.g_rho = 0.;
+    h.g_min = GRID_MIN_VERTICES;
+    h.g_every = GRID_REBUILD_EVERY;
+    if (const char *e = std::getenv("NIRRT_GRID_MIN")) h.g_min = std::max(2, std::atoi(e));         // test / tuning knobs
+    if (const char *e = std::getenv("NIRRT_GRID_REBUILD")) h.g_every = std::max(1, std::atoi(e));
+    for (int k = 0; k < 3; k++) {
+        double ext = k < D ? cfg->range_hi[k] - cfg->range_lo[k] : 1.0;
+        if (!(ext > 0.)) ext = 1.0;
+        h.g_inv_h[k] = (double)h.g_G / ext;
+        h.g_margin[k] = ext / (double)h.g_G / 256.0;
+    }
+    HIPCHK_T(hipMalloc(&h.g_rec, sizeof(float4) * np));
+    HIPCHK_T(hipMalloc(&h.g_start, sizeof(int) * (size_t)(h.g_ncell + 1)));
+    HIPCHK_T(hipMalloc(&h.g_cnt, sizeof(int) * (size_t)h.g_ncell));
+    HIPCHK_T(hipMalloc(&h.g_rank, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&t->dev, sizeof(TreeDev)));
     HIPCHK_T(hipHostMalloc((void **)&t->scratch, sizeof(Scratch), hipHostMallocMapped));
     HIPCHK_T(hipHostGetDevicePointer((void **)&t->scratch_dev, t->scratch, 0));
@@ -732,13 +756,13 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
 }
 
 /* debug: per-phase tick counters (all zero unless built with -DNIRRT_PROFILE) */
-extern "C" int nirrt_debug_prof(nirrt_tree *t, int64_t *out16)
+extern "C" int nirrt_debug_prof(nirrt_tree *t, int64_t *out24)
 {
-    if (!t || !out16) return NIRRT_E_ARG;
+    if (!t || !out24) return NIRRT_E_ARG;
     HIPCHK(hipSetDevice(t->device));
     TreeDev tmp;
     HIPCHK(hipMemcpy(&tmp, t->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 16; i++) out16[i] = tmp.prof[i];
+    for (int i = 0; i < 24; i++) out24[i] = tmp.prof[i];
     return NIRRT_OK;
 }
 
