@@ -66,6 +66,22 @@ struct __attribute__((aligned(16))) Aux {
     int pad;
 };
 
+// four hops of the parent chain in one 48-byte record: a cost() walk needs one memory round trip per FOUR edges.
+// e[j] / a[j] = length / upper end of the j-th edge above the vertex; beyond the root the entries are (0, 0), and
+// adding 0.0 to the (non-negative) running sum leaves it bit-identical, so a walk may run over the end of the chain.
+struct __attribute__((aligned(16))) Hop4 {
+    double e[4];
+    int a[4];
+};
+
+__device__ __forceinline__ Hop4 hop_shift(const Hop4 &p, double e0, int a0)
+{
+    Hop4 r;
+    r.e[0] = e0; r.e[1] = p.e[0]; r.e[2] = p.e[1]; r.e[3] = p.e[2];
+    r.a[0] = a0; r.a[1] = p.a[0]; r.a[2] = p.a[1]; r.a[3] = p.a[2];
+    return r;
+}
+
 // random-access twin of a vertex: one 32-byte record (half a 64-byte sector) holds everything the O(k) phases
 // need about a Near candidate - coordinates and the exact cost(v) - so a candidate costs ONE sector read
 struct __attribute__((aligned(32))) VRec {
@@ -78,6 +94,7 @@ struct TreeDev {
     float *cf[3];   // float32 twins of c[]: what the O(n) filter scans stream (4 B per coordinate)
     double cmax;    // max |coordinate| over the range box and every vertex stored so far (float32 rounding bound)
     Aux *aux;       // aux[cap]
+    Hop4 *hop;      // hop[cap]: aux of the vertex and of its next three ancestors (kept in step with aux)
     VRec *vrec;     // vrec[cap]: coordinates + exact cost for random access
     int *first_child, *next_sib, *prev_sib;   // child lists (-1 = none); the root is nobody's child
     int *bfs_q;     // scratch queue for subtree traversals
@@ -174,6 +191,9 @@ struct Lds {
     double chainE[CHAIN_MAX];
     // grid queries: slot ranges of g_rec to visit (rows of cells + the unsorted tail) and the hit bitmap
     int rg_n, hit_cnt;
+    // constants of the samplers (copied from the descriptor once per kernel)
+    double k_lo[3], k_hi[3], k_clr, k_cmin, k_xc[3], k_CLC[9];
+    Hop4 hop_new;                 // copy of hop[new_idx] of the current iteration (thread 0 reads it when re-parenting)
     int ob_n;                     // obstacles whose inflated box meets the Near ball's box (wg_near)
     short ob_list[2 * MAX_OBS];
     int rg_beg[GRID_RG_MAX], rg_len[GRID_RG_MAX], rg_flag[GRID_RG_MAX];
@@ -490,6 +510,30 @@ __device__ __forceinline__ bool point_in_obs(const Lds<NT> &s, const double *p, 
     return false;
 }
 
+// the same test spread over the lanes of ONE wave (every lane active, identical p): lane i takes obstacle i
+template <int D, int NT>
+__device__ __forceinline__ bool point_in_obs_wave(const Lds<NT> &s, const double *p, double clr)
+{
+    const int lane = threadIdx.x & 63;
+    bool hit = false;
+    for (int i = lane; i < s.n_round; i += 64) {
+        double rc = s.rnd[i][3] + clr;
+        double q = (p[0] - s.rnd[i][0]) * (p[0] - s.rnd[i][0]) + (p[1] - s.rnd[i][1]) * (p[1] - s.rnd[i][1]);
+        if (D == 3) q = q + (p[2] - s.rnd[i][2]) * (p[2] - s.rnd[i][2]);
+        hit = hit || (q < rc * rc);
+    }
+    for (int i = lane; i < s.n_box; i += 64) {
+        bool in = true;
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            double mx = s.box[i][k] + s.box[i][3 + k] + clr, mn = s.box[i][k] - clr;
+            in = in && (mn <= p[k]) && (p[k] <= mx);
+        }
+        hit = hit || in;
+    }
+    return __ballot(hit) != 0ull;
+}
+
 // points_in_range: the range as one rectangle tested with clearance = -clearance (:330-351)
 template <int D>
 __device__ __forceinline__ bool point_in_range(const TreeDev &t, const double *p)
@@ -505,6 +549,20 @@ __device__ __forceinline__ bool point_in_range(const TreeDev &t, const double *p
     return in;
 }
 
+template <int D, int NT>
+__device__ __forceinline__ bool point_in_range_lds(const Lds<NT> &s, const double *p)
+{
+    double clr = -s.k_clr;
+    bool in = true;
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        double w = s.k_hi[k] - s.k_lo[k];
+        double mx = s.k_lo[k] + w + clr, mn = s.k_lo[k] - clr;
+        in = in && (mn <= p[k]) && (p[k] <= mx);
+    }
+    return in;
+}
+
 // ------------------------------------------------------------------------------------------------
 // workgroup collectives
 // ------------------------------------------------------------------------------------------------
@@ -514,6 +572,9 @@ __device__ __forceinline__ void stage_obstacles(Lds<NT> &s, const TreeDev &t)
     int tid = threadIdx.x;
     if (tid == 0) { s.n_round = t.n_round; s.n_box = t.n_box; }
     for (int i = tid; i < GRID_BM_WORDS; i += NT) s.bm[i] = 0u;
+    if (tid < 3) { s.k_lo[tid] = t.lo[tid]; s.k_hi[tid] = t.hi[tid]; s.k_xc[tid] = t.x_center[tid]; }
+    if (tid < 9) s.k_CLC[tid] = t.CL_C[tid];
+    if (tid == 0) { s.k_clr = t.clearance; s.k_cmin = t.c_min; }
     for (int i = tid; i < t.n_round * 4; i += NT) s.rnd[i / 4][i % 4] = t.rnd[i / 4][i % 4];
     for (int i = tid; i < t.n_box * 6; i += NT) s.box[i / 6][i % 6] = t.box[i / 6][i % 6];
     // the prefilter bounds exactly as the reference forms them: c - r - clr, c + r + clr / x - clr, x + w + clr
@@ -1243,15 +1304,20 @@ __device__ __forceinline__ void walk_chains(const TreeDev &t, int (&idx)[WALK_R]
 #pragma unroll
         for (int r = 0; r < WALK_R; r++) any = any || (idx[r] > 0 && idx[r] != stop_at);
         if (!any || guard-- <= 0) break;
-        Aux a[WALK_R];
+        Hop4 h[WALK_R];
 #pragma unroll
         for (int r = 0; r < WALK_R; r++)
-            if (idx[r] > 0 && idx[r] != stop_at) a[r] = t.aux[idx[r]];
+            if (idx[r] > 0 && idx[r] != stop_at) h[r] = t.hop[idx[r]];
 #pragma unroll
         for (int r = 0; r < WALK_R; r++) {
             if (idx[r] > 0 && idx[r] != stop_at) {
-                acc[r] += a[r].elen;
-                idx[r] = a[r].parent;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (idx[r] > 0 && idx[r] != stop_at) {
+                        acc[r] += h[r].e[j];
+                        idx[r] = h[r].a[j];
+                    }
+                }
             }
         }
     }
@@ -1297,24 +1363,35 @@ template <int D, int NT>
 __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v, int through, int k_near = 0)
 {
     // k_near > 0: the current Near list t.nr_idx[0..k_near) (ascending) mirrors costs in t.nr_cost; members that
-    // are re-costed here are patched there too (binary search), so the rewire scan never re-reads scattered records
+    // are re-costed here are patched there too (binary search over the hot list: a per-vertex slot map was measured
+    // slower - two scattered write passes per iteration), so the rewire scan never re-reads scattered records
     const int tid = threadIdx.x;
     __syncthreads();
     if (tid == 0) { t.bfs_q[0] = v; s.bc_i[4] = 1; }
     __syncthreads();
-    int head = 0, tail = 1;
+    int head = 0, tail = 1, level = 0;
     while (head < tail) {   // one BFS level per trip; uniform
         for (int i = head + tid; i < tail; i += NT) {
-            int c = t.first_child[t.bfs_q[i]];
+            const int u = t.bfs_q[i];
+            int c = t.first_child[u];
+            // hop[v] was refreshed by the caller; the records of the next three levels mention v's edge too
+            Hop4 hu;
+            if (level < 3 && c >= 0) hu = t.hop[u];
             while (c >= 0) {
                 int pos = atomicAdd(&s.bc_i[4], 1);
                 t.bfs_q[pos] = c;
+                if (level < 3) {   // entry 0 of the child's record (its own edge) is unchanged
+                    Hop4 &hc = t.hop[c];
+                    hc.e[1] = hu.e[0]; hc.e[2] = hu.e[1]; hc.e[3] = hu.e[2];
+                    hc.a[1] = hu.a[0]; hc.a[2] = hu.a[1]; hc.a[3] = hu.a[2];
+                }
                 c = t.next_sib[c];
             }
         }
         __syncthreads();
         head = tail;
         tail = s.bc_i[4];
+        level++;
         __syncthreads();
     }
     for (int base = 0; base < tail; base += NT * WALK_R) {
@@ -1363,11 +1440,16 @@ __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeDev &t, 
         double acc = 0.;
         int i = new_idx, len = 0, guard = t.cap + 1;
         while (i > 0 && guard-- > 0) {
-            Aux a = t.aux[i];
-            acc += a.elen;
-            if (len < CHAIN_MAX) s.chainE[len] = a.elen;
-            len++;
-            i = a.parent;
+            const Hop4 h = t.hop[i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (i > 0) {
+                    acc += h.e[j];
+                    if (len < CHAIN_MAX) s.chainE[len] = h.e[j];
+                    len++;
+                    i = h.a[j];
+                }
+            }
         }
         s.chain_len = len <= CHAIN_MAX ? len : -1;
         s.bc_d[6] = acc;
@@ -1781,6 +1863,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         bool inserted = false;
         if (dup) {
             new_idx = ni;
+            if (tid == 0) s.hop_new = t.hop[ni];   // only thread 0 reads it back
 #pragma unroll
             for (int k = 0; k < D; k++) node_new[k] = nearest[k];
         } else if (n >= t.cap) {
@@ -1802,6 +1885,8 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 Aux a;
                 a.elen = edge_new; a.parent = ni; a.pad = 0;
                 t.aux[new_idx] = a;
+                s.hop_new = hop_shift(t.hop[ni], edge_new, ni);
+                t.hop[new_idx] = s.hop_new;
                 VRec vr;
                 vr.x = node_new[0]; vr.y = node_new[1]; vr.z = D == 3 ? node_new[D - 1] : 0.; vr.cost = 0.;
                 t.vrec[new_idx] = vr;
@@ -1843,8 +1928,11 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
 #pragma unroll
                     for (int c = 0; c < D; c++) d[c] = node_new[c] - v[c];
                     unlink_child(t, new_idx, t.aux[new_idx].parent);
+                    const double el = hypot_py<D>(d);
                     t.aux[new_idx].parent = best_parent;
-                    t.aux[new_idx].elen = hypot_py<D>(d);
+                    t.aux[new_idx].elen = el;
+                    s.hop_new = hop_shift(t.hop[best_parent], el, best_parent);
+                    t.hop[new_idx] = s.hop_new;
                     link_child(t, new_idx, best_parent);
                     if (dup) { t.sol_dirty = 1; t.gc_dirty = 1; }
                 }
@@ -1881,8 +1969,10 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
 #pragma unroll
                         for (int c = 0; c < D; c++) d[c] = v[c] - node_new[c];
                         unlink_child(t, vj, t.aux[vj].parent);
+                        const double el = hypot_py<D>(d);
                         t.aux[vj].parent = new_idx;
-                        t.aux[vj].elen = hypot_py<D>(d);
+                        t.aux[vj].elen = el;
+                        t.hop[vj] = hop_shift(s.hop_new, el, new_idx);
                         link_child(t, vj, new_idx);
                         t.sol_dirty = 1;
                         t.gc_dirty = 1;

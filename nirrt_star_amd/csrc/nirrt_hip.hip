@@ -25,14 +25,31 @@ struct RunDev {
     long long *iters_done;  // (n_trees,)
 };
 
+// Raw 32-bit outputs of a host generator, consumed in order.  Executed by ALL lanes of wave 0 with identical values:
+// lane i keeps word base+i of a 64-word window in a register, a word is fetched with v_readlane, and the window is
+// refilled with one coalesced load when the position leaves it (so a draw costs no memory round trip most of the time).
 struct WordStream {
     const unsigned *w;
     long long n, pos;
+    long long base;   // first word of the window, -1: nothing loaded
+    unsigned reg;     // this lane's word of the window
     __device__ __forceinline__ bool has(long long k) const { return pos + k <= n; }
+    __device__ __forceinline__ unsigned next_word()
+    {
+        long long rel = pos - base;
+        if (base < 0 || rel < 0 || rel >= 64) {   // wave-uniform
+            base = pos;
+            rel = 0;
+            const long long i = base + (long long)(threadIdx.x & 63);
+            reg = i < n ? w[i] : 0u;
+        }
+        const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)reg, __builtin_amdgcn_readfirstlane((int)rel));
+        pos++;
+        return v;
+    }
     __device__ __forceinline__ double next_double()
     {
-        unsigned a = w[pos] >> 5, b = w[pos + 1] >> 6;
-        pos += 2;
+        unsigned a = next_word() >> 5, b = next_word() >> 6;
         return (a * 67108864.0 + b) / 9007199254740992.0;
     }
 };
@@ -184,7 +201,7 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     TreeDev &h = t->host;
     void *bufs[] = {h.cf[0], h.cf[1], h.cf[2], h.st_c[0], h.st_c[1], h.st_c[2], h.c[0], h.c[1], h.c[2], h.aux, h.vrec, h.nr_cost, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.st_idx,
                     h.nr_idx, h.nr_flag, h.nr_dist, h.nr_c0, h.nr_c1, h.sol, h.sol_line, h.gc_idx, h.gc_dist, h.gc_col,
-                    h.g_rec, h.g_start, h.g_cnt, h.g_rank, t->near_r};
+                    h.g_rec, h.g_start, h.g_cnt, h.g_rank, h.hop, t->near_r};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (t->pc_dev) (void)hipFree(t->pc_dev);
@@ -274,6 +291,8 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         h.cmax = cmax;
     }
     HIPCHK_T(hipMalloc(&h.aux, sizeof(Aux) * np));
+    HIPCHK_T(hipMalloc(&h.hop, sizeof(Hop4) * np));
+    HIPCHK_T(hipMemset(h.hop, 0, sizeof(Hop4) * np));
     HIPCHK_T(hipMalloc(&h.vrec, sizeof(VRec) * np));
     HIPCHK_T(hipMalloc(&h.nr_cost, sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.first_child, sizeof(int) * np));
