@@ -69,11 +69,12 @@ struct RunSampleDev {
     int *stop_code;   // per tree: 0 done, NIRRT_E_STREAM, NIRRT_E_CAPACITY
 };
 
-// Two instantiations of every kernel: the workgroup size that is best for a batch (one wave per SIMD per tree, four
-// trees per CU: their latency phases overlap each other's streaming) is not the best for a single tree (all 16 waves
-// of a CU on one tree: measured 1.4x faster for one 50k-iteration IRRT* problem, 1.5-2.3x slower for 1024 of them).
+// Two instantiations of every kernel.  Batches: 128-thread workgroups, 8 trees per CU (2 waves each, 20 KB of LDS):
+// with the grid index an iteration is a chain of short dependent phases, so trees in flight per CU is what counts
+// (measured on 2048 problems: 1.2x IRRT*, 1.7x RRT* over 256-thread workgroups; 256 was best while the O(n) scans
+// dominated).  A single tree (or a few) gets all 16 waves of a CU.
 #ifndef NIRRT_NT_NARROW
-#define NIRRT_NT_NARROW 256
+#define NIRRT_NT_NARROW 128
 #endif
 #define NT NIRRT_NT_NARROW
 namespace narrow {
@@ -314,8 +315,8 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     HIPCHK_T(hipMalloc(&h.gc_dist, sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.gc_col, np));
     HIPCHK_T(hipMalloc(&t->near_r, sizeof(double) * (size_t)(t->cap + 1)));
-    // uniform-grid index: 64^2 / 16^3 cells over the range box
-    h.g_G = D == 2 ? 64 : 16;
+    // uniform-grid index: 128^2 / 16^3 cells over the range box
+    h.g_G = D == 2 ? 128 : 16;
     if (const char *e = std::getenv("NIRRT_GRID_G")) h.g_G = std::min(D == 2 ? 256 : 40, std::max(1, std::atoi(e)));
     h.g_ncell = D == 2 ? h.g_G * h.g_G : h.g_G * h.g_G * h.g_G;
     h.g_ns = 0;
