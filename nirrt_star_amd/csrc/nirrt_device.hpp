@@ -1497,8 +1497,11 @@ __device__ __forceinline__ bool wg_collision(const Lds<NT> &s, const double *a, 
 // On return t.nr_idx[0..k) ascending and t.nr_dist[0..k) the reference scan distances.  Returns k.
 template <int D, int NT>
 __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const double *node_new, int new_idx,
-                                       const double *q2 = nullptr, int *ni2 = nullptr, long long *scanned = nullptr)
+                                       const double *q2 = nullptr, int *ni2 = nullptr, long long *scanned = nullptr,
+                                       bool compact = true)
 {
+    // compact == false (the loop body): the list keeps its excluded members (t.nr_flag[a] != 0: the segment collides,
+    // or the member is new_idx itself) and the return value counts them too; the consumers skip flagged slots.
     constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
     const double r = t.near_r[n];
@@ -1673,6 +1676,7 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     }
     __syncthreads();
     PROF(10);
+    if (!compact) return kraw;
     // Pass C - stable in-place filter (index + distance)
     int k = 0;
     for (int base = 0; base < kraw; base += NT) {
@@ -1900,7 +1904,8 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         }
         if (new_idx >= 0) {
             long long sc_near = 0;
-            int k = wg_near<D, NT>(s, t, n, node_new, new_idx, q_next, &next_ni, &sc_near);
+            // k counts the slots of the Near list, excluded members (nr_flag) included
+            const int k = wg_near<D, NT>(s, t, n, node_new, new_idx, q_next, &next_ni, &sc_near, false);
             scanned += sc_near;
             alg += n;
             PROF(2);
@@ -1914,7 +1919,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 double cand = __builtin_inf();
                 int cj = 0x7fffffff;
                 for (int a = tid; a < k; a += NT) {
-                    double c = t.nr_cost[a] + t.nr_dist[a];
+                    double c = t.nr_flag[a] ? __builtin_inf() : t.nr_cost[a] + t.nr_dist[a];
                     if (c < cand) { cand = c; cj = a; }
                 }
                 block_argmin<NT>(s, cand, cj);
@@ -1958,13 +1963,14 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 while (start < k) {
                     int first = 0x7fffffff;
                     for (int a = start + tid; a < k; a += NT) {
-                        if (t.nr_cost[a] > new_cost + t.nr_dist[a]) { first = a; break; }
+                        if (!t.nr_flag[a] && t.nr_cost[a] > new_cost + t.nr_dist[a]) { first = a; break; }
                     }
                     first = block_min_int<NT>(s, first);
                     if (first == 0x7fffffff) break;
                     const int vj = t.nr_idx[first];
                     if (tid == 0) {
                         double v[D], d[D];
+                        const bool leaf = t.first_child[vj] < 0;
                         load_vertex<D>(t, vj, v);
 #pragma unroll
                         for (int c = 0; c < D; c++) d[c] = v[c] - node_new[c];
@@ -1976,10 +1982,24 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                         link_child(t, vj, new_idx);
                         t.sol_dirty = 1;
                         t.gc_dirty = 1;
+                        // a leaf (the common case) has nothing below it: its new cost is its edge followed by the
+                        // recorded chain new -> root, the same additions in the same order as a walk
+                        const int clen = s.chain_len;
+                        int fast = 0;
+                        if (leaf && clen >= 0) {
+                            double acc = 0.;
+                            acc += el;
+                            for (int i = 0; i < clen; i++) acc += s.chainE[i];
+                            t.vrec[vj].cost = acc;
+                            t.nr_cost[first] = acc;
+                            fast = 1;
+                        }
+                        s.bc_i[7] = fast;
                     }
                     n_rewired++;
                     start = first + 1;
-                    wg_recost_subtree<D, NT>(s, t, vj, new_idx, k);
+                    __syncthreads();
+                    if (!s.bc_i[7]) wg_recost_subtree<D, NT>(s, t, vj, new_idx, k);   // uniform
                 }
             }
             PROF(5);
@@ -1997,8 +2017,15 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                     }
                 }
             }
+            int n_near = 0;
+            if (res) {   // uniform: only the step API reports |Near|
+                for (int base = 0; base < k; base += NT) {
+                    const int a = base + tid;
+                    n_near += __syncthreads_count(a < k && t.nr_flag[a] == 0);
+                }
+            }
             if (res && tid == 0) {
-                res->inserted = inserted ? 1 : 0; res->new_idx = new_idx; res->n_near = k;
+                res->inserted = inserted ? 1 : 0; res->new_idx = new_idx; res->n_near = n_near;
                 res->reparented = reparented; res->n_rewired = n_rewired; res->in_goal = in_goal;
                 res->node_new[0] = node_new[0]; res->node_new[1] = node_new[1];
                 res->node_new[2] = D == 3 ? node_new[D - 1] : 0.;
