@@ -127,6 +127,7 @@ struct TreeDev {
     int *gc_idx;
     double *gc_dist;
     unsigned char *gc_col;
+    unsigned char *listed;   // per vertex: bit 0 = in sol[], bit 1 = in gc_idx[] (a re-costed listed vertex invalidates the cached best)
     int n_gc;
     int gc_dirty;
     int gc_best;
@@ -1418,6 +1419,9 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v,
         for (int r = 0; r < WALK_R; r++) {
             if (who[r] >= 0) {
                 t.vrec[who[r]].cost = acc[r];
+                const unsigned char li = t.listed[who[r]];
+                if (li & 1) t.sol_dirty = 1;
+                if (li & 2) t.gc_dirty = 1;
                 if (k_near > 0) {
                     int lo = 0, hi = k_near;
                     while (lo < hi) {
@@ -1696,7 +1700,7 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
 }
 
 // find_best_path_solution (irrt_star_2d.py:84-97): argmin_s cost(sol[s]) + Line(v_s, goal), first minimum.
-// The costs come from the exact cache; the argmin is only redone when some parent changed (sol_dirty),
+// The costs come from the exact cache; the argmin is only redone when a listed vertex was re-costed (sol_dirty),
 // a solution appended in between competes with the standing minimum (strict <, so the first minimum stays).
 template <int D, int NT>
 __device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double &c_best, int &x_best)
@@ -1733,6 +1737,7 @@ __device__ __forceinline__ void wg_append_solution(Lds<NT> &s, TreeDev &t, int i
             double line = hypot_py<D>(d);
             t.sol[q] = idx;
             t.sol_line[q] = line;
+            t.listed[idx] |= 1;
             if (!t.sol_dirty) {
                 double c = t.vrec[idx].cost + line;
                 if (q == 0 || c < t.sol_best_cost) { t.sol_best = q; t.sol_best_cost = c; }
@@ -1802,6 +1807,7 @@ __device__ __forceinline__ void wg_goal_candidate(Lds<NT> &s, TreeDev &t, int id
             int q = t.n_gc;
             t.gc_idx[q] = idx;
             t.gc_dist[q] = h;
+            t.listed[idx] |= 2;
             t.gc_col[q] = col ? 1 : 0;
             if (!t.gc_dirty) {
                 double c = col ? __builtin_inf() : t.vrec[idx].cost + h;
@@ -1939,7 +1945,6 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                     s.hop_new = hop_shift(t.hop[best_parent], el, best_parent);
                     t.hop[new_idx] = s.hop_new;
                     link_child(t, new_idx, best_parent);
-                    if (dup) { t.sol_dirty = 1; t.gc_dirty = 1; }
                 }
                 __syncthreads();
             }
@@ -1980,8 +1985,6 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                         t.aux[vj].elen = el;
                         t.hop[vj] = hop_shift(s.hop_new, el, new_idx);
                         link_child(t, vj, new_idx);
-                        t.sol_dirty = 1;
-                        t.gc_dirty = 1;
                         // a leaf (the common case) has nothing below it: its new cost is its edge followed by the
                         // recorded chain new -> root, the same additions in the same order as a walk
                         const int clen = s.chain_len;
@@ -1992,6 +1995,9 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                             for (int i = 0; i < clen; i++) acc += s.chainE[i];
                             t.vrec[vj].cost = acc;
                             t.nr_cost[first] = acc;
+                            const unsigned char li = t.listed[vj];
+                            if (li & 1) t.sol_dirty = 1;
+                            if (li & 2) t.gc_dirty = 1;
                             fast = 1;
                         }
                         s.bc_i[7] = fast;

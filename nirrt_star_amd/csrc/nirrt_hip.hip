@@ -202,7 +202,7 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     TreeDev &h = t->host;
     void *bufs[] = {h.cf[0], h.cf[1], h.cf[2], h.st_c[0], h.st_c[1], h.st_c[2], h.c[0], h.c[1], h.c[2], h.aux, h.vrec, h.nr_cost, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.st_idx,
                     h.nr_idx, h.nr_flag, h.nr_dist, h.nr_c0, h.nr_c1, h.sol, h.sol_line, h.gc_idx, h.gc_dist, h.gc_col,
-                    h.g_rec, h.g_start, h.g_cnt, h.g_rank, h.hop, t->near_r};
+                    h.g_rec, h.g_start, h.g_cnt, h.g_rank, h.hop, h.listed, t->near_r};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (t->pc_dev) (void)hipFree(t->pc_dev);
@@ -314,6 +314,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     HIPCHK_T(hipMalloc(&h.gc_idx, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.gc_dist, sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.gc_col, np));
+    HIPCHK_T(hipMalloc(&h.listed, np));
     HIPCHK_T(hipMalloc(&t->near_r, sizeof(double) * (size_t)(t->cap + 1)));
     // uniform-grid index: 128^2 / 16^3 cells over the range box
     h.g_G = D == 2 ? 128 : 16;
