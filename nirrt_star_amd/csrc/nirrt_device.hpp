@@ -179,7 +179,6 @@ struct Lds {
     int n_round, n_box;
     double rnd[MAX_OBS][4];
     double box[MAX_OBS][6];
-    double aabb[2 * MAX_OBS][6];   // clearance-inflated bounds lo[3], hi[3] per obstacle (round first, then boxes)
     double red_val[NW];
     double red_val2[NW];
     int red_idx[NW];
@@ -467,14 +466,23 @@ __device__ __forceinline__ bool seg_obstacle(const Lds<NT> &s, int o, const doub
     return seg_box_3d(a, b, s.box[o], clr);
 }
 
-// the AABB prefilter alone (same arithmetic as the first lines of the seg_* tests above)
+// the AABB prefilter alone (same arithmetic as the first lines of the seg_* tests above: c - r - clr, c + r + clr for
+// a circle / ball, x - clr, x + w + clr for a rectangle / box)
 template <int D, int NT>
 __device__ __forceinline__ bool seg_aabb_pass(const Lds<NT> &s, int o, const double *l0, const double *l1)
 {
-    // l0 / l1 = per-axis min / max of the segment end points; bounds precomputed by stage_obstacles
+    // l0 / l1 = per-axis min / max of the segment end points
+    const double clr = s.k_clr;
     bool pass = true;
+    if (o < s.n_round) {
+        const double cr = s.rnd[o][3];
 #pragma unroll
-    for (int k = 0; k < D; k++) pass = pass && (l0[k] <= s.aabb[o][3 + k]) && (l1[k] >= s.aabb[o][k]);
+        for (int k = 0; k < D; k++) pass = pass && (l0[k] <= s.rnd[o][k] + cr + clr) && (l1[k] >= s.rnd[o][k] - cr - clr);
+    } else {
+        o -= s.n_round;
+#pragma unroll
+        for (int k = 0; k < D; k++) pass = pass && (l0[k] <= s.box[o][k] + s.box[o][3 + k] + clr) && (l1[k] >= s.box[o][k] - clr);
+    }
     return pass;
 }
 
@@ -578,18 +586,6 @@ __device__ __forceinline__ void stage_obstacles(Lds<NT> &s, const TreeDev &t)
     if (tid == 0) { s.k_clr = t.clearance; s.k_cmin = t.c_min; }
     for (int i = tid; i < t.n_round * 4; i += NT) s.rnd[i / 4][i % 4] = t.rnd[i / 4][i % 4];
     for (int i = tid; i < t.n_box * 6; i += NT) s.box[i / 6][i % 6] = t.box[i / 6][i % 6];
-    // the prefilter bounds exactly as the reference forms them: c - r - clr, c + r + clr / x - clr, x + w + clr
-    const double clr = t.clearance;
-    for (int i = tid; i < t.n_round * 3; i += NT) {
-        int o = i / 3, k = i % 3;
-        s.aabb[o][k] = t.rnd[o][k] - t.rnd[o][3] - clr;
-        s.aabb[o][3 + k] = t.rnd[o][k] + t.rnd[o][3] + clr;
-    }
-    for (int i = tid; i < t.n_box * 3; i += NT) {
-        int o = i / 3, k = i % 3;
-        s.aabb[t.n_round + o][k] = t.box[o][k] - clr;
-        s.aabb[t.n_round + o][3 + k] = t.box[o][k] + t.box[o][3 + k] + clr;
-    }
     __syncthreads();
 }
 
@@ -1168,8 +1164,10 @@ __device__ __forceinline__ int wg_grid_query(Lds<NT> &s, const TreeDev &t, int n
     };
     if (!(brute_q && !wantN)) {
         __syncthreads();
-        if (tid < rowsN) put_row(tid, nb0, nb1, tid, GRID_N, pn, r);
-        else if (!brute_q && tid < rowsN + rowsQ) put_row(tid, qb0, qb1, tid - rowsN, GRID_Q, nullptr, 0.);
+        for (int row = tid; row < rowsN + (brute_q ? 0 : rowsQ); row += NT) {
+            if (row < rowsN) put_row(row, nb0, nb1, row, GRID_N, pn, r);
+            else put_row(row, qb0, qb1, row - rowsN, GRID_Q, nullptr, 0.);
+        }
         if (tid == 0) {
             const int R = rowsN + (brute_q ? 0 : rowsQ);
             s.rg_beg[R] = ns; s.rg_len[R] = n - ns;
@@ -1217,7 +1215,7 @@ __device__ __forceinline__ int wg_grid_query(Lds<NT> &s, const TreeDev &t, int n
             // another visit: the enlarged box + tail, nearest only (a fresh reduction: a vertex seen twice would look
             // like its own runner-up)
             __syncthreads();
-            if (tid < rowsE) put_row(tid, eb0, eb1, tid, GRID_Q, nullptr, 0.);
+            for (int row = tid; row < rowsE; row += NT) put_row(row, eb0, eb1, row, GRID_Q, nullptr, 0.);
             if (tid == 0) {
                 s.rg_beg[rowsE] = ns; s.rg_len[rowsE] = n - ns; s.rg_flag[rowsE] = GRID_Q;
                 s.rg_n = rowsE + 1;
