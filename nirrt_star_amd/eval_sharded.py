@@ -101,9 +101,71 @@ def plan_batch(problems, pids, args, device_id):
     return recs
 
 
+def first_below(trace, threshold):
+    """planning_block_gap's stopping rule (rrt_star_2d.py:159-196): number of iterations until the best path length is
+    below the threshold (the list the reference returns has exactly that many entries), or -1."""
+    hit = np.nonzero(np.asarray(trace) < threshold)[0]
+    return int(hit[0]) + 1 if len(hit) else -1
+
+
+def make_block_gap_record(pid, trace, threshold, n_vertices):
+    """record of a block / gap problem: iterations to get below the threshold (-1: never within iter_max), the
+    threshold, and the best cost at the fixed checkpoints counted from the FIRST solution like make_record"""
+    stop = first_below(trace, threshold)
+    rec = make_record(pid, trace[:stop] if stop > 0 else trace, n_vertices)
+    rec[3] = stop
+    return rec
+
+
+def plan_batch_block_gap(problems, pids, thresholds, args, device_id):
+    """planning_block_gap for a batch: the persistent loop runs in segments of args.segment iterations; after each
+    segment the problems whose best path length got below their threshold leave the batch.  An iteration's result
+    only depends on the iterations before it and every problem owns its generators, so truncating the cost trace at
+    the first sub-threshold entry gives exactly the list the reference's early-exit loop returns."""
+    from . import _hip, sampling
+    irrt = args.planner == "irrt_star"
+    flags = _hip.F_IRRT if irrt else _hip.F_GOAL_SCAN
+    trees, npw, pyw = [], [], []
+    for pr, pid in zip(problems, pids):
+        t = _hip.HipTree(2, args.iter_max, pr["x_start"], pr["x_goal"], args.step_len, pr["search_radius"], args.clearance,
+                         pr["env"], device_id=device_id)
+        t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
+        trees.append(t)
+        rs = np.random.RandomState(1000 + pid)
+        npw.append(rs.randint(0, 1 << 32, size=args.iter_max * 6 + 4096, dtype=np.uint32))
+        if irrt:
+            n = args.iter_max * 16 + 4096
+            bits = random.Random(1000 + pid).getrandbits(32 * n)
+            pyw.append(np.frombuffer(bits.to_bytes(4 * n, "little"), dtype="<u4").astype(np.uint32))
+    traces = [np.zeros(0) for _ in trees]
+    used_np = [0] * len(trees)
+    used_py = [0] * len(trees)
+    active = list(range(len(trees)))
+    done_iters = 0
+    while active and done_iters < args.iter_max:
+        seg = min(args.segment, args.iter_max - done_iters)
+        r = _hip.run_sampling([trees[i] for i in active], seg, [npw[i][used_np[i]:] for i in active],
+                              [pyw[i][used_py[i]:] for i in active] if irrt else None, flags=flags, want_trace=True)
+        still = []
+        for j, i in enumerate(active):
+            traces[i] = np.concatenate([traces[i], r["cost_trace"][j, : r["iters_done"][j]]])
+            used_np[i] += int(r["np_used"][j])
+            used_py[i] += int(r["py_used"][j])
+            if first_below(traces[i], thresholds[i]) < 0 and r["status"][j] == 0:
+                still.append(i)
+        active = still
+        done_iters += seg
+    recs = [make_block_gap_record(pid, tr, thr, t.n) for pid, tr, thr, t in zip(pids, traces, thresholds, trees)]
+    for t in trees:
+        t.close()
+    return recs
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--problem", default="random_2d", choices=["random_2d", "random_3d"])
+    ap.add_argument("--problem", default="random_2d", choices=["random_2d", "random_3d", "block", "gap"])
+    ap.add_argument("--path_len_threshold_percentage", type=float, default=0.02, help="block: stop below best_path_len * (1 + this)")
+    ap.add_argument("--segment", type=int, default=2000, help="block / gap: iterations per persistent launch")
     ap.add_argument("--planner", default="irrt_star", choices=["rrt_star", "irrt_star"])
     ap.add_argument("--iter_max", type=int, default=50000)
     ap.add_argument("--iter_after_initial", type=int, default=3000)
@@ -114,7 +176,7 @@ def main():
     ap.add_argument("--out", default="results/evaluation/sharded_result.json")
     args = ap.parse_args()
     if args.clearance is None:
-        args.clearance = 3 if args.problem == "random_2d" else 2
+        args.clearance = 2 if args.problem == "random_3d" else 3
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -130,6 +192,10 @@ def main():
     if args.problem == "random_2d":
         cfgs = P.get_random_2d_env_configs()
         get = P.get_random_2d_problem_input
+    elif args.problem == "block":
+        cfgs, get = P.get_block_env_configs(), P.get_block_problem_input
+    elif args.problem == "gap":
+        cfgs, get = P.get_gap_env_configs(), P.get_gap_problem_input
     else:
         cfgs = P.get_random_3d_env_configs()
         get = P.get_random_3d_problem_input
@@ -145,7 +211,13 @@ def main():
             if args.problem == "random_3d":
                 np.random.seed(i)   # gamma estimate consumes the global generator
             probs.append(get(cfgs[i]))
-        recs += plan_batch(probs, ids, args, local_rank)
+        if args.problem == "block":   # eval_planning_2d.py:117-121
+            recs += plan_batch_block_gap(probs, ids, [p["best_path_len"] * (1 + args.path_len_threshold_percentage) for p in probs],
+                                         args, local_rank)
+        elif args.problem == "gap":
+            recs += plan_batch_block_gap(probs, ids, [p["flank_path_len"] for p in probs], args, local_rank)
+        else:
+            recs += plan_batch(probs, ids, args, local_rank)
     allr = gather_records(np.array(recs).reshape(-1, RECORD_LEN), world, rank, device="cuda")
     if rank == 0:
         solved = allr[allr[:, 1] > 0]

@@ -355,6 +355,79 @@ def nrrt_fixture(name, dim, world_seed, iters, seed):
     print("   %s: n=%d path_len=%.4f png calls %d" % (name, n, float(planner.get_path_len(planner.path)), w.calls))
 
 
+def block_gap_fixture():
+    """Block / gap evaluation problems: the reference's generator script run in a scratch directory with a seeded
+    numpy generator (its JSON output is the fixture), and the problem dicts its own loader builds for a few of them.
+    cv2 is not installed: the only call on that path, cv2.rectangle(img, p0, p1, color, -1), is stood in by an
+    inclusive-corner fill (OpenCV's documented behaviour; pixel parity with real cv2 unpinned, as for random_2d)."""
+    import runpy
+    import tempfile
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        try:
+            np.random.seed(7)
+            with quiet():
+                runpy.run_path(os.path.join(refshim.REF, "generate_block_gap_env_2d.py"))
+            with open(os.path.join("data", "block_gap", "block_gap_configs.json")) as f:
+                cfg = json.load(f)
+        finally:
+            os.chdir(cwd)
+    import cv2
+
+    def rectangle(img, p0, p1, color, thickness):
+        assert thickness == -1
+        img[p0[1]:p1[1] + 1, p0[0]:p1[0] + 1] = color
+    cv2.rectangle = rectangle
+    from datasets.planning_problem_utils_2d import get_block_problem_input, get_gap_problem_input
+    picks = {"block": [0, 137, 250, 499], "gap": [0, 137, 250, 499]}
+    probs = {}
+    for kind, fn in (("block", get_block_problem_input), ("gap", get_gap_problem_input)):
+        for i in picks[kind]:
+            pr = fn(cfg[kind][i])
+            probs["%s_%d" % (kind, i)] = {
+                "x_start": [int(v) for v in pr["x_start"]], "x_goal": [int(v) for v in pr["x_goal"]],
+                "env_dims": [int(v) for v in pr["env_dict"]["env_dims"]],
+                "rectangle_obstacles": [[int(v) for v in r] for r in pr["env_dict"]["rectangle_obstacles"]],
+                "free_pixels": float(pr["binary_mask"].sum()), "search_radius": float(pr["search_radius"]),
+                "threshold": float(pr["best_path_len"] if kind == "block" else pr["flank_path_len"]),
+            }
+    with open(os.path.join(HERE, "block_gap_seed7.json"), "w") as f:
+        json.dump({"seed": 7, "configs": cfg, "problems": probs}, f)
+    print("block_gap_seed7.json: %d block, %d gap configs, %d problems" % (len(cfg["block"]), len(cfg["gap"]), len(probs)))
+
+
+def block_gap_run(name, algo, kind, idx, seed, iter_max, percentage=0.02):
+    """planning_block_gap() of the reference on one block / gap problem (problem dict from the reference's loader,
+    see block_gap_fixture for the cv2 stand-in): per-iteration path lengths until the threshold is met."""
+    with open(os.path.join(HERE, "block_gap_seed7.json")) as f:
+        cfg = json.load(f)["configs"][kind][idx]
+    import cv2
+
+    def rectangle(img, p0, p1, color, thickness):
+        img[p0[1]:p1[1] + 1, p0[0]:p1[0] + 1] = color
+    cv2.rectangle = rectangle
+    from datasets.planning_problem_utils_2d import get_block_problem_input, get_gap_problem_input
+    pr = get_block_problem_input(cfg) if kind == "block" else get_gap_problem_input(cfg)
+    thr = pr["best_path_len"] * (1 + percentage) if kind == "block" else pr["flank_path_len"]   # eval_planning_2d.py:117-121
+    cls = {"rrt": RRTStar2D, "irrt": IRRTStar2D}[algo]
+    planner = cls(pr["x_start"], pr["x_goal"], STEP_LEN, pr["search_radius"], iter_max, pr["env"], 3)
+    np.random.seed(seed)
+    random.seed(seed)
+    with quiet():
+        lst = planner.planning_block_gap(thr)
+    n = planner.num_vertices
+    ed = {k: ([list(map(int, r)) for r in v] if k.endswith("obstacles") else [list(map(int, q)) for q in v] if k in ("start", "goal") else list(map(int, v)))
+          for k, v in pr["env_dict"].items()}
+    save(name, env=env_json(ed), dim=np.array(2), algo=np.array(algo), seed=np.array(seed), iter_max=np.array(iter_max),
+         step_len=np.array(float(STEP_LEN)), clearance=np.array(3.0), search_radius=np.array(float(pr["search_radius"])),
+         x_start=np.array(pr["x_start"], dtype=np.float64), x_goal=np.array(pr["x_goal"], dtype=np.float64),
+         kind=np.array(kind), config=np.array(json.dumps(cfg)), threshold=np.array(float(thr)),
+         path_len_list=np.array(lst, dtype=np.float64), n=np.array(n),
+         vertices=planner.vertices[:n].copy(), parents=planner.vertex_parents[:n].astype(np.int64))
+    print("   %s: %d iterations, final %.4f < %.4f, n=%d" % (name, len(lst), lst[-1], thr, n))
+
+
 def pointnet2_fixture():
     """L4: the reference PointNet++ (CPU, fp32) on a seeded cloud.  Weights = torch.manual_seed(seed) init
     (regenerated by the test from the same seed - identical construction order) + the BatchNorm running
@@ -440,6 +513,9 @@ JOBS = {
     "run_nrrt2d_1500": lambda: nrrt_fixture("run_nrrt2d_1500", 2, 12, 1500, 1012),
     "run_nrrt3d_1500": lambda: nrrt_fixture("run_nrrt3d_1500", 3, 6, 1500, 1006),
     "random_irrt3d": lambda: run_planner("random_irrt3d", "irrt", 3, "ref3d", 3, 0, 5000, 1003, mode="random", iter_after_initial=300),
+    "block_gap": block_gap_fixture,
+    "blockgap_irrt_block": lambda: block_gap_run("blockgap_irrt_block", "irrt", "block", 137, 2001, 5000, percentage=0.1),
+    "blockgap_rrt_gap": lambda: block_gap_run("blockgap_rrt_gap", "rrt", "gap", 250, 2002, 6000),
 }
 
 if __name__ == "__main__":

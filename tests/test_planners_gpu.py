@@ -190,3 +190,46 @@ def test_nrrt_png_against_reference_run(name):
         p.planning()
         assert w.calls == int(g["png_calls"]) == 1
         _check_tree(p, g, exact=(mode == "exact" or dim == 3))
+
+
+@pytest.mark.parametrize("name", ["blockgap_irrt_block", "blockgap_rrt_gap"])
+def test_planning_block_gap_against_reference_run(name):
+    """planning_block_gap() on a block / gap problem built by OUR loader from the fixture's config: the per-iteration
+    path lengths (until the threshold is met, or iter_max) and the final tree equal the reference's run."""
+    from nirrt_star_amd import planners, problems
+    import json
+    g = load_golden(name)
+    cfg = json.loads(str(g["config"]))
+    pr = problems.get_block_problem_input(cfg) if str(g["kind"]) == "block" else problems.get_gap_problem_input(cfg)
+    assert float(pr["search_radius"]) == float(g["search_radius"])
+    cls = planners.IRRTStar2D if str(g["algo"]) == "irrt" else planners.RRTStar2D
+    p = cls(pr["x_start"], pr["x_goal"], 10, pr["search_radius"], int(g["iter_max"]), pr["env"], 3)
+    _seed(g)
+    lst = np.array(p.planning_block_gap(float(g["threshold"])))
+    exp = g["path_len_list"]
+    assert len(lst) == len(exp)
+    assert np.array_equal(np.isinf(lst), np.isinf(exp))
+    m = np.isfinite(exp)
+    if m.any():
+        assert np.max(np.abs(lst[m] - exp[m])) <= 1e-5
+    n = p.num_vertices
+    assert n == int(g["n"]) and np.array_equal(p.vertex_parents[:n], g["parents"])
+    assert np.max(np.abs(p.vertices[:n] - g["vertices"])) <= 1e-9
+
+
+def test_block_gap_batch_evaluation_is_segment_independent():
+    """eval_sharded's block / gap protocol: the persistent loop in short segments with problems leaving the batch as
+    they get below their threshold == one long launch truncated afterwards (same records)."""
+    from nirrt_star_amd import eval_sharded as E, problems
+    cfgs = problems.get_block_env_configs("/nonexistent")[:6]
+    probs = [problems.get_block_problem_input(c) for c in cfgs]
+    thr = [p["best_path_len"] * 1.1 for p in probs]
+    out = []
+    for seg in (250, 3000):
+        args = SimpleNamespace(planner="irrt_star", iter_max=3000, step_len=10, clearance=3, segment=seg)
+        out.append(np.array(E.plan_batch_block_gap(probs, list(range(6)), thr, args, 0)))
+    assert np.array_equal(out[0][:, [0, 1, 3]], out[1][:, [0, 1, 3]])          # ids, first-solution and stop iterations
+    fin = np.isfinite(out[1][:, 4:])
+    assert np.array_equal(np.isfinite(out[0][:, 4:]), fin)
+    assert np.array_equal(out[0][:, 4:][fin], out[1][:, 4:][fin])
+    assert (out[1][:, 3] > 0).any()                                              # some problem met its threshold
