@@ -2,20 +2,21 @@
 //
 // Execution model: ONE workgroup of NT threads (NT/64 wave64s) owns ONE tree; a launch runs many
 // trees (one per workgroup, several workgroups per CU) so that one tree's dependent-latency phases
-// (parent-chain walks, barriers) overlap another tree's streaming scans.
+// (parent-chain walks, barriers) overlap other trees' work.
 //
-//   * O(n) passes (nearest, Near): every wave streams a CONTIGUOUS segment of the SoA coordinate
-//     arrays with 16-byte loads (2 vertices per lane, 1 KiB per wave-instruction).  The per-vertex
-//     work is a squared distance and a compare; the reference's distance formula (glibc hypot /
-//     sqrt) is only evaluated for vertices inside a 2^-48 guard band around the decision threshold,
-//     which keeps the scans HBM-bound while every decision stays bit-identical to the reference.
-//     Reductions: wave64 __shfl_xor butterflies, then one LDS step across waves.
-//     Near hits are staged in index order with wave ballots (no atomics, no sort).
+//   * nearest / Near.  Small trees: every wave streams a CONTIGUOUS segment of the float32 twins of
+//     the SoA coordinate arrays with 16-byte loads; Near hits are staged in index order with wave
+//     ballots.  Trees of >= GRID_MIN_VERTICES vertices: a uniform-grid index (twins ordered by cell +
+//     unordered tail) is queried instead - only the cell rows that meet the query ball are visited,
+//     hits are put back in index order through an LDS bitmap.  Either way the per-vertex work is a
+//     float32 squared distance against thresholds with RIGOROUS error intervals; undecided vertices are
+//     re-decided in float64 (2^-48 guard band on d^2, the reference's own distance formula - glibc
+//     hypot / sqrt - inside the band), so every decision is bit-identical to the reference.
 //   * O(k) work (fan of segment tests, choose-parent, rewire) is lane-parallel.
 //   * cost(v) is the reference's leaf->root sum (math.hypot per edge, added in that order).  It is kept
-//     EXACT in a per-vertex cache: a walk chases one 16-byte {edge_len, parent} record per hop, and a
-//     re-parented vertex has its whole subtree (child / sibling links) re-walked right away, so every
-//     cost the loop compares is the value the reference's un-cached cost() would return.
+//     EXACT in a per-vertex cache: a walk chases one 48-byte record per FOUR hops, and a re-parented
+//     vertex has its whole subtree (child / sibling links) re-walked right away, so every cost the loop
+//     compares is the value the reference's un-cached cost() would return.
 //
 // Arithmetic: float64, compiled with -ffp-contract=off; per-call-site formulas of SURVEY.md App. A:
 //   np.hypot -> hypot_np()   math.hypot -> hypot_py<D>()   np.linalg.norm(axis) -> norm_axis<D>()
