@@ -41,6 +41,7 @@
 #define GRID_BM_WORDS 1024       // LDS hit bitmap: 32 768 vertices per ordering window
 #endif
 #define GRID_U 4                 // slots per lane and trip of a grid visit
+#define NEAR_U 4                 // Near members per lane and trip of the gather / choose-parent / rewire scans
 #define GRID_N 1u                // range serves the Near query
 #define GRID_Q 2u                // range serves the nearest query
 
@@ -1235,9 +1236,13 @@ __device__ __forceinline__ int wg_grid_query(Lds<NT> &s, const TreeDev &t, int n
         kraw = s.hit_cnt;
         int kout = 0;
         for (int wb = 0; wb < n && kout < kraw; wb += 32 * GRID_BM_WORDS) {
-            for (int a = tid; a < kraw; a += NT) {
-                const unsigned id = (unsigned)(t.bfs_q[a] - wb);
-                if (id < 32u * GRID_BM_WORDS) atomicOr(&s.bm[id >> 5], 1u << (id & 31u));
+            for (int a0 = tid; a0 < kraw; a0 += NT * NEAR_U) {
+                unsigned ids[NEAR_U];
+#pragma unroll
+                for (int u = 0; u < NEAR_U; u++) ids[u] = a0 + u * NT < kraw ? (unsigned)(t.bfs_q[a0 + u * NT] - wb) : 0xffffffffu;
+#pragma unroll
+                for (int u = 0; u < NEAR_U; u++)
+                    if (ids[u] < 32u * GRID_BM_WORDS) atomicOr(&s.bm[ids[u] >> 5], 1u << (ids[u] & 31u));
             }
             __syncthreads();
             const int left = n - wb;
@@ -1633,29 +1638,49 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     }
     __syncthreads();
     const int n_ob = s.ob_n;
-    for (int a = tid; a < kraw; a += NT) {
-        int ww = 0, offw = 0;
+    // NEAR_U slots per lane and trip: the index loads, then the 32-byte record loads, are issued back to back
+    for (int a0 = tid; a0 < kraw; a0 += NT * NEAR_U) {
+        int vs[NEAR_U];
+        VRec vrs[NEAR_U];
 #pragma unroll
-        for (int i = 1; i < NW; i++)
-            if (a >= woff[i]) { ww = i; offw = woff[i]; }
-        const int v = contig ? t.st_idx[a] : t.st_idx[ww * per + (a - offw)];
-        const VRec vr = t.vrec[v];
-        double vj[3] = {vr.x, vr.y, vr.z};
-        t.nr_cost[a] = vr.cost;
-        double d[3] = {node_new[0] - vj[0], node_new[1] - vj[1], D == 3 ? node_new[D - 1] - vj[2] : 0.};
-        t.nr_idx[a] = v;
-        t.nr_flag[a] = (v == new_idx) ? 1 : 0;   // excluded like the colliding ones
-        t.nr_dist[a] = dist_scan<D>(d);
-        cx[a] = vj[0]; cy[a] = vj[1];
-        if (D == 3) cz[a] = vj[2];
-        double l0[3], l1[3];
+        for (int u = 0; u < NEAR_U; u++) {
+            const int a = a0 + u * NT;
+            vs[u] = 0;
+            if (a < kraw) {
+                int ww = 0, offw = 0;
 #pragma unroll
-        for (int c = 0; c < D; c++) { l0[c] = fmin(node_new[c], vj[c]); l1[c] = fmax(node_new[c], vj[c]); }
-        for (int j = 0; j < n_ob; j++) {
-            const int o = s.ob_list[j];
-            if (seg_aabb_pass<D, NT>(s, o, l0, l1)) {
-                int pos = atomicAdd(&s.bc_i[5], 1);
-                if (pos < pair_cap) pairq[pos] = a * MAX_OBS * 2 + o;
+                for (int i = 1; i < NW; i++)
+                    if (a >= woff[i]) { ww = i; offw = woff[i]; }
+                vs[u] = contig ? t.st_idx[a] : t.st_idx[ww * per + (a - offw)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NEAR_U; u++)
+            if (a0 + u * NT < kraw) vrs[u] = t.vrec[vs[u]];
+#pragma unroll
+        for (int u = 0; u < NEAR_U; u++) {
+            const int a = a0 + u * NT;
+            if (a < kraw) {
+                const int v = vs[u];
+                const VRec vr = vrs[u];
+                double vj[3] = {vr.x, vr.y, vr.z};
+                t.nr_cost[a] = vr.cost;
+                double d[3] = {node_new[0] - vj[0], node_new[1] - vj[1], D == 3 ? node_new[D - 1] - vj[2] : 0.};
+                t.nr_idx[a] = v;
+                t.nr_flag[a] = (v == new_idx) ? 1 : 0;   // excluded like the colliding ones
+                t.nr_dist[a] = dist_scan<D>(d);
+                cx[a] = vj[0]; cy[a] = vj[1];
+                if (D == 3) cz[a] = vj[2];
+                double l0[3], l1[3];
+#pragma unroll
+                for (int c = 0; c < D; c++) { l0[c] = fmin(node_new[c], vj[c]); l1[c] = fmax(node_new[c], vj[c]); }
+                for (int j = 0; j < n_ob; j++) {
+                    const int o = s.ob_list[j];
+                    if (seg_aabb_pass<D, NT>(s, o, l0, l1)) {
+                        int pos = atomicAdd(&s.bc_i[5], 1);
+                        if (pos < pair_cap) pairq[pos] = a * MAX_OBS * 2 + o;
+                    }
+                }
             }
         }
     }
@@ -1923,9 +1948,20 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 // choose_parent (rrt_star_2d.py:80-90): argmin over the Near set of cost(j) + dist, first minimum
                 double cand = __builtin_inf();
                 int cj = 0x7fffffff;
-                for (int a = tid; a < k; a += NT) {
-                    double c = t.nr_flag[a] ? __builtin_inf() : t.nr_cost[a] + t.nr_dist[a];
-                    if (c < cand) { cand = c; cj = a; }
+                for (int a0 = tid; a0 < k; a0 += NT * NEAR_U) {
+                    int fl[NEAR_U];
+                    double co[NEAR_U], di[NEAR_U];
+#pragma unroll
+                    for (int u = 0; u < NEAR_U; u++) {
+                        const int a = a0 + u * NT;
+                        fl[u] = 1; co[u] = 0.; di[u] = 0.;
+                        if (a < k) { fl[u] = t.nr_flag[a]; co[u] = t.nr_cost[a]; di[u] = t.nr_dist[a]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < NEAR_U; u++) {
+                        const double c = fl[u] ? __builtin_inf() : co[u] + di[u];
+                        if (c < cand) { cand = c; cj = a0 + u * NT; }   // ascending a per lane: first minimum kept
+                    }
                 }
                 block_argmin<NT>(s, cand, cj);
                 if (cand < curr) { reparented = 1; best_parent = t.nr_idx[cj]; }
@@ -1966,8 +2002,18 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 int start = 0;
                 while (start < k) {
                     int first = 0x7fffffff;
-                    for (int a = start + tid; a < k; a += NT) {
-                        if (!t.nr_flag[a] && t.nr_cost[a] > new_cost + t.nr_dist[a]) { first = a; break; }
+                    for (int a0 = start + tid; a0 < k && first == 0x7fffffff; a0 += NT * NEAR_U) {
+                        int fl[NEAR_U];
+                        double co[NEAR_U], di[NEAR_U];
+#pragma unroll
+                        for (int u = 0; u < NEAR_U; u++) {
+                            const int a = a0 + u * NT;
+                            fl[u] = 1; co[u] = 0.; di[u] = 0.;
+                            if (a < k) { fl[u] = t.nr_flag[a]; co[u] = t.nr_cost[a]; di[u] = t.nr_dist[a]; }
+                        }
+#pragma unroll
+                        for (int u = NEAR_U - 1; u >= 0; u--)
+                            if (!fl[u] && co[u] > new_cost + di[u]) first = a0 + u * NT;   // lowest slot of the trip wins
                     }
                     first = block_min_int<NT>(s, first);
                     if (first == 0x7fffffff) break;
