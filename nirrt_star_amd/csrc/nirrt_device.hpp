@@ -40,7 +40,10 @@
 #ifndef GRID_BM_WORDS
 #define GRID_BM_WORDS 1024       // LDS hit bitmap: 32 768 vertices per ordering window
 #endif
+#ifndef GRID_U
 #define GRID_U 4                 // slots per lane and trip of a grid visit
+#endif
+#define LIST_U 8                 // solution / goal-candidate list entries per lane and trip
 #define NEAR_U 4                 // Near members per lane and trip of the gather / choose-parent / rewire scans
 #define GRID_N 1u                // range serves the Near query
 #define GRID_Q 2u                // range serves the nearest query
@@ -1016,7 +1019,16 @@ __device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeDev &t, int n)
         if (D == 3) c += G * G * grid_cell_axis(t, 2, (double)t.cf[D - 1][i]);
         return c;
     };
-    for (int i = tid; i < n; i += NT) t.g_rank[i] = atomicAdd(&t.g_cnt[cell_of(i)], 1);
+    for (int i0 = tid; i0 < n; i0 += NT * LIST_U) {
+        int cell[LIST_U], rk[LIST_U];
+#pragma unroll
+        for (int u = 0; u < LIST_U; u++) cell[u] = i0 + u * NT < n ? cell_of(i0 + u * NT) : -1;
+#pragma unroll
+        for (int u = 0; u < LIST_U; u++) rk[u] = cell[u] >= 0 ? atomicAdd(&t.g_cnt[cell[u]], 1) : 0;
+#pragma unroll
+        for (int u = 0; u < LIST_U; u++)
+            if (cell[u] >= 0) t.g_rank[i0 + u * NT] = rk[u];
+    }
     __syncthreads();
     const int per = (nc + NT - 1) / NT, b = tid * per;
     int sum = 0;
@@ -1033,9 +1045,26 @@ __device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeDev &t, int n)
     }
     if (tid == 0) t.g_start[nc] = n;
     __syncthreads();
-    for (int i = tid; i < n; i += NT) {
-        const int pos = t.g_start[cell_of(i)] + t.g_rank[i];
-        t.g_rec[pos] = make_float4(t.cf[0][i], t.cf[1][i], D == 3 ? t.cf[D - 1][i] : 0.f, __int_as_float(i));
+    for (int i0 = tid; i0 < n; i0 += NT * LIST_U) {
+        float fx[LIST_U], fy[LIST_U], fz[LIST_U];
+        int rk[LIST_U], st[LIST_U];
+#pragma unroll
+        for (int u = 0; u < LIST_U; u++) {
+            const int i = i0 + u * NT;
+            fx[u] = 0.f; fy[u] = 0.f; fz[u] = 0.f; rk[u] = 0;
+            if (i < n) { fx[u] = t.cf[0][i]; fy[u] = t.cf[1][i]; fz[u] = D == 3 ? t.cf[D - 1][i] : 0.f; rk[u] = t.g_rank[i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < LIST_U; u++) {
+            int c = grid_cell_axis(t, 0, (double)fx[u]) + G * grid_cell_axis(t, 1, (double)fy[u]);
+            if (D == 3) c += G * G * grid_cell_axis(t, 2, (double)fz[u]);
+            st[u] = i0 + u * NT < n ? t.g_start[c] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < LIST_U; u++) {
+            const int i = i0 + u * NT;
+            if (i < n) t.g_rec[st[u] + rk[u]] = make_float4(fx[u], fy[u], fz[u], __int_as_float(i));
+        }
     }
     if (tid == 0) t.g_ns = n;
     __syncthreads();
@@ -1689,11 +1718,28 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     // Pass B - exact segment tests for the queued pairs (node_new -> v_j vs obstacle o)
     const int npairs = s.bc_i[5];
     if (npairs <= pair_cap) {
-        for (int p = tid; p < npairs; p += NT) {
-            int code = pairq[p];
-            int j = code / (MAX_OBS * 2), o = code - j * (MAX_OBS * 2);
-            double vj[3] = {cx[j], cy[j], D == 3 ? cz[j] : 0.};
-            if (seg_obstacle<D, NT>(s, o, node_new, vj, clr)) t.nr_flag[j] = 1;
+        for (int p0 = tid; p0 < npairs; p0 += NT * NEAR_U) {
+            int code[NEAR_U];
+            double px[NEAR_U], py[NEAR_U], pz[NEAR_U];
+#pragma unroll
+            for (int u = 0; u < NEAR_U; u++) code[u] = p0 + u * NT < npairs ? pairq[p0 + u * NT] : -1;
+#pragma unroll
+            for (int u = 0; u < NEAR_U; u++) {
+                px[u] = 0.; py[u] = 0.; pz[u] = 0.;
+                if (code[u] >= 0) {
+                    const int j = code[u] / (MAX_OBS * 2);
+                    px[u] = cx[j]; py[u] = cy[j];
+                    if (D == 3) pz[u] = cz[j];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NEAR_U; u++) {
+                if (code[u] >= 0) {
+                    const int j = code[u] / (MAX_OBS * 2), o = code[u] - j * (MAX_OBS * 2);
+                    double vj[3] = {px[u], py[u], pz[u]};
+                    if (seg_obstacle<D, NT>(s, o, node_new, vj, clr)) t.nr_flag[j] = 1;
+                }
+            }
         }
     } else {
         // pair queue overflow (cannot happen unless almost every obstacle overlaps every segment): direct loop
@@ -1735,9 +1781,22 @@ __device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double 
     if (t.sol_dirty) {   // uniform
         double bv = __builtin_inf();
         int bs = 0x7fffffff;
-        for (int q = tid; q < ns; q += NT) {
-            double c = t.vrec[t.sol[q]].cost + t.sol_line[q];
-            if (c < bv) { bv = c; bs = q; }
+        for (int q0 = tid; q0 < ns; q0 += NT * LIST_U) {   // LIST_U entries per lane and trip, loads issued back to back
+            int vi[LIST_U];
+            double li[LIST_U], co[LIST_U];
+#pragma unroll
+            for (int u = 0; u < LIST_U; u++) {
+                const int q = q0 + u * NT;
+                vi[u] = 0; li[u] = __builtin_inf();
+                if (q < ns) { vi[u] = t.sol[q]; li[u] = t.sol_line[q]; }
+            }
+#pragma unroll
+            for (int u = 0; u < LIST_U; u++) co[u] = q0 + u * NT < ns ? t.vrec[vi[u]].cost : 0.;
+#pragma unroll
+            for (int u = 0; u < LIST_U; u++) {
+                const double c = co[u] + li[u];
+                if (q0 + u * NT < ns && c < bv) { bv = c; bs = q0 + u * NT; }
+            }
         }
         block_argmin<NT>(s, bv, bs);
         if (bs == 0x7fffffff) bs = 0;
@@ -1784,9 +1843,23 @@ __device__ __forceinline__ void wg_goal_parent(Lds<NT> &s, TreeDev &t, int &gp, 
     if (t.gc_dirty) {
         double bv = __builtin_inf();
         int bq = 0x7fffffff;
-        for (int q = tid; q < ng; q += NT) {
-            double c = t.gc_col[q] ? __builtin_inf() : t.vrec[t.gc_idx[q]].cost + t.gc_dist[q];
-            if (c < bv) { bv = c; bq = q; }
+        for (int q0 = tid; q0 < ng; q0 += NT * LIST_U) {
+            int vi[LIST_U];
+            double di[LIST_U], co[LIST_U];
+            bool col[LIST_U];
+#pragma unroll
+            for (int u = 0; u < LIST_U; u++) {
+                const int q = q0 + u * NT;
+                vi[u] = 0; di[u] = 0.; col[u] = true;
+                if (q < ng) { vi[u] = t.gc_idx[q]; di[u] = t.gc_dist[q]; col[u] = t.gc_col[q] != 0; }
+            }
+#pragma unroll
+            for (int u = 0; u < LIST_U; u++) co[u] = q0 + u * NT < ng ? t.vrec[vi[u]].cost : 0.;
+#pragma unroll
+            for (int u = 0; u < LIST_U; u++) {
+                const double c = col[u] ? __builtin_inf() : co[u] + di[u];
+                if (q0 + u * NT < ng && c < bv) { bv = c; bq = q0 + u * NT; }
+            }
         }
         block_argmin<NT>(s, bv, bq);
         if (bq == 0x7fffffff) bq = 0;  // every candidate collides: np.argmin of all-inf = 0
