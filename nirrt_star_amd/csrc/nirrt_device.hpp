@@ -113,13 +113,10 @@ struct TreeDev {
     long long alg_elems;   // vertices the reference algorithm scans: n per nearest_neighbor + n per find_near_neighbors
     // Near-set working arrays (capacity cap: a Near set can never exceed the tree)
     int *st_idx;     // ordered staging of scan hits, one region per wave segment
-    double *st_c[3]; // coordinates of the staged hits (captured while they are in registers)
     int *nr_idx;     // neighbour vertex index, ascending
     int *nr_flag;    // segment (new -> neighbour) hits an obstacle
     double *nr_dist; // scan distance new <-> neighbour (np.hypot / axis norm)
     double *nr_cost; // cost(neighbour), kept current through the rewire rounds
-    double *nr_c0;   // scratch: candidate x during the Near phase
-    double *nr_c1;   // scratch: candidate y during the Near phase
     // IRRT*: path_solutions (goal-parent indices, duplicates allowed) + cached costs
     int *sol;
     double *sol_line;   // Line(v, goal) of each solution vertex (static)
@@ -1196,17 +1193,19 @@ __device__ __forceinline__ int wg_grid_query(Lds<NT> &s, const TreeDev &t, int n
     if (!(brute_q && !wantN)) {
         __syncthreads();
         for (int row = tid; row < rowsN + (brute_q ? 0 : rowsQ); row += NT) {
-            if (row < rowsN) put_row(row, nb0, nb1, row, GRID_N, pn, r);
-            else put_row(row, qb0, qb1, row - rowsN, GRID_Q, nullptr, 0.);
+            if (row < rowsN) put_row(1 + row, nb0, nb1, row, GRID_N, pn, r);
+            else put_row(1 + row, qb0, qb1, row - rowsN, GRID_Q, nullptr, 0.);
         }
         if (tid == 0) {
             const int R = rowsN + (brute_q ? 0 : rowsQ);
-            s.rg_beg[R] = ns; s.rg_len[R] = n - ns;
-            s.rg_flag[R] = (wantN ? GRID_N : 0u) | ((wantQ && !brute_q) ? GRID_Q : 0u);
+            // slot 0 = the unordered tail (the largest range: found first by the lanes' linear search)
+            s.rg_beg[0] = ns; s.rg_len[0] = n - ns;
+            s.rg_flag[0] = (wantN ? GRID_N : 0u) | ((wantQ && !brute_q) ? GRID_Q : 0u);
             s.rg_n = R + 1;
             s.hit_cnt = 0;
         }
         __syncthreads();
+        PROF(20);
         visit();
     }
     PROF(13);
@@ -1246,9 +1245,9 @@ __device__ __forceinline__ int wg_grid_query(Lds<NT> &s, const TreeDev &t, int n
             // another visit: the enlarged box + tail, nearest only (a fresh reduction: a vertex seen twice would look
             // like its own runner-up)
             __syncthreads();
-            for (int row = tid; row < rowsE; row += NT) put_row(row, eb0, eb1, row, GRID_Q, nullptr, 0.);
+            for (int row = tid; row < rowsE; row += NT) put_row(1 + row, eb0, eb1, row, GRID_Q, nullptr, 0.);
             if (tid == 0) {
-                s.rg_beg[rowsE] = ns; s.rg_len[rowsE] = n - ns; s.rg_flag[rowsE] = GRID_Q;
+                s.rg_beg[0] = ns; s.rg_len[0] = n - ns; s.rg_flag[0] = GRID_Q;
                 s.rg_n = rowsE + 1;
             }
             __syncthreads();
@@ -1647,10 +1646,9 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     }
     const bool contig = kgrid >= 0;
     const int kraw = contig ? kgrid : woff[NW];
-    // Pass A - gather the staged hits (already ascending): index, coordinates (kept in nr_c0/nr_c1/st scratch
-    // for pass B), reference distance, and the AABB prefilter against every obstacle.  (segment, obstacle)
-    // pairs that survive the prefilter are queued so that the expensive exact tests run densely packed.
-    double *cx = t.nr_c0, *cy = t.nr_c1, *cz = t.st_c[0];
+    // Pass A - gather the staged hits (already ascending): index, exact cost and reference distance from the 32-byte
+    // record, and the AABB prefilter against the obstacles near the ball.  (segment, obstacle) pairs that survive the
+    // prefilter are queued so that the expensive exact tests run densely packed.
     int *pairq = t.bfs_q;
     const int pair_cap = t.cap;
     const int M = s.n_round + s.n_box;
@@ -1698,8 +1696,6 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
                 t.nr_idx[a] = v;
                 t.nr_flag[a] = (v == new_idx) ? 1 : 0;   // excluded like the colliding ones
                 t.nr_dist[a] = dist_scan<D>(d);
-                cx[a] = vj[0]; cy[a] = vj[1];
-                if (D == 3) cz[a] = vj[2];
                 double l0[3], l1[3];
 #pragma unroll
                 for (int c = 0; c < D; c++) { l0[c] = fmin(node_new[c], vj[c]); l1[c] = fmax(node_new[c], vj[c]); }
@@ -1719,24 +1715,20 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     const int npairs = s.bc_i[5];
     if (npairs <= pair_cap) {
         for (int p0 = tid; p0 < npairs; p0 += NT * NEAR_U) {
-            int code[NEAR_U];
-            double px[NEAR_U], py[NEAR_U], pz[NEAR_U];
+            int code[NEAR_U], vv[NEAR_U];
+            VRec pr[NEAR_U];
 #pragma unroll
             for (int u = 0; u < NEAR_U; u++) code[u] = p0 + u * NT < npairs ? pairq[p0 + u * NT] : -1;
 #pragma unroll
-            for (int u = 0; u < NEAR_U; u++) {
-                px[u] = 0.; py[u] = 0.; pz[u] = 0.;
-                if (code[u] >= 0) {
-                    const int j = code[u] / (MAX_OBS * 2);
-                    px[u] = cx[j]; py[u] = cy[j];
-                    if (D == 3) pz[u] = cz[j];
-                }
-            }
+            for (int u = 0; u < NEAR_U; u++) vv[u] = code[u] >= 0 ? t.nr_idx[code[u] / (MAX_OBS * 2)] : 0;
+#pragma unroll
+            for (int u = 0; u < NEAR_U; u++)
+                if (code[u] >= 0) pr[u] = t.vrec[vv[u]];   // the few queued segments re-read their end point (L2-hot)
 #pragma unroll
             for (int u = 0; u < NEAR_U; u++) {
                 if (code[u] >= 0) {
                     const int j = code[u] / (MAX_OBS * 2), o = code[u] - j * (MAX_OBS * 2);
-                    double vj[3] = {px[u], py[u], pz[u]};
+                    double vj[3] = {pr[u].x, pr[u].y, D == 3 ? pr[u].z : 0.};
                     if (seg_obstacle<D, NT>(s, o, node_new, vj, clr)) t.nr_flag[j] = 1;
                 }
             }
@@ -1744,7 +1736,8 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     } else {
         // pair queue overflow (cannot happen unless almost every obstacle overlaps every segment): direct loop
         for (int j = tid; j < kraw; j += NT) {
-            double vj[3] = {cx[j], cy[j], D == 3 ? cz[j] : 0.};
+            const VRec pr = t.vrec[t.nr_idx[j]];
+            double vj[3] = {pr.x, pr.y, D == 3 ? pr.z : 0.};
             if (seg_all<D, NT>(s, node_new, vj, clr)) t.nr_flag[j] = 1;
         }
     }

@@ -203,8 +203,8 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     TreeDev &h = t->host;
-    void *bufs[] = {h.cf[0], h.cf[1], h.cf[2], h.st_c[0], h.st_c[1], h.st_c[2], h.c[0], h.c[1], h.c[2], h.aux, h.vrec, h.nr_cost, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.st_idx,
-                    h.nr_idx, h.nr_flag, h.nr_dist, h.nr_c0, h.nr_c1, h.sol, h.sol_line, h.gc_idx, h.gc_dist, h.gc_col,
+    void *bufs[] = {h.cf[0], h.cf[1], h.cf[2], h.c[0], h.c[1], h.c[2], h.aux, h.vrec, h.nr_cost, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.st_idx,
+                    h.nr_idx, h.nr_flag, h.nr_dist, h.sol, h.sol_line, h.gc_idx, h.gc_dist, h.gc_col,
                     h.g_rec, h.g_start, h.g_cnt, h.g_rank, h.hop, h.listed, t->near_r};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -284,7 +284,6 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         HIPCHK_T(hipMalloc(&h.c[k], sizeof(double) * np));
         HIPCHK_T(hipMemset(h.c[k], 0, sizeof(double) * np));
     }
-    for (int k = 0; k < D; k++) HIPCHK_T(hipMalloc(&h.st_c[k], sizeof(double) * np));
     for (int k = 0; k < D; k++) {
         HIPCHK_T(hipMalloc(&h.cf[k], sizeof(float) * np));
         HIPCHK_T(hipMemset(h.cf[k], 0, sizeof(float) * np));
@@ -307,8 +306,6 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     HIPCHK_T(hipMalloc(&h.nr_idx, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.nr_flag, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.nr_dist, sizeof(double) * np));
-    HIPCHK_T(hipMalloc(&h.nr_c0, sizeof(double) * np));
-    HIPCHK_T(hipMalloc(&h.nr_c1, sizeof(double) * np));
     h.cap = t->cap;
     h.dim = D;
     h.cap_sol = t->cap;

@@ -45,7 +45,7 @@ print("first-solution iteration: median %s  (min %d max %d); final c_best median
          res["scan_elems"].sum() * dim * 8 / 1e9 / (ms / 1e3)))
 pr_ = np.array([t.debug_prof() for t in trees]).sum(0).astype(float)
 if pr_.sum() > 0:
-    names = ["nearest", "steer+edge", "near", "choose", "cost(new)", "rewire", "goal/ingoal", "report", "N.scan", "N.gather", "N.fan", "N.compact", "rebuild", "(G.visit)", "(G.nearest)", "(G.order)", "L.draw", "L.iteration", "L.report", "L.other", "", "", "", ""]
+    names = ["nearest", "steer+edge", "near", "choose", "cost(new)", "rewire", "goal/ingoal", "report", "N.scan", "N.gather", "N.fan", "N.compact", "rebuild", "(G.visit)", "(G.nearest)", "(G.order)", "L.draw", "L.iteration", "L.report", "L.other", "(G.setup)", "", "", ""]
     tot = pr_[16:20].sum() if pr_[16:20].sum() > 0 else pr_.sum()
     print("phase share: " + ", ".join("%s %.1f%%" % (n, 100 * v / tot) for n, v in zip(names, pr_) if v > 0),
           "| ticks/iter/tree %.0f (100MHz => %.1f us)" % (tot / done.sum(), tot / done.sum() / 100.0))
