@@ -98,7 +98,51 @@ def plan_batch(problems, pids, args, device_id):
     recs = [make_record(pid, tr, t.n) for pid, tr, t in zip(pids, traces, trees)]
     for t in trees:
         t.close()
-    return recs
+    return recs, traces
+
+
+def result_lists(kind, traces, thresholds=None):
+    """The `path_len_list` the reference's planner methods return (eval_planning_2d.py:115-126): planning_random ->
+    best path length after every iteration (inf before the first solution); planning_block_gap -> the same list cut
+    right after the first entry below the threshold."""
+    out = []
+    for i, tr in enumerate(traces):
+        tr = [float(v) for v in tr]
+        if kind in ("block", "gap"):
+            stop = first_below(tr, thresholds[i])
+            if stop > 0:
+                tr = tr[:stop]
+        out.append(tr)
+    return out
+
+
+def gather_results(local, world_size, rank):
+    """local: list of (problem id, path_len_list) -> rank 0 gets all of them sorted by id (variable-length lists travel
+    as pickled objects: one gather at the end of the run, off the data path)"""
+    if world_size == 1:
+        return sorted(local)
+    import torch.distributed as dist
+    out = [None] * world_size if rank == 0 else None
+    dist.gather_object(local, out, dst=0)
+    if rank != 0:
+        return None
+    return sorted(x for part in out for x in part)
+
+
+def write_reference_pickle(path, env_configs, results):
+    """eval_planning_2d.py:100-136 wire format: a pickled list of copies of the env config dicts, each with the
+    planner's path_len_list under 'result' - what result_analysis_*.py reads."""
+    import pickle
+    from copy import copy
+    lst = []
+    for pid, res in results:
+        d = copy(env_configs[pid])
+        d['result'] = res
+        lst.append(d)
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    with open(path, "wb") as f:
+        pickle.dump(lst, f)
+    return lst
 
 
 def first_below(trace, threshold):
@@ -158,7 +202,7 @@ def plan_batch_block_gap(problems, pids, thresholds, args, device_id):
     recs = [make_block_gap_record(pid, tr, thr, t.n) for pid, tr, thr, t in zip(pids, traces, thresholds, trees)]
     for t in trees:
         t.close()
-    return recs
+    return recs, traces
 
 
 def main():
@@ -174,6 +218,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--max_problems", type=int, default=None)
     ap.add_argument("--out", default="results/evaluation/sharded_result.json")
+    ap.add_argument("--pickle_out", default="auto",
+                    help="reference-format result pickle (list of env configs + 'result'); 'auto' = the reference's "
+                         "results/evaluation/{2d,3d}/<problem>-<planner>-none-<n>.pickle, 'none' = skip")
     args = ap.parse_args()
     if args.clearance is None:
         args.clearance = 2 if args.problem == "random_3d" else 3
@@ -203,7 +250,7 @@ def main():
         cfgs = cfgs[: args.max_problems]
     mine = shard_indices(len(cfgs), rank, world)
     t0 = time.time()
-    recs = []
+    recs, results = [], []
     for b0 in range(0, len(mine), args.batch):
         ids = mine[b0:b0 + args.batch]
         probs = []
@@ -211,14 +258,25 @@ def main():
             if args.problem == "random_3d":
                 np.random.seed(i)   # gamma estimate consumes the global generator
             probs.append(get(cfgs[i]))
+        thr = None
         if args.problem == "block":   # eval_planning_2d.py:117-121
-            recs += plan_batch_block_gap(probs, ids, [p["best_path_len"] * (1 + args.path_len_threshold_percentage) for p in probs],
-                                         args, local_rank)
+            thr = [p["best_path_len"] * (1 + args.path_len_threshold_percentage) for p in probs]
+            r, traces = plan_batch_block_gap(probs, ids, thr, args, local_rank)
         elif args.problem == "gap":
-            recs += plan_batch_block_gap(probs, ids, [p["flank_path_len"] for p in probs], args, local_rank)
+            thr = [p["flank_path_len"] for p in probs]
+            r, traces = plan_batch_block_gap(probs, ids, thr, args, local_rank)
         else:
-            recs += plan_batch(probs, ids, args, local_rank)
+            r, traces = plan_batch(probs, ids, args, local_rank)
+        recs += r
+        results += list(zip(ids, result_lists(args.problem, traces, thr)))
     allr = gather_records(np.array(recs).reshape(-1, RECORD_LEN), world, rank, device="cuda")
+    all_results = gather_results(results, world, rank) if args.pickle_out != "none" else None
+    if rank == 0 and all_results is not None:
+        path = args.pickle_out
+        if path == "auto":
+            path = os.path.join("results", "evaluation", "3d" if args.problem == "random_3d" else "2d",
+                                "%s-%s-none-%d.pickle" % (args.problem, args.planner, len(cfgs)))
+        write_reference_pickle(path, cfgs, all_results)
     if rank == 0:
         solved = allr[allr[:, 1] > 0]
         summary = {"problems": int(len(allr)), "solved": int(len(solved)), "world_size": world,

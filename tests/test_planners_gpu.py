@@ -162,7 +162,7 @@ def test_sharded_eval_batch_matches_planner_class():
     ed = [worlds.random_world_2d(i, "ref2d") for i in range(3)]
     probs = [worlds.problem_2d(e, 0) for e in ed]
     pids = [5, 6, 7]
-    recs = es.plan_batch(probs, pids, args, 0)
+    recs, _traces = es.plan_batch(probs, pids, args, 0)
     for pr, pid, rec in zip(probs, pids, recs):
         p = planners.IRRTStar2D(pr["x_start"], pr["x_goal"], 10, pr["search_radius"], 4250, pr["env"], 3)
         np.random.seed(1000 + pid)
@@ -171,6 +171,15 @@ def test_sharded_eval_batch_matches_planner_class():
         first = int(np.argmax(np.isfinite(lst))) + 1
         assert rec[0] == pid and rec[1] == first and rec[2] == p.num_vertices and rec[3] == len(lst)
         assert abs(rec[4] - lst[first - 1]) <= 1e-9 and abs(rec[5] - lst[first - 1 + 250]) <= 1e-9
+    # the reference's result wire format: the full per-iteration lists
+    for pr, pid, res in zip(probs, pids, es.result_lists("random_2d", _traces)):
+        p = planners.IRRTStar2D(pr["x_start"], pr["x_goal"], 10, pr["search_radius"], 4250, pr["env"], 3)
+        np.random.seed(1000 + pid)
+        random.seed(1000 + pid)
+        lst = np.array(p.planning_random(250))
+        res = np.array(res)
+        assert len(res) == len(lst) and np.array_equal(np.isinf(res), np.isinf(lst))
+        assert np.max(np.abs(res[np.isfinite(lst)] - lst[np.isfinite(lst)])) <= 1e-9
 
 
 @pytest.mark.parametrize("name", ["run_nrrt2d_1500", "run_nrrt3d_1500"])
@@ -227,7 +236,7 @@ def test_block_gap_batch_evaluation_is_segment_independent():
     out = []
     for seg in (250, 3000):
         args = SimpleNamespace(planner="irrt_star", iter_max=3000, step_len=10, clearance=3, segment=seg)
-        out.append(np.array(E.plan_batch_block_gap(probs, list(range(6)), thr, args, 0)))
+        out.append(np.array(E.plan_batch_block_gap(probs, list(range(6)), thr, args, 0)[0]))
     assert np.array_equal(out[0][:, [0, 1, 3]], out[1][:, [0, 1, 3]])          # ids, first-solution and stop iterations
     fin = np.isfinite(out[1][:, 4:])
     assert np.array_equal(np.isfinite(out[0][:, 4:]), fin)
