@@ -43,8 +43,12 @@
 #ifndef GRID_U
 #define GRID_U 4                 // slots per lane and trip of a grid visit
 #endif
+#ifndef LIST_U
 #define LIST_U 8                 // solution / goal-candidate list entries per lane and trip
+#endif
+#ifndef NEAR_U
 #define NEAR_U 4                 // Near members per lane and trip of the gather / choose-parent / rewire scans
+#endif
 #define GRID_N 1u                // range serves the Near query
 #define GRID_Q 2u                // range serves the nearest query
 
