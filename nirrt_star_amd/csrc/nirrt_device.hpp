@@ -200,6 +200,7 @@ struct Lds {
     // constants of the samplers (copied from the descriptor once per kernel)
     double k_lo[3], k_hi[3], k_clr, k_cmin, k_xc[3], k_CLC[9];
     Hop4 hop_new;                 // copy of hop[new_idx] of the current iteration (thread 0 reads it when re-parenting)
+    int new_next, new_fc;         // thread 0: next sibling of the vertex inserted this iteration / head of its child list
     int ob_n;                     // obstacles whose inflated box meets the Near ball's box (wg_near)
     short ob_list[2 * MAX_OBS];
     int rg_beg[GRID_RG_MAX], rg_len[GRID_RG_MAX], rg_flag[GRID_RG_MAX];
@@ -1976,7 +1977,10 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         } else {
             new_idx = n;
             if (tid == 0) {
+                // loads first (one round trip), then the stores
                 double cm = t.cmax;
+                const Hop4 hp = t.hop[ni];
+                const int fc_ni = t.first_child[ni];
 #pragma unroll
                 for (int k = 0; k < D; k++) {
                     t.c[k][new_idx] = node_new[k];
@@ -1989,13 +1993,19 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 Aux a;
                 a.elen = edge_new; a.parent = ni; a.pad = 0;
                 t.aux[new_idx] = a;
-                s.hop_new = hop_shift(t.hop[ni], edge_new, ni);
+                s.hop_new = hop_shift(hp, edge_new, ni);
                 t.hop[new_idx] = s.hop_new;
                 VRec vr;
                 vr.x = node_new[0]; vr.y = node_new[1]; vr.z = D == 3 ? node_new[D - 1] : 0.; vr.cost = 0.;
                 t.vrec[new_idx] = vr;
                 t.first_child[new_idx] = -1;
-                link_child(t, new_idx, ni);
+                // link_child(new_idx, ni) with the head read above; new's own links are remembered for a re-parenting
+                t.next_sib[new_idx] = fc_ni;
+                t.prev_sib[new_idx] = -1;
+                if (fc_ni >= 0) t.prev_sib[fc_ni] = new_idx;
+                t.first_child[ni] = new_idx;
+                s.new_next = fc_ni;
+                s.new_fc = -1;
                 t.n = n + 1;
             }
             n = n + 1;
@@ -2039,17 +2049,32 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
             PROF(3);
             if (reparented) {
                 if (tid == 0) {
+                    // loads first (one round trip), then the stores
                     double v[D], d[D];
                     load_vertex<D>(t, best_parent, v);
+                    const Hop4 hp = t.hop[best_parent];
+                    const int fc_bp = t.first_child[best_parent];
+                    int old_p, nx, pv;
+                    if (dup) { old_p = t.aux[new_idx].parent; nx = t.next_sib[new_idx]; pv = t.prev_sib[new_idx]; }
+                    else { old_p = ni; nx = s.new_next; pv = -1; }   // just inserted at the head of ni's children
 #pragma unroll
                     for (int c = 0; c < D; c++) d[c] = node_new[c] - v[c];
-                    unlink_child(t, new_idx, t.aux[new_idx].parent);
                     const double el = hypot_py<D>(d);
+                    // unlink from the old parent
+                    if (pv >= 0) t.next_sib[pv] = nx; else t.first_child[old_p] = nx;
+                    if (nx >= 0) t.prev_sib[nx] = pv;
                     t.aux[new_idx].parent = best_parent;
                     t.aux[new_idx].elen = el;
-                    s.hop_new = hop_shift(t.hop[best_parent], el, best_parent);
+                    s.hop_new = hop_shift(hp, el, best_parent);
                     t.hop[new_idx] = s.hop_new;
-                    link_child(t, new_idx, best_parent);
+                    // link under the new parent; if that is the old parent again (its Near distance can beat the steer
+                    // edge by an ulp) the head read above may be new_idx itself: use the list as the unlink left it
+                    const int head = (best_parent == old_p && pv < 0) ? nx : fc_bp;
+                    t.next_sib[new_idx] = head;
+                    t.prev_sib[new_idx] = -1;
+                    if (head >= 0) t.prev_sib[head] = new_idx;
+                    t.first_child[best_parent] = new_idx;
+                    s.new_next = head;
                 }
                 __syncthreads();
             }
@@ -2089,17 +2114,27 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                     if (first == 0x7fffffff) break;
                     const int vj = t.nr_idx[first];
                     if (tid == 0) {
+                        // loads first (one round trip), then the stores
                         double v[D], d[D];
                         const bool leaf = t.first_child[vj] < 0;
                         load_vertex<D>(t, vj, v);
+                        const int old_p = t.aux[vj].parent, nx = t.next_sib[vj], pv = t.prev_sib[vj];
+                        const unsigned char li = t.listed[vj];
+                        const int fc_new = dup ? t.first_child[new_idx] : s.new_fc;   // a fresh vertex's child list lives in LDS
 #pragma unroll
                         for (int c = 0; c < D; c++) d[c] = v[c] - node_new[c];
-                        unlink_child(t, vj, t.aux[vj].parent);
                         const double el = hypot_py<D>(d);
+                        if (pv >= 0) t.next_sib[pv] = nx; else t.first_child[old_p] = nx;
+                        if (nx >= 0) t.prev_sib[nx] = pv;
                         t.aux[vj].parent = new_idx;
                         t.aux[vj].elen = el;
                         t.hop[vj] = hop_shift(s.hop_new, el, new_idx);
-                        link_child(t, vj, new_idx);
+                        const int head = (old_p == new_idx && pv < 0) ? nx : fc_new;   // vj may already hang under new ("same point")
+                        t.next_sib[vj] = head;
+                        t.prev_sib[vj] = -1;
+                        if (head >= 0) t.prev_sib[head] = vj;
+                        t.first_child[new_idx] = vj;
+                        s.new_fc = vj;
                         // a leaf (the common case) has nothing below it: its new cost is its edge followed by the
                         // recorded chain new -> root, the same additions in the same order as a walk
                         const int clen = s.chain_len;
@@ -2110,7 +2145,6 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                             for (int i = 0; i < clen; i++) acc += s.chainE[i];
                             t.vrec[vj].cost = acc;
                             t.nr_cost[first] = acc;
-                            const unsigned char li = t.listed[vj];
                             if (li & 1) t.sol_dirty = 1;
                             if (li & 2) t.gc_dirty = 1;
                             fast = 1;
