@@ -15,7 +15,10 @@ SO = os.path.join(HERE, "libnirrt_hip.so")
 SOURCES = [os.path.join(CSRC, "nirrt_hip.hip"), os.path.join(CSRC, "pointops.hip")]
 DEPS = SOURCES + [os.path.join(CSRC, "nirrt_device.hpp"), os.path.join(CSRC, "nirrt_kernels.inc"),
                   os.path.join(os.path.dirname(HERE), "include", "nirrt_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# one module-wide LDS object at the same address in every kernel: the non-inlined loop-body functions then address it
+# with constant offsets instead of a per-kernel offset-table lookup (see LdsData in csrc/nirrt_device.hpp)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-mllvm", "-amdgpu-lower-module-lds-strategy=module"]
 
 
 def needs_build():

@@ -179,16 +179,27 @@ struct TreeDev {
 // ------------------------------------------------------------------------------------------------
 // LDS working set of one workgroup
 // ------------------------------------------------------------------------------------------------
-template <int NT>
-struct Lds {
-    static constexpr int NW = NT / 64;
+// Generator state of one tree between draws: stream positions and the 64-word windows (see WordStream in
+// nirrt_hip.hip) live in LDS, so the persistent loop carries no sampler registers across the loop-body call.
+struct StreamState {
+    const unsigned *w;
+    long long n, pos, base;
+    unsigned buf[64];
+};
+
+// ONE LDS object for every kernel of the library (both workgroup sizes): with a single module-wide variable the
+// compiler can give it the same address in every kernel, so the non-inlined loop-body functions address it with
+// constant offsets (-mllvm -amdgpu-lower-module-lds-strategy=module) instead of looking its offset up per kernel.
+#define LDS_NW_MAX 16   // waves of the widest workgroup
+struct LdsData {
     int n_round, n_box;
     double rnd[MAX_OBS][4];
     double box[MAX_OBS][6];
-    double red_val[NW];
-    double red_val2[NW];
-    int red_idx[NW];
-    int wave_tot[NW];
+    double red_val[LDS_NW_MAX];
+    double red_val2[LDS_NW_MAX];
+    int red_idx[LDS_NW_MAX];
+    int wave_tot[LDS_NW_MAX];
+    StreamState st[2];            // [0] numpy, [1] python
     double bc_d[8];
     int bc_i[8];
     // edge lengths along the chain new -> root of the current iteration (every vertex re-costed in this
@@ -206,6 +217,9 @@ struct Lds {
     int rg_beg[GRID_RG_MAX], rg_len[GRID_RG_MAX], rg_flag[GRID_RG_MAX];
     unsigned bm[GRID_BM_WORDS];   // one bit per vertex of a 32*GRID_BM_WORDS window; all-zero between uses
 };
+template <int NT>
+using Lds = LdsData;   // the per-instantiation name the device functions use
+
 
 // ------------------------------------------------------------------------------------------------
 // distance primitives
@@ -1539,13 +1553,13 @@ __device__ __forceinline__ bool wg_collision(const Lds<NT> &s, const double *a, 
 template <int D, int NT>
 __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const double *node_new, int new_idx,
                                        const double *q2 = nullptr, int *ni2 = nullptr, long long *scanned = nullptr,
-                                       bool compact = true)
+                                       bool compact = true, double r_known = -1.)
 {
     // compact == false (the loop body): the list keeps its excluded members (t.nr_flag[a] != 0: the segment collides,
     // or the member is new_idx itself) and the return value counts them too; the consumers skip flagged slots.
     constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
-    const double r = t.near_r[n];
+    const double r = r_known >= 0. ? r_known : t.near_r[n];   // the loop body prefetches the table entry
     const double r2 = r * r, r2lo = r2 * BAND_LO, r2hi = r2 * BAND_HI;
     const double clr = t.clearance;
     int beg, end, per;
@@ -1771,7 +1785,7 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
 // The costs come from the exact cache; the argmin is only redone when a listed vertex was re-costed (sol_dirty),
 // a solution appended in between competes with the standing minimum (strict <, so the first minimum stays).
 template <int D, int NT>
-__device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double &c_best, int &x_best)
+__device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double &c_best, int &x_best, bool want_x = true)
 {
     const int tid = threadIdx.x;
     const int ns = t.n_sol;
@@ -1802,7 +1816,7 @@ __device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double 
         __syncthreads();
     }
     c_best = t.sol_best_cost;
-    x_best = t.sol[t.sol_best];
+    x_best = want_x ? t.sol[t.sol_best] : -1;   // the persistent loops only need the cost: one dependent load less
 }
 
 // append a solution (InGoalRegion true).  Uniform; thread 0 writes.
@@ -1940,16 +1954,20 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
     double node_new[D], nearest[D];
     if (host_steer) {
         ni = nearest_in;
-        load_vertex<D>(t, ni, nearest);
 #pragma unroll
         for (int k = 0; k < D; k++) node_new[k] = node_in[k];
     } else {
         if (pref_ni >= 0) ni = pref_ni;
         else ni = wg_nearest<D, NT>(s, t, n, node_in, &scanned);
         PROF(0);
-        load_vertex<D>(t, ni, nearest);
-        steer<D>(t, nearest, node_in, node_new);
     }
+    // coordinates and exact cost of the nearest vertex in one 32-byte record; the Near radii the iteration can need
+    // (tree size unchanged for a "same point", + 1 otherwise) ride along in the same round trip
+    const VRec vnear = t.vrec[ni];
+    const double r_same = t.near_r[n], r_grown = t.near_r[n + 1 <= t.cap ? n + 1 : n];
+    nearest[0] = vnear.x; nearest[1] = vnear.y;
+    if (D == 3) nearest[D - 1] = vnear.z;
+    if (!host_steer) steer<D>(t, nearest, node_in, node_new);
     int next_ni = -1;
     if (res && tid == 0) {
         res->collided = 0; res->inserted = 0; res->nearest_idx = ni; res->new_idx = -1; res->n_near = 0;
@@ -2015,13 +2033,14 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         if (new_idx >= 0) {
             long long sc_near = 0;
             // k counts the slots of the Near list, excluded members (nr_flag) included
-            const int k = wg_near<D, NT>(s, t, n, node_new, new_idx, q_next, &next_ni, &sc_near, false);
+            const int k = wg_near<D, NT>(s, t, n, node_new, new_idx, q_next, &next_ni, &sc_near, false,
+                                         inserted ? r_grown : r_same);
             scanned += sc_near;
             alg += n;
             PROF(2);
             int reparented = 0, n_rewired = 0;
             // curr_node_new_cost (rrt_star_2d.py:45 "same point" / :51)
-            const double cost_ni = t.vrec[ni].cost;
+            const double cost_ni = vnear.cost;   // no tree operation since the load changes a cost
             const double curr = dup ? cost_ni : cost_ni + edge_new;
             int best_parent = -1;
             if (k > 0) {
@@ -2196,10 +2215,10 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
 
 // end-of-iteration report shared by the step kernel and the persistent loops
 template <int D, int NT>
-__device__ __forceinline__ void wg_report(Lds<NT> &s, TreeDev &t, unsigned flags, double &cb, int &xb)
+__device__ __forceinline__ void wg_report(Lds<NT> &s, TreeDev &t, unsigned flags, double &cb, int &xb, bool want_x = true)
 {
     cb = __builtin_inf();
     xb = -1;
-    if (flags & NIRRT_F_IRRT) wg_best_solution<D, NT>(s, t, cb, xb);
+    if (flags & NIRRT_F_IRRT) wg_best_solution<D, NT>(s, t, cb, xb, want_x);
     else if (flags & NIRRT_F_GOAL_SCAN) wg_goal_parent<D, NT>(s, t, xb, cb);
 }

@@ -73,6 +73,8 @@ struct RunSampleDev {
 // with the grid index an iteration is a chain of short dependent phases, so trees in flight per CU is what counts
 // (measured on 2048 problems: 1.2x IRRT*, 1.7x RRT* over 256-thread workgroups; 256 was best while the O(n) scans
 // dominated).  A single tree (or a few) gets all 16 waves of a CU.
+__shared__ LdsData g_lds;   // see LdsData in nirrt_device.hpp
+
 #ifndef NIRRT_WAVES_PER_EU
 #define NIRRT_WAVES_PER_EU 4   // second __launch_bounds__ argument of the persistent kernels (register budget 512 / this)
 #endif
