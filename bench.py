@@ -15,8 +15,9 @@ with its own B problems (weak scaling); the only collectives are the timing prot
 max-reduce and a gather of per-rank iteration counts.
 
 Prints ONE JSON line (rank 0): the driver's contract fields plus
-  roofline     — HBM roofline of the persistent kernel: algorithmic bytes (vertices streamed by the nearest
-                 + Near passes x dim x 8 B, counted exactly in the kernel) / HIP-event kernel time
+  roofline     — HBM roofline of the persistent kernel: algorithmic bytes (vertices the REFERENCE algorithm's nearest
+                 + Near scans touch x dim x 8 B, counted exactly in the kernel) / HIP-event kernel time; the kernel
+                 itself answers both through a grid index and visits far fewer (streamed_GBps, traffic)
   cpu_baseline — the oracle (oracle/nirrt_oracle.c, C port of the reference loop incl. sampling) on this
                  box's host, 1 core, on problem 0 of the same batch for a bounded time
   time_to_first_solution — iterations / seconds until c_best first becomes finite (median over the batch)
