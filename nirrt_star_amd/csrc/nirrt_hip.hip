@@ -69,10 +69,11 @@ struct RunSampleDev {
     int *stop_code;   // per tree: 0 done, NIRRT_E_STREAM, NIRRT_E_CAPACITY
 };
 
-// Two instantiations of every kernel.  Batches: 128-thread workgroups, 8 trees per CU (2 waves each, 20 KB of LDS):
-// with the grid index an iteration is a chain of short dependent phases, so trees in flight per CU is what counts
-// (measured on 2048 problems: 1.2x IRRT*, 1.7x RRT* over 256-thread workgroups; 256 was best while the O(n) scans
-// dominated).  A single tree (or a few) gets all 16 waves of a CU.
+// Two instantiations of every kernel.  Batches ("narrow"): 128-thread workgroups, 8 trees per CU (2 waves each, 14 KB
+// of LDS): with the grid index an iteration is a chain of short dependent phases, so trees in flight per CU is what
+// counts (measured on 2048 problems: 1.2x IRRT*, 1.7x RRT* over 256-thread workgroups; 256 was best while the O(n)
+// scans dominated).  One or a few trees ("wide"): 256 threads - measured for one 50k-iteration problem: IRRT* 2.10 s
+// (128 threads 2.66 s, 1024 threads 2.24 s), RRT* 1.4x faster than with 1024 threads, which had been best for the scans.
 __shared__ LdsData g_lds;   // see LdsData in nirrt_device.hpp
 
 #ifndef NIRRT_WAVES_PER_EU
@@ -86,14 +87,22 @@ namespace narrow {
 #include "nirrt_kernels.inc"
 }
 #undef NT
-#define NT 1024
+#ifndef NIRRT_NT_WIDE
+#define NIRRT_NT_WIDE 256
+#endif
+#define NT NIRRT_NT_WIDE
 namespace wide {
 #include "nirrt_kernels.inc"
 }
 #undef NT
 #define NT_NARROW NIRRT_NT_NARROW
-#define NT_WIDE 1024
-#define WIDE_MAX_TREES 96   // nirrt_run: batches up to this many trees use the wide kernels ...
+#define NT_WIDE NIRRT_NT_WIDE
+static int wide_max_trees()
+{
+    static const int v = [] { const char *e = std::getenv("NIRRT_WIDE_MAX_TREES"); return e ? std::atoi(e) : 96; }();
+    return v;   // tuning knob: 0 = always the narrow kernels
+}
+#define WIDE_MAX_TREES wide_max_trees()   // nirrt_run: batches up to this many trees use the wide kernels ...
 #define WIDE_MIN_VERTICES 16000   // ... once the trees are (or will grow) this big; small trees sync cheaper with 4 waves
 
 // ------------------------------------------------------------------------------------------------
