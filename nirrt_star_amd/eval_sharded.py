@@ -215,7 +215,7 @@ def main():
     ap.add_argument("--iter_after_initial", type=int, default=3000)
     ap.add_argument("--step_len", type=float, default=10)
     ap.add_argument("--clearance", type=float, default=None)
-    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--max_problems", type=int, default=None)
     ap.add_argument("--out", default="results/evaluation/sharded_result.json")
     ap.add_argument("--pickle_out", default="auto",
