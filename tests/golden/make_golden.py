@@ -428,6 +428,36 @@ def block_gap_run(name, algo, kind, idx, seed, iter_max, percentage=0.02):
     print("   %s: %d iterations, final %.4f < %.4f, n=%d" % (name, len(lst), lst[-1], thr, n))
 
 
+def analysis_fixture():
+    """The reference's own analysis script (result_analysis_random_world_2d.py) run on synthetic result pickles in a scratch
+    directory: its path-cost-ratio means and first-solution indices are the expected values for nirrt_star_amd.analysis."""
+    import pickle
+    import runpy
+    import tempfile
+    import analysis_inputs
+    n, methods, data = analysis_inputs.N_PROBLEMS, analysis_inputs.STEMS, analysis_inputs.make_inputs()
+    cwd, argv = os.getcwd(), sys.argv
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        try:
+            os.makedirs('results/evaluation/2d')
+            for m in methods:
+                with open('results/evaluation/2d/random_2d-%s-%d.pickle' % (m, n), 'wb') as f:
+                    pickle.dump(data[m], f)
+            sys.argv = ['x', '--random_dataset_len', str(n)]
+            with quiet():
+                g = runpy.run_path(os.path.join(refshim.REF, 'result_analysis_random_world_2d.py'))
+        finally:
+            os.chdir(cwd)
+            sys.argv = argv
+    out = {'n': n,
+           'path_cost_mean': {k: [float(x) for x in v] for k, v in g['path_cost_mean'].items()},
+           'first_solution': {k: [int(x) for x in v] for k, v in g['random_analysis'].items()}}
+    with open(os.path.join(HERE, 'analysis_ref.json'), 'w') as f:
+        json.dump(out, f)
+    print('analysis_ref.json: %d methods x %d problems' % (len(methods), n))
+
+
 def pointnet2_fixture():
     """L4: the reference PointNet++ (CPU, fp32) on a seeded cloud.  Weights = torch.manual_seed(seed) init
     (regenerated by the test from the same seed - identical construction order) + the BatchNorm running
@@ -514,6 +544,7 @@ JOBS = {
     "run_nrrt3d_1500": lambda: nrrt_fixture("run_nrrt3d_1500", 3, 6, 1500, 1006),
     "random_irrt3d": lambda: run_planner("random_irrt3d", "irrt", 3, "ref3d", 3, 0, 5000, 1003, mode="random", iter_after_initial=300),
     "block_gap": block_gap_fixture,
+    "analysis_ref": analysis_fixture,
     "blockgap_irrt_block": lambda: block_gap_run("blockgap_irrt_block", "irrt", "block", 137, 2001, 5000, percentage=0.1),
     "blockgap_rrt_gap": lambda: block_gap_run("blockgap_rrt_gap", "rrt", "gap", 250, 2002, 6000),
 }
