@@ -36,8 +36,25 @@ def get_random_2d_env_configs(root_dir='.'):
     return out
 
 
-def get_random_2d_problem_input(random_2d_env_config):
-    return worlds.problem_2d(random_2d_env_config['env_dict'], 0)
+def read_env_image_mask(path):
+    """get_binary_mask(cv2.imread(path)) (datasets/point_cloud_mask_utils.py:8-17) without cv2: 1.0 where the first
+    colour channel of the PNG is non-zero.  cv2.imread returns BGR and the dataset images are black / white, so which
+    channel is read makes no difference for them; PIL (a matplotlib dependency) decodes the file."""
+    import numpy as np
+    from PIL import Image
+    img = np.asarray(Image.open(path).convert("RGB"))
+    return (img[:, :, 2] != 0).astype(np.float64)          # channel 0 of cv2's BGR = blue
+
+
+def get_random_2d_problem_input(random_2d_env_config, root_dir='.'):
+    """planning_problem_utils_2d.py:145-162.  With the dataset's env_imgs/<img_idx>.png present the free-space mask (and
+    with it gamma) comes from the image like in the reference; otherwise it is rasterised from the obstacle lists."""
+    problem = worlds.problem_2d(random_2d_env_config['env_dict'], 0)
+    png = join(root_dir, "data", "random_2d", "test", "env_imgs", "%s.png" % random_2d_env_config.get('img_idx'))
+    if os.path.exists(png):
+        problem['binary_mask'] = read_env_image_mask(png)
+        problem['search_radius'] = compute_gamma_rrt_star(problem['binary_mask'], dim=2)
+    return problem
 
 
 # ------------------------------------------------------------------------------------------------

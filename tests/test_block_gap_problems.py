@@ -48,3 +48,29 @@ def test_offline_config_set_is_fixed_and_leaves_the_generator_alone(tmp_path):
     assert np.array_equal(before, np.random.get_state()[1])
     assert len(a) == 500 and len(b) == 500
     assert a == problems.get_block_env_configs(str(tmp_path))
+
+
+def test_random_2d_loader_uses_dataset_images_when_present(tmp_path):
+    """envs.json + env_imgs/<i>.png as the reference's dataset lays them out: mask and gamma come from the image"""
+    from PIL import Image
+    from nirrt_star_amd import worlds
+    ed = worlds.random_world_2d(3, "ref2d")
+    d = tmp_path / "data" / "random_2d" / "test"
+    (d / "env_imgs").mkdir(parents=True)
+    with open(d / "envs.json", "w") as f:
+        json.dump([ed], f)
+    mask = worlds.rasterize_mask_2d(ed["env_dims"], ed["rectangle_obstacles"], ed["circle_obstacles"])
+    mask[:5, :] = 0.0                                          # the image differs from the analytic raster on purpose
+    img = np.repeat((mask * 255).astype(np.uint8)[:, :, None], 3, axis=2)
+    Image.fromarray(img).save(d / "env_imgs" / "0.png")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        cfgs = problems.get_random_2d_env_configs()
+        assert len(cfgs) == len(ed["start"]) and cfgs[1]["start_goal_idx"] == 1 and cfgs[1]["img_idx"] == 0
+        pr = problems.get_random_2d_problem_input(cfgs[1])
+    finally:
+        os.chdir(cwd)
+    assert np.array_equal(pr["binary_mask"], mask)
+    assert pr["search_radius"] == problems.compute_gamma_rrt_star(mask)
+    assert pr["x_start"] == tuple(ed["start"][1]) and pr["x_goal"] == tuple(ed["goal"][1])
