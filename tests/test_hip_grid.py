@@ -73,3 +73,43 @@ def test_grid_primitives_after_a_run(oracle, forced_grid, name):
         assert np.array_equal(t.near(v[i], i), o.near(v[i], i))
     t.close()
     o.close()
+
+
+def _problem(dim, seed):
+    from nirrt_star_amd import worlds
+    if dim == 2:
+        pr = worlds.problem_2d(worlds.random_world_2d(seed, "b30"), 0)
+        return pr, 3.0
+    np.random.seed(seed)
+    return worlds.problem_3d(worlds.random_world_3d(seed)), 2.0
+
+
+@pytest.mark.parametrize("dim,irrt,iters", [(2, False, 12000), (2, True, 9000), (3, False, 12000), (2, True, 22000)])
+def test_default_index_against_the_oracle_at_mid_size(oracle, dim, irrt, iters):
+    """Default settings (index from 2048 vertices, rebuild every 1024, 128^2 / 16^3 cells): whole loops with in-kernel
+    sampling on trees several times larger than the golden runs, HIP vs the C oracle fed with the same generator words -
+    same vertex count, parents, solution list, generator words consumed; coordinates bit-equal in 3D, <= 1e-9 in 2D."""
+    from nirrt_star_amd import _hip, sampling
+    pr, clr = _problem(dim, 11 + dim)
+    t = _hip.HipTree(dim, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], clr, pr["env"])
+    o = oracle.OracleTree(dim, iters, pr["x_start"], pr["x_goal"], 10.0, float(pr["search_radius"]), clr, pr["env_dict"])
+    frame = sampling.informed_frame(pr["x_start"], pr["x_goal"])
+    t.set_informed(*frame)
+    rs = np.random.RandomState(77)
+    npw = rs.randint(0, 1 << 32, size=iters * 40 + 4096, dtype=np.uint32)
+    pyw = rs.randint(0, 1 << 32, size=iters * 24 + 4096, dtype=np.uint32) if (irrt and dim == 2) else None
+    res = _hip.run_sampling([t], iters, [npw], [pyw] if pyw is not None else None, flags=_hip.F_IRRT if irrt else 0)
+    ro = o.run_sampling(iters, npw, pyw, irrt=irrt, frame=frame)
+    assert res["iters_done"][0] == iters == ro["iters_done"] and res["status"][0] == 0
+    assert int(res["np_used"][0]) == ro["np_used"] and int(res["py_used"][0]) == ro["py_used"]
+    v, p = t.download()
+    assert len(v) == o.n > 4000                                   # well past the index threshold
+    assert np.array_equal(p, o.parents)
+    if dim == 3:
+        assert np.array_equal(v, o.vertices)
+    else:
+        assert np.max(np.abs(v - o.vertices)) <= 1e-9
+    if irrt:
+        assert np.array_equal(t.solutions, o.solutions) and len(t.solutions) > 0
+    t.close()
+    o.close()
