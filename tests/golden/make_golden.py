@@ -458,6 +458,28 @@ def analysis_fixture():
     print('analysis_ref.json: %d methods x %d problems' % (len(methods), n))
 
 
+def dataset_fixture():
+    """The reference's training Dataset (pointnet_pointnet2/PathPlanDataLoader.py) on a small synthetic .npz in the
+    generator's schema: items and label weights are the expected values for nirrt_star_amd.path_plan_dataset."""
+    import tempfile
+    from pointnet_pointnet2.PathPlanDataLoader import PathPlanDataset
+    rng = np.random.default_rng(33)
+    n, m = 5, 64
+    cols = {"token": np.array(["test-%d_0" % i for i in range(n)]), "pc": rng.uniform(0, 224, size=(n, m, 2)).astype(np.float32)}
+    for k, p in (("start", 0.05), ("goal", 0.05), ("astar", 0.3)):
+        cols[k] = (rng.uniform(size=(n, m)) < p).astype(np.float32)
+    cols["free"] = ((1 - cols["start"]) * (1 - cols["goal"])).astype(np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "test.npz")
+        np.savez(path, **cols)
+        with quiet():
+            ds = PathPlanDataset(path)
+        items = [ds[i] for i in (0, 3)]
+    save("dataset_ref", **{"in_" + k: v for k, v in cols.items()}, labelweights=ds.labelweights, length=np.array(len(ds)),
+         item0_raw=items[0][0], item0_xyz=items[0][1], item0_feat=items[0][2], item0_lab=items[0][3], item0_tok=np.array(str(items[0][4])),
+         item3_raw=items[1][0], item3_xyz=items[1][1], item3_feat=items[1][2], item3_lab=items[1][3], item3_tok=np.array(str(items[1][4])))
+
+
 def pointnet2_fixture():
     """L4: the reference PointNet++ (CPU, fp32) on a seeded cloud.  Weights = torch.manual_seed(seed) init
     (regenerated by the test from the same seed - identical construction order) + the BatchNorm running
@@ -545,6 +567,7 @@ JOBS = {
     "random_irrt3d": lambda: run_planner("random_irrt3d", "irrt", 3, "ref3d", 3, 0, 5000, 1003, mode="random", iter_after_initial=300),
     "block_gap": block_gap_fixture,
     "analysis_ref": analysis_fixture,
+    "dataset_ref": dataset_fixture,
     "blockgap_irrt_block": lambda: block_gap_run("blockgap_irrt_block", "irrt", "block", 137, 2001, 5000, percentage=0.1),
     "blockgap_rrt_gap": lambda: block_gap_run("blockgap_rrt_gap", "rrt", "gap", 250, 2002, 6000),
 }
