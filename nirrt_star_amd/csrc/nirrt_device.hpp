@@ -610,17 +610,73 @@ __device__ __forceinline__ void stage_obstacles(Lds<NT> &s, const TreeDev &t)
     __syncthreads();
 }
 
+// wave64 reductions without LDS traffic: four DPP steps (quad swaps, half-row and row mirrors) leave every 16-lane row
+// holding its result, v_readlane pulls the four row results into scalars (the result is wave-uniform)
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = dpp_mov<CTRL>((int)b), hi = dpp_mov<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) { return __int_as_float(dpp_mov<CTRL>(__float_as_int(x))); }
+__device__ __forceinline__ int lane_get(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ float lane_get(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ double lane_get(double x, int l)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// (value, index) -> lexicographic minimum over the wave, lowest index on ties
+template <typename T>
+__device__ __forceinline__ void wave_argmin(T &v, int &idx)
+{
+#define NIRRT_ARGMIN_STEP(C)                                             \
+    {                                                                    \
+        const T ov = dpp_mov<C>(v);                                      \
+        const int oi = dpp_mov<C>(idx);                                  \
+        if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }       \
+    }
+    NIRRT_ARGMIN_STEP(0xB1) NIRRT_ARGMIN_STEP(0x4E) NIRRT_ARGMIN_STEP(0x141) NIRRT_ARGMIN_STEP(0x140)
+#undef NIRRT_ARGMIN_STEP
+    T rv = lane_get(v, 0);
+    int ri = lane_get(idx, 0);
+#pragma unroll
+    for (int row = 1; row < 4; row++) {
+        const T ov = lane_get(v, 16 * row);
+        const int oi = lane_get(idx, 16 * row);
+        if (ov < rv || (ov == rv && oi < ri)) { rv = ov; ri = oi; }
+    }
+    v = rv;
+    idx = ri;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_min(T v)
+{
+#define NIRRT_MIN_STEP(C) { const T ov = dpp_mov<C>(v); v = ov < v ? ov : v; }
+    NIRRT_MIN_STEP(0xB1) NIRRT_MIN_STEP(0x4E) NIRRT_MIN_STEP(0x141) NIRRT_MIN_STEP(0x140)
+#undef NIRRT_MIN_STEP
+    T rv = lane_get(v, 0);
+#pragma unroll
+    for (int row = 1; row < 4; row++) {
+        const T ov = lane_get(v, 16 * row);
+        rv = ov < rv ? ov : rv;
+    }
+    return rv;
+}
+
 // lexicographic (value, index) minimum over the workgroup; every thread gets the result.
 // Ties keep the LOWEST index (np.argmin).  Threads with nothing pass idx = INT_MAX, v = +inf.
 template <int NT>
 __device__ __forceinline__ void block_argmin(Lds<NT> &s, double &v, int &idx)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double ov = __shfl_xor(v, off);
-        int oi = __shfl_xor(idx, off);
-        if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+    wave_argmin(v, idx);
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();  // protect red_* reuse
     if (lane == 0) { s.red_val[w] = v; s.red_idx[w] = idx; }
@@ -639,11 +695,7 @@ __device__ __forceinline__ void block_argmin(Lds<NT> &s, double &v, int &idx)
 template <int NT>
 __device__ __forceinline__ int block_min_int(Lds<NT> &s, int v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        int o = __shfl_xor(v, off);
-        v = o < v ? o : v;
-    }
+    v = wave_min(v);
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) s.red_idx[w] = v;
@@ -726,18 +778,9 @@ __device__ __forceinline__ int wg_nearest_finish(Lds<NT> &s, const TreeDev &t, i
     // wave: minimum (m1, i1) and the second-smallest value seen by the wave
     double wm = m1;
     int wi = i1;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double ov = __shfl_xor(wm, off);
-        int oi = __shfl_xor(wi, off);
-        if (ov < wm || (ov == wm && oi < wi)) { wm = ov; wi = oi; }
-    }
+    wave_argmin(wm, wi);
     double ws = (i1 == wi) ? m2 : m1;  // this lane's best that is NOT the wave winner
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double ov = __shfl_xor(ws, off);
-        ws = ov < ws ? ov : ws;
-    }
+    ws = wave_min(ws);
     __syncthreads();
     if (lane == 0) { s.red_val[w] = wm; s.red_idx[w] = wi; s.red_val2[w] = ws; }
     __syncthreads();
@@ -884,18 +927,9 @@ __device__ __forceinline__ int wg_nearest_finish32(Lds<NT> &s, double e, float m
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float wm = m1;
     int wi = i1;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        float ov = __shfl_xor(wm, off);
-        int oi = __shfl_xor(wi, off);
-        if (ov < wm || (ov == wm && oi < wi)) { wm = ov; wi = oi; }
-    }
+    wave_argmin(wm, wi);
     float ws = (i1 == wi) ? m2 : m1;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        float ov = __shfl_xor(ws, off);
-        ws = ov < ws ? ov : ws;
-    }
+    ws = wave_min(ws);
     __syncthreads();
     if (lane == 0) { s.red_val[w] = wm; s.red_idx[w] = wi; s.red_val2[w] = ws; }
     __syncthreads();
