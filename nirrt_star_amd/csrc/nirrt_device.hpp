@@ -66,6 +66,17 @@
 #define PROF(slot)
 #endif
 
+// Values that are identical in every lane by construction (read from LDS / the tree descriptor, results of the
+// workgroup-wide reductions) are moved to scalar registers explicitly: control flow that depends on them compiles to
+// scalar branches instead of exec-masked regions, and they stop occupying vector registers.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v)
+{
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-tree state in HBM
 // ------------------------------------------------------------------------------------------------
@@ -1199,7 +1210,7 @@ __device__ __forceinline__ int wg_grid_query(Lds<NT> &s, const TreeDev &t, int n
     // one visit of the ranges in s.rg_*; uniform trip counts.  GRID_U slots per lane and trip: all their 16-byte
     // loads are issued before the first use
     auto visit = [&]() {
-        const int R = s.rg_n;
+        const int R = uni(s.rg_n);
         int total = 0;
         for (int i = 0; i < R; i++) total += s.rg_len[i];
         scanned += total;
@@ -1236,7 +1247,7 @@ __device__ __forceinline__ int wg_grid_query(Lds<NT> &s, const TreeDev &t, int n
                     if (mk) {
                         int base = 0;
                         if (lane == 0) base = atomicAdd(&s.hit_cnt, __popcll(mk));
-                        base = __shfl(base, 0);
+                        base = __builtin_amdgcn_readfirstlane(base);   // lane 0 did the add; every lane is active here
                         if (hit) t.bfs_q[base + __popcll(mk & lt)] = id;
                     }
                 }
@@ -1314,7 +1325,7 @@ __device__ __forceinline__ int wg_grid_query(Lds<NT> &s, const TreeDev &t, int n
     PROF(14);
     if (wantN) {
         // ascending order through the bitmap, one 32 768-vertex window at a time
-        kraw = s.hit_cnt;
+        kraw = uni(s.hit_cnt);
         int kout = 0;
         for (int wb = 0; wb < n && kout < kraw; wb += 32 * GRID_BM_WORDS) {
             for (int a0 = tid; a0 < kraw; a0 += NT * NEAR_U) {
@@ -1698,7 +1709,7 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
         for (int i = 0; i < NW; i++) woff[i + 1] = woff[i] + s.wave_tot[i];
     }
     const bool contig = kgrid >= 0;
-    const int kraw = contig ? kgrid : woff[NW];
+    const int kraw = uni(contig ? kgrid : woff[NW]);
     // Pass A - gather the staged hits (already ascending): index, exact cost and reference distance from the 32-byte
     // record, and the AABB prefilter against the obstacles near the ball.  (segment, obstacle) pairs that survive the
     // prefilter are queued so that the expensive exact tests run densely packed.
@@ -1717,7 +1728,7 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
         if (seg_aabb_pass<D, NT>(s, o, l0, l1)) s.ob_list[atomicAdd(&s.ob_n, 1)] = (short)o;
     }
     __syncthreads();
-    const int n_ob = s.ob_n;
+    const int n_ob = uni(s.ob_n);
     // NEAR_U slots per lane and trip: the index loads, then the 32-byte record loads, are issued back to back
     for (int a0 = tid; a0 < kraw; a0 += NT * NEAR_U) {
         int vs[NEAR_U];
@@ -1765,7 +1776,7 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
     __syncthreads();
     PROF(9);
     // Pass B - exact segment tests for the queued pairs (node_new -> v_j vs obstacle o)
-    const int npairs = s.bc_i[5];
+    const int npairs = uni(s.bc_i[5]);
     if (npairs <= pair_cap) {
         for (int p0 = tid; p0 < npairs; p0 += NT * NEAR_U) {
             int code[NEAR_U], vv[NEAR_U];
@@ -1977,7 +1988,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
     // left in s.bc_i[6] (else -1) for the caller to pass back as pref_ni.
     const int tid = threadIdx.x;
     const double clr = t.clearance;
-    int n = t.n;
+    int n = uni(t.n);
     long long scanned = 0;
     long long alg = host_steer ? 0 : n;
     PROF_DECL
@@ -1995,6 +2006,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         else ni = wg_nearest<D, NT>(s, t, n, node_in, &scanned);
         PROF(0);
     }
+    ni = uni(ni);
     // coordinates and exact cost of the nearest vertex in one 32-byte record; the Near radii the iteration can need
     // (tree size unchanged for a "same point", + 1 otherwise) ride along in the same round trip
     const VRec vnear = t.vrec[ni];
@@ -2097,6 +2109,8 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                     }
                 }
                 block_argmin<NT>(s, cand, cj);
+                cand = uni(cand);
+                cj = uni(cj);
                 if (cand < curr) { reparented = 1; best_parent = t.nr_idx[cj]; }
             }
             PROF(3);
@@ -2163,9 +2177,9 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                         for (int u = NEAR_U - 1; u >= 0; u--)
                             if (!fl[u] && co[u] > new_cost + di[u]) first = a0 + u * NT;   // lowest slot of the trip wins
                     }
-                    first = block_min_int<NT>(s, first);
+                    first = uni(block_min_int<NT>(s, first));
                     if (first == 0x7fffffff) break;
-                    const int vj = t.nr_idx[first];
+                    const int vj = uni(t.nr_idx[first]);
                     if (tid == 0) {
                         // loads first (one round trip), then the stores
                         double v[D], d[D];
