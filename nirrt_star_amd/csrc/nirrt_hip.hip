@@ -628,8 +628,8 @@ extern "C" int nirrt_set_informed(nirrt_tree *t, double c_min, const double *x_c
     t->host.c_min = c_min;
     for (int k = 0; k < 3; k++) t->host.x_center[k] = k < t->dim ? x_center[k] : 0.;
     for (int k = 0; k < 9; k++) t->host.CL_C[k] = C[k];
-    size_t off = offsetof(TreeDev, c_min);
-    HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, sizeof(TreeDev) - off, hipMemcpyHostToDevice, t->stream));
+    const size_t off = offsetof(TreeDev, c_min), end = offsetof(TreeDev, prof);   // c_min, x_center, CL_C
+    HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, end - off, hipMemcpyHostToDevice, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     return NIRRT_OK;
 }
@@ -650,8 +650,8 @@ extern "C" int nirrt_set_cloud(nirrt_tree *t, int64_t n, const double *pts, doub
     t->host.pc_rate = sample_rate;
     t->host.pc_ratio = update_cost_ratio;
     t->host.c_update = c_update;
-    size_t off = offsetof(TreeDev, pc);
-    HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, sizeof(TreeDev) - off, hipMemcpyHostToDevice, t->stream));
+    const size_t off = offsetof(TreeDev, pc), end = offsetof(TreeDev, g_rec);   // pc, pc_n, pc_rate, pc_ratio, c_update
+    HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, end - off, hipMemcpyHostToDevice, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     return NIRRT_OK;
 }
