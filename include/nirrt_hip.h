@@ -15,7 +15,12 @@
  *   - one tree = one opaque handle = one HIP stream; a handle is not thread-safe.
  *   - vertices cross the boundary as (n, dim) row-major float64 (the reference's
  *     `self.vertices[:n]`), parents as int64 (`self.vertex_parents[:n]`).  In HBM the tree is a
- *     flat SoA: x[cap], y[cap](, z[cap]) f64 + parent[cap] i32.
+ *     flat SoA: x[cap], y[cap](, z[cap]) f64 + parent[cap] i32, plus derived copies the kernels keep in
+ *     step (float32 twins ordered by grid cell, packed records).
+ *   - nearest_neighbor / find_near_neighbors answers come from a uniform-grid index on large trees and
+ *     from whole scans on small ones; both give exactly the reference's answers (ties, ordering).
+ *     Environment knobs read by nirrt_create: NIRRT_GRID_MIN, NIRRT_GRID_REBUILD, NIRRT_GRID_G;
+ *     by nirrt_run: NIRRT_WIDE_MAX_TREES.
  *   - all planner arithmetic is float64 and follows the reference's per-call-site formulas
  *     (SURVEY.md Appendix A); integer bookkeeping (indices, parents, n) is exact.
  */
