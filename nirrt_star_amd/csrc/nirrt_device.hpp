@@ -32,13 +32,13 @@
 #define WALK_R 4         // parent chains chased concurrently per lane
 #define SCAN_U 4         // 128-vertex chunks a wave loads per scan trip (16-byte loads issued back to back)
 #ifndef CHAIN_MAX
-#define CHAIN_MAX 256    // LDS slots for the new->root edge-length sequence (deeper chains fall back to global walks)
+#define CHAIN_MAX 128    // LDS slots for the new->root edge-length sequence (deeper chains fall back to global walks)
 #endif
 #define GRID_MIN_VERTICES 2048   // smaller trees are scanned whole
 #define GRID_REBUILD_EVERY 1024  // vertices appended behind the cell-ordered part before it is rebuilt
 #define GRID_RG_MAX 96           // slot ranges per query (rows of cells + tail); larger boxes fall back to whole scans
 #ifndef GRID_BM_WORDS
-#define GRID_BM_WORDS 1024       // LDS hit bitmap: 32 768 vertices per ordering window
+#define GRID_BM_WORDS 512        // LDS hit bitmap: 16 384 vertices per ordering window
 #endif
 #ifndef GRID_U
 #define GRID_U 4                 // slots per lane and trip of a grid visit
@@ -1324,7 +1324,7 @@ __device__ __forceinline__ int wg_grid_query(Lds<NT> &s, const TreeDev &t, int n
     __syncthreads();
     PROF(14);
     if (wantN) {
-        // ascending order through the bitmap, one 32 768-vertex window at a time
+        // ascending order through the bitmap, one 16 384-vertex window at a time
         kraw = uni(s.hit_cnt);
         int kout = 0;
         for (int wb = 0; wb < n && kout < kraw; wb += 32 * GRID_BM_WORDS) {

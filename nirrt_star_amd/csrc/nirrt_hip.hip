@@ -69,11 +69,13 @@ struct RunSampleDev {
     int *stop_code;   // per tree: 0 done, NIRRT_E_STREAM, NIRRT_E_CAPACITY
 };
 
-// Two instantiations of every kernel.  Batches ("narrow"): 128-thread workgroups, 8 trees per CU (2 waves each, 14 KB
-// of LDS): with the grid index an iteration is a chain of short dependent phases, so trees in flight per CU is what
-// counts (measured on 2048 problems: 1.2x IRRT*, 1.7x RRT* over 256-thread workgroups; 256 was best while the O(n)
-// scans dominated).  One or a few trees ("wide"): 256 threads - measured for one 50k-iteration problem: IRRT* 2.10 s
-// (128 threads 2.66 s, 1024 threads 2.24 s), RRT* 1.4x faster than with 1024 threads, which had been best for the scans.
+// Three instantiations of every kernel; nirrt_run picks by batch size so that the CU's 16 wave slots are busy:
+//   slim   64 threads (one wave per tree, 14 trees per CU): batches of more than 2048 trees;
+//   narrow 128 threads (8 trees per CU): with the grid index an iteration is a chain of short dependent phases, so trees
+//          in flight per CU is what counts (measured on 2048 problems: 1.2x IRRT*, 1.7x RRT* over 256-thread workgroups;
+//          256 was best while the O(n) scans dominated);
+//   wide   256 threads: one or a few trees - measured for one 50k-iteration problem: IRRT* 2.10 s (128 threads 2.66 s,
+//          1024 threads 2.24 s), RRT* 1.4x faster than with 1024 threads, which had been best for the scans.
 __shared__ LdsData g_lds;   // see LdsData in nirrt_device.hpp
 
 #ifndef NIRRT_WAVES_PER_EU
@@ -95,8 +97,22 @@ namespace wide {
 #include "nirrt_kernels.inc"
 }
 #undef NT
+#define NT 64
+namespace slim {
+#include "nirrt_kernels.inc"
+}
+#undef NT
 #define NT_NARROW NIRRT_NT_NARROW
 #define NT_WIDE NIRRT_NT_WIDE
+#define NT_SLIM 64
+// nirrt_run: batches larger than the 2048 workgroup slots of the 128-thread kernels run one wave per tree (14 trees per
+// CU with 11 KB of LDS): measured on 3584 problems 11.8 vs 10.9 M it/s (IRRT*), 36.8 vs 26.3 M it/s (RRT*); at 2048
+// problems the 128-thread kernels win (IRRT* 10.9 vs 8.6) or tie (RRT*).  NIRRT_SLIM_MIN_TREES overrides the threshold.
+static int slim_min_trees()
+{
+    static const int v = [] { const char *e = std::getenv("NIRRT_SLIM_MIN_TREES"); return e ? std::atoi(e) : 2049; }();
+    return v;
+}
 // nirrt_run: batches up to this many trees use the 256-thread kernels (4 trees per CU fill its 16 wave slots); measured
 // on 1024 problems: IRRT* (hundreds of Near members per iteration) 8.5 vs 7.3 M it/s, RRT* 15.2 vs 16.9 M it/s.
 // NIRRT_WIDE_MAX_TREES overrides both (0 = always the 128-thread kernels).
@@ -748,7 +764,10 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
     long long n_hi = 0;
     for (int i = 0; i < n_trees; i++) n_hi = std::max(n_hi, trees[i]->last_n);
     const bool use_wide = n_trees <= wide_max_trees(a->flags) && n_hi + a->iters >= WIDE_MIN_VERTICES;
-    if (use_wide) {
+    if (n_trees >= slim_min_trees()) {
+        if (D == 2) hipLaunchKernelGGL(slim::k_run_sample<2>, dim3(n_trees), dim3(NT_SLIM), 0, st, (TreeDev *const *)d_ptrs, rd);
+        else hipLaunchKernelGGL(slim::k_run_sample<3>, dim3(n_trees), dim3(NT_SLIM), 0, st, (TreeDev *const *)d_ptrs, rd);
+    } else if (use_wide) {
         if (D == 2) hipLaunchKernelGGL(wide::k_run_sample<2>, dim3(n_trees), dim3(NT_WIDE), 0, st, (TreeDev *const *)d_ptrs, rd);
         else hipLaunchKernelGGL(wide::k_run_sample<3>, dim3(n_trees), dim3(NT_WIDE), 0, st, (TreeDev *const *)d_ptrs, rd);
     } else {
@@ -846,7 +865,10 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
     long long n_hi = 0;
     for (int i = 0; i < n_trees; i++) n_hi = std::max(n_hi, trees[i]->last_n);
     const bool use_wide = n_trees <= wide_max_trees(a->flags) && n_hi + a->iters >= WIDE_MIN_VERTICES;
-    if (use_wide) {
+    if (n_trees >= slim_min_trees()) {
+        if (D == 2) hipLaunchKernelGGL(slim::k_run_replay<2>, dim3(n_trees), dim3(NT_SLIM), 0, st, (TreeDev *const *)d_ptrs, rd);
+        else hipLaunchKernelGGL(slim::k_run_replay<3>, dim3(n_trees), dim3(NT_SLIM), 0, st, (TreeDev *const *)d_ptrs, rd);
+    } else if (use_wide) {
         if (D == 2) hipLaunchKernelGGL(wide::k_run_replay<2>, dim3(n_trees), dim3(NT_WIDE), 0, st, (TreeDev *const *)d_ptrs, rd);
         else hipLaunchKernelGGL(wide::k_run_replay<3>, dim3(n_trees), dim3(NT_WIDE), 0, st, (TreeDev *const *)d_ptrs, rd);
     } else {

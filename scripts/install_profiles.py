@@ -39,7 +39,7 @@ for algo in ("irrt", "rrt"):
         p = os.path.join(src, "pmc_%s_%s" % (algo, c), "bench_counter_collection.csv")
         shutil.copy(p, os.path.join(dst, "r01_pmc_%s2d_%s.csv" % (algo, c)))
         vals[c] = float(next(csv.DictReader(open(p)))["Counter_Value"])
-    key = "%s_2d_2048x50000" % algo
+    key = "%s_2d_3584x50000" % algo
     traffic[key] = {"FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"],
                     "traffic_bytes": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024}
     print("%s traffic %.2f TB" % (algo, traffic[key]["traffic_bytes"] / 1e12))
