@@ -3,7 +3,7 @@
 #   bench lines, rocprofv3 --kernel-trace --stats of the same command, and separate --pmc passes for HBM traffic.
 set -x
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_r01h
+OUT=$R/gpurun_out/prof_r01i
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/bench_irrt.json 2> $OUT/err.log

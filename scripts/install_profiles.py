@@ -31,7 +31,7 @@ with open(os.path.join(dst, "r01_bench_irrt2d_kernel_stats.csv"), "w") as f:
     f.writelines(rows)
 k = next(csv.DictReader(rows))
 tot, mn, mx, calls = float(k["TotalDurationNs"]) / 1e6, float(k["MinNs"]) / 1e6, float(k["MaxNs"]) / 1e6, int(k["Calls"])
-print("kernel stats: %d calls, total %.1f ms, max %.1f, min %.1f -> full-launch average %.1f ms" % (calls, tot, mx, mn, (tot - mn) / (calls - 1)))
+print("kernel stats (%s): %d calls, total %.1f ms, average %.1f, max %.1f, min %.1f" % (k["Name"][:40], calls, tot, tot / calls, mx, mn))
 traffic = json.load(open(os.path.join(dst, "r01_traffic.json")))
 for algo in ("irrt", "rrt"):
     vals = {}
