@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--trees", type=int, default=3584, help="problems per GPU per step (3584 = 14 one-wave workgroups per CU, all resident)")
+    ap.add_argument("--trees", type=int, default=4096, help="problems per GPU per step (4096 = 16 one-wave workgroups per CU, all resident)")
     ap.add_argument("--iters", type=int, default=50000, help="planner iterations per problem (tree capacity)")
     ap.add_argument("--dim", type=int, default=2)
     ap.add_argument("--algo", default="irrt", choices=["irrt", "rrt"])

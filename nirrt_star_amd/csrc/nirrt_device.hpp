@@ -32,7 +32,7 @@
 #define WALK_R 4         // parent chains chased concurrently per lane
 #define SCAN_U 4         // 128-vertex chunks a wave loads per scan trip (16-byte loads issued back to back)
 #ifndef CHAIN_MAX
-#define CHAIN_MAX 128    // LDS slots for the new->root edge-length sequence (deeper chains fall back to global walks)
+#define CHAIN_MAX 96     // LDS slots for the new->root edge-length sequence (deeper chains fall back to global walks)
 #endif
 #define GRID_MIN_VERTICES 2048   // smaller trees are scanned whole
 #define GRID_REBUILD_EVERY 1024  // vertices appended behind the cell-ordered part before it is rebuilt
@@ -201,7 +201,7 @@ struct StreamState {
 // ONE LDS object for every kernel of the library (both workgroup sizes): with a single module-wide variable the
 // compiler can give it the same address in every kernel, so the non-inlined loop-body functions address it with
 // constant offsets (-mllvm -amdgpu-lower-module-lds-strategy=module) instead of looking its offset up per kernel.
-#define LDS_NW_MAX 16   // waves of the widest workgroup
+#define LDS_NW_MAX 4    // waves of the widest workgroup (256 threads)
 struct LdsData {
     int n_round, n_box;
     double rnd[MAX_OBS][4];
@@ -224,8 +224,9 @@ struct LdsData {
     Hop4 hop_new;                 // copy of hop[new_idx] of the current iteration (thread 0 reads it when re-parenting)
     int new_next, new_fc;         // thread 0: next sibling of the vertex inserted this iteration / head of its child list
     int ob_n;                     // obstacles whose inflated box meets the Near ball's box (wg_near)
-    short ob_list[2 * MAX_OBS];
-    int rg_beg[GRID_RG_MAX], rg_len[GRID_RG_MAX], rg_flag[GRID_RG_MAX];
+    unsigned char ob_list[2 * MAX_OBS];
+    int rg_beg[GRID_RG_MAX], rg_len[GRID_RG_MAX];
+    unsigned char rg_flag[GRID_RG_MAX];
     unsigned bm[GRID_BM_WORDS];   // one bit per vertex of a 32*GRID_BM_WORDS window; all-zero between uses
 };
 template <int NT>
@@ -1725,7 +1726,7 @@ __device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const doub
         double l0[3], l1[3];
 #pragma unroll
         for (int c = 0; c < D; c++) { l0[c] = node_new[c] - rb; l1[c] = node_new[c] + rb; }
-        if (seg_aabb_pass<D, NT>(s, o, l0, l1)) s.ob_list[atomicAdd(&s.ob_n, 1)] = (short)o;
+        if (seg_aabb_pass<D, NT>(s, o, l0, l1)) s.ob_list[atomicAdd(&s.ob_n, 1)] = (unsigned char)o;
     }
     __syncthreads();
     const int n_ob = uni(s.ob_n);

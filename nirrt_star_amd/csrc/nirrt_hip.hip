@@ -105,6 +105,7 @@ namespace slim {
 #define NT_NARROW NIRRT_NT_NARROW
 #define NT_WIDE NIRRT_NT_WIDE
 #define NT_SLIM 64
+static_assert(NT_WIDE / 64 <= LDS_NW_MAX && NT_NARROW / 64 <= LDS_NW_MAX, "LdsData reduction slots: raise LDS_NW_MAX");
 // nirrt_run: batches larger than the 2048 workgroup slots of the 128-thread kernels run one wave per tree (14 trees per
 // CU with 11 KB of LDS): measured on 3584 problems 11.8 vs 10.9 M it/s (IRRT*), 36.8 vs 26.3 M it/s (RRT*); at 2048
 // problems the 128-thread kernels win (IRRT* 10.9 vs 8.6) or tie (RRT*).  NIRRT_SLIM_MIN_TREES overrides the threshold.

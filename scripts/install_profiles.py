@@ -34,12 +34,14 @@ tot, mn, mx, calls = float(k["TotalDurationNs"]) / 1e6, float(k["MinNs"]) / 1e6,
 print("kernel stats (%s): %d calls, total %.1f ms, average %.1f, max %.1f, min %.1f" % (k["Name"][:40], calls, tot, tot / calls, mx, mn))
 traffic = json.load(open(os.path.join(dst, "r01_traffic.json")))
 for algo in ("irrt", "rrt"):
+    if not os.path.exists(os.path.join(src, "pmc_%s_FETCH_SIZE" % algo)):
+        continue
     vals = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         p = os.path.join(src, "pmc_%s_%s" % (algo, c), "bench_counter_collection.csv")
         shutil.copy(p, os.path.join(dst, "r01_pmc_%s2d_%s.csv" % (algo, c)))
         vals[c] = float(next(csv.DictReader(open(p)))["Counter_Value"])
-    key = "%s_2d_3584x50000" % algo
+    key = "%s_2d_4096x50000" % algo
     traffic[key] = {"FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"],
                     "traffic_bytes": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024}
     print("%s traffic %.2f TB" % (algo, traffic[key]["traffic_bytes"] / 1e12))
