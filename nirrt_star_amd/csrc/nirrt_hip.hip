@@ -70,7 +70,7 @@ struct RunSampleDev {
 };
 
 // Three instantiations of every kernel; nirrt_run picks by batch size so that the CU's 16 wave slots are busy:
-//   slim   64 threads (one wave per tree, 14 trees per CU): batches of more than 2048 trees;
+//   slim   64 threads (one wave per tree, 16 trees per CU = every wave slot): batches of more than 2048 trees;
 //   narrow 128 threads (8 trees per CU): with the grid index an iteration is a chain of short dependent phases, so trees
 //          in flight per CU is what counts (measured on 2048 problems: 1.2x IRRT*, 1.7x RRT* over 256-thread workgroups;
 //          256 was best while the O(n) scans dominated);
@@ -106,8 +106,8 @@ namespace slim {
 #define NT_WIDE NIRRT_NT_WIDE
 #define NT_SLIM 64
 static_assert(NT_WIDE / 64 <= LDS_NW_MAX && NT_NARROW / 64 <= LDS_NW_MAX, "LdsData reduction slots: raise LDS_NW_MAX");
-// nirrt_run: batches larger than the 2048 workgroup slots of the 128-thread kernels run one wave per tree (14 trees per
-// CU with 11 KB of LDS): measured on 3584 problems 11.8 vs 10.9 M it/s (IRRT*), 36.8 vs 26.3 M it/s (RRT*); at 2048
+// nirrt_run: batches larger than the 2048 workgroup slots of the 128-thread kernels run one wave per tree (16 trees per
+// CU with 10 KB of LDS): measured on 4096 problems 12.8 vs 10.9 M it/s (IRRT*), 39.0 vs 26.3 M it/s (RRT*); at 2048
 // problems the 128-thread kernels win (IRRT* 10.9 vs 8.6) or tie (RRT*).  NIRRT_SLIM_MIN_TREES overrides the threshold.
 static int slim_min_trees()
 {
