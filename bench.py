@@ -114,20 +114,30 @@ def main():
         trees.append(t)
     # inputs: each problem's generator outputs (np.random.seed(s); random.seed(s)), resident in HBM
     n_np, n_py = word_budgets(args)
-    h_np = np.empty((B, n_np), dtype=np.uint32)
-    h_py = np.empty((B, max(n_py, 1)), dtype=np.uint32)
-    for b, pr in enumerate(probs):
-        np.random.seed(1000 + pr["pid"])
-        random.seed(1000 + pr["pid"])
-        h_np[b] = sampling.peek_np_words(n_np)
-        if n_py:
-            h_py[b] = sampling.peek_py_words(n_py)
     dev = "cuda:%d" % local_rank
-    d_np = torch.from_numpy(h_np.view(np.int32)).to(dev)
-    d_py = torch.from_numpy(h_py.view(np.int32)).to(dev)
+    py_stride = max(n_py, 1)
+    d_np = torch.empty((B, n_np), dtype=torch.int32, device=dev)
+    d_py = torch.empty((B, py_stride), dtype=torch.int32, device=dev)
+    cpu_np = cpu_py = None
+    CH = 256   # generated and uploaded in chunks: the host never holds more than ~1 GB of the ~16 GB of words
+    for c0 in range(0, B, CH):
+        c1 = min(B, c0 + CH)
+        h_np = np.empty((c1 - c0, n_np), dtype=np.uint32)
+        h_py = np.empty((c1 - c0, py_stride), dtype=np.uint32)
+        for b in range(c0, c1):
+            np.random.seed(1000 + probs[b]["pid"])
+            random.seed(1000 + probs[b]["pid"])
+            h_np[b - c0] = sampling.peek_np_words(n_np)
+            if n_py:
+                h_py[b - c0] = sampling.peek_py_words(n_py)
+        if c0 == 0:   # problem 0's words also feed the CPU baseline
+            cpu_np, cpu_py = h_np[0].copy(), (h_py[0].copy() if n_py else None)
+        d_np[c0:c1].copy_(torch.from_numpy(h_np.view(np.int32)))
+        d_py[c0:c1].copy_(torch.from_numpy(h_py.view(np.int32)))
     np_tab = [(d_np.data_ptr() + 4 * n_np * b, n_np) for b in range(B)]
-    py_tab = [(d_py.data_ptr() + 4 * h_py.shape[1] * b, n_py) for b in range(B)] if n_py else None
+    py_tab = [(d_py.data_ptr() + 4 * py_stride * b, n_py) for b in range(B)] if n_py else None
     torch.cuda.synchronize()
+    del h_np, h_py
 
     def barrier():
         torch.cuda.synchronize()
@@ -209,7 +219,7 @@ def main():
             "reference_python_survey_container_its": REF_PY[args.algo],
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, probs[0], h_np[0], h_py[0] if n_py else None)
+            out["cpu_baseline"] = cpu_baseline(args, probs[0], cpu_np, cpu_py)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
