@@ -21,22 +21,34 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-mllvm", "-amdgpu-lower-module-lds-strategy=module"]
 
 
-def needs_build():
-    if not os.path.exists(SO):
+# Test-only second build with tiny compile-time limits, so that the overflow paths of the loop body (parent chains longer
+# than the LDS chain cache, Near sets larger than the LDS stash) run in the parity suite (tests/test_hip_variants.py loads it
+# through NIRRT_HIP_SO).  Same sources, same flags, different -D limits.
+SO_SMALL = os.path.join(HERE, "libnirrt_hip_small.so")
+SMALL_FLAGS = ["-DCHAIN_MAX=8", "-DGRID_BM_WORDS=32"]
+
+
+def needs_build(so=SO):
+    if not os.path.exists(so):
         return True
-    so_m = os.path.getmtime(SO)
-    return any(os.path.getmtime(p) > so_m for p in DEPS)
+    so_m = os.path.getmtime(so)
+    return any(os.path.getmtime(p) > so_m for p in DEPS + [os.path.abspath(__file__)])
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return SO
+def _compile(so, extra, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("NIRRT_EXTRA_FLAGS", "").split()
-    cmd = [hipcc] + FLAGS + extra + ["-o", SO] + SOURCES
+    cmd = [hipcc] + FLAGS + extra + ["-o", so] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+
+
+def build(force=False, verbose=False, small=True):
+    """Compile libnirrt_hip.so (and the small-limits test build) when a source is newer than the library."""
+    if force or needs_build(SO):
+        _compile(SO, os.environ.get("NIRRT_EXTRA_FLAGS", "").split(), verbose)
+    if small and (force or needs_build(SO_SMALL)):
+        _compile(SO_SMALL, SMALL_FLAGS, verbose)
     return SO
 
 

@@ -109,19 +109,33 @@ static_assert(NT_WIDE / 64 <= LDS_NW_MAX && NT_NARROW / 64 <= LDS_NW_MAX, "LdsDa
 // nirrt_run: batches larger than the 2048 workgroup slots of the 128-thread kernels run one wave per tree (16 trees per
 // CU with 10 KB of LDS): measured on 4096 problems 12.8 vs 10.9 M it/s (IRRT*), 39.0 vs 26.3 M it/s (RRT*); at 2048
 // problems the 128-thread kernels win (IRRT* 10.9 vs 8.6) or tie (RRT*).  NIRRT_SLIM_MIN_TREES overrides the threshold.
-static int slim_min_trees()
+// The knobs are read on every call (tests switch them inside one process).
+static int env_int(const char *name, int dflt)
 {
-    static const int v = [] { const char *e = std::getenv("NIRRT_SLIM_MIN_TREES"); return e ? std::atoi(e) : 2049; }();
-    return v;
+    const char *e = std::getenv(name);
+    return (e && *e) ? std::atoi(e) : dflt;
 }
+static int slim_min_trees() { return env_int("NIRRT_SLIM_MIN_TREES", 2049); }
 // nirrt_run: batches up to this many trees use the 256-thread kernels (4 trees per CU fill its 16 wave slots); measured
 // on 1024 problems: IRRT* (hundreds of Near members per iteration) 8.5 vs 7.3 M it/s, RRT* 15.2 vs 16.9 M it/s.
 // NIRRT_WIDE_MAX_TREES overrides both (0 = always the 128-thread kernels).
 static int wide_max_trees(unsigned flags)
 {
-    static const int env = [] { const char *e = std::getenv("NIRRT_WIDE_MAX_TREES"); return e ? std::atoi(e) : -1; }();
+    const int env = env_int("NIRRT_WIDE_MAX_TREES", -1);
     if (env >= 0) return env;
     return (flags & NIRRT_F_IRRT) ? 1024 : 256;
+}
+// NIRRT_FORCE_VARIANT=slim|narrow|wide pins EVERY kernel launch of the library (primitives, step, persistent loops) to
+// one instantiation: the parity suite runs whole under each of them (tests/test_hip_variants.py).
+enum Variant { V_AUTO = 0, V_SLIM, V_NARROW, V_WIDE };
+static Variant forced_variant()
+{
+    const char *e = std::getenv("NIRRT_FORCE_VARIANT");
+    if (!e || !*e) return V_AUTO;
+    if (!std::strcmp(e, "slim")) return V_SLIM;
+    if (!std::strcmp(e, "narrow")) return V_NARROW;
+    if (!std::strcmp(e, "wide")) return V_WIDE;
+    return V_AUTO;
 }
 #define WIDE_MIN_VERTICES 16000   // ... once the trees are (or will grow) this big
 
@@ -198,22 +212,48 @@ extern "C" int nirrt_device_count(int *count)
     return NIRRT_OK;
 }
 
-#define DISPATCH_DIM(t, KERNEL, grid, ...)                                                     \
+#define LAUNCH_V(var, dimv, KERNEL, grid, st, ...)                                             \
     do {                                                                                       \
-        if ((t)->dim == 2) hipLaunchKernelGGL(wide::KERNEL<2>, dim3(grid), dim3(NT_WIDE), 0, (t)->stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL(wide::KERNEL<3>, dim3(grid), dim3(NT_WIDE), 0, (t)->stream, __VA_ARGS__); \
-    } while (0)
-
-#define DISPATCH_BY_SIZE(t, KERNEL, ...)                                                        \
-    do {                                                                                       \
-        if ((t)->last_n >= WIDE_MIN_VERTICES) {                                                \
-            if ((t)->dim == 2) hipLaunchKernelGGL(wide::KERNEL<2>, dim3(1), dim3(NT_WIDE), 0, (t)->stream, __VA_ARGS__); \
-            else hipLaunchKernelGGL(wide::KERNEL<3>, dim3(1), dim3(NT_WIDE), 0, (t)->stream, __VA_ARGS__); \
-        } else {                                                                               \
-            if ((t)->dim == 2) hipLaunchKernelGGL(narrow::KERNEL<2>, dim3(1), dim3(NT_NARROW), 0, (t)->stream, __VA_ARGS__); \
-            else hipLaunchKernelGGL(narrow::KERNEL<3>, dim3(1), dim3(NT_NARROW), 0, (t)->stream, __VA_ARGS__); \
+        switch (var) {                                                                         \
+        case V_SLIM:                                                                           \
+            if ((dimv) == 2) hipLaunchKernelGGL(slim::KERNEL<2>, dim3(grid), dim3(NT_SLIM), 0, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL(slim::KERNEL<3>, dim3(grid), dim3(NT_SLIM), 0, st, __VA_ARGS__); \
+            break;                                                                             \
+        case V_NARROW:                                                                         \
+            if ((dimv) == 2) hipLaunchKernelGGL(narrow::KERNEL<2>, dim3(grid), dim3(NT_NARROW), 0, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL(narrow::KERNEL<3>, dim3(grid), dim3(NT_NARROW), 0, st, __VA_ARGS__); \
+            break;                                                                             \
+        default:                                                                               \
+            if ((dimv) == 2) hipLaunchKernelGGL(wide::KERNEL<2>, dim3(grid), dim3(NT_WIDE), 0, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL(wide::KERNEL<3>, dim3(grid), dim3(NT_WIDE), 0, st, __VA_ARGS__); \
+            break;                                                                             \
         }                                                                                      \
     } while (0)
+
+// grid-stride / one-off kernels: 256 threads unless a variant is forced
+#define DISPATCH_DIM(t, KERNEL, grid, ...)                                                     \
+    do {                                                                                       \
+        const Variant fv_ = forced_variant();                                                  \
+        LAUNCH_V(fv_ == V_AUTO ? V_WIDE : fv_, (t)->dim, KERNEL, grid, (t)->stream, __VA_ARGS__); \
+    } while (0)
+
+// single-tree kernels: by tree size
+#define DISPATCH_BY_SIZE(t, KERNEL, ...)                                                        \
+    do {                                                                                       \
+        const Variant fv_ = forced_variant();                                                  \
+        const Variant v_ = fv_ != V_AUTO ? fv_ : ((t)->last_n >= WIDE_MIN_VERTICES ? V_WIDE : V_NARROW); \
+        LAUNCH_V(v_, (t)->dim, KERNEL, 1, (t)->stream, __VA_ARGS__);                           \
+    } while (0)
+
+// persistent loops: by batch size and algorithm (see the notes above the three namespaces)
+static Variant run_variant(int n_trees, unsigned flags, long long n_hi, long long iters)
+{
+    const Variant fv = forced_variant();
+    if (fv != V_AUTO) return fv;
+    if (n_trees >= slim_min_trees()) return V_SLIM;
+    if (n_trees <= wide_max_trees(flags) && n_hi + iters >= WIDE_MIN_VERTICES) return V_WIDE;
+    return V_NARROW;
+}
 
 static int sync_check(nirrt_tree *t)
 {
@@ -764,17 +804,7 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
     HIPCHK_R(hipEventRecord(e0, st));
     long long n_hi = 0;
     for (int i = 0; i < n_trees; i++) n_hi = std::max(n_hi, trees[i]->last_n);
-    const bool use_wide = n_trees <= wide_max_trees(a->flags) && n_hi + a->iters >= WIDE_MIN_VERTICES;
-    if (n_trees >= slim_min_trees()) {
-        if (D == 2) hipLaunchKernelGGL(slim::k_run_sample<2>, dim3(n_trees), dim3(NT_SLIM), 0, st, (TreeDev *const *)d_ptrs, rd);
-        else hipLaunchKernelGGL(slim::k_run_sample<3>, dim3(n_trees), dim3(NT_SLIM), 0, st, (TreeDev *const *)d_ptrs, rd);
-    } else if (use_wide) {
-        if (D == 2) hipLaunchKernelGGL(wide::k_run_sample<2>, dim3(n_trees), dim3(NT_WIDE), 0, st, (TreeDev *const *)d_ptrs, rd);
-        else hipLaunchKernelGGL(wide::k_run_sample<3>, dim3(n_trees), dim3(NT_WIDE), 0, st, (TreeDev *const *)d_ptrs, rd);
-    } else {
-        if (D == 2) hipLaunchKernelGGL(narrow::k_run_sample<2>, dim3(n_trees), dim3(NT_NARROW), 0, st, (TreeDev *const *)d_ptrs, rd);
-        else hipLaunchKernelGGL(narrow::k_run_sample<3>, dim3(n_trees), dim3(NT_NARROW), 0, st, (TreeDev *const *)d_ptrs, rd);
-    }
+    LAUNCH_V(run_variant(n_trees, a->flags, n_hi, a->iters), D, k_run_sample, n_trees, st, (TreeDev *const *)d_ptrs, rd);
     HIPCHK_R(hipEventRecord(e1, st));
     HIPCHK_R(hipGetLastError());
     HIPCHK_R(hipStreamSynchronize(st));
@@ -865,17 +895,7 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
     HIPCHK(hipEventRecord(e0, st));
     long long n_hi = 0;
     for (int i = 0; i < n_trees; i++) n_hi = std::max(n_hi, trees[i]->last_n);
-    const bool use_wide = n_trees <= wide_max_trees(a->flags) && n_hi + a->iters >= WIDE_MIN_VERTICES;
-    if (n_trees >= slim_min_trees()) {
-        if (D == 2) hipLaunchKernelGGL(slim::k_run_replay<2>, dim3(n_trees), dim3(NT_SLIM), 0, st, (TreeDev *const *)d_ptrs, rd);
-        else hipLaunchKernelGGL(slim::k_run_replay<3>, dim3(n_trees), dim3(NT_SLIM), 0, st, (TreeDev *const *)d_ptrs, rd);
-    } else if (use_wide) {
-        if (D == 2) hipLaunchKernelGGL(wide::k_run_replay<2>, dim3(n_trees), dim3(NT_WIDE), 0, st, (TreeDev *const *)d_ptrs, rd);
-        else hipLaunchKernelGGL(wide::k_run_replay<3>, dim3(n_trees), dim3(NT_WIDE), 0, st, (TreeDev *const *)d_ptrs, rd);
-    } else {
-        if (D == 2) hipLaunchKernelGGL(narrow::k_run_replay<2>, dim3(n_trees), dim3(NT_NARROW), 0, st, (TreeDev *const *)d_ptrs, rd);
-        else hipLaunchKernelGGL(narrow::k_run_replay<3>, dim3(n_trees), dim3(NT_NARROW), 0, st, (TreeDev *const *)d_ptrs, rd);
-    }
+    LAUNCH_V(run_variant(n_trees, a->flags, n_hi, a->iters), D, k_run_replay, n_trees, st, (TreeDev *const *)d_ptrs, rd);
     HIPCHK(hipEventRecord(e1, st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));

@@ -1,6 +1,6 @@
 """GPU parity at BASELINE.json's full size (50 000 iterations, 50k-vertex trees) through properties that do not
 need a 50k-iteration reference run: brute-force numpy checks of the filtered scans on the big tree, structural
-invariants of the tree, cache-vs-walk cost consistency, batch (narrow) vs single (wide) kernel agreement,
+invariants of the tree, cache-vs-walk cost consistency, agreement of all three kernel instantiations,
 plus ONE full oracle comparison (3D RRT*, bit-exact)."""
 import random
 
@@ -118,11 +118,14 @@ def test_filtered_scans_equal_brute_force_at_50k(big_irrt2d):
         assert np.array_equal(t.near(q, n), cand)
 
 
-def test_batch_kernels_equal_single_tree_kernels_at_50k(big_irrt2d):
-    """narrow (256-thread, many trees) and wide (1024-thread, one tree) instantiations: same seeds -> same tree"""
+@pytest.mark.parametrize("variant", ["slim", "narrow", "wide"])
+def test_batch_kernels_equal_single_tree_kernels_at_50k(big_irrt2d, monkeypatch, variant):
+    """every instantiation (slim = 64 threads / one wave per tree, narrow = 128, wide = 256 threads) on a batch of 100
+    copies of the problem: same seeds -> the very tree the single-tree launch of the fixture grew (that one ran `wide`)"""
     from nirrt_star_amd import _hip
     pr, t_wide, v, p, res_w, npw, pyw = big_irrt2d
-    n_copies = 100                                             # > WIDE_MAX_TREES -> narrow kernels
+    n_copies = 100
+    monkeypatch.setenv("NIRRT_FORCE_VARIANT", variant)
     _, trees, _, _ = _grow(2, 11, _hip.F_IRRT, n_copies)
     res = _hip.run_sampling(trees, ITERS, [npw] * n_copies, [pyw] * n_copies, flags=_hip.F_IRRT)
     assert (res["iters_done"] == ITERS).all() and not res["status"].any()
