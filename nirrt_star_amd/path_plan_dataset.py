@@ -34,32 +34,35 @@ def save_dataset(path, samples):
 
 
 class PathPlanDataset(_Base):
-    """`dataset_filepath`: 'data/random_2d/' + mode + '.npz' (mode = train / val / test).  __getitem__ returns
-    (pc_xyz_raw (n, 3), pc_xyz normalised (n, 3), pc_features (n, 3) = start / goal / free, pc_labels (n,), token)."""
+    """Indexable view of one split file ('data/random_2d/' + mode + '.npz', mode = train / val / test) with the item layout
+    the reference's training and evaluation loops unpack (PathPlanDataLoader.py:7-52):
+        (raw xyz (n, 3), normalised xyz (n, 3), features (n, 3) = start / goal / free, labels (n,), token)
+    and `.labelweights` = (max class frequency / class frequency) ** (1/3) over the two label classes.
+    Everything is float32; planar clouds get a zero z column when the file is opened."""
+
+    _MASKS = (("start_mask", "start"), ("goal_mask", "goal"), ("free_mask", "free"), ("astar_mask", "astar"))
 
     def __init__(self, dataset_filepath):
-        data = np.load(dataset_filepath)
-        self.pc = data['pc'].astype(np.float32)
-        self.start_mask = data['start'].astype(np.float32)
-        self.goal_mask = data['goal'].astype(np.float32)
-        self.free_mask = data['free'].astype(np.float32)
-        self.astar_mask = data['astar'].astype(np.float32)
-        self.token = data['token']
-        if self.pc.shape[2] == 2:   # 2D clouds get a zero z column
-            self.pc = np.concatenate((self.pc, np.zeros((self.pc.shape[0], self.pc.shape[1], 1)).astype(np.float32)), axis=2)
-        if self.pc.shape[2] != 3:
-            raise RuntimeError("Point cloud is not 3D.")
-        labelweights, _ = np.histogram(self.astar_mask, range(3))
-        labelweights = labelweights.astype(np.float32)
-        labelweights = labelweights / np.sum(labelweights)
-        self.labelweights = np.power(np.amax(labelweights) / labelweights, 1 / 3.0)
-        print(self.labelweights)
+        with np.load(dataset_filepath) as z:
+            cloud = np.asarray(z["pc"], dtype=np.float32)
+            for attr, key in self._MASKS:
+                setattr(self, attr, np.asarray(z[key], dtype=np.float32))
+            self.token = z["token"]
+        width = cloud.shape[-1]
+        if width not in (2, 3):
+            raise RuntimeError("point clouds must be (count, n_points, 2 or 3), got last axis %d" % width)
+        if width == 2:
+            cloud = np.pad(cloud, ((0, 0), (0, 0), (0, 1)))
+        self.pc = cloud
+        # class balance of the path labels: bins [0, 1) and [1, 2]
+        freq = np.histogram(self.astar_mask, bins=(0, 1, 2))[0].astype(np.float32)
+        freq /= freq.sum()
+        self.labelweights = np.power(freq.max() / freq, 1 / 3.0)
 
     def __len__(self):
-        return len(self.pc)
+        return self.pc.shape[0]
 
     def __getitem__(self, index):
-        pc_xyz_raw = self.pc[index]
-        pc_xyz = pc_normalize(pc_xyz_raw)
-        pc_features = np.stack((self.start_mask[index], self.goal_mask[index], self.free_mask[index]), axis=-1)
-        return pc_xyz_raw, pc_xyz, pc_features, self.astar_mask[index], self.token[index]
+        raw = self.pc[index]
+        channels = [getattr(self, attr)[index] for attr, _ in self._MASKS[:3]]
+        return raw, pc_normalize(raw), np.stack(channels, axis=-1), self.astar_mask[index], self.token[index]

@@ -202,9 +202,29 @@ class _HipPlanner:
     def _progress(self, k):
         print(k)
 
-    def visualize(self, *a, **k):
-        from .visualizer import draw_tree
-        draw_tree(self, *a, **k)
+    # ---- plotting (reference: rrt_star_2d.py:146-157 and the per-planner overrides) ---------
+    _vis_kind = "RRTStarVisualizer"      # class of nirrt_star_amd.visualizer (3D planners append "3D")
+    _vis_tag = "rrt*"
+
+    @property
+    def visualizer(self):
+        """the reference builds it in __init__; here matplotlib is only touched when somebody asks"""
+        if getattr(self, "_visualizer", None) is None:
+            from . import visualizer as V
+            self._visualizer = getattr(V, self._vis_kind + ("3D" if self.dim == 3 else ""))(self.x_start, self.x_goal, self.env)
+        return self._visualizer
+
+    def _vis_defaults(self, figure_title, img_filename):
+        if figure_title is None:
+            figure_title = "%s %dD, iteration %d" % (self._vis_tag, self.dim, self.iter_max)
+        if img_filename is None:
+            img_filename = "%s_%dd_example.png" % (self._vis_tag.replace("(c)", "_c"), self.dim)
+        return figure_title, img_filename
+
+    def visualize(self, figure_title=None, img_filename=None):
+        figure_title, img_filename = self._vis_defaults(figure_title, img_filename)
+        self.visualizer.animation(self.vertices[:self.num_vertices], self.vertex_parents[:self.num_vertices], self.path,
+                                  figure_title, animation=False, img_filename=img_filename)
 
 
 class _Utils:
@@ -338,6 +358,26 @@ class _IRRTStar(_RRTStar):
         c, x = self.tree.best_solution()
         return c, x
 
+    _vis_kind = "IRRTStarVisualizer"
+    _vis_tag = "irrt*"
+
+    def visualize(self, x_center=None, c_best=None, start_goal_straightline_dist=None, theta=None, figure_title=None,
+                  img_filename=None):
+        """irrt_star_2d.py:163-178 (3D: the rotation matrix C in place of theta, irrt_star_3d.py:176-192); called without
+        arguments it draws the informed set of the current best solution"""
+        if x_center is None:
+            frame = self.init()
+            x_center, start_goal_straightline_dist = (frame[2], frame[1]) if self.dim == 2 else (frame[1], frame[0])
+            theta = frame[0] if self.dim == 2 else frame[2]
+            c_best = self.find_best_path_solution()[0] if len(self.tree.solutions) else np.inf
+        figure_title, img_filename = self._vis_defaults(figure_title, img_filename)
+        self._vis_sync_clouds()
+        self.visualizer.animation(self.vertices[:self.num_vertices], self.vertex_parents[:self.num_vertices], self.path,
+                                  figure_title, x_center, c_best, start_goal_straightline_dist, theta, img_filename=img_filename)
+
+    def _vis_sync_clouds(self):
+        pass
+
     # --- sampling with the reference's own calls (host loop modes) -----------------------------
     def SampleUnitBall(self):
         if self.dim == 2:
@@ -451,6 +491,12 @@ class _NIRRTStarPNG(_IRRTStar):
     # when the guidance cloud is due for a refresh (PointNet++), O(10) times per run
     default_mode = "resident"
     connect = False
+    _vis_kind = "NIRRTStarVisualizer"
+    _vis_tag = "nirrt*"
+
+    def _vis_sync_clouds(self):
+        self.visualizer.set_path_point_cloud_pred(self.path_point_cloud_pred)
+        self.visualizer.set_path_point_cloud_other(self.path_point_cloud_other)
 
     def _png_init(self, png_wrapper, binary_mask, pc_n_points, pc_over_sample_scale, pc_sample_rate, pc_update_cost_ratio,
                   env_dict=None, connect_max_trial_attempts=None):
@@ -616,6 +662,7 @@ class NIRRTStarPNG2D(_NIRRTStarPNG):
 class NIRRTStarPNGC2D(_NIRRTStarPNG):
     dim = 2
     connect = True
+    _vis_tag = "nirrt*(c)"
 
     def __init__(self, x_start, x_goal, step_len, search_radius, iter_max, env_dict, png_wrapper_connect, binary_mask, clearance,
                  pc_n_points, pc_over_sample_scale, pc_sample_rate, pc_update_cost_ratio, connect_max_trial_attempts,
@@ -637,6 +684,7 @@ class NIRRTStarPNG3D(_NIRRTStarPNG):
 class NIRRTStarPNGC3D(_NIRRTStarPNG):
     dim = 3
     connect = True
+    _vis_tag = "nirrt*(c)"
 
     def __init__(self, x_start, x_goal, step_len, search_radius, iter_max, env_dict, png_wrapper_connect, clearance,
                  pc_n_points, pc_over_sample_scale, pc_sample_rate, pc_update_cost_ratio, connect_max_trial_attempts,
@@ -654,6 +702,12 @@ class _NRRTStarPNG(_RRTStar):
     (nrrt_star_png_2d.py:52-59); the cloud is computed once (init_pc) and never refreshed."""
     _extra_flags = _hip.F_PNG
     connect = False
+    _vis_kind = "NRRTStarPNGVisualizer"
+    _vis_tag = "nrrt*-png"
+
+    def visualize(self, figure_title=None, img_filename=None):
+        self.visualizer.set_path_point_cloud_pred(self.path_point_cloud_pred)
+        _RRTStar.visualize(self, figure_title, img_filename)
 
     def _nrrt_init(self, png_wrapper, binary_mask, pc_n_points, pc_over_sample_scale, pc_sample_rate, env_dict=None,
                    connect_max_trial_attempts=None):
@@ -724,6 +778,7 @@ class NRRTStarPNG2D(_NRRTStarPNG):
 class NRRTStarPNGC2D(_NRRTStarPNG):
     dim = 2
     connect = True
+    _vis_tag = "nrrt*-png(c)"
 
     def __init__(self, x_start, x_goal, step_len, search_radius, iter_max, env_dict, png_wrapper_connect, binary_mask, clearance,
                  pc_n_points, pc_over_sample_scale, pc_sample_rate, connect_max_trial_attempts, mode=None, device_id=0):
@@ -744,6 +799,7 @@ class NRRTStarPNG3D(_NRRTStarPNG):
 class NRRTStarPNGC3D(_NRRTStarPNG):
     dim = 3
     connect = True
+    _vis_tag = "nrrt*-png(c)"
 
     def __init__(self, x_start, x_goal, step_len, search_radius, iter_max, env_dict, png_wrapper_connect, clearance,
                  pc_n_points, pc_over_sample_scale, pc_sample_rate, connect_max_trial_attempts, mode=None, device_id=0):

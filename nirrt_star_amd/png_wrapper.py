@@ -80,19 +80,37 @@ class PNGWrapper:
         self.model = self.model.eval().fold()
         print("PointNet++ wrapper%s is initialized." % ("" if self.dim == 2 else " 3d"))
 
-    def classify_path_points(self, pc, start_mask, goal_mask):
+    @staticmethod
+    def network_input(pc, start_mask, goal_mask):
+        """one cloud -> the (6, N) float32 channel block the net consumes: xyz (z = 0 for planar clouds) shifted to the
+        centroid and scaled by the largest norm, then the start / goal indicator channels and the "neither" channel
+        (reference: pointnet2_wrapper.py:43-58; arithmetic kept in float32 numpy like there)"""
+        cloud = np.asarray(pc, dtype=np.float32)
+        n = len(cloud)
+        block = np.zeros((6, n), dtype=np.float32)
+        block[: cloud.shape[1]] = pc_normalize(cloud).T if cloud.shape[1] == 3 else \
+            pc_normalize(np.concatenate([cloud, np.zeros((n, 1), dtype=np.float32)], axis=1)).T[:2]
+        s = np.asarray(start_mask, dtype=np.float32)
+        g = np.asarray(goal_mask, dtype=np.float32)
+        block[3], block[4] = s, g
+        block[5] = ((s + g) == 0).astype(np.float32)
+        return block
+
+    def classify_batch(self, clouds, start_masks, goal_masks, fps_starts=None):
+        """B clouds of equal size in ONE forward: lists / arrays of (N, 2|3) clouds and (N,) masks ->
+        (path_pred int64 (B, N), path_score float32 (B, N)).  The input block is assembled once on the host, crosses to
+        the device once, and only the two result rows per cloud come back."""
+        x = np.stack([self.network_input(c, s, g) for c, s, g in zip(clouds, start_masks, goal_masks)], axis=0)
         with torch.no_grad():
-            n_points = pc.shape[0]
-            if pc.shape[1] == 2:
-                pc = np.concatenate((pc, np.zeros((n_points, 1)).astype(np.float32)), axis=1)
-            pc_xyz = torch.from_numpy(pc_normalize(pc)).to(self.device)
-            free_mask = 1 - (start_mask + goal_mask).astype(bool)
-            pc_features = torch.from_numpy(np.stack((start_mask, goal_mask, free_mask.astype(np.float32)), axis=-1)).to(self.device)
-            model_inputs = torch.cat([pc_xyz, pc_features], dim=1).permute(1, 0).unsqueeze(0)
-            seg_pred, _ = self.model(model_inputs.float())
-            path_pred = np.argmax(seg_pred.detach().to('cpu').numpy(), 2)[0]
-            path_score = torch.softmax(seg_pred, dim=-1)[0, :, 1].detach().to('cpu').numpy()   # on the device, like the reference
-            return path_pred, path_score
+            logp, _ = self.model(torch.from_numpy(x).to(self.device), fps_starts=fps_starts)   # (B, N, classes)
+            pred = logp.argmax(dim=2)
+            score = torch.softmax(logp, dim=2)[:, :, 1]
+            return pred.cpu().numpy(), score.cpu().numpy()
+
+    def classify_path_points(self, pc, start_mask, goal_mask):
+        """reference signature (pointnet2_wrapper.py:43-63): one cloud -> (path_pred (N,), path_score (N,))"""
+        pred, score = self.classify_batch([pc], [start_mask], [goal_mask])
+        return pred[0], score[0]
 
     def generate_connected_path_points(self, pc, x_start, x_goal, env_dict, neighbor_radius, max_trial_attempts,
                                        visualize=False, vis_folderpath="", token=""):

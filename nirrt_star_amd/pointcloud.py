@@ -4,42 +4,28 @@ Same function names / arguments / RNG consumption (global numpy legacy generator
 The farthest-point down-sampling step is open3d's `farthest_point_down_sample` in the reference
 (un-vendored dependency, open3d 0.17): restated here from its published behaviour - greedy max-min
 squared distance starting at point 0, result returned in ORIGINAL index order - parity at this
-boundary is unpinned, so fixtures are defined downstream of the cloud.
+boundary is unpinned; everything UP TO that call (the candidate sets) and the masks are
+pinned by reference-generated fixtures (tests/golden/guidance_*.npz).
 """
 import math
 
 import numpy as np
 
 
-def farthest_point_down_sample(points, num_samples):
-    """open3d.geometry.PointCloud.farthest_point_down_sample restated (points (n, 3) f64): greedy max-min
-    squared distance from point 0, first maximum on ties, survivors in original order.  Runs as a HIP kernel
-    (csrc/pointops.hip k_fps_f64, same float64 arithmetic) when a GPU is visible; the numpy loop below is the
-    host implementation used where there is no device (fixture generation, CPU tests)."""
+def farthest_point_down_sample(points, num_samples, device_id=0):
+    """open3d.geometry.PointCloud.farthest_point_down_sample restated (points (n, 3) f64): greedy max-min squared
+    distance from point 0, first maximum on ties, survivors in original order.  HIP kernel k_fps_f64 (csrc/pointops.hip,
+    float64 arithmetic) on GPU `device_id`; like open3d, asking for more samples than there are points is an error."""
     pts = np.ascontiguousarray(points, dtype=np.float64)
     n = len(pts)
-    if num_samples >= n:
+    if num_samples > n:
+        raise ValueError("farthest_point_down_sample: num_samples (%d) exceeds the cloud size (%d)" % (num_samples, n))
+    if num_samples == n:
         return pts.copy()
-    from . import _hip
-    if pts.shape[1] == 3 and n <= 16384 and _hip.device_count() > 0:
-        import ctypes as C
-        L = _hip.load()
-        sel8 = np.zeros(n, dtype=np.uint8)
-        L.nirrt_fps_f64.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
-        L.nirrt_fps_f64.restype = C.c_int
-        rc = L.nirrt_fps_f64(pts.ctypes.data, n, int(num_samples), sel8.ctypes.data, 0)
-        if rc != 0:
-            raise _hip.NirrtError("nirrt_fps_f64 failed (%d)" % rc)
-        return pts[sel8.astype(bool)]
-    sel = np.zeros(n, dtype=bool)
-    dist = np.full(n, np.inf)
-    far = 0
-    for _ in range(num_samples):
-        sel[far] = True
-        d = ((pts - pts[far]) ** 2).sum(axis=1)
-        np.minimum(dist, d, out=dist)
-        far = int(np.argmax(dist))
-    return pts[sel]
+    if pts.shape[1] != 3:
+        raise ValueError("farthest_point_down_sample expects (n, 3) points")
+    from . import pointops
+    return pts[pointops.farthest_point_down_sample_f64(pts, num_samples, device_id)]
 
 
 def get_point_cloud_mask_around_points(point_cloud, points, neighbor_radius=3):

@@ -8,11 +8,11 @@ on MI355X:
   * at eval time every 1x1 conv + BatchNorm pair is folded into ONE weight/bias (`fold()`), so a
     grouping MLP layer is a single GEMM (+bias+ReLU) over [C_in x K*S] columns - the rocBLAS/hipBLASLt
     fp32 path, i.e. v_mfma_f32_* on gfx950;
-  * farthest point sampling, ball query and 3-NN search run as hand-written HIP kernels from
-    libnirrt_hip.so when the tensors are on the GPU (nirrt_star_amd/csrc/pointops.hip): FPS is one
-    persistent workgroup with the cloud in LDS instead of ~1360 dependent torch launches;
-    ball query is a first-K-in-index-order scan instead of an O(N log N) sort.
-    On CPU tensors (tests, fixtures) the same semantics run as plain torch ops.
+  * farthest point sampling, ball query and 3-NN search are hand-written HIP kernels from
+    libnirrt_hip.so (nirrt_star_amd/csrc/pointops.hip): FPS is one persistent workgroup per cloud
+    instead of ~1360 dependent torch launches; ball query is a first-K-in-index-order scan instead of an
+    O(N log N) sort.  The model therefore runs on 'cuda' only (pointops raises on CPU tensors; the test
+    suite installs oracle/pointops_ref.py for its CPU runs).
 
 Semantics kept from the reference: FPS starts at torch.randint(0, N) drawn from the CPU generator
 (pointnet2_utils.py:77); ball query = first K indices in ascending order with squared distance

@@ -1,12 +1,32 @@
-"""Point operators of the PointNet++ guidance net.
+"""Point operators of the PointNet++ guidance net: hand-written HIP kernels of libnirrt_hip.so (csrc/pointops.hip),
+launched on the current torch stream.
 
-GPU tensors -> hand-written HIP kernels in libnirrt_hip.so (csrc/pointops.hip) on the current torch
-stream; the library being absent is an error (no silent fallback on a GPU).  CPU tensors (explicit
-device='cpu', used by the CPU test-suite and fixture generation) -> the same semantics in torch ops.
+ONE implementation: tensors must live on the GPU; the library being absent, or a CPU tensor, is an error.  (The CPU
+test-suite and the fixture generator install `oracle/pointops_ref.py` through `install_cpu_reference` - that module is
+test infrastructure and is never imported from the package.)
+
+Semantics (reference pointnet_pointnet2/models/pointnet2_utils.py): farthest_point_sample :65-86 with the start index
+drawn by torch.randint on the CPU generator, query_ball_point :89-109 (first K indices in ascending order, padded with
+the first), 3-NN of the feature propagation :295-299.
 """
 import ctypes as C
 
 import torch
+
+_CPU_REF = None
+
+
+def install_cpu_reference(module):
+    """route CPU tensors to `module` (tests / fixture generation only); None removes it again"""
+    global _CPU_REF
+    _CPU_REF = module
+
+
+def _cpu(name):
+    if _CPU_REF is None:
+        raise RuntimeError("nirrt_star_amd.pointops.%s got a CPU tensor: the package only has the HIP kernels "
+                           "(move the model / cloud to 'cuda'); CPU references live in oracle/pointops_ref.py" % name)
+    return getattr(_CPU_REF, name)
 
 
 def _lib():
@@ -17,7 +37,8 @@ def _lib():
         L.nirrt_pn2_fps.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         L.nirrt_pn2_ball_query.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
         L.nirrt_pn2_three_nn.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
-        for f in (L.nirrt_pn2_fps, L.nirrt_pn2_ball_query, L.nirrt_pn2_three_nn):
+        L.nirrt_fps_f64.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+        for f in (L.nirrt_pn2_fps, L.nirrt_pn2_ball_query, L.nirrt_pn2_three_nn, L.nirrt_fps_f64):
             f.restype = C.c_int
         L._pn2_ready = True
     return L
@@ -32,64 +53,55 @@ def _check(rc, what):
         raise RuntimeError("libnirrt_hip %s failed (%d)" % (what, rc))
 
 
-def square_distance(src, dst):
-    """(B, N, 3), (B, M, 3) -> (B, N, M): -2 src.dst^T + |src|^2 + |dst|^2 in that order (pointnet2_utils.py:21-42)"""
-    d = -2 * torch.matmul(src, dst.permute(0, 2, 1))
-    d += torch.sum(src ** 2, -1)[:, :, None]
-    d += torch.sum(dst ** 2, -1)[:, None, :]
-    return d
-
-
 def farthest_point_sample(xyz, npoint, start=None):
     """xyz (B, N, 3) -> indices (B, npoint) long; start (B,) long or drawn with torch.randint on the CPU generator"""
     B, N, _ = xyz.shape
     if start is None:
         start = torch.randint(0, N, (B,), dtype=torch.long)
+    if not xyz.is_cuda:
+        return _cpu("farthest_point_sample")(xyz, npoint, start)
     start = start.to(xyz.device)
-    if xyz.is_cuda:
-        xyz = xyz.contiguous().float()
-        out = torch.empty(B, npoint, dtype=torch.long, device=xyz.device)
-        _check(_lib().nirrt_pn2_fps(xyz.data_ptr(), B, N, npoint, start.contiguous().data_ptr(), out.data_ptr(), _stream(xyz)), "fps")
-        return out
-    cent = torch.zeros(B, npoint, dtype=torch.long)
-    dist = torch.ones(B, N) * 1e10
-    far = start.clone()
-    ar = torch.arange(B)
-    for i in range(npoint):
-        cent[:, i] = far
-        c = xyz[ar, far, :].view(B, 1, 3)
-        d = torch.sum((xyz - c) ** 2, -1)
-        dist = torch.minimum(dist, d)
-        far = torch.max(dist, -1)[1]
-    return cent
+    xyz = xyz.contiguous().float()
+    out = torch.empty(B, npoint, dtype=torch.long, device=xyz.device)
+    _check(_lib().nirrt_pn2_fps(xyz.data_ptr(), B, N, npoint, start.contiguous().data_ptr(), out.data_ptr(), _stream(xyz)), "fps")
+    return out
 
 
 def ball_query(radius, nsample, xyz, new_xyz):
     """first `nsample` indices in ascending order within `radius` of each query, padded with the first -> (B, S, K) long"""
+    if not xyz.is_cuda:
+        return _cpu("ball_query")(radius, nsample, xyz, new_xyz)
     B, N, _ = xyz.shape
     S = new_xyz.shape[1]
-    if xyz.is_cuda:
-        out = torch.empty(B, S, nsample, dtype=torch.long, device=xyz.device)
-        r2 = float(torch.tensor(radius ** 2, dtype=torch.float32))
-        _check(_lib().nirrt_pn2_ball_query(xyz.contiguous().data_ptr(), new_xyz.contiguous().data_ptr(), B, N, S, nsample,
-                                           C.c_float(r2), out.data_ptr(), _stream(xyz)), "ball_query")
-        return out
-    idx = torch.arange(N, dtype=torch.long).view(1, 1, N).repeat(B, S, 1)
-    idx[square_distance(new_xyz, xyz) > radius ** 2] = N
-    idx = idx.sort(dim=-1)[0][:, :, :nsample]
-    first = idx[:, :, 0:1].expand(-1, -1, nsample)
-    return torch.where(idx == N, first, idx)
+    out = torch.empty(B, S, nsample, dtype=torch.long, device=xyz.device)
+    r2 = float(torch.tensor(radius ** 2, dtype=torch.float32))
+    _check(_lib().nirrt_pn2_ball_query(xyz.contiguous().data_ptr(), new_xyz.contiguous().data_ptr(), B, N, S, nsample,
+                                       C.c_float(r2), out.data_ptr(), _stream(xyz)), "ball_query")
+    return out
 
 
 def three_nn(xyz1, xyz2):
     """3 nearest coarse points per fine point -> (squared distances (B, N, 3), indices (B, N, 3))"""
+    if not xyz1.is_cuda:
+        return _cpu("three_nn")(xyz1, xyz2)
     B, N, _ = xyz1.shape
     S = xyz2.shape[1]
-    if xyz1.is_cuda:
-        d = torch.empty(B, N, 3, dtype=torch.float32, device=xyz1.device)
-        i = torch.empty(B, N, 3, dtype=torch.long, device=xyz1.device)
-        _check(_lib().nirrt_pn2_three_nn(xyz1.contiguous().data_ptr(), xyz2.contiguous().data_ptr(), B, N, S, d.data_ptr(),
-                                         i.data_ptr(), _stream(xyz1)), "three_nn")
-        return d, i
-    d, i = square_distance(xyz1, xyz2).sort(dim=-1)
-    return d[:, :, :3], i[:, :, :3]
+    d = torch.empty(B, N, 3, dtype=torch.float32, device=xyz1.device)
+    i = torch.empty(B, N, 3, dtype=torch.long, device=xyz1.device)
+    _check(_lib().nirrt_pn2_three_nn(xyz1.contiguous().data_ptr(), xyz2.contiguous().data_ptr(), B, N, S, d.data_ptr(),
+                                     i.data_ptr(), _stream(xyz1)), "three_nn")
+    return d, i
+
+
+def farthest_point_down_sample_f64(pts, num_samples, device_id=0):
+    """float64 greedy max-min down-sampling of a host cloud (n, 3) -> bool mask (n,) of the survivors (k_fps_f64)"""
+    import numpy as np
+    from . import _hip
+    n = len(pts)
+    if _hip.device_count() <= 0:
+        return _cpu("farthest_point_down_sample_f64")(pts, num_samples)
+    sel8 = np.zeros(n, dtype=np.uint8)
+    rc = _lib().nirrt_fps_f64(pts.ctypes.data, n, int(num_samples), sel8.ctypes.data, int(device_id))
+    if rc != 0:
+        raise _hip.NirrtError("nirrt_fps_f64 failed (%d)" % rc)
+    return sel8.astype(bool)

@@ -1,0 +1,68 @@
+"""CPU references of the point operators (TEST INFRASTRUCTURE ONLY - see oracle/oracle.py).
+
+The product package (nirrt_star_amd.pointops / pointcloud) has ONE implementation of these operators, the HIP kernels
+of csrc/pointops.hip, and raises on CPU tensors.  The CPU test-suite, the fixture generator (tests/golden/make_golden.py)
+and the GPU tests that compare "HIP vs plain torch / numpy" install this module through
+`nirrt_star_amd.pointops.install_cpu_reference(oracle.pointops_ref)`; only then are CPU tensors routed here.
+
+Restated from the reference, plain torch ops in fp32 / numpy in fp64:
+  square_distance          pointnet_pointnet2/models/pointnet2_utils.py:21-42
+  farthest_point_sample    :65-86   (start index injected by the caller)
+  ball_query               :89-109  (query_ball_point: first K in ascending index order, padded with the first)
+  three_nn                 :295-299 (sort of the distance matrix, first three)
+  farthest_point_down_sample_f64   open3d 0.17 PointCloud.farthest_point_down_sample as recollected in SURVEY.md §8c
+                           (start at point 0, greedy max-min squared distance, survivors in original order) - unpinned
+"""
+import numpy as np
+import torch
+
+
+def square_distance(src, dst):
+    d = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    d += torch.sum(src ** 2, -1)[:, :, None]
+    d += torch.sum(dst ** 2, -1)[:, None, :]
+    return d
+
+
+def farthest_point_sample(xyz, npoint, start):
+    B, N, _ = xyz.shape
+    cent = torch.zeros(B, npoint, dtype=torch.long)
+    dist = torch.ones(B, N) * 1e10
+    far = start.clone()
+    ar = torch.arange(B)
+    for i in range(npoint):
+        cent[:, i] = far
+        c = xyz[ar, far, :].view(B, 1, 3)
+        d = torch.sum((xyz - c) ** 2, -1)
+        dist = torch.minimum(dist, d)
+        far = torch.max(dist, -1)[1]
+    return cent
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    idx = torch.arange(N, dtype=torch.long).view(1, 1, N).repeat(B, S, 1)
+    idx[square_distance(new_xyz, xyz) > radius ** 2] = N
+    idx = idx.sort(dim=-1)[0][:, :, :nsample]
+    first = idx[:, :, 0:1].expand(-1, -1, nsample)
+    return torch.where(idx == N, first, idx)
+
+
+def three_nn(xyz1, xyz2):
+    d, i = square_distance(xyz1, xyz2).sort(dim=-1)
+    return d[:, :, :3], i[:, :, :3]
+
+
+def farthest_point_down_sample_f64(pts, num_samples):
+    """pts (n, 3) float64 -> bool mask (n,) of the survivors"""
+    n = len(pts)
+    sel = np.zeros(n, dtype=bool)
+    dist = np.full(n, np.inf)
+    far = 0
+    for _ in range(num_samples):
+        sel[far] = True
+        d = ((pts - pts[far]) ** 2).sum(axis=1)
+        np.minimum(dist, d, out=dist)
+        far = int(np.argmax(dist))
+    return sel

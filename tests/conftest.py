@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # the package has only the HIP point operators; CPU tensors (CPU tests, fixtures) go to the oracle's torch / numpy ones
+    from nirrt_star_amd import pointops
+    from oracle import pointops_ref
+    pointops.install_cpu_reference(pointops_ref)
 
 
 def load_golden(name):

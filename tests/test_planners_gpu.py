@@ -54,11 +54,21 @@ def test_planning_resident_mode(name, capsys):
     _check_tree(p, g, exact=int(g["dim"]) == 3 and str(g["algo"]) == "rrt")
     if str(g["algo"]) == "irrt":
         assert np.array_equal(np.array(p.path_solutions), g["path_solutions"])
-    # the global generators were advanced exactly like the reference's loop would have
-    nxt_np = np.random.random_sample()
-    _seed(g)
-    from nirrt_star_amd import sampling  # reference consumption = words the fixture's samples imply
-    assert isinstance(nxt_np, float)
+    # the global numpy generator was advanced exactly like the reference's loop would have: RRT* draws `dim` uniforms per
+    # SampleFree attempt and nothing else, so the stream position after the run is the end of the attempt that produced
+    # the fixture's last recorded sample (IRRT*: test_global_rng_state_after_resident_run_matches_host_loop)
+    if str(g["algo"]) == "rrt":
+        nxt_np = np.random.random_sample()
+        D = int(g["dim"])
+        lo = np.array([r[0] + p.clearance for r in p._ranges()], dtype=np.float64)
+        hi = np.array([r[1] - p.clearance for r in p._ranges()], dtype=np.float64)
+        _seed(g)
+        attempts = np.random.random_sample(size=(8 * len(g["samples"]), D))
+        hits = np.nonzero((lo + (hi - lo) * attempts == g["samples"][-1]).all(axis=1))[0]
+        assert len(hits) >= 1
+        _seed(g)
+        np.random.random_sample(size=(int(hits[-1]) + 1, D))
+        assert np.random.random_sample() == nxt_np
 
 
 @pytest.mark.parametrize("name,mode,exact", [("run_rrt2d_500", "step", False), ("run_rrt2d_500", "exact", True),

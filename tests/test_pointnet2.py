@@ -71,19 +71,21 @@ def test_gpu_hip_pointops_match_reference():
 
 @pytest.mark.gpu
 def test_gpu_pointops_equal_cpu_semantics():
+    """HIP kernels vs the plain-torch restatement of the reference operators (oracle/pointops_ref.py)"""
     from nirrt_star_amd import pointops
+    from oracle import pointops_ref as ref
     torch.manual_seed(0)
     xyz = torch.rand(2, 2048, 3)
     start = torch.tensor([5, 77])
-    a = pointops.farthest_point_sample(xyz, 256, start)
+    a = ref.farthest_point_sample(xyz, 256, start)
     b = pointops.farthest_point_sample(xyz.cuda(), 256, start).cpu()
     assert torch.equal(a, b)
     new = torch.gather(xyz, 1, a[..., None].expand(2, 256, 3))
     for r, k in ((0.1, 16), (0.2, 32)):
-        ga = pointops.ball_query(r, k, xyz, new)
+        ga = ref.ball_query(r, k, xyz, new)
         gb = pointops.ball_query(r, k, xyz.cuda(), new.cuda()).cpu()
         assert (ga == gb).float().mean() > 0.999   # membership on the r^2 boundary depends on the matmul rounding
-    da, ia = pointops.three_nn(xyz, new)
+    da, ia = ref.three_nn(xyz, new)
     db, ib = pointops.three_nn(xyz.cuda(), new.cuda())
     assert (ia == ib.cpu()).float().mean() > 0.999
     assert torch.allclose(da, db.cpu(), atol=1e-6)
@@ -94,15 +96,16 @@ def test_gpu_pointops_equal_cpu_semantics():
 def test_gpu_fps_every_kernel_variant(n, s):
     """each (points-per-lane, waves) instantiation of k_fps_wave and the LDS k_fps pick the reference's indices"""
     from nirrt_star_amd import pointops
+    from oracle import pointops_ref as ref
     torch.manual_seed(n)
     xyz = torch.rand(3, n, 3)
     xyz[1, : n // 2] = xyz[1, n // 2: 2 * (n // 2)]        # duplicated points: ties resolved to the lowest index
     start = torch.tensor([0, n - 1, n // 3])
-    a = pointops.farthest_point_sample(xyz, s, start)
+    a = ref.farthest_point_sample(xyz, s, start)
     b = pointops.farthest_point_sample(xyz.cuda(), s, start).cpu()
     assert torch.equal(a, b)
     new = torch.gather(xyz, 1, a[..., None].expand(3, s, 3))
-    da, ia = pointops.three_nn(xyz, new)
+    da, ia = ref.three_nn(xyz, new)
     db, ib = pointops.three_nn(xyz.cuda(), new.cuda())
     assert (ia == ib.cpu()).float().mean() > 0.99
     assert torch.allclose(da, db.cpu(), atol=1e-6)
@@ -110,18 +113,16 @@ def test_gpu_fps_every_kernel_variant(n, s):
 
 @pytest.mark.gpu
 def test_gpu_cloud_downsampling_equals_host_restatement():
-    """k_fps_f64 == the numpy restatement of open3d's farthest_point_down_sample (same float64 arithmetic)"""
+    """k_fps_f64 == the numpy restatement of open3d's farthest_point_down_sample (oracle/pointops_ref.py, same float64
+    arithmetic); asking for more samples than points is an error like in open3d"""
     from nirrt_star_amd import pointcloud
+    from oracle import pointops_ref as ref
     rng = np.random.default_rng(5)
-    for n, s in ((9000, 2048), (3000, 2048), (2500, 100)):
+    for n, s in ((9000, 2048), (3000, 2048), (2500, 100), (10240, 2048)):
         pts = np.concatenate([rng.uniform(0, 224, size=(n, 2)), np.zeros((n, 1))], axis=1)
-        got = pointcloud.farthest_point_down_sample(pts, s)            # HIP (a device is visible)
-        sel = np.zeros(n, dtype=bool)
-        dist = np.full(n, np.inf)
-        far = 0
-        for _ in range(s):
-            sel[far] = True
-            d = ((pts - pts[far]) ** 2).sum(axis=1)
-            np.minimum(dist, d, out=dist)
-            far = int(np.argmax(dist))
-        assert np.array_equal(got, pts[sel])
+        got = pointcloud.farthest_point_down_sample(pts, s)            # HIP
+        assert np.array_equal(got, pts[ref.farthest_point_down_sample_f64(pts, s)])
+    pts3 = rng.uniform(0, 50, size=(7000, 3))
+    assert np.array_equal(pointcloud.farthest_point_down_sample(pts3, 2048), pts3[ref.farthest_point_down_sample_f64(pts3, 2048)])
+    with pytest.raises(ValueError):
+        pointcloud.farthest_point_down_sample(pts3[:10], 11)
