@@ -1,31 +1,39 @@
 #!/usr/bin/env python3
-"""bench.py — RRT*-family iterations/s while growing 50k-node trees on random_2d (BASELINE.json).
+"""bench.py — RRT*-family iterations/s while growing 50k-node trees on random_2d / random_3d (BASELINE.json).
 
 Workload (BASELINE.json configs[1]): `irrt_star random_2d, 50k iters`, batched on one MI355X:
 B independent planning problems (224x224 world, 30 circle obstacles, clearance 3, step_len 10), each
 planned for `--iters` iterations (default 50 000) by the device-resident loop - ONE persistent
 workgroup per tree; sampling (SampleFree, then informed once a solution exists), nearest, steer,
 collision, Near, choose-parent, rewire, goal bookkeeping and best-solution tracking all happen in the
-kernel.  `--algo rrt` runs plain RRT* on the same problems (uniform sampling, no solution tracking).
+kernel.  `--algo rrt` runs plain RRT* on the same problems (uniform sampling, no solution tracking),
+`--dim 3` the random_3d worlds (boxes + balls), `--world b30r16` the r in [16, 24] circles of SURVEY.md §8d.
 
 One "step" = one pass of that loop over the whole batch (B x iters iterations), starting from fresh
 one-vertex trees.  Inputs (the raw MT19937 outputs of each problem's seeded numpy / python generators)
 are resident in HBM before the timed region.  N GPUs = N processes (torch.distributed / RCCL), each
 with its own B problems (weak scaling); the only collectives are the timing protocol's barrier /
-max-reduce and a gather of per-rank iteration counts.
+max-reduce and a gather of per-rank iteration counts.  `--gpus N` without a launcher re-executes itself
+under `python -m torch.distributed.run --nproc-per-node N` (the driver's own torchrun launch is used as is).
 
 Prints ONE JSON line (rank 0): the driver's contract fields plus
-  roofline     — HBM roofline of the persistent kernel: algorithmic bytes (vertices the REFERENCE algorithm's nearest
-                 + Near scans touch x dim x 8 B, counted exactly in the kernel) / HIP-event kernel time; the kernel
-                 itself answers both through a grid index and visits far fewer (streamed_GBps, traffic)
-  cpu_baseline — the oracle (oracle/nirrt_oracle.c, C port of the reference loop incl. sampling) on this
-                 box's host, 1 core, on problem 0 of the same batch for a bounded time
-  time_to_first_solution — iterations / seconds until c_best first becomes finite (median over the batch)
+  roofline     — HBM roofline of the persistent kernel.  `achieved` = bytes the IMPLEMENTED algorithm has to move
+                 (counted by the kernel: visited index slots, chain records, candidate records, re-costed vertices, list
+                 re-evaluations, inserts, index rebuilds - nirrt_star_amd/_hip.useful_bytes) / HIP-event kernel time;
+                 `traffic` = HBM-side bytes of a separate rocprofv3 --pmc pass of this exact configuration (named in
+                 `traffic_source`; null when none was collected) and `wasted_traffic_ratio` = traffic / useful bytes;
+                 `reference_scan_equiv_GBps` = what the REFERENCE algorithm's two O(n) scans per iteration would have
+                 had to stream in the same time (a speed-up over the scan algorithm, not a roofline figure)
+  cpu_baseline — the oracle (oracle/nirrt_oracle.c, C port of the reference loop incl. sampling) on this box's host
+                 cores: C independent processes, one problem each, bounded iteration count
+  time_to_first_solution — measured NIRRT_F_STOP_FIRST launches: problems run ONE AT A TIME (kernel time of each
+                 launch) and as one batch (per-tree device clock from loop start to the first finite c_best)
 """
 import argparse
 import json
 import os
 import random
+import subprocess
 import sys
 import time
 
@@ -36,23 +44,32 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.3 TB/s achievable)
 REF_PY = {"rrt": 153.0, "irrt": 43.0}  # reference numpy path in the survey container: context only
+WORLDS = {"b30": "224x224, 30 circle obstacles r in [8, 12]", "b30r16": "224x224, 30 circle obstacles r in [16, 24], start / goal in one free component",
+          "ref2d": "224x224, 8-12 rectangles (16-24) + 8-12 circles r in [16, 24]"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--trees", type=int, default=4096, help="problems per GPU per step (4096 = 16 one-wave workgroups per CU, all resident)")
+    ap.add_argument("--trees", type=int, default=4096, help="problems per GPU per step (4096 = 16 one-wave workgroups per CU, all resident; more queue up behind them)")
     ap.add_argument("--iters", type=int, default=50000, help="planner iterations per problem (tree capacity)")
     ap.add_argument("--dim", type=int, default=2)
     ap.add_argument("--algo", default="irrt", choices=["irrt", "rrt"])
-    ap.add_argument("--world", default="b30")
+    ap.add_argument("--world", default="b30", choices=sorted(WORLDS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
-    ap.add_argument("--traffic-gb", type=float, default=None,
-                    help="HBM GB per launch from a separate rocprofv3 --pmc run (default: profiles/r01_traffic.json if it has this config)")
-    return ap.parse_args()
+    ap.add_argument("--cpu-iters", type=int, default=20000, help="iterations each CPU-baseline process runs")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline processes (0 = min(host cores, 32))")
+    ap.add_argument("--no-ttfs", action="store_true")
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "r02_traffic.json"),
+                    help="PMC traffic table written by scripts/collect_traffic.py (an entry is used only if its key names this exact configuration)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / process-group / timing protocol only, no GPU work (CPU test of --gpus N)")
+    return ap.parse_args(argv)
+
+
+def config_key(args):
+    return "%s_%dd_%s_%dx%d" % (args.algo, args.dim, args.world if args.dim == 2 else "ref3d", args.trees, args.iters)
 
 
 def make_problems(args, rank):
@@ -62,19 +79,26 @@ def make_problems(args, rank):
     probs, cache = [], {}
     for b in range(args.trees):
         pid = rank * args.trees + b
-        if args.dim == 2:
-            w = pid % 250
-            if w not in cache:
-                cache[w] = worlds.random_world_2d(w, args.world)
-            pr = worlds.problem_2d(cache[w], (pid // 250) % 4)
-            pr["clearance"] = 3
-        else:
-            np.random.seed(pid)
-            pr = worlds.problem_3d(worlds.random_world_3d(pid % 1000))
-            pr["clearance"] = 2
-        pr["pid"] = pid
-        probs.append(pr)
+        probs.append(make_problem(args, pid, cache))
     return probs
+
+
+def make_problem(args, pid, cache=None):
+    from nirrt_star_amd import worlds
+    cache = {} if cache is None else cache
+    if args.dim == 2:
+        w = pid % 250
+        if w not in cache:
+            kind, rr = {"b30": ("b30", None), "b30r16": ("b30", (16, 24)), "ref2d": ("ref2d", None)}[args.world]
+            cache[w] = worlds.random_world_2d(w, kind, circle_radius_range=rr)
+        pr = worlds.problem_2d(cache[w], (pid // 250) % 4)
+        pr["clearance"] = 3
+    else:
+        np.random.seed(pid)
+        pr = worlds.problem_3d(worlds.random_world_3d(pid % 1000))
+        pr["clearance"] = 2
+    pr["pid"] = pid
+    return pr
 
 
 def word_budgets(args):
@@ -86,19 +110,80 @@ def word_budgets(args):
     return it * 6 * 40 + 4096, 0                 # 3D informed sampling stays on the numpy stream
 
 
+def problem_words(args, pid, n_np, n_py):
+    """raw generator outputs of problem `pid`: np.random.seed(1000 + pid); random.seed(1000 + pid)"""
+    from nirrt_star_amd import sampling
+    np.random.seed(1000 + pid)
+    random.seed(1000 + pid)
+    return sampling.peek_np_words(n_np), (sampling.peek_py_words(n_py) if n_py else None)
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with no launcher around it: become N ranks (one per GPU) ourselves."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(respawn_under_torchrun(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
+    have_gpu = torch.cuda.is_available()
+    if not have_gpu and not args.dry_run:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    if have_gpu:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if have_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    dev = "cuda:%d" % local_rank if have_gpu else "cpu"
+
+    def barrier():
+        if have_gpu:
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        if have_gpu:
+            torch.cuda.synchronize()
+
+    def reduce_time_and_work(elapsed, work):
+        tot = torch.tensor([elapsed, float(work)], dtype=torch.float64, device=dev)
+        if world > 1:
+            tmax = tot.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            return float(tmax[0].item()), float(tot[1].item())
+        return elapsed, float(work)
+
+    if args.dry_run:
+        barrier()
+        t0 = time.perf_counter()
+        barrier()
+        emax, total = reduce_time_and_work(time.perf_counter() - t0, args.trees * args.iters * args.steps)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "work_all_ranks": total, "config": {"workload": config_key(args)}}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from nirrt_star_amd import _hip, build, sampling
     build.build()
@@ -114,36 +199,25 @@ def main():
         trees.append(t)
     # inputs: each problem's generator outputs (np.random.seed(s); random.seed(s)), resident in HBM
     n_np, n_py = word_budgets(args)
-    dev = "cuda:%d" % local_rank
     py_stride = max(n_py, 1)
     d_np = torch.empty((B, n_np), dtype=torch.int32, device=dev)
     d_py = torch.empty((B, py_stride), dtype=torch.int32, device=dev)
-    cpu_np = cpu_py = None
     CH = 256   # generated and uploaded in chunks: the host never holds more than ~1 GB of the ~16 GB of words
     for c0 in range(0, B, CH):
         c1 = min(B, c0 + CH)
         h_np = np.empty((c1 - c0, n_np), dtype=np.uint32)
         h_py = np.empty((c1 - c0, py_stride), dtype=np.uint32)
         for b in range(c0, c1):
-            np.random.seed(1000 + probs[b]["pid"])
-            random.seed(1000 + probs[b]["pid"])
-            h_np[b - c0] = sampling.peek_np_words(n_np)
+            w_np, w_py = problem_words(args, probs[b]["pid"], n_np, n_py)
+            h_np[b - c0] = w_np
             if n_py:
-                h_py[b - c0] = sampling.peek_py_words(n_py)
-        if c0 == 0:   # problem 0's words also feed the CPU baseline
-            cpu_np, cpu_py = h_np[0].copy(), (h_py[0].copy() if n_py else None)
+                h_py[b - c0] = w_py
         d_np[c0:c1].copy_(torch.from_numpy(h_np.view(np.int32)))
         d_py[c0:c1].copy_(torch.from_numpy(h_py.view(np.int32)))
     np_tab = [(d_np.data_ptr() + 4 * n_np * b, n_np) for b in range(B)]
     py_tab = [(d_py.data_ptr() + 4 * py_stride * b, n_py) for b in range(B)] if n_py else None
     torch.cuda.synchronize()
     del h_np, h_py
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     def one_step(want_trace=False):
         for t in trees:
@@ -152,13 +226,14 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    kernel_ms, scan_elems, alg_elems, done_iters = [], [], [], []
+    kernel_ms, useful, alg_elems, done_iters, visit_b = [], [], [], [], []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         r = one_step()
         kernel_ms.append(r["kernel_ms"])
-        scan_elems.append(int(r["scan_elems"].sum()))
+        useful.append(_hip.useful_bytes(r["stats"], D))
+        visit_b.append(float(r["stats"][:, 1].sum()))
         alg_elems.append(int(r["alg_elems"].sum()))
         done_iters.append(int(r["iters_done"].sum()))
     barrier()
@@ -166,102 +241,126 @@ def main():
     n_final = [t.n for t in trees]
     n_sol = [len(trees[b].solutions) for b in range(0, B, max(1, B // 16))]
     short = int((r["iters_done"] < iters).sum())
-
-    tot = torch.tensor([elapsed, float(sum(done_iters))], dtype=torch.float64, device="cuda")
-    if world > 1:
-        tmax = tot.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed_max, total_iters = float(tmax[0].item()), float(tot[1].item())
-    else:
-        elapsed_max, total_iters = elapsed, float(sum(done_iters))
+    st = r["stats"].astype(np.float64)
+    tree_s = (st[:, 15] - st[:, 14]) / 1e8          # per-tree seconds inside the last launch (100 MHz device wall clock)
+    elapsed_max, total_iters = reduce_time_and_work(elapsed, sum(done_iters))
     value = total_iters / elapsed_max
 
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
-        # algorithmic bytes: the reference algorithm's two O(n) coordinate passes per iteration
-        # (nearest_neighbor + find_near_neighbors), n*D*8 bytes each, counted exactly by the kernel.  The kernel
-        # itself streams less: the Near pass of iteration k also answers iteration k+1's nearest query.
-        alg_bytes = float(np.mean(alg_elems)) * D * 8.0
-        streamed_bytes = float(np.mean(scan_elems)) * D * 8.0
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        # time to first solution (untimed extra pass over a slice of the batch, with the per-iteration trace)
-        sub = list(range(0, B, max(1, B // 64)))
-        for b in sub:
-            trees[b].reset()
-        tr = _hip.run_sampling([trees[b] for b in sub], min(iters, 5000), [np_tab[b] for b in sub],
-                               [py_tab[b] for b in sub] if py_tab else None, flags=flags | _hip.F_GOAL_SCAN * (args.algo == "rrt"),
-                               want_trace=True, on_device=True)
-        first = np.array([int(np.argmax(np.isfinite(c))) + 1 if np.isfinite(c).any() else -1 for c in tr["cost_trace"]])
-        found = first[first > 0]
-        ttfs_it = float(np.median(found)) if len(found) else None
-        ttfs_s = (ttfs_it / min(iters, 5000)) * tr["kernel_ms"] * 1e-3 if ttfs_it else None   # resident loop, batch running concurrently
+        k_s = k_ms * 1e-3
+        useful_b = float(np.mean(useful))
+        achieved = useful_b / k_s / 1e9
+        traffic, traffic_src = measured_traffic(args)
+        per_it = st.sum(axis=0) / max(1.0, st[:, 13].sum())
         out = {
             "metric": "RRT* iters/sec (50k-node tree), random_%dd" % D,
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s_star random_%dd (%s: 224x224, 30 circle obstacles), %d problems/GPU x %d iters, "
-                                   "device-resident batched loop with in-kernel sampling" % (args.algo, D, args.world, B, iters)
-                       if D == 2 else "%s_star random_3d, %d problems/GPU x %d iters" % (args.algo, B, iters),
-                       "trees_per_gpu": B, "iters": iters, "dim": D, "step_len": 10, "clearance": probs[0]["clearance"],
-                       "mean_final_vertices": float(np.mean(n_final)), "mean_solutions_per_tree": float(np.mean(n_sol)),
-                       "trees_stopped_early": short,
-                       "per_tree_iters_per_s": iters / (k_ms * 1e-3)},
+            "config": {"workload": ("%s_star random_2d (%s: %s; clearance 3, step_len 10), %d problems/GPU x %d iters, "
+                                    "device-resident batched loop with in-kernel sampling" % (args.algo, args.world, WORLDS[args.world], B, iters))
+                       if D == 2 else ("%s_star random_3d (50^3, 6-9 boxes + 6-9 balls; clearance 2, step_len 10), %d problems/GPU x %d iters, "
+                                       "device-resident batched loop with in-kernel sampling" % (args.algo, B, iters)),
+                       "key": config_key(args), "trees_per_gpu": B, "iters": iters, "dim": D, "step_len": 10,
+                       "clearance": probs[0]["clearance"], "mean_final_vertices": float(np.mean(n_final)),
+                       "mean_solutions_per_tree": float(np.mean(n_sol)), "trees_stopped_early": short,
+                       "per_tree_seconds": {"mean": float(tree_s.mean()), "median": float(np.median(tree_s)), "max": float(tree_s.max())}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args),
-                         "kernel": "k_run_sample<%d>" % D, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "scan_bytes_streamed_per_launch": streamed_bytes,
-                         "streamed_GBps": streamed_bytes / (k_ms * 1e-3) / 1e9},
-            "time_to_first_solution": {"median_iterations": ttfs_it, "median_seconds_in_batch": ttfs_s,
-                                       "problems": len(sub), "solved_within_%d" % min(iters, 5000): int(len(found))},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "wasted_traffic_ratio": (traffic / useful_b) if traffic else None,
+                         "kernel": "k_run_sample<%d>" % D, "kernel_ms": k_ms,
+                         "useful_bytes_per_launch": useful_b, "visited_index_bytes_per_launch": float(np.mean(visit_b)),
+                         "per_iteration": {"visited_slots": per_it[0], "visit_bytes": per_it[1], "near_members": per_it[2],
+                                           "members_spilled": per_it[3], "chain_records": per_it[4], "rewire_candidates": per_it[5],
+                                           "rewired": per_it[6], "recosted": per_it[7], "list_entries": per_it[8],
+                                           "useful_bytes": useful_b / max(1.0, float(np.mean(done_iters)))},
+                         "reference_scan_equiv_GBps": float(np.mean(alg_elems)) * D * 8.0 / k_s / 1e9},
             "reference_python_survey_container_its": REF_PY[args.algo],
         }
+        if not args.no_ttfs:
+            out["time_to_first_solution"] = time_to_first_solution(args, trees, np_tab, py_tab, flags)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, probs[0], cpu_np, cpu_py)
+            out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def time_to_first_solution(args, trees, np_tab, py_tab, flags):
+    """Measured, not interpolated: NIRRT_F_STOP_FIRST launches on the first problems of the batch.  `single` = one
+    problem per launch (the whole GPU serves one tree, 256-thread kernels): HIP-event time of the launch.  `batch` =
+    the same problems in ONE launch: per-tree device clock (stats[14..15]) from the start of the tree's loop to the
+    iteration that produced its first finite best cost."""
+    from nirrt_star_amd import _hip
+    cap = min(args.iters, 20000)
+    fl = flags | _hip.F_STOP_FIRST | (_hip.F_GOAL_SCAN if args.algo == "rrt" else 0)
+    n_single, n_batch = min(16, len(trees)), min(256, len(trees))
+    single_ms, single_it = [], []
+    for b in range(n_single):
+        trees[b].reset()
+        r = _hip.run_sampling([trees[b]], cap, [np_tab[b]], [py_tab[b]] if py_tab else None, flags=fl, want_trace=True, on_device=True)
+        it = int(r["iters_done"][0])
+        if it > 0 and np.isfinite(r["cost_trace"][0, it - 1]):
+            single_ms.append(r["kernel_ms"])
+            single_it.append(it)
+    sub = list(range(n_batch))
+    for b in sub:
+        trees[b].reset()
+    r = _hip.run_sampling([trees[b] for b in sub], cap, [np_tab[b] for b in sub], [py_tab[b] for b in sub] if py_tab else None,
+                          flags=fl, want_trace=True, on_device=True)
+    its = r["iters_done"]
+    found = np.array([its[j] > 0 and np.isfinite(r["cost_trace"][j, its[j] - 1]) for j in range(len(sub))])
+    secs = (r["stats"][:, 15] - r["stats"][:, 14]) / 1e8
+    return {"single": {"problems": n_single, "solved": len(single_ms), "median_seconds": float(np.median(single_ms)) * 1e-3 if single_ms else None,
+                       "median_iterations": float(np.median(single_it)) if single_it else None},
+            "batch": {"problems": n_batch, "solved": int(found.sum()), "launch_ms": r["kernel_ms"],
+                      "median_seconds": float(np.median(secs[found])) if found.any() else None,
+                      "max_seconds": float(secs[found].max()) if found.any() else None,
+                      "median_iterations": float(np.median(its[found])) if found.any() else None},
+            "iteration_cap": cap, "how": "NIRRT_F_STOP_FIRST launches; single = HIP-event time per one-problem launch, "
+                                         "batch = per-tree device wall clock inside one launch"}
+
+
 def measured_traffic(args):
-    """HBM bytes per launch from the PMC passes committed under profiles/ (collected separately, as the
-    profiling guide prescribes); None for configurations that were not profiled."""
-    if args.traffic_gb:
-        return args.traffic_gb * 1e9
+    """HBM-side bytes per launch from the PMC passes of scripts/collect_traffic.py (collected separately, as the profiling
+    guide prescribes) - only if the table holds THIS configuration; the source is named in the line."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        with open(args.traffic_file) as f:
             tab = json.load(f)
-        return tab["%s_%dd_%dx%d" % (args.algo, args.dim, args.trees, args.iters)]["traffic_bytes"]
+        e = tab["entries"][config_key(args)]
+        return float(e["traffic_bytes"]), {"file": os.path.relpath(args.traffic_file, ROOT), "collected": e.get("collected"),
+                                           "kernel": e.get("kernel"), "formula": tab.get("formula")}
     except Exception:
+        return None, None
+
+
+def cpu_baseline(args):
+    """The oracle (C port of the reference loop, incl. sampling and the reference's un-cached cost walks) on this box's
+    host cores: C independent processes (oracle/cpu_bench.py), process i plans problem i of the batch for --cpu-iters
+    iterations from its own seeded generators.  value = iterations of all processes / wall time of the slowest."""
+    procs = args.cpu_procs or min(os.cpu_count() or 1, 32)
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--algo", args.algo, "--dim", str(args.dim),
+           "--world", args.world, "--iters", str(min(args.cpu_iters, args.iters)), "--cap", str(args.iters)]
+    t0 = time.perf_counter()
+    ps = [subprocess.Popen(cmd + ["--pid", str(i)], stdout=subprocess.PIPE, text=True) for i in range(procs)]
+    res = []
+    for p in ps:
+        outp = p.communicate()[0]
+        if p.returncode == 0:
+            res.append(json.loads(outp.strip().splitlines()[-1]))
+    wall = time.perf_counter() - t0
+    if not res:
         return None
-
-
-def cpu_baseline(args, pr, npw, pyw):
-    """The oracle (C port of the reference loop, incl. sampling and the reference's un-cached
-    find_best_path_solution) on problem 0 of this very batch: 1 host core, at most --cpu-budget-s."""
-    from nirrt_star_amd import sampling
-    from oracle import oracle as orc
-    orc.build()
-    o = orc.OracleTree(args.dim, args.iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env_dict"])
-    frame = sampling.informed_frame(pr["x_start"], pr["x_goal"])
-    done, np_pos, py_pos, t0 = 0, 0, 0, time.perf_counter()
-    chunk = 1000
-    while done < args.iters and time.perf_counter() - t0 < args.cpu_budget_s:
-        r = o.run_sampling(min(chunk, args.iters - done), npw[np_pos:], pyw[py_pos:] if pyw is not None else None,
-                           irrt=args.algo == "irrt", frame=frame)
-        if r["iters_done"] == 0:
-            break
-        done += r["iters_done"]
-        np_pos += r["np_used"]
-        py_pos += r["py_used"]
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": "problem 0 of the batch, first %d of %d iterations (tree grown to %d vertices, %d solutions) in %.1f s; "
-                      "the CPU rate falls as the tree grows, so a truncated sample flatters the CPU"
-                      % (done, args.iters, o.n, len(o.solutions), dt)}
+    loop_s = max(r["seconds"] for r in res)
+    rates = sorted(r["iters"] / r["seconds"] for r in res)
+    return {"value": sum(r["iters"] for r in res) / loop_s, "unit": "iterations/s", "cores": len(res), "kind": "port",
+            "single_core_median": rates[len(rates) // 2], "single_core_min": rates[0], "single_core_max": rates[-1],
+            "sample": "%d processes x first %d of %d iterations of problems 0..%d of the batch (oracle loop only, %.1f s for the "
+                      "slowest, %.1f s incl. start-up); the per-iteration cost grows with the tree, so a truncated sample flatters the CPU"
+                      % (len(res), res[0]["iters"], args.iters, len(res) - 1, loop_s, wall)}
 
 
 if __name__ == "__main__":

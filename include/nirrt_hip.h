@@ -42,6 +42,8 @@ extern "C" {
 #define NIRRT_E_CLOUD (-6)    /* nirrt_run + NIRRT_F_PNG: guidance cloud refresh due (not an error) */
 
 #define NIRRT_MAX_OBSTACLES 64 /* per kind (round / box) */
+#define NIRRT_OBSTACLE_POOL 640 /* = 4 * 64 + 6 * 64: the tables live in LDS, 4 * n_round + 6 * n_box doubles of them */
+#define NIRRT_N_STATS 20       /* per-tree counters of a nirrt_run launch, see nirrt_run_args.stats */
 #define NIRRT_NEAR_CAPACITY 0 /* unlimited: Near-set scratch is sized like the tree */
 
 typedef struct nirrt_tree nirrt_tree;
@@ -190,6 +192,17 @@ typedef struct nirrt_run_args {
     int64_t *alg_elems;  /* optional (n_trees,): vertices the reference algorithm scans for the same iterations - n per
                             nearest_neighbor + n per find_near_neighbors - i.e. algorithmic bytes = alg_elems * dim * 8
                             (B_iter = 2*n*D*8) */
+    int64_t *stats;      /* optional (n_trees, NIRRT_N_STATS): what this launch did per tree -
+                            [0] slots visited by the fused nearest / Near passes, [1] bytes those visits read,
+                            [2] Near members, [3] members spilled out of LDS, [4] 48-byte chain records walked,
+                            [5] rewire candidates examined, [6] vertices rewired, [7] vertices re-costed,
+                            [8] solution / goal-candidate list entries re-evaluated, [9] vertices inserted,
+                            [10] vertices passed through index rebuilds, [11] widened nearest visits,
+                            [12] whole-tree visits, [13] iterations, [14] / [15] device wall clock (100 MHz ticks)
+                            when the tree's loop started / ended, [16] = alg_elems, [17..19] reserved */
+    const int64_t *iters_each; /* optional (n_trees,), sampling mode: tree i runs at most iters_each[i] <= iters iterations
+                            (trees of one batch resumed after stopping at different iterations, e.g. NIRRT_E_CLOUD);
+                            cost_trace rows stay `iters` long */
 } nirrt_run_args;
 int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *args);
 

@@ -57,7 +57,25 @@ class RunArgs(C.Structure):
                 ("cost_trace", C.POINTER(C.c_double)), ("np_used", C.POINTER(C.c_int64)),
                 ("py_used", C.POINTER(C.c_int64)), ("iters_done", C.POINTER(C.c_int64)),
                 ("status", C.POINTER(C.c_int32)), ("kernel_ms", C.POINTER(C.c_double)),
-                ("scan_elems", C.POINTER(C.c_int64)), ("alg_elems", C.POINTER(C.c_int64))]
+                ("scan_elems", C.POINTER(C.c_int64)), ("alg_elems", C.POINTER(C.c_int64)),
+                ("stats", C.POINTER(C.c_int64)), ("iters_each", C.POINTER(C.c_int64))]
+
+N_STATS = 20
+STAT_NAMES = ["visited", "visit_bytes", "members", "spilled", "hop_records", "rewire_candidates", "rewired", "recosted",
+              "list_entries", "inserted", "rebuilt", "revisits", "whole_tree_visits", "iterations", "t0_ticks", "t1_ticks",
+              "alg_elems", "r17", "r18", "r19"]
+
+
+def useful_bytes(stats, dim):
+    """Bytes the IMPLEMENTED algorithm has to move for what a launch did (per tree or summed), from the kernel's own
+    counters (include/nirrt_hip.h, nirrt_run_args.stats): visited slots (28 / 36 B per cell-ordered slot, 32 B per tail
+    record - already in bytes), 48 B per chain record walked, one 32-byte record per rewire candidate and 32 + 8 B written
+    per re-costed vertex, 12 B + one 32-byte record per re-evaluated list entry, ~160 B written per inserted vertex
+    (coordinates, record, aux, 4-hop record, links), 32 B read + (8 * dim + 16) B written per vertex of an index rebuild."""
+    st = np.asarray(stats, dtype=np.float64).reshape(-1, N_STATS).sum(axis=0)
+    return float(st[1] + 48 * st[4] + 32 * st[5] + 40 * st[7] + 44 * st[8] + (112 + 16 * dim) * st[9]
+                 + (32 + 8 * dim + 16 + 8) * st[10])
+
 
 
 _lib = None
@@ -327,8 +345,10 @@ def run_replay(trees, samples, flags=0, want_trace=False, device_ptr=None, iters
         a.samples = C.cast(C.c_void_p(int(device_ptr)), C.POINTER(C.c_double))
     scan = np.zeros(nt, dtype=np.int64)
     alg = np.zeros(nt, dtype=np.int64)
+    stats = np.zeros((nt, N_STATS), dtype=np.int64)
     a.scan_elems = _ip(scan)
     a.alg_elems = _ip(alg)
+    a.stats = _ip(stats)
     a.cost_trace = _dp(trace) if want_trace else None
     a.iters_done = _ip(done)
     a.status = status.ctypes.data_as(C.POINTER(C.c_int32))
@@ -337,10 +357,10 @@ def run_replay(trees, samples, flags=0, want_trace=False, device_ptr=None, iters
     if rc != E_CAPACITY:        # a full tree is reported per tree in status[] (the reference raises IndexError there)
         _check(rc)
     return {"iters_done": done, "status": status, "kernel_ms": ms.value, "cost_trace": trace, "scan_elems": scan,
-            "alg_elems": alg}
+            "alg_elems": alg, "stats": stats}
 
 
-def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=False, on_device=False):
+def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=False, on_device=False, iters_each=None):
     """Device-resident loop with in-kernel sampling.  np_words / py_words: per-tree uint32 arrays of
     raw MT19937 outputs (numpy legacy global stream / python `random`); with on_device=True they are
     per-tree (device_address, n_words) pairs of buffers already resident in HBM (e.g. slices of a
@@ -368,6 +388,11 @@ def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=Fals
     a.flags = int(flags)
     a.inputs_on_device = 1 if on_device else 0
     a.iters = int(iters)
+    if iters_each is not None:     # per-tree budgets <= iters (trees resumed after stopping at different iterations)
+        each = np.ascontiguousarray(iters_each, dtype=np.int64)
+        assert len(each) == nt
+        keep.append(each)
+        a.iters_each = _ip(each)
     a.samples = None
     a.np_words, a.n_np = table(np_words)
     if py_words is not None:
@@ -379,6 +404,8 @@ def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=Fals
     scan = np.zeros(nt, dtype=np.int64)
     alg = np.zeros(nt, dtype=np.int64)
     ms = C.c_double(0)
+    stats = np.zeros((nt, N_STATS), dtype=np.int64)
+    a.stats = _ip(stats)
     trace = np.zeros((nt, iters), dtype=np.float64) if want_trace else None
     a.cost_trace = _dp(trace) if want_trace else None
     a.alg_elems = _ip(alg)
@@ -390,4 +417,4 @@ def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=Fals
     if rc != E_CAPACITY:        # a full tree is reported per tree in status[] (the reference raises IndexError there)
         _check(rc)
     return {"iters_done": done, "np_used": np_used, "py_used": py_used, "status": status, "kernel_ms": ms.value,
-            "cost_trace": trace, "scan_elems": scan, "alg_elems": alg}
+            "cost_trace": trace, "scan_elems": scan, "alg_elems": alg, "stats": stats}

@@ -4,15 +4,16 @@
 // trees (one per workgroup, several workgroups per CU) so that one tree's dependent-latency phases
 // (parent-chain walks, barriers) overlap other trees' work.
 //
-//   * nearest / Near.  Small trees: every wave streams a CONTIGUOUS segment of the float32 twins of
-//     the SoA coordinate arrays with 16-byte loads; Near hits are staged in index order with wave
-//     ballots.  Trees of >= GRID_MIN_VERTICES vertices: a uniform-grid index (twins ordered by cell +
-//     unordered tail) is queried instead - only the cell rows that meet the query ball are visited,
-//     hits are put back in index order through an LDS bitmap.  Either way the per-vertex work is a
-//     float32 squared distance against thresholds with RIGOROUS error intervals; undecided vertices are
-//     re-decided in float64 (2^-48 guard band on d^2, the reference's own distance formula - glibc
-//     hypot / sqrt - inside the band), so every decision is bit-identical to the reference.
-//   * O(k) work (fan of segment tests, choose-parent, rewire) is lane-parallel.
+//   * nearest / Near.  ONE fused visit per iteration answers find_near_neighbors(node_new), choose_parent's argmin
+//     and the NEXT iteration's nearest_neighbor query.  Vertices are kept ordered by cell of a uniform grid
+//     (float64 SoA mirror g_x / g_cost / g_idx, rebuilt by a counting sort every GRID_REBUILD_EVERY insertions)
+//     followed by the not yet ordered tail, which is read straight from the per-vertex records; a query streams
+//     the rows of cells that meet its ball + the tail.  Every visited vertex is decided in float64: squared
+//     distance against a 2^-48 guard band, the reference's own distance formula (glibc hypot / sqrt) inside the
+//     band and for every member.  Members are not stored as a list: the visit keeps the running
+//     argmin of cost + dist for choose_parent and leaves (index, cost - dist) pairs in an LDS stash (spilling to
+//     HBM only beyond the stash capacity), from which rewire later picks, in ascending index order, the few members
+//     that can pass `cost(j) > cost(new) + dist`.
 //   * cost(v) is the reference's leaf->root sum (math.hypot per edge, added in that order).  It is kept
 //     EXACT in a per-vertex cache: a walk chases one 48-byte record per FOUR hops, and a re-parented
 //     vertex has its whole subtree (child / sibling links) re-walked right away, so every cost the loop
@@ -28,29 +29,47 @@
 #include "../../include/nirrt_hip.h"
 
 #define MAX_OBS NIRRT_MAX_OBSTACLES
+#define LDS_POOL 896     // 8-byte LDS slots shared by the obstacle tables (4 per round + 6 per box obstacle) and the Near stash
+#define OB_POOL NIRRT_OBSTACLE_POOL   // slots the obstacle tables may take (the rest, >= 256 entries, is the stash)
 #define SCAN_PAD 256     // extra elements allocated behind every per-vertex array (vector loads may overrun n)
 #define WALK_R 4         // parent chains chased concurrently per lane
-#define SCAN_U 4         // 128-vertex chunks a wave loads per scan trip (16-byte loads issued back to back)
 #ifndef CHAIN_MAX
 #define CHAIN_MAX 96     // LDS slots for the new->root edge-length sequence (deeper chains fall back to global walks)
 #endif
-#define GRID_MIN_VERTICES 2048   // smaller trees are scanned whole
+#define GRID_MIN_VERTICES 2048   // smaller trees are visited whole (everything is "tail")
 #define GRID_REBUILD_EVERY 1024  // vertices appended behind the cell-ordered part before it is rebuilt
-#define GRID_RG_MAX 96           // slot ranges per query (rows of cells + tail); larger boxes fall back to whole scans
-#ifndef GRID_BM_WORDS
-#define GRID_BM_WORDS 512        // LDS hit bitmap: 16 384 vertices per ordering window
-#endif
+#define GRID_RG_MAX 64           // rows of cells per query; larger boxes fall back to visiting the whole tree
+#ifndef NEAR_STASH
+#define NEAR_STASH LDS_POOL      // upper limit of Near members whose (index, bound) pair stays in LDS (the pool slots the
+#endif                           // obstacle tables leave free); the rest spills to nr_idx / nr_m.  Test builds set it to 8.
 #ifndef GRID_U
 #define GRID_U 4                 // slots per lane and trip of a grid visit
 #endif
 #ifndef LIST_U
 #define LIST_U 8                 // solution / goal-candidate list entries per lane and trip
 #endif
-#ifndef NEAR_U
-#define NEAR_U 4                 // Near members per lane and trip of the gather / choose-parent / rewire scans
-#endif
 #define GRID_N 1u                // range serves the Near query
 #define GRID_Q 2u                // range serves the nearest query
+
+// per-tree counters of one launch (nirrt_run_args.stats; accumulated in LDS, flushed when the kernel ends)
+#define ST_VISITED 0     // slots visited by the fused nearest / Near passes
+#define ST_VISIT_B 1     // bytes those visits read (28 / 36 B per cell-ordered slot, 32 B per tail record)
+#define ST_MEMBERS 2     // Near members (collision-free, not the new vertex itself)
+#define ST_SPILLED 3     // members that did not fit the LDS stash
+#define ST_HOPREC 4      // 48-byte chain records read by cost walks (cost(new) + subtree re-costing)
+#define ST_ROUNDS 5      // rewire candidates examined (one 32-byte record each)
+#define ST_REWIRED 6     // vertices re-parented by rewire
+#define ST_RECOST 7      // vertices re-costed below re-parented vertices
+#define ST_LISTSCAN 8    // solution / goal-candidate list entries re-evaluated (12 B + one 32-byte record each)
+#define ST_INSERTED 9    // vertices appended
+#define ST_REBUILT 10    // vertices passed through index rebuilds (32 B read + 28 / 36 B + 4 B written each)
+#define ST_REVISITS 11   // additional visits of a widened nearest box
+#define ST_BRUTE 12      // queries answered by visiting the whole tree (no index yet / box too large / tie)
+#define ST_ITERS 13
+#define ST_T0 14         // wall_clock64 (100 MHz) when the tree's loop started / ended
+#define ST_T1 15
+#define ST_ALG 16        // vertices the REFERENCE algorithm scans for the same iterations: n per nearest_neighbor + n per find_near_neighbors
+#define NSTAT NIRRT_N_STATS
 
 // optional per-phase cycle accounting (build with -DNIRRT_PROFILE; scripts/perf_phases.py reads prof[])
 #ifdef NIRRT_PROFILE
@@ -110,28 +129,20 @@ struct __attribute__((aligned(32))) VRec {
 };
 
 struct TreeDev {
-    double *c[3];   // SoA coordinates x[cap], y[cap], z[cap] (exact values; streamed only by the fallback scans)
-    float *cf[3];   // float32 twins of c[]: what the O(n) filter scans stream (4 B per coordinate)
-    double cmax;    // max |coordinate| over the range box and every vertex stored so far (float32 rounding bound)
+    double *c[3];   // SoA coordinates x[cap], y[cap], z[cap] (exact values, insertion order; download + exact fallback scans)
     Aux *aux;       // aux[cap]
     Hop4 *hop;      // hop[cap]: aux of the vertex and of its next three ancestors (kept in step with aux)
-    VRec *vrec;     // vrec[cap]: coordinates + exact cost for random access
+    VRec *vrec;     // vrec[cap]: coordinates + exact cost, insertion order (random access AND the tail of the index)
     int *first_child, *next_sib, *prev_sib;   // child lists (-1 = none); the root is nobody's child
     int *bfs_q;     // scratch queue for subtree traversals
     int cap;
     int n;          // num_vertices
     int dim;
     int status;     // sticky NIRRT_E_* code
-    int stamp;      // iterations executed (diagnostic)
-    int pad0;
-    long long scan_elems;  // vertices actually streamed by the O(n) passes (fused passes count once)
-    long long alg_elems;   // vertices the reference algorithm scans: n per nearest_neighbor + n per find_near_neighbors
-    // Near-set working arrays (capacity cap: a Near set can never exceed the tree)
-    int *st_idx;     // ordered staging of scan hits, one region per wave segment
-    int *nr_idx;     // neighbour vertex index, ascending
-    int *nr_flag;    // segment (new -> neighbour) hits an obstacle
-    double *nr_dist; // scan distance new <-> neighbour (np.hypot / axis norm)
-    double *nr_cost; // cost(neighbour), kept current through the rewire rounds
+    long long stat[NSTAT];   // counters since creation / reset (ST_*); a launch reports the difference
+    // continuation of the LDS Near stash (members beyond NEAR_STASH; the nirrt_near primitive puts all of them here)
+    int *nr_idx;
+    double *nr_m;
     // IRRT*: path_solutions (goal-parent indices, duplicates allowed) + cached costs
     int *sol;
     double *sol_line;   // Line(v, goal) of each solution vertex (static)
@@ -171,8 +182,11 @@ struct TreeDev {
     double pc_rate;          // pc_sample_rate
     double pc_ratio;         // pc_update_cost_ratio
     double c_update;         // best cost at the last cloud refresh (inf before the first solution)
-    // uniform-grid index over the float32 twins (see "uniform-grid index" below)
-    float4 *g_rec;           // {x, y, z, bits(vertex index)}: [0, g_ns) ordered by cell, [g_ns, n) in insertion order
+    // uniform-grid index (see "uniform-grid index" below): float64 mirror of vertices [0, g_ns) ordered by cell
+    double *g_x[3];          // coordinates by slot
+    double *g_cost;          // exact cost(v) by slot, kept in step with vrec[v].cost
+    int *g_idx;              // vertex index by slot
+    int *pos;                // slot of vertex i (valid for i < g_ns)
     int *g_start;            // g_start[c] .. g_start[c+1]: slots of cell c inside [0, g_ns); g_ncell + 1 entries
     int *g_cnt;              // rebuild scratch: per-cell counters
     int *g_rank;             // rebuild scratch: rank of vertex i inside its cell
@@ -184,7 +198,7 @@ struct TreeDev {
     int pad3;
     double g_rho;            // running estimate of the nearest-vertex distance of the samples (first box of a nearest query)
     double g_inv_h[3];       // cells per unit length, per axis
-    double g_margin[3];      // slack added to every query box (covers the float32 rounding of the twins)
+    double g_margin[3];      // slack added to every query box
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -204,8 +218,10 @@ struct StreamState {
 #define LDS_NW_MAX 4    // waves of the widest workgroup (256 threads)
 struct LdsData {
     int n_round, n_box;
-    double rnd[MAX_OBS][4];
-    double box[MAX_OBS][6];
+    int stash_off, stash_cap;     // first pool slot / number of slots of the Near stash
+    // round obstacles (cx, cy, cz, r) first, then boxes (x, y, z, w, h, d), then the Near stash: stash_cap doubles
+    // cost(member) - dist(member, new) followed by stash_cap vertex indices (12 bytes per member)
+    double pool[LDS_POOL];
     double red_val[LDS_NW_MAX];
     double red_val2[LDS_NW_MAX];
     int red_idx[LDS_NW_MAX];
@@ -217,17 +233,17 @@ struct LdsData {
     // iteration hangs below `new`, so its walk ends with exactly this sequence)
     int chain_len;          // entries valid in chainE, or -1 if the chain is longer than CHAIN_MAX
     double chainE[CHAIN_MAX];
-    // grid queries: slot ranges of g_rec to visit (rows of cells + the unsorted tail) and the hit bitmap
+    // grid queries: slot ranges of the cell-ordered mirror to visit (rows of cells)
     int rg_n, hit_cnt;
     // constants of the samplers (copied from the descriptor once per kernel)
     double k_lo[3], k_hi[3], k_clr, k_cmin, k_xc[3], k_CLC[9];
     Hop4 hop_new;                 // copy of hop[new_idx] of the current iteration (thread 0 reads it when re-parenting)
     int new_next, new_fc;         // thread 0: next sibling of the vertex inserted this iteration / head of its child list
-    int ob_n;                     // obstacles whose inflated box meets the Near ball's box (wg_near)
+    int ob_n;                     // obstacles whose inflated box meets the Near ball's box
     unsigned char ob_list[2 * MAX_OBS];
     int rg_beg[GRID_RG_MAX], rg_len[GRID_RG_MAX];
     unsigned char rg_flag[GRID_RG_MAX];
-    unsigned bm[GRID_BM_WORDS];   // one bit per vertex of a 32*GRID_BM_WORDS window; all-zero between uses
+    long long stat[NSTAT];
 };
 template <int NT>
 using Lds = LdsData;   // the per-instantiation name the device functions use
@@ -486,17 +502,28 @@ __device__ __forceinline__ bool seg_box_3d(const double *p0, const double *p1, c
     return true;
 }
 
+// obstacle tables in the LDS pool: round obstacles first (4 doubles each), boxes behind them (6 doubles each)
+__device__ __forceinline__ const double *ob_rnd(const LdsData &s, int i) { return &s.pool[4 * i]; }
+__device__ __forceinline__ const double *ob_box(const LdsData &s, int i) { return &s.pool[4 * s.n_round + 6 * i]; }
+// Near stash entry p (p < s.stash_cap): margin in pool[stash_off + p], index in the int array behind the margins
+__device__ __forceinline__ int *stash_ids(LdsData &s) { return reinterpret_cast<int *>(&s.pool[s.stash_off + s.stash_cap]); }
+__device__ __forceinline__ void stash_put(LdsData &s, int p, int id, double m)
+{
+    s.pool[s.stash_off + p] = m;
+    stash_ids(s)[p] = id;
+}
+
 // segment vs obstacle #o of the LDS tables (o < n_round: round, else box)
 template <int D, int NT>
 __device__ __forceinline__ bool seg_obstacle(const Lds<NT> &s, int o, const double *a, const double *b, double clr)
 {
     if (o < s.n_round) {
-        if (D == 2) return seg_round_2d(a, b, s.rnd[o], clr);
-        return seg_round_3d(a, b, s.rnd[o], clr);
+        if (D == 2) return seg_round_2d(a, b, ob_rnd(s, o), clr);
+        return seg_round_3d(a, b, ob_rnd(s, o), clr);
     }
     o -= s.n_round;
-    if (D == 2) return seg_box_2d(a, b, s.box[o], clr);
-    return seg_box_3d(a, b, s.box[o], clr);
+    if (D == 2) return seg_box_2d(a, b, ob_box(s, o), clr);
+    return seg_box_3d(a, b, ob_box(s, o), clr);
 }
 
 // the AABB prefilter alone (same arithmetic as the first lines of the seg_* tests above: c - r - clr, c + r + clr for
@@ -508,13 +535,14 @@ __device__ __forceinline__ bool seg_aabb_pass(const Lds<NT> &s, int o, const dou
     const double clr = s.k_clr;
     bool pass = true;
     if (o < s.n_round) {
-        const double cr = s.rnd[o][3];
+        const double *c = ob_rnd(s, o);
+        const double cr = c[3];
 #pragma unroll
-        for (int k = 0; k < D; k++) pass = pass && (l0[k] <= s.rnd[o][k] + cr + clr) && (l1[k] >= s.rnd[o][k] - cr - clr);
+        for (int k = 0; k < D; k++) pass = pass && (l0[k] <= c[k] + cr + clr) && (l1[k] >= c[k] - cr - clr);
     } else {
-        o -= s.n_round;
+        const double *b = ob_box(s, o - s.n_round);
 #pragma unroll
-        for (int k = 0; k < D; k++) pass = pass && (l0[k] <= s.box[o][k] + s.box[o][3 + k] + clr) && (l1[k] >= s.box[o][k] - clr);
+        for (int k = 0; k < D; k++) pass = pass && (l0[k] <= b[k] + b[3 + k] + clr) && (l1[k] >= b[k] - clr);
     }
     return pass;
 }
@@ -532,23 +560,34 @@ __device__ __forceinline__ bool seg_all(const Lds<NT> &s, const double *a, const
 // points_in_circles / points_in_balls: strict <  (collision_check_utils.py:292, _3d.py:299)
 // points_in_rectangles / points_in_boxes: inclusive (:254, _3d.py:260)
 template <int D, int NT>
+__device__ __forceinline__ bool point_in_round(const Lds<NT> &s, int i, const double *p, double clr)
+{
+    const double *c = ob_rnd(s, i);
+    double rc = c[3] + clr;
+    double q = (p[0] - c[0]) * (p[0] - c[0]) + (p[1] - c[1]) * (p[1] - c[1]);
+    if (D == 3) q = q + (p[2] - c[2]) * (p[2] - c[2]);
+    return q < rc * rc;
+}
+template <int D, int NT>
+__device__ __forceinline__ bool point_in_box(const Lds<NT> &s, int i, const double *p, double clr)
+{
+    const double *b = ob_box(s, i);
+    bool in = true;
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        double mx = b[k] + b[3 + k] + clr, mn = b[k] - clr;
+        in = in && (mn <= p[k]) && (p[k] <= mx);
+    }
+    return in;
+}
+
+template <int D, int NT>
 __device__ __forceinline__ bool point_in_obs(const Lds<NT> &s, const double *p, double clr)
 {
-    for (int i = 0; i < s.n_round; i++) {
-        double rc = s.rnd[i][3] + clr;
-        double q = (p[0] - s.rnd[i][0]) * (p[0] - s.rnd[i][0]) + (p[1] - s.rnd[i][1]) * (p[1] - s.rnd[i][1]);
-        if (D == 3) q = q + (p[2] - s.rnd[i][2]) * (p[2] - s.rnd[i][2]);
-        if (q < rc * rc) return true;
-    }
-    for (int i = 0; i < s.n_box; i++) {
-        bool in = true;
-#pragma unroll
-        for (int k = 0; k < D; k++) {
-            double mx = s.box[i][k] + s.box[i][3 + k] + clr, mn = s.box[i][k] - clr;
-            in = in && (mn <= p[k]) && (p[k] <= mx);
-        }
-        if (in) return true;
-    }
+    for (int i = 0; i < s.n_round; i++)
+        if (point_in_round<D, NT>(s, i, p, clr)) return true;
+    for (int i = 0; i < s.n_box; i++)
+        if (point_in_box<D, NT>(s, i, p, clr)) return true;
     return false;
 }
 
@@ -558,21 +597,8 @@ __device__ __forceinline__ bool point_in_obs_wave(const Lds<NT> &s, const double
 {
     const int lane = threadIdx.x & 63;
     bool hit = false;
-    for (int i = lane; i < s.n_round; i += 64) {
-        double rc = s.rnd[i][3] + clr;
-        double q = (p[0] - s.rnd[i][0]) * (p[0] - s.rnd[i][0]) + (p[1] - s.rnd[i][1]) * (p[1] - s.rnd[i][1]);
-        if (D == 3) q = q + (p[2] - s.rnd[i][2]) * (p[2] - s.rnd[i][2]);
-        hit = hit || (q < rc * rc);
-    }
-    for (int i = lane; i < s.n_box; i += 64) {
-        bool in = true;
-#pragma unroll
-        for (int k = 0; k < D; k++) {
-            double mx = s.box[i][k] + s.box[i][3 + k] + clr, mn = s.box[i][k] - clr;
-            in = in && (mn <= p[k]) && (p[k] <= mx);
-        }
-        hit = hit || in;
-    }
+    for (int i = lane; i < s.n_round; i += 64) hit = hit || point_in_round<D, NT>(s, i, p, clr);
+    for (int i = lane; i < s.n_box; i += 64) hit = hit || point_in_box<D, NT>(s, i, p, clr);
     return __ballot(hit) != 0ull;
 }
 
@@ -612,14 +638,28 @@ template <int NT>
 __device__ __forceinline__ void stage_obstacles(Lds<NT> &s, const TreeDev &t)
 {
     int tid = threadIdx.x;
-    if (tid == 0) { s.n_round = t.n_round; s.n_box = t.n_box; }
-    for (int i = tid; i < GRID_BM_WORDS; i += NT) s.bm[i] = 0u;
+    if (tid == 0) {
+        s.n_round = t.n_round; s.n_box = t.n_box;
+        s.stash_off = 4 * t.n_round + 6 * t.n_box;
+        const int room = ((LDS_POOL - s.stash_off) * 2) / 3;   // 8 + 4 bytes per entry
+        s.stash_cap = room < NEAR_STASH ? room : NEAR_STASH;
+    }
+    if (tid < NSTAT) s.stat[tid] = 0;
     if (tid < 3) { s.k_lo[tid] = t.lo[tid]; s.k_hi[tid] = t.hi[tid]; s.k_xc[tid] = t.x_center[tid]; }
     if (tid < 9) s.k_CLC[tid] = t.CL_C[tid];
     if (tid == 0) { s.k_clr = t.clearance; s.k_cmin = t.c_min; }
-    for (int i = tid; i < t.n_round * 4; i += NT) s.rnd[i / 4][i % 4] = t.rnd[i / 4][i % 4];
-    for (int i = tid; i < t.n_box * 6; i += NT) s.box[i / 6][i % 6] = t.box[i / 6][i % 6];
+    const int nr4 = t.n_round * 4;   // the host refuses worlds whose tables exceed OB_POOL
+    for (int i = tid; i < nr4; i += NT) s.pool[i] = t.rnd[i / 4][i % 4];
+    for (int i = tid; i < t.n_box * 6; i += NT) s.pool[nr4 + i] = t.box[i / 6][i % 6];
     __syncthreads();
+}
+
+// add this launch's LDS counters to the descriptor (thread 0, end of a kernel)
+__device__ __forceinline__ void flush_stats(LdsData &s, TreeDev &t)
+{
+    if (threadIdx.x == 0)
+        for (int i = 0; i < NSTAT; i++)
+            if (i != ST_T0 && i != ST_T1) t.stat[i] += s.stat[i];
 }
 
 // wave64 reductions without LDS traffic: four DPP steps (quad swaps, half-row and row mirrors) leave every 16-lane row
@@ -751,19 +791,7 @@ __device__ __forceinline__ void load_vertex(const TreeDev &t, int i, double *v)
     for (int k = 0; k < D; k++) v[k] = t.c[k][i];
 }
 
-// wave segment of the scans: wave w streams [beg, end), `per` a multiple of 128
-template <int NT>
-__device__ __forceinline__ void wave_segment(int n, int &beg, int &end)
-{
-    constexpr int NW = NT / 64;
-    int per = ((n + NW * 128 - 1) / (NW * 128)) * 128;
-    int w = threadIdx.x >> 6;
-    beg = w * per;
-    end = beg + per < n ? beg + per : n;
-    if (beg > n) beg = n;
-}
-
-// exact (reference-formula) nearest scan; only used when the filtered scan sees a near-tie
+// exact (reference-formula) nearest scan over the SoA coordinates; only used when a visit sees a near-tie
 template <int D, int NT>
 __device__ __noinline__ int wg_nearest_exact(Lds<NT> &s, const TreeDev &t, int n, const double *q)
 {
@@ -780,14 +808,14 @@ __device__ __noinline__ int wg_nearest_exact(Lds<NT> &s, const TreeDev &t, int n
     return bi;
 }
 
-// workgroup reduction of the per-lane (smallest d2, its index, second-smallest d2) triples of a nearest scan;
-// falls back to the reference-formula scan when the runner-up is inside the guard band of the minimum
+// workgroup reduction of the per-lane (smallest d2, its index, second-smallest d2) triples of a nearest visit.
+// Returns the winner's index, or -1 when a second vertex lies inside the guard band of the minimum (the caller then
+// lets the reference formula decide, wg_nearest_exact); *g1_out = the smallest squared distance seen (inf: nothing).
 template <int D, int NT>
-__device__ __forceinline__ int wg_nearest_finish(Lds<NT> &s, const TreeDev &t, int n, const double *q, double m1, int i1, double m2)
+__device__ __forceinline__ int wg_nearest_finish(Lds<NT> &s, double m1, int i1, double m2, double *g1_out)
 {
     constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // wave: minimum (m1, i1) and the second-smallest value seen by the wave
     double wm = m1;
     int wi = i1;
     wave_argmin(wm, wi);
@@ -810,215 +838,21 @@ __device__ __forceinline__ int wg_nearest_finish(Lds<NT> &s, const TreeDev &t, i
         double c = (i == gw) ? s.red_val2[i] : s.red_val[i];
         g2 = c < g2 ? c : g2;
     }
-    if (g2 <= g1 * BAND_HI) return wg_nearest_exact<D, NT>(s, t, n, q);  // uniform branch (rare)
-    return gi;
-}
-
-// float64 nearest scan (fallback of the float32 filter scan below).
-// Squared distances decide; if a second vertex lies within the guard band of the minimum the
-// reference formula decides instead (wg_nearest_exact).
-template <int D, int NT>
-__device__ __noinline__ int wg_nearest64(Lds<NT> &s, const TreeDev &t, int n, const double *q)
-{
-    constexpr int NW = NT / 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int beg, end;
-    wave_segment<NT>(n, beg, end);
-    double m1 = __builtin_inf(), m2 = __builtin_inf();
-    int i1 = 0x7fffffff;
-    const double2 *X = reinterpret_cast<const double2 *>(t.c[0]);
-    const double2 *Y = reinterpret_cast<const double2 *>(t.c[1]);
-    const double2 *Z = reinterpret_cast<const double2 *>(t.c[D - 1]);
-    for (int base = beg + 2 * lane; base < end; base += 128 * SCAN_U) {
-        // SCAN_U 128-vertex chunks per trip; all 16-byte loads are issued before the first use so that
-        // each wave keeps SCAN_U * D KiB in flight
-        double2 xv[SCAN_U], yv[SCAN_U], zv[SCAN_U];
-#pragma unroll
-        for (int u = 0; u < SCAN_U; u++) {
-            const int bu = base + 128 * u;
-            if (bu < end) {
-                xv[u] = X[bu >> 1]; yv[u] = Y[bu >> 1];
-                if (D == 3) zv[u] = Z[bu >> 1];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < SCAN_U; u++) {
-            const int bu = base + 128 * u;
-            if (bu < end) {
-                double da[3] = {q[0] - xv[u].x, q[1] - yv[u].x, D == 3 ? q[D - 1] - zv[u].x : 0.};
-                double db[3] = {q[0] - xv[u].y, q[1] - yv[u].y, D == 3 ? q[D - 1] - zv[u].y : 0.};
-                double va = dist2<D>(da);
-                double vb = bu + 1 < end ? dist2<D>(db) : __builtin_inf();
-                if (va < m1) { m2 = m1; m1 = va; i1 = bu; } else if (va < m2) m2 = va;
-                if (vb < m1) { m2 = m1; m1 = vb; i1 = bu + 1; } else if (vb < m2) m2 = vb;
-            }
-        }
-    }
-    return wg_nearest_finish<D, NT>(s, t, n, q, m1, i1, m2);
-}
-
-// ------------------------------------------------------------------------------------------------
-// float32 filter scans.  The O(n) passes stream the float32 twins of the coordinates (half the bytes, twice the
-// VALU rate of float64) and decide with a RIGOROUS error bound; only vertices whose float32 squared distance is
-// within that bound of a decision threshold are re-decided from the float64 coordinates with the float64 logic
-// (guard band + reference formula).  Every decision therefore equals the float64 path's decision.
-//
-// Bound: with e = f32_eps >= |float(x) - x| for every coordinate, u = 2^-24, d = true distance:
-//   |d2_f32 - d2| <= 4.01 e sqrt(D) d + 6 u d^2 + D (2.1 e + u d)^2  <=  E(d2) := 8 e sqrt(D d2) + 2e-6 d2 + 64 e^2
-// ------------------------------------------------------------------------------------------------
-// e for one scan: covers the stored vertices (cmax) and the query point(s) of that scan
-__device__ __forceinline__ double f32_eps_for(const TreeDev &t, const double *q, int D, const double *q2 = nullptr)
-{
-    double m = t.cmax;
-    for (int k = 0; k < D; k++) {
-        m = fmax(m, fabs(q[k]));
-        if (q2) m = fmax(m, fabs(q2[k]));
-    }
-    return 0x1p-24 * 1.01 * m;
-}
-template <int D>
-__device__ __forceinline__ double f32_err(double e, double d2)
-{
-    return 8.0 * e * __builtin_sqrt((double)D * d2) + 2e-6 * d2 + 64.0 * e * e;
-}
-__device__ __forceinline__ float f32_down(double z)   // largest float <= z (z > 0), or -1 if z <= 0
-{
-    if (!(z > 0.0)) return -1.f;
-    float f = (float)z;
-    if ((double)f > z) f = __uint_as_float(__float_as_uint(f) - 1u);
-    return f;
-}
-__device__ __forceinline__ float f32_up(double z)     // smallest float >= z (z >= 0)
-{
-    float f = (float)z;
-    if ((double)f < z) f = __uint_as_float(__float_as_uint(f) + 1u);
-    return f;
-}
-// |y - z| <= E(y) with E(y) = a sqrt(y) + b y + c  =>  y in [f32_lower(z), f32_upper(z)]  (y true d2, z float32 d2)
-template <int D>
-__device__ __forceinline__ double f32_upper(double e, double z)
-{
-    const double a = 8.0 * e * __builtin_sqrt((double)D), b = 2e-6, c = 64.0 * e * e;
-    double r = (a + __builtin_sqrt(a * a + 4.0 * (1.0 - b) * (z + c))) / (2.0 * (1.0 - b));
-    return r * r * (1.0 + 1e-12);
-}
-template <int D>
-__device__ __forceinline__ double f32_lower(double e, double z)
-{
-    const double a = 8.0 * e * __builtin_sqrt((double)D), b = 2e-6, c = 64.0 * e * e;
-    if (!(z > c)) return 0.0;
-    double r = (-a + __builtin_sqrt(a * a + 4.0 * (1.0 + b) * (z - c))) / (2.0 * (1.0 + b));
-    return r <= 0.0 ? 0.0 : r * r * (1.0 - 1e-12);
-}
-
-template <int NT>
-__device__ __forceinline__ void wave_segment256(int n, int &beg, int &end, int &per)
-{
-    constexpr int NW = NT / 64;
-    per = ((n + NW * 256 - 1) / (NW * 256)) * 256;
-    int w = threadIdx.x >> 6;
-    beg = w * per;
-    end = beg + per < n ? beg + per : n;
-    if (beg > n) beg = n;
-}
-
-template <int D>
-__device__ __forceinline__ float dist2f(float ax, float ay, float az)
-{
-    float s = ax * ax + ay * ay;
-    if (D == 3) s = s + az * az;
-    return s;
-}
-
-// workgroup reduction of per-lane float32 (min d2, its index, second-smallest d2); returns the winner's index or
-// -1 when the runner-up is too close to call in float32 (caller falls back to the float64 scan)
-template <int D, int NT>
-__device__ __forceinline__ int wg_nearest_finish32(Lds<NT> &s, double e, float m1, int i1, float m2, double *g1_out = nullptr)
-{
-    constexpr int NW = NT / 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float wm = m1;
-    int wi = i1;
-    wave_argmin(wm, wi);
-    float ws = (i1 == wi) ? m2 : m1;
-    ws = wave_min(ws);
-    __syncthreads();
-    if (lane == 0) { s.red_val[w] = wm; s.red_idx[w] = wi; s.red_val2[w] = ws; }
-    __syncthreads();
-    double g1 = s.red_val[0];
-    int gi = s.red_idx[0], gw = 0;
-#pragma unroll
-    for (int i = 1; i < NW; i++) {
-        double ov = s.red_val[i];
-        int oi = s.red_idx[i];
-        if (ov < g1 || (ov == g1 && oi < gi)) { g1 = ov; gi = oi; gw = i; }
-    }
-    double g2 = __builtin_inf();
-#pragma unroll
-    for (int i = 0; i < NW; i++) {
-        double c = (i == gw) ? s.red_val2[i] : s.red_val[i];
-        g2 = c < g2 ? c : g2;
-    }
-    if (g1_out) *g1_out = g1;
-    // unambiguous iff every other vertex is provably farther (by more than the float64 path's own tie band)
-    const bool clear = g2 == __builtin_inf() || f32_upper<D>(e, g1) < f32_lower<D>(e, g2) * BAND_LO;
-    return clear ? gi : -1;
-}
-
-// nearest_neighbor by a whole float32 scan: argmin_i dist(q, v_i), lowest index on ties (np.argmin)
-template <int D, int NT>
-__device__ __forceinline__ int wg_nearest_scan(Lds<NT> &s, const TreeDev &t, int n, const double *q)
-{
-    const int lane = threadIdx.x & 63;
-    int beg, end, per;
-    wave_segment256<NT>(n, beg, end, per);
-    const float qx = (float)q[0], qy = (float)q[1], qz = D == 3 ? (float)q[D - 1] : 0.f;
-    float m1 = __builtin_inff(), m2 = __builtin_inff();
-    int i1 = 0x7fffffff;
-    const float4 *X = reinterpret_cast<const float4 *>(t.cf[0]);
-    const float4 *Y = reinterpret_cast<const float4 *>(t.cf[1]);
-    const float4 *Z = reinterpret_cast<const float4 *>(t.cf[D - 1]);
-    for (int base = beg + 4 * lane; base < end; base += 256 * SCAN_U) {
-        float4 xv[SCAN_U], yv[SCAN_U], zv[SCAN_U];
-#pragma unroll
-        for (int u = 0; u < SCAN_U; u++) {
-            const int bu = base + 256 * u;
-            if (bu < end) {
-                xv[u] = X[bu >> 2]; yv[u] = Y[bu >> 2];
-                if (D == 3) zv[u] = Z[bu >> 2];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < SCAN_U; u++) {
-            const int bu = base + 256 * u;
-            if (bu < end) {
-                const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
-                const float ys[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
-                const float zs[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float v = bu + e < end ? dist2f<D>(qx - xs[e], qy - ys[e], D == 3 ? qz - zs[e] : 0.f) : __builtin_inff();
-                    if (v < m1) { m2 = m1; m1 = v; i1 = bu + e; } else if (v < m2) m2 = v;
-                }
-            }
-        }
-    }
-    int gi = wg_nearest_finish32<D, NT>(s, f32_eps_for(t, q, D), m1, i1, m2);
-    if (gi < 0) gi = wg_nearest64<D, NT>(s, t, n, q);   // uniform (rare)
-    return gi;
+    *g1_out = g1;
+    if (g1 == __builtin_inf()) return -1;
+    return (g2 <= g1 * BAND_HI) ? -1 : gi;
 }
 
 // ------------------------------------------------------------------------------------------------
 // uniform-grid index.  The reference scans every vertex for nearest_neighbor and find_near_neighbors; the
-// answers only depend on the vertices inside a small ball around the query, so large trees keep their float32
-// twins ordered by cell of a G^D grid over the range box (g_rec[0, g_ns), rebuilt by a counting sort every
-// GRID_REBUILD_EVERY insertions) followed by the not yet ordered tail g_rec[g_ns, n).  A query visits the rows
-// of cells (contiguous slot ranges) that intersect its box plus the tail, with exactly the filter arithmetic
-// of the whole scans: float32 squared distances with rigorous error bounds, float64 / reference formula inside
-// the bands.  Completeness: cell(x) is monotone in x per axis and computed from the twin, whose distance to the
-// exact coordinate is far below g_margin, so every vertex within `rad` of p (per axis) lies in a cell of
-// grid_box(p, rad).  Near hits are put in ascending vertex order through an LDS bitmap (the reference's
-// np.where order, which choose_parent's first-minimum and the sequential rewire depend on).
+// answers only depend on the vertices inside a small ball around the query, so large trees keep a float64 mirror
+// of their vertices ordered by cell of a G^D grid over the range box (g_x / g_cost / g_idx [0, g_ns), rebuilt by
+// a counting sort every GRID_REBUILD_EVERY insertions); vertices [g_ns, n) - the tail - are read from their
+// records vrec[] in insertion order.  A query visits the rows of cells (contiguous slot ranges) that intersect its
+// box plus the tail.  Completeness: cell(x) is monotone in x per axis, so every vertex within `rad` of p (per axis)
+// lies in a cell of grid_box(p, rad) (g_margin is slack on top); vertices outside the range box fall into border
+// cells, which extend to infinity.  The order inside a cell is whatever the atomics produce; no result depends on
+// it (minima are reduced as (value, index) pairs, rewire selects by index).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int grid_cell_axis(const TreeDev &t, int k, double x)
 {
@@ -1068,27 +902,30 @@ __device__ __forceinline__ int block_excl_scan(Lds<NT> &s, int v, int &off)
     return tot;
 }
 
-// counting sort of the twins of vertices [0, n) by cell.  The order inside a cell is whatever the atomics
-// produce; no result depends on it (minima are reduced as (value, index) pairs, hits are re-ordered by index).
+// counting sort of vertices [0, n) by cell into the float64 mirror.
 template <int D, int NT>
 __device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeDev &t, int n)
 {
     const int tid = threadIdx.x, nc = t.g_ncell, G = t.g_G;
     for (int c = tid; c < nc; c += NT) t.g_cnt[c] = 0;
     __syncthreads();
-    auto cell_of = [&](int i) -> int {
-        int c = grid_cell_axis(t, 0, (double)t.cf[0][i]) + G * grid_cell_axis(t, 1, (double)t.cf[1][i]);
-        if (D == 3) c += G * G * grid_cell_axis(t, 2, (double)t.cf[D - 1][i]);
+    auto cell_of = [&](const VRec &v) -> int {
+        int c = grid_cell_axis(t, 0, v.x) + G * grid_cell_axis(t, 1, v.y);
+        if (D == 3) c += G * G * grid_cell_axis(t, 2, v.z);
         return c;
     };
-    for (int i0 = tid; i0 < n; i0 += NT * LIST_U) {
-        int cell[LIST_U], rk[LIST_U];
+    for (int i0 = tid; i0 < n; i0 += NT * GRID_U) {
+        VRec v[GRID_U];
+        int cell[GRID_U], rk[GRID_U];
 #pragma unroll
-        for (int u = 0; u < LIST_U; u++) cell[u] = i0 + u * NT < n ? cell_of(i0 + u * NT) : -1;
+        for (int u = 0; u < GRID_U; u++)
+            if (i0 + u * NT < n) v[u] = t.vrec[i0 + u * NT];
 #pragma unroll
-        for (int u = 0; u < LIST_U; u++) rk[u] = cell[u] >= 0 ? atomicAdd(&t.g_cnt[cell[u]], 1) : 0;
+        for (int u = 0; u < GRID_U; u++) cell[u] = i0 + u * NT < n ? cell_of(v[u]) : -1;
 #pragma unroll
-        for (int u = 0; u < LIST_U; u++)
+        for (int u = 0; u < GRID_U; u++) rk[u] = cell[u] >= 0 ? atomicAdd(&t.g_cnt[cell[u]], 1) : 0;
+#pragma unroll
+        for (int u = 0; u < GRID_U; u++)
             if (cell[u] >= 0) t.g_rank[i0 + u * NT] = rk[u];
     }
     __syncthreads();
@@ -1107,55 +944,74 @@ __device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeDev &t, int n)
     }
     if (tid == 0) t.g_start[nc] = n;
     __syncthreads();
-    for (int i0 = tid; i0 < n; i0 += NT * LIST_U) {
-        float fx[LIST_U], fy[LIST_U], fz[LIST_U];
-        int rk[LIST_U], st[LIST_U];
+    for (int i0 = tid; i0 < n; i0 += NT * GRID_U) {
+        VRec v[GRID_U];
+        int rk[GRID_U], st[GRID_U];
 #pragma unroll
-        for (int u = 0; u < LIST_U; u++) {
+        for (int u = 0; u < GRID_U; u++) {
             const int i = i0 + u * NT;
-            fx[u] = 0.f; fy[u] = 0.f; fz[u] = 0.f; rk[u] = 0;
-            if (i < n) { fx[u] = t.cf[0][i]; fy[u] = t.cf[1][i]; fz[u] = D == 3 ? t.cf[D - 1][i] : 0.f; rk[u] = t.g_rank[i]; }
+            rk[u] = 0;
+            if (i < n) { v[u] = t.vrec[i]; rk[u] = t.g_rank[i]; }
         }
 #pragma unroll
-        for (int u = 0; u < LIST_U; u++) {
-            int c = grid_cell_axis(t, 0, (double)fx[u]) + G * grid_cell_axis(t, 1, (double)fy[u]);
-            if (D == 3) c += G * G * grid_cell_axis(t, 2, (double)fz[u]);
-            st[u] = i0 + u * NT < n ? t.g_start[c] : 0;
-        }
+        for (int u = 0; u < GRID_U; u++) st[u] = i0 + u * NT < n ? t.g_start[cell_of(v[u])] : 0;
 #pragma unroll
-        for (int u = 0; u < LIST_U; u++) {
+        for (int u = 0; u < GRID_U; u++) {
             const int i = i0 + u * NT;
-            if (i < n) t.g_rec[st[u] + rk[u]] = make_float4(fx[u], fy[u], fz[u], __int_as_float(i));
+            if (i < n) {
+                const int sl = st[u] + rk[u];
+                t.g_x[0][sl] = v[u].x; t.g_x[1][sl] = v[u].y;
+                if (D == 3) t.g_x[D - 1][sl] = v[u].z;
+                t.g_cost[sl] = v[u].cost;
+                t.g_idx[sl] = i;
+                t.pos[i] = sl;
+            }
         }
     }
-    if (tid == 0) t.g_ns = n;
+    if (tid == 0) { t.g_ns = n; s.stat[ST_REBUILT] += n; }
     __syncthreads();
 }
 
-// Near set of pn (radius r, may be null) and / or nearest vertex of q (may be null) through the grid.
-// Near hits end up ascending in t.st_idx[0, kraw); returns kraw.  *ni = nearest index of q.
-// `scanned` = slots visited.
+// result of the Near part of a query
+struct NearResult {
+    int k;          // members: collision-free vertices within r of node_new other than new_idx
+    double cand;    // min over members of cost(j) + dist(j, new)   (inf if none)
+    int cj;         // its vertex index, lowest index on ties (np.argmin over the ascending neighbour list)
+};
+
+// ONE fused query (find_near_neighbors rrt_star_2d.py:125-144 + choose_parent's argmin :80-90 + the nearest_neighbor
+// rrt_base_2d.py:94-107 of another point):
+//   pn != nullptr: Near set of pn with radius r on the current tree -> *nr; member (index, bound) pairs go to the
+//                  stash: entries [0, lds_cap) in LDS, the rest in t.nr_idx / t.nr_m;
+//   q  != nullptr: *ni = argmin_i dist(q, v_i), lowest index on ties (np.argmin).
 template <int D, int NT>
-__device__ __forceinline__ int wg_grid_query(Lds<NT> &s, const TreeDev &t, int n, const double *pn, double r, const double *q,
-                                             int *ni, long long &scanned)
+__device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeDev &t, int n, const double *pn, double r, int new_idx,
+                                         const double *q, int *ni, NearResult *nr, int lds_cap)
 {
     const int tid = threadIdx.x, lane = tid & 63, G = t.g_G;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int ns = t.g_ns;
+    const int ns = uni(t.g_ns);
     const bool wantN = pn != nullptr, wantQ = q != nullptr;
     const double r2 = r * r, r2lo = r2 * BAND_LO, r2hi = r2 * BAND_HI;
-    const double e32 = f32_eps_for(t, wantN ? pn : q, D, wantN ? q : nullptr);
-    const float lo_f = wantN ? f32_down(r2lo - f32_err<D>(e32, r2lo)) : -1.f;
-    const float hi_f = wantN ? f32_up(r2hi + f32_err<D>(e32, r2hi)) : -1.f;
-    const float nx = wantN ? (float)pn[0] : 0.f, ny = wantN ? (float)pn[1] : 0.f, nz = (wantN && D == 3) ? (float)pn[D - 1] : 0.f;
-    const float qx = wantQ ? (float)q[0] : 0.f, qy = wantQ ? (float)q[1] : 0.f, qz = (wantQ && D == 3) ? (float)q[D - 1] : 0.f;
-    auto exact_hit = [&](int i) -> bool {
-        double d[3] = {pn[0] - t.c[0][i], pn[1] - t.c[1][i], D == 3 ? pn[D - 1] - t.c[D - 1][i] : 0.};
-        double v = dist2<D>(d);
-        if (v <= r2lo) return true;
-        if (v > r2hi) return false;
-        return dist_scan<D>(d) <= r;
-    };
+    const double clr = s.k_clr;
+    long long visited = 0, vbytes = 0;
+    int revisits = 0, brutes = 0;
+    PROF_DECL
+    __syncthreads();
+    if (tid == 0) { s.ob_n = 0; s.hit_cnt = 0; }
+    __syncthreads();
+    // obstacles whose inflated box meets the box of the Near ball: a segment new -> v_j (|v_j - new| <= r per axis)
+    // can only pass the AABB prefilter of those.  Same comparisons as seg_aabb_pass, on a superset of every segment's box.
+    if (wantN) {
+        const int M = s.n_round + s.n_box;
+        for (int o = tid; o < M; o += NT) {
+            const double rb = r * (1.0 + 1e-9);
+            double l0[3], l1[3];
+#pragma unroll
+            for (int c = 0; c < D; c++) { l0[c] = pn[c] - rb; l1[c] = pn[c] + rb; }
+            if (seg_aabb_pass<D, NT>(s, o, l0, l1)) s.ob_list[atomicAdd(&s.ob_n, 1)] = (unsigned char)o;
+        }
+    }
     // row `row` of box (c0, c1) -> slot range.  ball != nullptr: only the cells of the row that the ball (ball, rad)
     // can reach are kept (the corner cells of the box are dropped)
     auto put_row = [&](int slot, const int (&c0)[3], const int (&c1)[3], int row, int flag, const double *ball, double rad) {
@@ -1190,114 +1046,179 @@ __device__ __forceinline__ int wg_grid_query(Lds<NT> &s, const TreeDev &t, int n
     };
     int nb0[3] = {0, 0, 0}, nb1[3] = {0, 0, 0}, qb0[3] = {0, 0, 0}, qb1[3] = {0, 0, 0};
     int rowsN = 0, rowsQ = 0;
-    if (wantN) { grid_box<D>(t, pn, r, nb0, nb1); rowsN = grid_rows(nb0, nb1); }
-    if (wantQ) {
-        // first guess: the cells within 1.5x the typical nearest distance seen so far (the cell of q itself at first)
-        grid_box<D>(t, q, 1.5 * t.g_rho, qb0, qb1);
-        rowsQ = grid_rows(qb0, qb1);
+    // whole-tree visit: no index yet, or a box of more rows than the range list holds (never the case for the Near
+    // radius of an indexed tree): every vertex is read from its record
+    bool brute = ns == 0;
+    if (!brute) {
+        if (wantN) { grid_box<D>(t, pn, r, nb0, nb1); rowsN = grid_rows(nb0, nb1); }
+        if (wantQ) {
+            // first guess: the cells within 1.5x the typical nearest distance seen so far (the cell of q itself at first)
+            grid_box<D>(t, q, 1.5 * t.g_rho, qb0, qb1);
+            rowsQ = grid_rows(qb0, qb1);
+        }
+        if (rowsN + rowsQ > GRID_RG_MAX) brute = true;
     }
-    int result_ni = -1;
-    bool brute_q = false;
-    if (rowsN + rowsQ + 1 > GRID_RG_MAX) {
-        // a box that large is not worth indexing (never the case for the Near radius of a tree this size)
-        if (wantN) return -1;   // caller scans whole
-        brute_q = true;
-    }
-    float m1 = __builtin_inff(), m2 = __builtin_inff();
+    double m1 = __builtin_inf(), m2 = __builtin_inf();   // nearest: smallest / second-smallest squared distance of this lane
     int i1 = 0x7fffffff;
-    int kraw = 0;
-    scanned = 0;
-    PROF_DECL
-    // one visit of the ranges in s.rg_*; uniform trip counts.  GRID_U slots per lane and trip: all their 16-byte
-    // loads are issued before the first use
-    auto visit = [&]() {
+    double cand = __builtin_inf();                        // Near: this lane's best cost + dist
+    int cj = 0x7fffffff;
+    __syncthreads();
+    const int n_ob = wantN ? uni(s.ob_n) : 0;
+    // one visited vertex (coordinates, exact cost, index) of a range flagged fl; true = Near member (sm = cost - dist, what
+    // rewire compares with cost(new) later: members of a dense, well optimised tree sit within 1e-5 of that threshold by the
+    // dozen, so the margin is kept in full float64)
+    auto process = [&](double px, double py, double pz, double pcost, int id, unsigned fl, double &sm) -> bool {
+        if (fl & GRID_Q) {
+            double d[3] = {q[0] - px, q[1] - py, D == 3 ? q[D - 1] - pz : 0.};
+            const double wv = dist2<D>(d);
+            if (wv < m1 || (wv == m1 && id < i1)) { m2 = m1; m1 = wv; i1 = id; } else if (wv < m2) m2 = wv;
+        }
+        bool member = false;
+        if (fl & GRID_N) {
+            double d[3] = {pn[0] - px, pn[1] - py, D == 3 ? pn[D - 1] - pz : 0.};
+            const double v = dist2<D>(d);
+            if (v <= r2hi && id != new_idx) {
+                const double dj = dist_scan<D>(d);      // the reference's own distance: decides inside the band, and is d_j
+                if (v <= r2lo || dj <= r) {
+                    bool col = false;
+                    if (n_ob > 0) {
+                        double vj[3] = {px, py, pz}, l0[3], l1[3];
+#pragma unroll
+                        for (int c = 0; c < D; c++) { l0[c] = fmin(pn[c], vj[c]); l1[c] = fmax(pn[c], vj[c]); }
+                        for (int j = 0; j < n_ob && !col; j++) {
+                            const int o = s.ob_list[j];
+                            if (seg_aabb_pass<D, NT>(s, o, l0, l1)) col = seg_obstacle<D, NT>(s, o, pn, vj, clr);
+                        }
+                    }
+                    if (!col) {
+                        member = true;
+                        const double c = pcost + dj;
+                        if (c < cand || (c == cand && id < cj)) { cand = c; cj = id; }
+                        sm = pcost - dj;
+                    }
+                }
+            }
+        }
+        return member;
+    };
+    // members of one trip slot -> stash positions (wave ballot + one LDS atomic per wave); every lane of the wave is here
+    auto stash = [&](bool member, int id, double sm) {
+        const unsigned long long mk = __ballot(member);
+        if (mk) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s.hit_cnt, __popcll(mk));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (member) {
+                const int p = base + __popcll(mk & lt);
+                if (p < lds_cap) stash_put(s, p, id, sm);
+                else { t.nr_idx[p - lds_cap] = id; t.nr_m[p - lds_cap] = sm; }
+            }
+        }
+    };
+    // vertices [beg, n) straight from their records (the tail of the index, or the whole tree); uniform trip counts,
+    // GRID_U records per lane and trip, all loads issued before the first use
+    auto visit_records = [&](int beg, unsigned fl) {
+        visited += n - beg;
+        vbytes += (long long)(n - beg) * (long long)sizeof(VRec);
+        for (int f0 = beg; f0 < n; f0 += NT * GRID_U) {
+            VRec v[GRID_U];
+#pragma unroll
+            for (int u = 0; u < GRID_U; u++) {
+                const int i = f0 + u * NT + tid;
+                if (i < n) v[u] = t.vrec[i];
+            }
+#pragma unroll
+            for (int u = 0; u < GRID_U; u++) {
+                if (f0 + u * NT < n) {   // uniform
+                    const int i = f0 + u * NT + tid;
+                    double sm = 0.;
+                    const bool member = i < n ? process(v[u].x, v[u].y, v[u].z, v[u].cost, i, fl, sm) : false;
+                    if (fl & GRID_N) stash(member, i, sm);
+                }
+            }
+        }
+    };
+    // the slot ranges in s.rg_* from the cell-ordered mirror
+    auto visit_ranges = [&]() {
         const int R = uni(s.rg_n);
         int total = 0;
         for (int i = 0; i < R; i++) total += s.rg_len[i];
-        scanned += total;
+        visited += total;
+        vbytes += (long long)total * (8 * D + 12);
         for (int f0 = 0; f0 < total; f0 += NT * GRID_U) {
-            float4 rec[GRID_U];
+            double px[GRID_U], py[GRID_U], pz[GRID_U], pc[GRID_U];
+            int id[GRID_U];
             unsigned flag[GRID_U];
 #pragma unroll
             for (int u = 0; u < GRID_U; u++) {
                 int off = f0 + u * NT + tid;
-                rec[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                px[u] = 0.; py[u] = 0.; pz[u] = 0.; pc[u] = 0.; id[u] = 0;
                 flag[u] = 0u;
                 if (off < total) {
                     int rr = 0, len = s.rg_len[0];
                     while (off >= len) { off -= len; rr++; len = s.rg_len[rr]; }
-                    rec[u] = t.g_rec[s.rg_beg[rr] + off];
+                    const int sl = s.rg_beg[rr] + off;
+                    px[u] = t.g_x[0][sl]; py[u] = t.g_x[1][sl];
+                    if (D == 3) pz[u] = t.g_x[D - 1][sl];
+                    pc[u] = t.g_cost[sl];
+                    id[u] = t.g_idx[sl];
                     flag[u] = (unsigned)s.rg_flag[rr];
                 }
             }
 #pragma unroll
             for (int u = 0; u < GRID_U; u++) {
                 if (f0 + u * NT < total) {   // uniform
-                    const int id = __float_as_int(rec[u].w);
-                    if (flag[u] & GRID_Q) {
-                        float wv = dist2f<D>(qx - rec[u].x, qy - rec[u].y, D == 3 ? qz - rec[u].z : 0.f);
-                        if (wv < m1 || (wv == m1 && id < i1)) { m2 = m1; m1 = wv; i1 = id; } else if (wv < m2) m2 = wv;
-                    }
-                    bool hit = false;
-                    if (flag[u] & GRID_N) {
-                        float v = dist2f<D>(nx - rec[u].x, ny - rec[u].y, D == 3 ? nz - rec[u].z : 0.f);
-                        hit = v <= lo_f;
-                        if (!hit && v <= hi_f) hit = exact_hit(id);
-                    }
-                    const unsigned long long mk = __ballot(hit);
-                    if (mk) {
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(&s.hit_cnt, __popcll(mk));
-                        base = __builtin_amdgcn_readfirstlane(base);   // lane 0 did the add; every lane is active here
-                        if (hit) t.bfs_q[base + __popcll(mk & lt)] = id;
-                    }
+                    double sm = 0.;
+                    const bool member = flag[u] ? process(px[u], py[u], pz[u], pc[u], id[u], flag[u], sm) : false;
+                    if (wantN) stash(member, id[u], sm);
                 }
             }
         }
     };
-    if (!(brute_q && !wantN)) {
-        __syncthreads();
-        for (int row = tid; row < rowsN + (brute_q ? 0 : rowsQ); row += NT) {
-            if (row < rowsN) put_row(1 + row, nb0, nb1, row, GRID_N, pn, r);
-            else put_row(1 + row, qb0, qb1, row - rowsN, GRID_Q, nullptr, 0.);
+    const unsigned fl_all = (wantN ? GRID_N : 0u) | (wantQ ? GRID_Q : 0u);
+    if (brute) {
+        brutes++;
+        visit_records(0, fl_all);
+    } else {
+        for (int row = tid; row < rowsN + rowsQ; row += NT) {
+            if (row < rowsN) put_row(row, nb0, nb1, row, GRID_N, pn, r);
+            else put_row(row, qb0, qb1, row - rowsN, GRID_Q, nullptr, 0.);
         }
-        if (tid == 0) {
-            const int R = rowsN + (brute_q ? 0 : rowsQ);
-            // slot 0 = the unordered tail (the largest range: found first by the lanes' linear search)
-            s.rg_beg[0] = ns; s.rg_len[0] = n - ns;
-            s.rg_flag[0] = (wantN ? GRID_N : 0u) | ((wantQ && !brute_q) ? GRID_Q : 0u);
-            s.rg_n = R + 1;
-            s.hit_cnt = 0;
-        }
+        if (tid == 0) s.rg_n = rowsN + rowsQ;
         __syncthreads();
         PROF(20);
-        visit();
+        visit_records(ns, fl_all);   // the tail first (its loads do not wait on the range list)
+        visit_ranges();
     }
     PROF(13);
-    if (wantQ && !brute_q) {
+    int result_ni = -1;
+    if (wantQ) {
         // widen the box until it provably contains the nearest vertex: nothing found -> one more ring of cells (twice),
-        // something found -> the box of the ball through the float32 winner's upper distance bound (then final)
+        // something found -> the box of the ball through the winner's distance (then final)
         double ring = 0.;
         for (int pass = 0;; pass++) {   // uniform
             double g1;
-            int gi = wg_nearest_finish32<D, NT>(s, e32, m1, i1, m2, &g1);
+            const int gi = wg_nearest_finish<D, NT>(s, m1, i1, m2, &g1);
+            if (brute) {   // the whole tree was visited
+                result_ni = gi >= 0 ? gi : wg_nearest_exact<D, NT>(s, t, n, q);
+                break;
+            }
             int eb0[3], eb1[3];
             if (g1 == __builtin_inf()) {
-                if (pass >= 2) { brute_q = true; break; }
                 double h = 0.;
 #pragma unroll
                 for (int k = 0; k < D; k++) h = fmax(h, 1.0 / t.g_inv_h[k]);
                 ring += h;
                 grid_box<D>(t, q, ring, eb0, eb1);
             } else {
-                // every vertex that could beat the float32 winner lies within sqrt(upper bound of its true d2) of q
-                const double rad = __builtin_sqrt(f32_upper<D>(e32, g1)) * (1.0 + 1e-9);
+                // every vertex that could beat (or tie with) the winner lies within its distance of q
+                const double rad = __builtin_sqrt(g1 * BAND_HI) * (1.0 + 1e-9);
                 grid_box<D>(t, q, rad, eb0, eb1);
                 bool covered = true;
 #pragma unroll
                 for (int k = 0; k < D; k++) covered = covered && eb0[k] >= qb0[k] && eb1[k] <= qb1[k];
                 if (covered) {
-                    if (gi < 0) brute_q = true; else result_ni = gi;
+                    result_ni = gi >= 0 ? gi : wg_nearest_exact<D, NT>(s, t, n, q);
                     if (tid == 0) {   // statistics only: no decision depends on it
                         TreeDev &tw = const_cast<TreeDev &>(t);
                         tw.g_rho = 0.875 * tw.g_rho + 0.125 * __builtin_sqrt(g1);
@@ -1306,87 +1227,52 @@ __device__ __forceinline__ int wg_grid_query(Lds<NT> &s, const TreeDev &t, int n
                 }
             }
             const int rowsE = grid_rows(eb0, eb1);
-            if (rowsE + 1 > GRID_RG_MAX || pass >= 3) { brute_q = true; break; }
-            // another visit: the enlarged box + tail, nearest only (a fresh reduction: a vertex seen twice would look
-            // like its own runner-up)
-            __syncthreads();
-            for (int row = tid; row < rowsE; row += NT) put_row(1 + row, eb0, eb1, row, GRID_Q, nullptr, 0.);
-            if (tid == 0) {
-                s.rg_beg[0] = ns; s.rg_len[0] = n - ns; s.rg_flag[0] = GRID_Q;
-                s.rg_n = rowsE + 1;
+            // another visit, nearest only, with a fresh reduction (a vertex seen twice would look like its own runner-up)
+            m1 = __builtin_inf(); m2 = __builtin_inf(); i1 = 0x7fffffff;
+            if (rowsE > GRID_RG_MAX || pass >= 3 || (g1 == __builtin_inf() && pass >= 2)) {
+                brute = true;
+                brutes++;
+                visit_records(0, GRID_Q);
+                continue;
             }
+            revisits++;
+            __syncthreads();
+            for (int row = tid; row < rowsE; row += NT) put_row(row, eb0, eb1, row, GRID_Q, nullptr, 0.);
+            if (tid == 0) s.rg_n = rowsE;
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 3; k++) { qb0[k] = eb0[k]; qb1[k] = eb1[k]; }
-            m1 = __builtin_inff(); m2 = __builtin_inff(); i1 = 0x7fffffff;
-            visit();
-        }
-    }
-    __syncthreads();
-    PROF(14);
-    if (wantN) {
-        // ascending order through the bitmap, one 16 384-vertex window at a time
-        kraw = uni(s.hit_cnt);
-        int kout = 0;
-        for (int wb = 0; wb < n && kout < kraw; wb += 32 * GRID_BM_WORDS) {
-            for (int a0 = tid; a0 < kraw; a0 += NT * NEAR_U) {
-                unsigned ids[NEAR_U];
-#pragma unroll
-                for (int u = 0; u < NEAR_U; u++) ids[u] = a0 + u * NT < kraw ? (unsigned)(t.bfs_q[a0 + u * NT] - wb) : 0xffffffffu;
-#pragma unroll
-                for (int u = 0; u < NEAR_U; u++)
-                    if (ids[u] < 32u * GRID_BM_WORDS) atomicOr(&s.bm[ids[u] >> 5], 1u << (ids[u] & 31u));
-            }
-            __syncthreads();
-            const int left = n - wb;
-            const int nw = left >= 32 * GRID_BM_WORDS ? GRID_BM_WORDS : (left + 31) >> 5;
-            const int per = (nw + NT - 1) / NT, b = tid * per;
-            int cnt = 0;
-            for (int j = 0; j < per; j++)
-                if (b + j < nw) cnt += __popc(s.bm[b + j]);
-            int off;
-            const int tot = block_excl_scan<NT>(s, cnt, off);
-            int o = kout + off;
-            for (int j = 0; j < per; j++) {
-                if (b + j < nw) {
-                    unsigned m = s.bm[b + j];
-                    if (m) {
-                        s.bm[b + j] = 0u;
-                        while (m) {
-                            t.st_idx[o++] = wb + ((b + j) << 5) + __builtin_ctz(m);
-                            m &= m - 1u;
-                        }
-                    }
-                }
-            }
-            kout += tot;
-            __syncthreads();
-        }
-    }
-    PROF(15);
-    if (wantQ) {
-        if (brute_q) {
-            result_ni = wg_nearest_scan<D, NT>(s, t, n, q);   // uniform (rare)
-            scanned += n;
+            visit_records(ns, GRID_Q);
+            visit_ranges();
         }
         *ni = result_ni;
     }
-    return kraw;
+    PROF(14);
+    if (wantN) {
+        block_argmin<NT>(s, cand, cj);   // lexicographic (value, index): np.argmin's first minimum of the ascending list
+        nr->cand = uni(cand);
+        nr->cj = uni(cj);
+        nr->k = uni(s.hit_cnt);
+    }
+    if (tid == 0) {
+        s.stat[ST_VISITED] += visited; s.stat[ST_VISIT_B] += vbytes; s.stat[ST_REVISITS] += revisits; s.stat[ST_BRUTE] += brutes;
+        if (wantN) {
+            const int k = s.hit_cnt;
+            s.stat[ST_MEMBERS] += k;
+            if (k > lds_cap) s.stat[ST_SPILLED] += k - lds_cap;
+        }
+    }
+    __syncthreads();
+    PROF(15);
 }
 
 // nearest_neighbor: argmin_i dist(q, v_i), lowest index on ties (np.argmin)
 template <int D, int NT>
-__device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, const double *q, long long *scanned = nullptr)
+__device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, const double *q)
 {
-    if (t.g_ns > 0) {
-        int ni = -1;
-        long long sc = 0;
-        wg_grid_query<D, NT>(s, t, n, nullptr, 0., q, &ni, sc);
-        if (scanned) *scanned = sc;
-        return ni;
-    }
-    if (scanned) *scanned = n;
-    return wg_nearest_scan<D, NT>(s, t, n, q);
+    int ni = -1;
+    wg_query<D, NT>(s, t, n, nullptr, 0., -1, q, &ni, nullptr, 0);
+    return ni;
 }
 
 // chase parent chains leaf -> root (RRTBase.cost, rrt_base_2d.py:54-61): acc = 0; acc += elen[v]; v = parent[v] ...
@@ -1394,9 +1280,9 @@ __device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, c
 // idx[r] <= 0: inactive slot (the root costs 0).  A chain stops early when it reaches `stop_at` (> 0):
 // the caller then continues the very same left-to-right sum with the cached tail of that vertex.
 template <int D>
-__device__ __forceinline__ void walk_chains(const TreeDev &t, int (&idx)[WALK_R], double (&acc)[WALK_R], int stop_at)
+__device__ __forceinline__ int walk_chains(const TreeDev &t, int (&idx)[WALK_R], double (&acc)[WALK_R], int stop_at)
 {
-    int guard = t.cap + 1;
+    int guard = t.cap + 1, nrec = 0;
     for (;;) {
         bool any = false;
 #pragma unroll
@@ -1405,7 +1291,7 @@ __device__ __forceinline__ void walk_chains(const TreeDev &t, int (&idx)[WALK_R]
         Hop4 h[WALK_R];
 #pragma unroll
         for (int r = 0; r < WALK_R; r++)
-            if (idx[r] > 0 && idx[r] != stop_at) h[r] = t.hop[idx[r]];
+            if (idx[r] > 0 && idx[r] != stop_at) { h[r] = t.hop[idx[r]]; nrec++; }
 #pragma unroll
         for (int r = 0; r < WALK_R; r++) {
             if (idx[r] > 0 && idx[r] != stop_at) {
@@ -1419,6 +1305,7 @@ __device__ __forceinline__ void walk_chains(const TreeDev &t, int (&idx)[WALK_R]
             }
         }
     }
+    return nrec;
 }
 
 // single chain
@@ -1456,14 +1343,13 @@ __device__ __forceinline__ void unlink_child(TreeDev &t, int v, int p)
 // one leaf->root walk per collected vertex (WALK_R chains per lane).  Every such walk passes through
 // `through` (= new_idx, the vertex they were all just hung under): it is chased in memory only up to
 // there and finished from s.chainE, the edge-length sequence through -> root recorded this iteration
-// - the same additions in the same order as a full walk.
+// - the same additions in the same order as a full walk.  The cost lands in the vertex's record and, for vertices
+// of the cell-ordered part of the index, in the mirror slot the Near visits read.
 template <int D, int NT>
-__device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v, int through, int k_near = 0)
+__device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v, int through)
 {
-    // k_near > 0: the current Near list t.nr_idx[0..k_near) (ascending) mirrors costs in t.nr_cost; members that
-    // are re-costed here are patched there too (binary search over the hot list: a per-vertex slot map was measured
-    // slower - two scattered write passes per iteration), so the rewire scan never re-reads scattered records
     const int tid = threadIdx.x;
+    const int ns = uni(t.g_ns);
     __syncthreads();
     if (tid == 0) { t.bfs_q[0] = v; s.bc_i[4] = 1; }
     __syncthreads();
@@ -1492,8 +1378,9 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v,
         level++;
         __syncthreads();
     }
+    int nrec = 0;
     for (int base = 0; base < tail; base += NT * WALK_R) {
-        int idx[WALK_R], who[WALK_R];
+        int idx[WALK_R], who[WALK_R], slot[WALK_R];
         double acc[WALK_R];
 #pragma unroll
         for (int r = 0; r < WALK_R; r++) {
@@ -1502,9 +1389,11 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v,
             idx[r] = who[r];
             acc[r] = 0.;
         }
+#pragma unroll
+        for (int r = 0; r < WALK_R; r++) slot[r] = (who[r] >= 0 && who[r] < ns) ? t.pos[who[r]] : -1;
         const int clen = s.chain_len;
         const int stop_at = clen >= 0 ? through : -1;
-        walk_chains<D>(t, idx, acc, stop_at);
+        nrec += walk_chains<D>(t, idx, acc, stop_at);
         if (clen >= 0) {
 #pragma unroll
             for (int r = 0; r < WALK_R; r++) {
@@ -1516,20 +1405,16 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v,
         for (int r = 0; r < WALK_R; r++) {
             if (who[r] >= 0) {
                 t.vrec[who[r]].cost = acc[r];
+                if (slot[r] >= 0) t.g_cost[slot[r]] = acc[r];
                 const unsigned char li = t.listed[who[r]];
                 if (li & 1) t.sol_dirty = 1;
                 if (li & 2) t.gc_dirty = 1;
-                if (k_near > 0) {
-                    int lo = 0, hi = k_near;
-                    while (lo < hi) {
-                        int mid = (lo + hi) >> 1;
-                        if (t.nr_idx[mid] < who[r]) lo = mid + 1; else hi = mid;
-                    }
-                    if (lo < k_near && t.nr_idx[lo] == who[r]) t.nr_cost[lo] = acc[r];
-                }
             }
         }
     }
+    // counters: every lane adds its own records (LDS atomic), the member count is uniform
+    if (nrec) atomicAdd((unsigned long long *)&s.stat[ST_HOPREC], (unsigned long long)nrec);
+    if (tid == 0) s.stat[ST_RECOST] += tail;
     __syncthreads();
 }
 
@@ -1539,9 +1424,10 @@ __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeDev &t, 
 {
     if (threadIdx.x == 0) {
         double acc = 0.;
-        int i = new_idx, len = 0, guard = t.cap + 1;
+        int i = new_idx, len = 0, guard = t.cap + 1, nrec = 0;
         while (i > 0 && guard-- > 0) {
             const Hop4 h = t.hop[i];
+            nrec++;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (i > 0) {
@@ -1554,6 +1440,7 @@ __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeDev &t, 
         }
         s.chain_len = len <= CHAIN_MAX ? len : -1;
         s.bc_d[6] = acc;
+        s.stat[ST_HOPREC] += nrec;
     }
     __syncthreads();
     double c = s.bc_d[6];
@@ -1594,237 +1481,14 @@ __device__ __forceinline__ bool wg_collision(const Lds<NT> &s, const double *a, 
     return block_any(hit);
 }
 
-// Near set of node_new on the current tree (find_near_neighbors, rrt_star_2d.py:125-144).
-// On return t.nr_idx[0..k) ascending and t.nr_dist[0..k) the reference scan distances.  Returns k.
+// find_near_neighbors as a primitive (nirrt_near): every member index goes to t.nr_idx[0, k) in visiting order (the host
+// sorts them ascending, which is the reference's np.where order); returns k.
 template <int D, int NT>
-__device__ __forceinline__ int wg_near(Lds<NT> &s, TreeDev &t, int n, const double *node_new, int new_idx,
-                                       const double *q2 = nullptr, int *ni2 = nullptr, long long *scanned = nullptr,
-                                       bool compact = true, double r_known = -1.)
+__device__ __forceinline__ int wg_near_list(Lds<NT> &s, TreeDev &t, int n, const double *node_new, int new_idx)
 {
-    // compact == false (the loop body): the list keeps its excluded members (t.nr_flag[a] != 0: the segment collides,
-    // or the member is new_idx itself) and the return value counts them too; the consumers skip flagged slots.
-    constexpr int NW = NT / 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
-    const double r = r_known >= 0. ? r_known : t.near_r[n];   // the loop body prefetches the table entry
-    const double r2 = r * r, r2lo = r2 * BAND_LO, r2hi = r2 * BAND_HI;
-    const double clr = t.clearance;
-    int beg, end, per;
-    wave_segment256<NT>(n, beg, end, per);
-    int woff[NW + 1];
-#pragma unroll
-    for (int i = 0; i <= NW; i++) woff[i] = 0;
-    int kgrid = -1;
-    PROF_DECL
-    if (t.g_ns > 0) {   // uniform: large tree, indexed
-        long long sc = 0;
-        kgrid = wg_grid_query<D, NT>(s, t, n, node_new, r, q2, ni2, sc);
-        if (kgrid >= 0 && scanned) *scanned = sc;
-        PROF(8);
-    }
-    if (kgrid < 0) {
-        if (scanned) *scanned = n;
-        const float4 *X = reinterpret_cast<const float4 *>(t.cf[0]);
-        const float4 *Y = reinterpret_cast<const float4 *>(t.cf[1]);
-        const float4 *Z = reinterpret_cast<const float4 *>(t.cf[D - 1]);
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        int cnt = 0;  // wave-uniform
-        // float32 thresholds of the filter: z <= lo_f => certainly d2 <= r2lo (inside); z > hi_f => certainly d2 > r2hi
-        // (outside); anything between is re-decided from the float64 coordinates with the float64 logic
-        const double e32 = f32_eps_for(t, node_new, D, q2);
-        const float lo_f = f32_down(r2lo - f32_err<D>(e32, r2lo)), hi_f = f32_up(r2hi + f32_err<D>(e32, r2hi));
-        const float nx = (float)node_new[0], ny = (float)node_new[1], nz = D == 3 ? (float)node_new[D - 1] : 0.f;
-        // the same pass can serve the NEXT iteration's nearest query (q2): vertices never move and this scan already
-        // covers the vertex just appended, so argmin_i |q2 - v_i| over [0, n) is exactly what nearest_neighbor will need
-        const bool fuse = q2 != nullptr;
-        const float qx = fuse ? (float)q2[0] : 0.f, qy = fuse ? (float)q2[1] : 0.f, qz = (fuse && D == 3) ? (float)q2[D - 1] : 0.f;
-        float m1 = __builtin_inff(), m2 = __builtin_inff();
-        int i1 = 0x7fffffff;
-        // exact (float64) Near membership of one vertex: the float64 guard-band logic
-        auto exact_hit = [&](int i) -> bool {
-            double d[3] = {node_new[0] - t.c[0][i], node_new[1] - t.c[1][i], D == 3 ? node_new[D - 1] - t.c[D - 1][i] : 0.};
-            double v = dist2<D>(d);
-            if (v <= r2lo) return true;
-            if (v > r2hi) return false;
-            return dist_scan<D>(d) <= r;
-        };
-        // one 256-vertex chunk: filter test for this lane's four vertices + ordered staging
-        auto chunk = [&](int base, const float4 &xv, const float4 &yv, const float4 &zv) {
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-            const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
-            const float zs[4] = {zv.x, zv.y, zv.z, zv.w};
-            bool h[4] = {false, false, false, false};
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int i = base + e;
-                if (i < end) {
-                    if (fuse) {
-                        float wv = dist2f<D>(qx - xs[e], qy - ys[e], D == 3 ? qz - zs[e] : 0.f);
-                        if (wv < m1) { m2 = m1; m1 = wv; i1 = i; } else if (wv < m2) m2 = wv;
-                    }
-                    float v = dist2f<D>(nx - xs[e], ny - ys[e], D == 3 ? nz - zs[e] : 0.f);
-                    h[e] = v <= lo_f;
-                    if (!h[e] && v <= hi_f) h[e] = exact_hit(i);   // inside the float32 error band: float64 decides
-                }
-            }
-            unsigned long long mk[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) mk[e] = __ballot(h[e]);
-            if (mk[0] | mk[1] | mk[2] | mk[3]) {
-                int pos = beg + cnt;
-#pragma unroll
-                for (int e = 0; e < 4; e++) pos += __popcll(mk[e] & lt);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    if (h[e]) { t.st_idx[pos] = base + e; pos++; }
-                }
-                cnt += __popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3]);
-            }
-        };
-        for (int cb = beg; cb < end; cb += 256 * SCAN_U) {
-            // SCAN_U chunks per trip; all 16-byte loads are issued before the first use
-            float4 xv[SCAN_U], yv[SCAN_U], zv[SCAN_U];
-#pragma unroll
-            for (int u = 0; u < SCAN_U; u++) {
-                const int bu = cb + 256 * u + 4 * lane;
-                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); yv[u] = xv[u]; zv[u] = xv[u];
-                if (bu < end) {
-                    xv[u] = X[bu >> 2]; yv[u] = Y[bu >> 2];
-                    if (D == 3) zv[u] = Z[bu >> 2];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < SCAN_U; u++)
-                if (cb + 256 * u < end) chunk(cb + 256 * u + 4 * lane, xv[u], yv[u], zv[u]);   // wave-uniform
-        }
-        if (fuse) {
-            int gi = wg_nearest_finish32<D, NT>(s, e32, m1, i1, m2);
-            if (gi < 0) gi = wg_nearest64<D, NT>(s, t, n, q2);   // uniform (rare)
-            *ni2 = gi;
-        }
-        __syncthreads();
-        PROF(8);
-        if (lane == 0) s.wave_tot[w] = cnt;
-        __syncthreads();
-        woff[0] = 0;
-#pragma unroll
-        for (int i = 0; i < NW; i++) woff[i + 1] = woff[i] + s.wave_tot[i];
-    }
-    const bool contig = kgrid >= 0;
-    const int kraw = uni(contig ? kgrid : woff[NW]);
-    // Pass A - gather the staged hits (already ascending): index, exact cost and reference distance from the 32-byte
-    // record, and the AABB prefilter against the obstacles near the ball.  (segment, obstacle) pairs that survive the
-    // prefilter are queued so that the expensive exact tests run densely packed.
-    int *pairq = t.bfs_q;
-    const int pair_cap = t.cap;
-    const int M = s.n_round + s.n_box;
-    if (tid == 0) { s.bc_i[5] = 0; s.ob_n = 0; }
-    __syncthreads();
-    // obstacles whose inflated box meets the box of the Near ball: a segment new -> v_j (|v_j - new| <= r per axis)
-    // can only pass the prefilter of those.  Same comparisons as seg_aabb_pass, on a superset of every segment's box.
-    for (int o = tid; o < M; o += NT) {
-        const double rb = r * (1.0 + 1e-9);
-        double l0[3], l1[3];
-#pragma unroll
-        for (int c = 0; c < D; c++) { l0[c] = node_new[c] - rb; l1[c] = node_new[c] + rb; }
-        if (seg_aabb_pass<D, NT>(s, o, l0, l1)) s.ob_list[atomicAdd(&s.ob_n, 1)] = (unsigned char)o;
-    }
-    __syncthreads();
-    const int n_ob = uni(s.ob_n);
-    // NEAR_U slots per lane and trip: the index loads, then the 32-byte record loads, are issued back to back
-    for (int a0 = tid; a0 < kraw; a0 += NT * NEAR_U) {
-        int vs[NEAR_U];
-        VRec vrs[NEAR_U];
-#pragma unroll
-        for (int u = 0; u < NEAR_U; u++) {
-            const int a = a0 + u * NT;
-            vs[u] = 0;
-            if (a < kraw) {
-                int ww = 0, offw = 0;
-#pragma unroll
-                for (int i = 1; i < NW; i++)
-                    if (a >= woff[i]) { ww = i; offw = woff[i]; }
-                vs[u] = contig ? t.st_idx[a] : t.st_idx[ww * per + (a - offw)];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NEAR_U; u++)
-            if (a0 + u * NT < kraw) vrs[u] = t.vrec[vs[u]];
-#pragma unroll
-        for (int u = 0; u < NEAR_U; u++) {
-            const int a = a0 + u * NT;
-            if (a < kraw) {
-                const int v = vs[u];
-                const VRec vr = vrs[u];
-                double vj[3] = {vr.x, vr.y, vr.z};
-                t.nr_cost[a] = vr.cost;
-                double d[3] = {node_new[0] - vj[0], node_new[1] - vj[1], D == 3 ? node_new[D - 1] - vj[2] : 0.};
-                t.nr_idx[a] = v;
-                t.nr_flag[a] = (v == new_idx) ? 1 : 0;   // excluded like the colliding ones
-                t.nr_dist[a] = dist_scan<D>(d);
-                double l0[3], l1[3];
-#pragma unroll
-                for (int c = 0; c < D; c++) { l0[c] = fmin(node_new[c], vj[c]); l1[c] = fmax(node_new[c], vj[c]); }
-                for (int j = 0; j < n_ob; j++) {
-                    const int o = s.ob_list[j];
-                    if (seg_aabb_pass<D, NT>(s, o, l0, l1)) {
-                        int pos = atomicAdd(&s.bc_i[5], 1);
-                        if (pos < pair_cap) pairq[pos] = a * MAX_OBS * 2 + o;
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    PROF(9);
-    // Pass B - exact segment tests for the queued pairs (node_new -> v_j vs obstacle o)
-    const int npairs = uni(s.bc_i[5]);
-    if (npairs <= pair_cap) {
-        for (int p0 = tid; p0 < npairs; p0 += NT * NEAR_U) {
-            int code[NEAR_U], vv[NEAR_U];
-            VRec pr[NEAR_U];
-#pragma unroll
-            for (int u = 0; u < NEAR_U; u++) code[u] = p0 + u * NT < npairs ? pairq[p0 + u * NT] : -1;
-#pragma unroll
-            for (int u = 0; u < NEAR_U; u++) vv[u] = code[u] >= 0 ? t.nr_idx[code[u] / (MAX_OBS * 2)] : 0;
-#pragma unroll
-            for (int u = 0; u < NEAR_U; u++)
-                if (code[u] >= 0) pr[u] = t.vrec[vv[u]];   // the few queued segments re-read their end point (L2-hot)
-#pragma unroll
-            for (int u = 0; u < NEAR_U; u++) {
-                if (code[u] >= 0) {
-                    const int j = code[u] / (MAX_OBS * 2), o = code[u] - j * (MAX_OBS * 2);
-                    double vj[3] = {pr[u].x, pr[u].y, D == 3 ? pr[u].z : 0.};
-                    if (seg_obstacle<D, NT>(s, o, node_new, vj, clr)) t.nr_flag[j] = 1;
-                }
-            }
-        }
-    } else {
-        // pair queue overflow (cannot happen unless almost every obstacle overlaps every segment): direct loop
-        for (int j = tid; j < kraw; j += NT) {
-            const VRec pr = t.vrec[t.nr_idx[j]];
-            double vj[3] = {pr.x, pr.y, D == 3 ? pr.z : 0.};
-            if (seg_all<D, NT>(s, node_new, vj, clr)) t.nr_flag[j] = 1;
-        }
-    }
-    __syncthreads();
-    PROF(10);
-    if (!compact) return kraw;
-    // Pass C - stable in-place filter (index + distance)
-    int k = 0;
-    for (int base = 0; base < kraw; base += NT) {
-        int a = base + tid;
-        int vi = 0;
-        double vd = 0., vc = 0.;
-        bool keep = false;
-        if (a < kraw) { vi = t.nr_idx[a]; vd = t.nr_dist[a]; vc = t.nr_cost[a]; keep = t.nr_flag[a] == 0; }
-        int pos;
-        int tot = block_compact<NT>(s, keep, pos);
-        if (keep) { t.nr_idx[k + pos] = vi; t.nr_dist[k + pos] = vd; t.nr_cost[k + pos] = vc; }
-        k += tot;
-    }
-    __syncthreads();
-    PROF(11);
-    return k;
+    NearResult nr;
+    wg_query<D, NT>(s, t, n, node_new, t.near_r[n], new_idx, nullptr, nullptr, &nr, 0);
+    return nr.k;
 }
 
 // find_best_path_solution (irrt_star_2d.py:84-97): argmin_s cost(sol[s]) + Line(v_s, goal), first minimum.
@@ -1858,7 +1522,7 @@ __device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double 
         }
         block_argmin<NT>(s, bv, bs);
         if (bs == 0x7fffffff) bs = 0;
-        if (tid == 0) { t.sol_dirty = 0; t.sol_best = bs; t.sol_best_cost = bv; }
+        if (tid == 0) { t.sol_dirty = 0; t.sol_best = bs; t.sol_best_cost = bv; s.stat[ST_LISTSCAN] += ns; }
         __syncthreads();
     }
     c_best = t.sol_best_cost;
@@ -1921,7 +1585,7 @@ __device__ __forceinline__ void wg_goal_parent(Lds<NT> &s, TreeDev &t, int &gp, 
         }
         block_argmin<NT>(s, bv, bq);
         if (bq == 0x7fffffff) bq = 0;  // every candidate collides: np.argmin of all-inf = 0
-        if (tid == 0) { t.gc_dirty = 0; t.gc_best = bq; t.gc_best_cost = bv; }
+        if (tid == 0) { t.gc_dirty = 0; t.gc_best = bq; t.gc_best_cost = bv; s.stat[ST_LISTSCAN] += ng; }
         __syncthreads();
     }
     gp = t.gc_idx[t.gc_best];
@@ -1984,13 +1648,12 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                                              int nearest_in, unsigned flags, nirrt_step_result *res,
                                              int pref_ni = -1, const double *q_next = nullptr)
 {
-    // pref_ni >= 0: nearest_neighbor(node_in) already known from the previous iteration's fused Near scan.
-    // q_next != nullptr: the next iteration's node_rand; if this iteration runs a Near scan its nearest index is
+    // pref_ni >= 0: nearest_neighbor(node_in) already known from the previous iteration's fused query.
+    // q_next != nullptr: the next iteration's node_rand; if this iteration runs a Near query its nearest index is
     // left in s.bc_i[6] (else -1) for the caller to pass back as pref_ni.
     const int tid = threadIdx.x;
     const double clr = t.clearance;
     int n = uni(t.n);
-    long long scanned = 0;
     long long alg = host_steer ? 0 : n;
     PROF_DECL
     // keep the cell-ordered part of the grid index within GRID_REBUILD_EVERY vertices of the tree
@@ -2004,7 +1667,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         for (int k = 0; k < D; k++) node_new[k] = node_in[k];
     } else {
         if (pref_ni >= 0) ni = pref_ni;
-        else ni = wg_nearest<D, NT>(s, t, n, node_in, &scanned);
+        else ni = wg_nearest<D, NT>(s, t, n, node_in);
         PROF(0);
     }
     ni = uni(ni);
@@ -2043,18 +1706,10 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
             new_idx = n;
             if (tid == 0) {
                 // loads first (one round trip), then the stores
-                double cm = t.cmax;
                 const Hop4 hp = t.hop[ni];
                 const int fc_ni = t.first_child[ni];
 #pragma unroll
-                for (int k = 0; k < D; k++) {
-                    t.c[k][new_idx] = node_new[k];
-                    t.cf[k][new_idx] = (float)node_new[k];
-                    cm = fmax(cm, fabs(node_new[k]));
-                }
-                t.g_rec[new_idx] = make_float4((float)node_new[0], (float)node_new[1], D == 3 ? (float)node_new[D - 1] : 0.f,
-                                               __int_as_float(new_idx));
-                t.cmax = cm;
+                for (int k = 0; k < D; k++) t.c[k][new_idx] = node_new[k];
                 Aux a;
                 a.elen = edge_new; a.parent = ni; a.pad = 0;
                 t.aux[new_idx] = a;
@@ -2062,7 +1717,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 t.hop[new_idx] = s.hop_new;
                 VRec vr;
                 vr.x = node_new[0]; vr.y = node_new[1]; vr.z = D == 3 ? node_new[D - 1] : 0.; vr.cost = 0.;
-                t.vrec[new_idx] = vr;
+                t.vrec[new_idx] = vr;   // also its entry in the tail of the index
                 t.first_child[new_idx] = -1;
                 // link_child(new_idx, ni) with the head read above; new's own links are remembered for a re-parenting
                 t.next_sib[new_idx] = fc_ni;
@@ -2072,17 +1727,18 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 s.new_next = fc_ni;
                 s.new_fc = -1;
                 t.n = n + 1;
+                s.stat[ST_INSERTED] += 1;
             }
             n = n + 1;
             inserted = true;
             __syncthreads();
         }
         if (new_idx >= 0) {
-            long long sc_near = 0;
-            // k counts the slots of the Near list, excluded members (nr_flag) included
-            const int k = wg_near<D, NT>(s, t, n, node_new, new_idx, q_next, &next_ni, &sc_near, false,
-                                         inserted ? r_grown : r_same);
-            scanned += sc_near;
+            // the fused query: Near members of node_new (stash + choose_parent's argmin) and the next sample's nearest vertex
+            NearResult nr;
+            const int cap_lds = uni(s.stash_cap);
+            wg_query<D, NT>(s, t, n, node_new, inserted ? r_grown : r_same, new_idx, q_next, &next_ni, &nr, cap_lds);
+            const int k = nr.k;
             alg += n;
             PROF(2);
             int reparented = 0, n_rewired = 0;
@@ -2090,43 +1746,21 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
             const double cost_ni = vnear.cost;   // no tree operation since the load changes a cost
             const double curr = dup ? cost_ni : cost_ni + edge_new;
             int best_parent = -1;
-            if (k > 0) {
-                // choose_parent (rrt_star_2d.py:80-90): argmin over the Near set of cost(j) + dist, first minimum
-                double cand = __builtin_inf();
-                int cj = 0x7fffffff;
-                for (int a0 = tid; a0 < k; a0 += NT * NEAR_U) {
-                    int fl[NEAR_U];
-                    double co[NEAR_U], di[NEAR_U];
-#pragma unroll
-                    for (int u = 0; u < NEAR_U; u++) {
-                        const int a = a0 + u * NT;
-                        fl[u] = 1; co[u] = 0.; di[u] = 0.;
-                        if (a < k) { fl[u] = t.nr_flag[a]; co[u] = t.nr_cost[a]; di[u] = t.nr_dist[a]; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < NEAR_U; u++) {
-                        const double c = fl[u] ? __builtin_inf() : co[u] + di[u];
-                        if (c < cand) { cand = c; cj = a0 + u * NT; }   // ascending a per lane: first minimum kept
-                    }
-                }
-                block_argmin<NT>(s, cand, cj);
-                cand = uni(cand);
-                cj = uni(cj);
-                if (cand < curr) { reparented = 1; best_parent = t.nr_idx[cj]; }
-            }
+            // choose_parent (rrt_star_2d.py:80-90): argmin over the Near set of cost(j) + dist, first minimum
+            if (k > 0 && nr.cand < curr) { reparented = 1; best_parent = nr.cj; }
             PROF(3);
             if (reparented) {
                 if (tid == 0) {
                     // loads first (one round trip), then the stores
-                    double v[D], d[D];
-                    load_vertex<D>(t, best_parent, v);
+                    const VRec vb = t.vrec[best_parent];
                     const Hop4 hp = t.hop[best_parent];
                     const int fc_bp = t.first_child[best_parent];
                     int old_p, nx, pv;
                     if (dup) { old_p = t.aux[new_idx].parent; nx = t.next_sib[new_idx]; pv = t.prev_sib[new_idx]; }
                     else { old_p = ni; nx = s.new_next; pv = -1; }   // just inserted at the head of ni's children
-#pragma unroll
-                    for (int c = 0; c < D; c++) d[c] = node_new[c] - v[c];
+                    double d[D];
+                    d[0] = node_new[0] - vb.x; d[1] = node_new[1] - vb.y;
+                    if (D == 3) d[D - 1] = node_new[D - 1] - vb.z;
                     const double el = hypot_py<D>(d);
                     // unlink from the old parent
                     if (pv >= 0) t.next_sib[pv] = nx; else t.first_child[old_p] = nx;
@@ -2152,45 +1786,51 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
             if (k > 0 || !dup) {
                 new_cost = wg_chain_of_new<D, NT>(s, t, new_idx);
                 if (dup) {
-                    if (reparented) wg_recost_subtree<D, NT>(s, t, new_idx, new_idx, k);
+                    if (reparented) wg_recost_subtree<D, NT>(s, t, new_idx, new_idx);
                 } else {
                     if (tid == 0) t.vrec[new_idx].cost = new_cost;
                 }
             }
             PROF(4);
             if (k > 0) {
-                // rewire (rrt_star_2d.py:92-99): sequential semantics.  Decisions up to and including the first
-                // "true" are exact with the cached costs; the re-parented vertex's subtree is re-costed before
-                // the scan resumes, so later decisions see the updated costs exactly like the reference.
-                int start = 0;
-                while (start < k) {
+                // rewire (rrt_star_2d.py:92-99), sequential semantics: members in ascending index order, each tested with
+                // its CURRENT cost.  Costs only ever drop during a rewire pass, so a member can only pass
+                // `cost(j) > cost(new) + d_j` if its stashed margin cost(j) - d_j (visit time, rounding ~1e-13) reaches
+                // cost(new): the stash is searched for the lowest such index above the last one handled, that member's
+                // record is read afresh and the reference's test decides; a re-parented vertex's subtree is re-costed
+                // before the search resumes.
+                const double thr = new_cost - (1e-10 + 1e-12 * new_cost);
+                const int k_lds = k < cap_lds ? k : cap_lds;
+                int last = -1;
+                for (;;) {
                     int first = 0x7fffffff;
-                    for (int a0 = start + tid; a0 < k && first == 0x7fffffff; a0 += NT * NEAR_U) {
-                        int fl[NEAR_U];
-                        double co[NEAR_U], di[NEAR_U];
-#pragma unroll
-                        for (int u = 0; u < NEAR_U; u++) {
-                            const int a = a0 + u * NT;
-                            fl[u] = 1; co[u] = 0.; di[u] = 0.;
-                            if (a < k) { fl[u] = t.nr_flag[a]; co[u] = t.nr_cost[a]; di[u] = t.nr_dist[a]; }
-                        }
-#pragma unroll
-                        for (int u = NEAR_U - 1; u >= 0; u--)
-                            if (!fl[u] && co[u] > new_cost + di[u]) first = a0 + u * NT;   // lowest slot of the trip wins
+                    const int *ids = stash_ids(s);
+                    for (int a = tid; a < k_lds; a += NT) {
+                        const int id = ids[a];
+                        if (id > last && id < first && s.pool[s.stash_off + a] >= thr) first = id;
+                    }
+                    for (int a = cap_lds + tid; a < k; a += NT) {   // spilled part (large Near sets only)
+                        const int id = t.nr_idx[a - cap_lds];
+                        if (id > last && id < first && t.nr_m[a - cap_lds] >= thr) first = id;
                     }
                     first = uni(block_min_int<NT>(s, first));
                     if (first == 0x7fffffff) break;
-                    const int vj = uni(t.nr_idx[first]);
+                    const int vj = first;
+                    last = vj;
+                    const VRec vr = t.vrec[vj];   // current cost + coordinates (same address in every lane)
+                    double d[D];
+                    d[0] = vr.x - node_new[0]; d[1] = vr.y - node_new[1];
+                    if (D == 3) d[D - 1] = vr.z - node_new[D - 1];
+                    const double dj = dist_scan<D>(d);
+                    if (tid == 0) s.stat[ST_ROUNDS] += 1;
+                    if (!(uni(vr.cost) > new_cost + dj)) continue;   // uniform
                     if (tid == 0) {
                         // loads first (one round trip), then the stores
-                        double v[D], d[D];
                         const bool leaf = t.first_child[vj] < 0;
-                        load_vertex<D>(t, vj, v);
                         const int old_p = t.aux[vj].parent, nx = t.next_sib[vj], pv = t.prev_sib[vj];
                         const unsigned char li = t.listed[vj];
+                        const int slot = vj < t.g_ns ? t.pos[vj] : -1;
                         const int fc_new = dup ? t.first_child[new_idx] : s.new_fc;   // a fresh vertex's child list lives in LDS
-#pragma unroll
-                        for (int c = 0; c < D; c++) d[c] = v[c] - node_new[c];
                         const double el = hypot_py<D>(d);
                         if (pv >= 0) t.next_sib[pv] = nx; else t.first_child[old_p] = nx;
                         if (nx >= 0) t.prev_sib[nx] = pv;
@@ -2212,17 +1852,17 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                             acc += el;
                             for (int i = 0; i < clen; i++) acc += s.chainE[i];
                             t.vrec[vj].cost = acc;
-                            t.nr_cost[first] = acc;
+                            if (slot >= 0) t.g_cost[slot] = acc;
                             if (li & 1) t.sol_dirty = 1;
                             if (li & 2) t.gc_dirty = 1;
                             fast = 1;
                         }
                         s.bc_i[7] = fast;
+                        s.stat[ST_REWIRED] += 1;
                     }
                     n_rewired++;
-                    start = first + 1;
                     __syncthreads();
-                    if (!s.bc_i[7]) wg_recost_subtree<D, NT>(s, t, vj, new_idx, k);   // uniform
+                    if (!s.bc_i[7]) wg_recost_subtree<D, NT>(s, t, vj, new_idx);   // uniform
                 }
             }
             PROF(5);
@@ -2240,15 +1880,8 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                     }
                 }
             }
-            int n_near = 0;
-            if (res) {   // uniform: only the step API reports |Near|
-                for (int base = 0; base < k; base += NT) {
-                    const int a = base + tid;
-                    n_near += __syncthreads_count(a < k && t.nr_flag[a] == 0);
-                }
-            }
             if (res && tid == 0) {
-                res->inserted = inserted ? 1 : 0; res->new_idx = new_idx; res->n_near = n_near;
+                res->inserted = inserted ? 1 : 0; res->new_idx = new_idx; res->n_near = k;
                 res->reparented = reparented; res->n_rewired = n_rewired; res->in_goal = in_goal;
                 res->node_new[0] = node_new[0]; res->node_new[1] = node_new[1];
                 res->node_new[2] = D == 3 ? node_new[D - 1] : 0.;
@@ -2258,7 +1891,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
         res->collided = 1;
     }
     PROF(6);
-    if (tid == 0) { t.stamp = t.stamp + 1; t.scan_elems += scanned; t.alg_elems += alg; s.bc_i[6] = next_ni; }
+    if (tid == 0) { s.stat[ST_ITERS] += 1; s.stat[ST_ALG] += alg; s.bc_i[6] = next_ni; }
     __syncthreads();
 }
 

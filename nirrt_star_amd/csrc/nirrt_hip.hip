@@ -67,6 +67,7 @@ struct RunSampleDev {
     double *cost_trace;
     long long *iters_done;
     int *stop_code;   // per tree: 0 done, NIRRT_E_STREAM, NIRRT_E_CAPACITY
+    const long long *iters_each;   // optional per-tree iteration budgets (<= iters)
 };
 
 // Three instantiations of every kernel; nirrt_run picks by batch size so that the CU's 16 wave slots are busy:
@@ -106,6 +107,7 @@ namespace slim {
 #define NT_WIDE NIRRT_NT_WIDE
 #define NT_SLIM 64
 static_assert(NT_WIDE / 64 <= LDS_NW_MAX && NT_NARROW / 64 <= LDS_NW_MAX, "LdsData reduction slots: raise LDS_NW_MAX");
+static_assert(sizeof(LdsData) <= 10240, "LdsData must fit 16 times into a CU's 160 KB of LDS (16 one-wave trees per CU)");
 // nirrt_run: batches larger than the 2048 workgroup slots of the 128-thread kernels run one wave per tree (16 trees per
 // CU with 10 KB of LDS): measured on 4096 problems 12.8 vs 10.9 M it/s (IRRT*), 39.0 vs 26.3 M it/s (RRT*); at 2048
 // problems the 128-thread kernels win (IRRT* 10.9 vs 8.6) or tie (RRT*).  NIRRT_SLIM_MIN_TREES overrides the threshold.
@@ -274,9 +276,9 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     TreeDev &h = t->host;
-    void *bufs[] = {h.cf[0], h.cf[1], h.cf[2], h.c[0], h.c[1], h.c[2], h.aux, h.vrec, h.nr_cost, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.st_idx,
-                    h.nr_idx, h.nr_flag, h.nr_dist, h.sol, h.sol_line, h.gc_idx, h.gc_dist, h.gc_col,
-                    h.g_rec, h.g_start, h.g_cnt, h.g_rank, h.hop, h.listed, t->near_r};
+    void *bufs[] = {h.c[0], h.c[1], h.c[2], h.aux, h.vrec, h.first_child, h.next_sib, h.prev_sib, h.bfs_q,
+                    h.nr_idx, h.nr_m, h.sol, h.sol_line, h.gc_idx, h.gc_dist, h.gc_col,
+                    h.g_x[0], h.g_x[1], h.g_x[2], h.g_cost, h.g_idx, h.pos, h.g_start, h.g_cnt, h.g_rank, h.hop, h.listed, t->near_r};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (t->pc_dev) (void)hipFree(t->pc_dev);
@@ -299,9 +301,7 @@ extern "C" int nirrt_reset(nirrt_tree *t)
     t->host.n_sol = 0;
     t->host.n_gc = 0;
     t->host.status = 0;
-    t->host.stamp = 0;
-    t->host.scan_elems = 0;
-    t->host.alg_elems = 0;
+    for (int i = 0; i < NSTAT; i++) t->host.stat[i] = 0;
     int rc = push_desc(t);
     if (rc) return rc;
     DISPATCH_DIM(t, k_init, 1, t->dev);
@@ -319,6 +319,10 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         return NIRRT_E_CAPACITY;
     }
     if ((cfg->n_round > 0 && !cfg->round_obs) || (cfg->n_box > 0 && !cfg->box_obs)) { g_err = "null obstacle table"; return NIRRT_E_ARG; }
+    if (4 * cfg->n_round + 6 * cfg->n_box > OB_POOL) {
+        g_err = "obstacle tables exceed the LDS pool (4 * n_round + 6 * n_box <= NIRRT_OBSTACLE_POOL)";
+        return NIRRT_E_CAPACITY;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         (void)hipGetLastError();
@@ -355,28 +359,16 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         HIPCHK_T(hipMalloc(&h.c[k], sizeof(double) * np));
         HIPCHK_T(hipMemset(h.c[k], 0, sizeof(double) * np));
     }
-    for (int k = 0; k < D; k++) {
-        HIPCHK_T(hipMalloc(&h.cf[k], sizeof(float) * np));
-        HIPCHK_T(hipMemset(h.cf[k], 0, sizeof(float) * np));
-    }
-    {
-        double cmax = 0.;
-        for (int k = 0; k < D; k++) cmax = std::fmax(cmax, std::fmax(std::fabs(cfg->range_lo[k]), std::fabs(cfg->range_hi[k])));
-        h.cmax = cmax;
-    }
     HIPCHK_T(hipMalloc(&h.aux, sizeof(Aux) * np));
     HIPCHK_T(hipMalloc(&h.hop, sizeof(Hop4) * np));
     HIPCHK_T(hipMemset(h.hop, 0, sizeof(Hop4) * np));
     HIPCHK_T(hipMalloc(&h.vrec, sizeof(VRec) * np));
-    HIPCHK_T(hipMalloc(&h.nr_cost, sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.first_child, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.next_sib, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.prev_sib, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.bfs_q, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.st_idx, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.nr_idx, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.nr_flag, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.nr_dist, sizeof(double) * np));
+    HIPCHK_T(hipMalloc(&h.nr_m, sizeof(double) * np));
     h.cap = t->cap;
     h.dim = D;
     h.cap_sol = t->cap;
@@ -403,7 +395,10 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         h.g_inv_h[k] = (double)h.g_G / ext;
         h.g_margin[k] = ext / (double)h.g_G / 256.0;
     }
-    HIPCHK_T(hipMalloc(&h.g_rec, sizeof(float4) * np));
+    for (int k = 0; k < D; k++) HIPCHK_T(hipMalloc(&h.g_x[k], sizeof(double) * np));
+    HIPCHK_T(hipMalloc(&h.g_cost, sizeof(double) * np));
+    HIPCHK_T(hipMalloc(&h.g_idx, sizeof(int) * np));
+    HIPCHK_T(hipMalloc(&h.pos, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.g_start, sizeof(int) * (size_t)(h.g_ncell + 1)));
     HIPCHK_T(hipMalloc(&h.g_cnt, sizeof(int) * (size_t)h.g_ncell));
     HIPCHK_T(hipMalloc(&h.g_rank, sizeof(int) * np));
@@ -589,6 +584,7 @@ extern "C" int nirrt_near(nirrt_tree *t, const double *node_new, int64_t new_idx
     if (idx_out && kk > 0) {
         std::vector<int> tmp((size_t)kk);
         HIPCHK(hipMemcpy(tmp.data(), t->host.nr_idx, sizeof(int) * (size_t)kk, hipMemcpyDeviceToHost));
+        std::sort(tmp.begin(), tmp.end());   // the kernel leaves the members in visiting order; np.where lists them ascending
         for (int i = 0; i < kk && i < cap; i++) idx_out[i] = tmp[(size_t)i];
     }
     return NIRRT_OK;
@@ -707,10 +703,22 @@ extern "C" int nirrt_set_cloud(nirrt_tree *t, int64_t n, const double *pts, doub
     t->host.pc_rate = sample_rate;
     t->host.pc_ratio = update_cost_ratio;
     t->host.c_update = c_update;
-    const size_t off = offsetof(TreeDev, pc), end = offsetof(TreeDev, g_rec);   // pc, pc_n, pc_rate, pc_ratio, c_update
+    const size_t off = offsetof(TreeDev, pc), end = offsetof(TreeDev, g_x);   // pc, pc_n, pc_rate, pc_ratio, c_update
     HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, end - off, hipMemcpyHostToDevice, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     return NIRRT_OK;
+}
+
+// per-tree counters of one launch: the descriptor accumulates since reset, a launch reports the difference
+static void report_stats(const nirrt_run_args *a, int i, const TreeDev &after, const long long *before)
+{
+    if (a->scan_elems) a->scan_elems[i] = after.stat[ST_VISITED] - before[ST_VISITED];
+    if (a->alg_elems) a->alg_elems[i] = after.stat[ST_ALG] - before[ST_ALG];
+    if (a->stats) {
+        for (int j = 0; j < NSTAT; j++) a->stats[(size_t)i * NSTAT + j] = after.stat[j] - before[j];
+        a->stats[(size_t)i * NSTAT + ST_T0] = after.stat[ST_T0];
+        a->stats[(size_t)i * NSTAT + ST_T1] = after.stat[ST_T1];
+    }
 }
 
 static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *a)
@@ -741,13 +749,11 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         return e;
     };
     std::vector<TreeDev *> ptrs((size_t)n_trees);
-    std::vector<long long> scan0((size_t)n_trees, 0), alg0((size_t)n_trees, 0);
+    std::vector<long long> stat0((size_t)n_trees * NSTAT, 0);
     for (int i = 0; i < n_trees; i++) {
         ptrs[(size_t)i] = trees[i]->dev;
-        TreeDev tmp;
-        HIPCHK_R(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
-        scan0[(size_t)i] = tmp.scan_elems;
-        alg0[(size_t)i] = tmp.alg_elems;
+        HIPCHK_R(hipMemcpy(&stat0[(size_t)i * NSTAT], (char *)trees[i]->dev + offsetof(TreeDev, stat), sizeof(long long) * NSTAT,
+                           hipMemcpyDeviceToHost));
     }
     // word streams -> device (one slab per generator) unless they already live there
     std::vector<const unsigned *> npp((size_t)n_trees), pyp((size_t)n_trees, nullptr);
@@ -794,7 +800,18 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
     HIPCHK_R(hipMemcpyAsync(d_pyp, pyp.data(), sizeof(void *) * nt, hipMemcpyHostToDevice, st));
     HIPCHK_R(hipMemcpyAsync(d_nnp, nnp.data(), sizeof(long long) * nt, hipMemcpyHostToDevice, st));
     HIPCHK_R(hipMemcpyAsync(d_npy, npy.data(), sizeof(long long) * nt, hipMemcpyHostToDevice, st));
+    long long *d_each = nullptr;
+    if (a->iters_each) {
+        std::vector<long long> each(nt);
+        for (int i = 0; i < n_trees; i++) {
+            if (a->iters_each[i] < 0 || a->iters_each[i] > a->iters) { g_err = "nirrt_run: iters_each[i] must be in [0, iters]"; cleanup(); return NIRRT_E_ARG; }
+            each[(size_t)i] = a->iters_each[i];
+        }
+        HIPCHK_R(dalloc(sizeof(long long) * nt, (void **)&d_each));
+        HIPCHK_R(hipMemcpy(d_each, each.data(), sizeof(long long) * nt, hipMemcpyHostToDevice));
+    }
     RunSampleDev rd;
+    rd.iters_each = d_each;
     rd.flags = a->flags; rd.pad = 0; rd.iters = a->iters;
     rd.np_words = d_npp; rd.n_np = d_nnp; rd.py_words = a->py_words ? d_pyp : nullptr; rd.n_py = d_npy;
     rd.np_used = d_npu; rd.py_used = d_pyu; rd.cost_trace = d_trace; rd.iters_done = d_done; rd.stop_code = d_stop;
@@ -829,8 +846,7 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         {
             TreeDev tmp;
             HIPCHK_R(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
-            if (a->scan_elems) a->scan_elems[i] = tmp.scan_elems - scan0[(size_t)i];
-            if (a->alg_elems) a->alg_elems[i] = tmp.alg_elems - alg0[(size_t)i];
+            report_stats(a, i, tmp, &stat0[(size_t)i * NSTAT]);
             trees[i]->last_n = tmp.n;
         }
         if (stop[(size_t)i] == NIRRT_E_CAPACITY) rc_all = NIRRT_E_CAPACITY;
@@ -874,13 +890,10 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
     long long *d_done = nullptr;
     size_t sbytes = sizeof(double) * (size_t)n_trees * (size_t)a->iters * D;
     HIPCHK(hipMalloc(&d_ptrs, sizeof(TreeDev *) * (size_t)n_trees));
-    std::vector<long long> scan0((size_t)n_trees, 0), alg0((size_t)n_trees, 0);
-    for (int i = 0; i < n_trees; i++) {
-        TreeDev tmp;
-        HIPCHK(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
-        scan0[(size_t)i] = tmp.scan_elems;
-        alg0[(size_t)i] = tmp.alg_elems;
-    }
+    std::vector<long long> stat0((size_t)n_trees * NSTAT, 0);
+    for (int i = 0; i < n_trees; i++)
+        HIPCHK(hipMemcpy(&stat0[(size_t)i * NSTAT], (char *)trees[i]->dev + offsetof(TreeDev, stat), sizeof(long long) * NSTAT,
+                         hipMemcpyDeviceToHost));
     if (a->inputs_on_device) d_samples = const_cast<double *>(a->samples);
     else HIPCHK(hipMalloc(&d_samples, sbytes ? sbytes : 8));
     HIPCHK(hipMalloc(&d_done, sizeof(long long) * (size_t)n_trees));
@@ -917,8 +930,7 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
         HIPCHK(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
         if (a->status) a->status[i] = tmp.status;
         trees[i]->last_n = tmp.n;
-        if (a->scan_elems) a->scan_elems[i] = tmp.scan_elems - scan0[(size_t)i];
-        if (a->alg_elems) a->alg_elems[i] = tmp.alg_elems - alg0[(size_t)i];
+        report_stats(a, i, tmp, &stat0[(size_t)i * NSTAT]);
         if (tmp.status) rc_all = tmp.status;
     }
     (void)hipFree(d_ptrs);

@@ -269,11 +269,18 @@ extern "C" int nirrt_pn2_three_nn(const float *xyz1, const float *xyz2, int B, i
 // ------------------------------------------------------------------------------------------------
 #define FPS64_MAX_PER_THREAD 16   // N <= 16384
 
-__global__ __launch_bounds__(FPS_NT) void k_fps_f64(const double *__restrict__ x, const double *__restrict__ y,
-                                                   const double *__restrict__ z, int N, int S, unsigned char *__restrict__ sel)
+// one workgroup per cloud: cloud b = points [off[b], off[b] + cnt[b]) of the concatenated SoA buffer
+// (x of all clouds, then y, then z; `total` points in all), ns[b] survivors, sel concatenated likewise
+__global__ __launch_bounds__(FPS_NT) void k_fps_f64(const double *__restrict__ buf, long long total, const long long *__restrict__ off,
+                                                   const int *__restrict__ cnt, const int *__restrict__ ns,
+                                                   unsigned char *__restrict__ sel_all)
 {
     __shared__ double rv[FPS_NT / 64];
     __shared__ int ri[FPS_NT / 64];
+    const long long o = off[blockIdx.x];
+    const int N = cnt[blockIdx.x], S = ns[blockIdx.x];
+    const double *x = buf + o, *y = buf + total + o, *z = buf + 2 * total + o;
+    unsigned char *sel = sel_all + o;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     double dist[FPS64_MAX_PER_THREAD];
 #pragma unroll
@@ -297,9 +304,9 @@ __global__ __launch_bounds__(FPS_NT) void k_fps_f64(const double *__restrict__ x
             }
         }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            double ov = __shfl_xor(bv, off);
-            int oi = __shfl_xor(bi, off);
+        for (int off2 = 32; off2 >= 1; off2 >>= 1) {
+            double ov = __shfl_xor(bv, off2);
+            int oi = __shfl_xor(bi, off2);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
         __syncthreads();
@@ -316,26 +323,54 @@ __global__ __launch_bounds__(FPS_NT) void k_fps_f64(const double *__restrict__ x
     }
 }
 
-// host pointers in / out: pts (N,3) row-major f64, sel (N,) bytes (1 = kept)
-extern "C" int nirrt_fps_f64(const double *pts, int N, int num_samples, unsigned char *sel, int device_id)
+// Down-sampling of n_clouds clouds in ONE launch (one workgroup each).  Host pointers in / out: pts = the clouds' (cnt[b], 3)
+// row-major f64 points back to back, sel = their keep-bytes back to back (1 = kept), num_samples[b] < cnt[b].
+extern "C" int nirrt_fps_f64_batch(const double *pts, int n_clouds, const int *cnt, const int *num_samples, unsigned char *sel,
+                                   int device_id)
 {
-    if (!pts || !sel || N <= 0 || num_samples <= 0 || N > FPS_NT * FPS64_MAX_PER_THREAD) return -1;
+    if (!pts || !sel || !cnt || !num_samples || n_clouds <= 0) return -1;
     if (hipSetDevice(device_id) != hipSuccess) return -4;
+    long long total = 0;
+    long long *h_off = (long long *)malloc(sizeof(long long) * (size_t)n_clouds);
+    for (int b = 0; b < n_clouds; b++) {
+        if (cnt[b] <= 0 || num_samples[b] <= 0 || num_samples[b] > cnt[b] || cnt[b] > FPS_NT * FPS64_MAX_PER_THREAD) { free(h_off); return -1; }
+        h_off[b] = total;
+        total += cnt[b];
+    }
+    double *h = (double *)malloc(sizeof(double) * 3 * (size_t)total);
+    for (long long i = 0; i < total; i++) { h[i] = pts[3 * i]; h[total + i] = pts[3 * i + 1]; h[2 * total + i] = pts[3 * i + 2]; }
     double *d = nullptr;
     unsigned char *ds = nullptr;
-    if (hipMalloc(&d, sizeof(double) * 3 * (size_t)N) != hipSuccess) return -2;
-    if (hipMalloc(&ds, (size_t)N) != hipSuccess) { (void)hipFree(d); return -2; }
-    double *h = (double *)malloc(sizeof(double) * 3 * (size_t)N);
-    for (int i = 0; i < N; i++) { h[i] = pts[3 * i]; h[N + i] = pts[3 * i + 1]; h[2 * (size_t)N + i] = pts[3 * i + 2]; }
+    long long *d_off = nullptr;
+    int *d_cnt = nullptr, *d_ns = nullptr;
     int rc = 0;
-    if (hipMemcpy(d, h, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice) != hipSuccess) rc = -2;
+    if (hipMalloc(&d, sizeof(double) * 3 * (size_t)total) != hipSuccess || hipMalloc(&ds, (size_t)total) != hipSuccess ||
+        hipMalloc(&d_off, sizeof(long long) * (size_t)n_clouds) != hipSuccess || hipMalloc(&d_cnt, sizeof(int) * (size_t)n_clouds) != hipSuccess ||
+        hipMalloc(&d_ns, sizeof(int) * (size_t)n_clouds) != hipSuccess)
+        rc = -2;
+    if (!rc && (hipMemcpy(d, h, sizeof(double) * 3 * (size_t)total, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(d_off, h_off, sizeof(long long) * (size_t)n_clouds, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(d_cnt, cnt, sizeof(int) * (size_t)n_clouds, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(d_ns, num_samples, sizeof(int) * (size_t)n_clouds, hipMemcpyHostToDevice) != hipSuccess))
+        rc = -2;
     if (!rc) {
-        hipLaunchKernelGGL(k_fps_f64, dim3(1), dim3(FPS_NT), 0, 0, (const double *)d, (const double *)(d + N), (const double *)(d + 2 * (size_t)N),
-                           N, num_samples, ds);
-        if (hipGetLastError() != hipSuccess || hipMemcpy(sel, ds, (size_t)N, hipMemcpyDeviceToHost) != hipSuccess) rc = -2;
+        hipLaunchKernelGGL(k_fps_f64, dim3(n_clouds), dim3(FPS_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
+                           (const int *)d_cnt, (const int *)d_ns, ds);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(sel, ds, (size_t)total, hipMemcpyDeviceToHost) != hipSuccess) rc = -2;
     }
     free(h);
-    (void)hipFree(d);
-    (void)hipFree(ds);
+    free(h_off);
+    if (d) (void)hipFree(d);
+    if (ds) (void)hipFree(ds);
+    if (d_off) (void)hipFree(d_off);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (d_ns) (void)hipFree(d_ns);
     return rc;
+}
+
+// one cloud: pts (N,3) row-major f64, sel (N,) bytes (1 = kept)
+extern "C" int nirrt_fps_f64(const double *pts, int N, int num_samples, unsigned char *sel, int device_id)
+{
+    if (N <= 0 || num_samples <= 0) return -1;
+    return nirrt_fps_f64_batch(pts, 1, &N, &num_samples, sel, device_id);
 }

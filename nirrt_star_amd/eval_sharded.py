@@ -65,36 +65,66 @@ def make_record(pid, trace, n_vertices):
     return rec
 
 
-def plan_batch(problems, pids, args, device_id):
-    """planning_random for a batch of problems in two persistent launches (until-first-solution, then
-    iter_after_initial more).  Each problem uses its own seeded generator pair (1000 + problem id)."""
-    from . import _hip, sampling
-    dim = 2 if args.problem == "random_2d" else 3
-    irrt = args.planner == "irrt_star"
-    flags = _hip.F_IRRT if irrt else _hip.F_GOAL_SCAN
-    cap = args.iter_max + args.iter_after_initial
-    trees, npw, pyw = [], [], []
+PLANNERS = ("rrt_star", "irrt_star", "nirrt_star", "nirrt_star_c", "nrrt_star", "nrrt_star_c")
+
+
+def make_wrapper(args, dim, device):
+    """PNGWrapper / PNGWrapper3D on `device` (the reference's `-n pointnet2`); without trained weights on disk a seeded
+    synthetic checkpoint in the reference's format is written first (there is no network access to fetch real ones)"""
+    import os
+    from . import png_wrapper as W
+    path = W.checkpoint_path(args.root_dir, dim)
+    if not os.path.exists(path):
+        W.make_synthetic_checkpoint(path, seed=0, dim=dim, device=device)
+    return (W.PNGWrapper if dim == 2 else W.PNGWrapper3D)(root_dir=args.root_dir, device=device)
+
+
+def _batch_setup(problems, pids, args, device_id, cap, wrapper):
+    from . import _hip, batch, sampling
+    dim = 3 if args.problem == "random_3d" else 2
+    planner = args.planner
+    informed = planner in ("irrt_star", "nirrt_star", "nirrt_star_c")
+    flags = _hip.F_IRRT if informed else _hip.F_GOAL_SCAN
+    trees, streams, frames = [], [], []
     for pr, pid in zip(problems, pids):
         t = _hip.HipTree(dim, cap, pr["x_start"], pr["x_goal"], args.step_len, pr["search_radius"], args.clearance, pr["env"],
                          device_id=device_id)
-        t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
+        frames.append(sampling.informed_frame(pr["x_start"], pr["x_goal"]))
+        t.set_informed(*frames[-1])
         trees.append(t)
-        rs = np.random.RandomState(1000 + pid)
-        npw.append(rs.randint(0, 1 << 32, size=cap * (6 if dim == 2 else 240) + 4096, dtype=np.uint32))
-        if dim == 2 and irrt:
-            n = cap * 16 + 4096
-            bits = random.Random(1000 + pid).getrandbits(32 * n)
-            pyw.append(np.frombuffer(bits.to_bytes(4 * n, "little"), dtype="<u4").astype(np.uint32))
-    use_py = bool(pyw)
-    r1 = _hip.run_sampling(trees, args.iter_max, npw, pyw if use_py else None, flags=flags | _hip.F_STOP_FIRST, want_trace=True)
-    traces = [r1["cost_trace"][i, : r1["iters_done"][i]] for i in range(len(trees))]
+        streams.append(batch.ProblemStreams(1000 + pid))
+    guidance = None
+    if planner.startswith("n"):
+        if wrapper is None:
+            raise ValueError("planner %s needs a PointNet++ wrapper (-n pointnet2)" % planner)
+        guidance = batch.Guidance(wrapper, dim, args.step_len, args.pc_n_points, args.pc_over_sample_scale, args.pc_sample_rate,
+                                  args.pc_update_cost_ratio, connect=planner.endswith("_c"),
+                                  connect_max_trial_attempts=args.connect_max_trial_attempts, informed=informed, device_id=device_id)
+    return dim, flags, trees, streams, frames, guidance
+
+
+def _raise_failures(res, pids):
+    if res["failed"]:
+        raise RuntimeError("planning stopped abnormally: " + "; ".join("problem %d: %s" % (pids[i], m) for i, m in sorted(res["failed"].items())))
+
+
+def plan_batch(problems, pids, args, device_id, wrapper=None):
+    """planning_random for a batch of problems: persistent launches until every tree has its first solution (or spent
+    iter_max iterations), then iter_after_initial more for the solved ones.  Each problem uses its own seeded generators
+    (1000 + problem id); word windows are refilled and guidance clouds refreshed between launches (nirrt_star_amd/batch.py)."""
+    from . import batch
+    cap = args.iter_max + args.iter_after_initial
+    dim, flags, trees, streams, frames, guidance = _batch_setup(problems, pids, args, device_id, cap, wrapper)
+    r1 = batch.run_batch(trees, streams, args.iter_max, flags, dim, problems, guidance, frames, want_trace=True, stop_first=True)
+    _raise_failures(r1, pids)
+    traces = list(r1["traces"])
     solved = [i for i in range(len(trees)) if len(traces[i]) and np.isfinite(traces[i][-1])]
     if solved and args.iter_after_initial > 0:
-        r2 = _hip.run_sampling([trees[i] for i in solved], args.iter_after_initial,
-                               [npw[i][r1["np_used"][i]:] for i in solved],
-                               [pyw[i][r1["py_used"][i]:] for i in solved] if use_py else None, flags=flags, want_trace=True)
+        r2 = batch.run_batch([trees[i] for i in solved], [streams[i] for i in solved], args.iter_after_initial, flags, dim,
+                             [problems[i] for i in solved], guidance, [frames[i] for i in solved], want_trace=True, init_clouds=False)
+        _raise_failures(r2, [pids[i] for i in solved])
         for j, i in enumerate(solved):
-            traces[i] = np.concatenate([traces[i], r2["cost_trace"][j, : r2["iters_done"][j]]])
+            traces[i] = np.concatenate([traces[i], r2["traces"][j]])
     recs = [make_record(pid, tr, t.n) for pid, tr, t in zip(pids, traces, trees)]
     for t in trees:
         t.close()
@@ -161,41 +191,25 @@ def make_block_gap_record(pid, trace, threshold, n_vertices):
     return rec
 
 
-def plan_batch_block_gap(problems, pids, thresholds, args, device_id):
+def plan_batch_block_gap(problems, pids, thresholds, args, device_id, wrapper=None):
     """planning_block_gap for a batch: the persistent loop runs in segments of args.segment iterations; after each
     segment the problems whose best path length got below their threshold leave the batch.  An iteration's result
     only depends on the iterations before it and every problem owns its generators, so truncating the cost trace at
     the first sub-threshold entry gives exactly the list the reference's early-exit loop returns."""
-    from . import _hip, sampling
-    irrt = args.planner == "irrt_star"
-    flags = _hip.F_IRRT if irrt else _hip.F_GOAL_SCAN
-    trees, npw, pyw = [], [], []
-    for pr, pid in zip(problems, pids):
-        t = _hip.HipTree(2, args.iter_max, pr["x_start"], pr["x_goal"], args.step_len, pr["search_radius"], args.clearance,
-                         pr["env"], device_id=device_id)
-        t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
-        trees.append(t)
-        rs = np.random.RandomState(1000 + pid)
-        npw.append(rs.randint(0, 1 << 32, size=args.iter_max * 6 + 4096, dtype=np.uint32))
-        if irrt:
-            n = args.iter_max * 16 + 4096
-            bits = random.Random(1000 + pid).getrandbits(32 * n)
-            pyw.append(np.frombuffer(bits.to_bytes(4 * n, "little"), dtype="<u4").astype(np.uint32))
+    from . import batch
+    dim, flags, trees, streams, frames, guidance = _batch_setup(problems, pids, args, device_id, args.iter_max, wrapper)
     traces = [np.zeros(0) for _ in trees]
-    used_np = [0] * len(trees)
-    used_py = [0] * len(trees)
     active = list(range(len(trees)))
     done_iters = 0
     while active and done_iters < args.iter_max:
         seg = min(args.segment, args.iter_max - done_iters)
-        r = _hip.run_sampling([trees[i] for i in active], seg, [npw[i][used_np[i]:] for i in active],
-                              [pyw[i][used_py[i]:] for i in active] if irrt else None, flags=flags, want_trace=True)
+        r = batch.run_batch([trees[i] for i in active], [streams[i] for i in active], seg, flags, dim, [problems[i] for i in active],
+                            guidance, [frames[i] for i in active], want_trace=True, init_clouds=done_iters == 0)
+        _raise_failures(r, [pids[i] for i in active])
         still = []
         for j, i in enumerate(active):
-            traces[i] = np.concatenate([traces[i], r["cost_trace"][j, : r["iters_done"][j]]])
-            used_np[i] += int(r["np_used"][j])
-            used_py[i] += int(r["py_used"][j])
-            if first_below(traces[i], thresholds[i]) < 0 and r["status"][j] == 0:
+            traces[i] = np.concatenate([traces[i], r["traces"][j]])
+            if first_below(traces[i], thresholds[i]) < 0:
                 still.append(i)
         active = still
         done_iters += seg
@@ -210,7 +224,16 @@ def main():
     ap.add_argument("--problem", default="random_2d", choices=["random_2d", "random_3d", "block", "gap"])
     ap.add_argument("--path_len_threshold_percentage", type=float, default=0.02, help="block: stop below best_path_len * (1 + this)")
     ap.add_argument("--segment", type=int, default=2000, help="block / gap: iterations per persistent launch")
-    ap.add_argument("--planner", default="irrt_star", choices=["rrt_star", "irrt_star"])
+    ap.add_argument("--planner", "-p", default="irrt_star", choices=list(PLANNERS))
+    ap.add_argument("--neural_net", "-n", default="none", choices=["none", "pointnet2"],
+                    help="nirrt_star / nrrt_star planners: the guidance network (demo_planning_2d.py:13-14)")
+    ap.add_argument("--connect", "-c", default="none", choices=["none", "bfs"], help="bfs = the -C planners (neural connect)")
+    ap.add_argument("--root_dir", default=".", help="where results/model_training/pointnet2_{2d,3d}/checkpoints/ lives")
+    ap.add_argument("--pc_n_points", type=int, default=2048)
+    ap.add_argument("--pc_over_sample_scale", type=int, default=5)
+    ap.add_argument("--pc_sample_rate", type=float, default=0.5)
+    ap.add_argument("--pc_update_cost_ratio", type=float, default=0.9)
+    ap.add_argument("--connect_max_trial_attempts", type=int, default=5)
     ap.add_argument("--iter_max", type=int, default=50000)
     ap.add_argument("--iter_after_initial", type=int, default=3000)
     ap.add_argument("--step_len", type=float, default=10)
@@ -224,6 +247,10 @@ def main():
     args = ap.parse_args()
     if args.clearance is None:
         args.clearance = 2 if args.problem == "random_3d" else 3
+    if args.connect == "bfs" and not args.planner.endswith("_c"):
+        args.planner += "_c"
+    if args.planner.startswith("n") and args.neural_net == "none":
+        args.neural_net = "pointnet2"
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -249,6 +276,7 @@ def main():
     if args.max_problems:
         cfgs = cfgs[: args.max_problems]
     mine = shard_indices(len(cfgs), rank, world)
+    wrapper = make_wrapper(args, 3 if args.problem == "random_3d" else 2, "cuda:%d" % local_rank) if args.neural_net == "pointnet2" else None
     t0 = time.time()
     recs, results = [], []
     for b0 in range(0, len(mine), args.batch):
@@ -261,12 +289,12 @@ def main():
         thr = None
         if args.problem == "block":   # eval_planning_2d.py:117-121
             thr = [p["best_path_len"] * (1 + args.path_len_threshold_percentage) for p in probs]
-            r, traces = plan_batch_block_gap(probs, ids, thr, args, local_rank)
+            r, traces = plan_batch_block_gap(probs, ids, thr, args, local_rank, wrapper)
         elif args.problem == "gap":
             thr = [p["flank_path_len"] for p in probs]
-            r, traces = plan_batch_block_gap(probs, ids, thr, args, local_rank)
+            r, traces = plan_batch_block_gap(probs, ids, thr, args, local_rank, wrapper)
         else:
-            r, traces = plan_batch(probs, ids, args, local_rank)
+            r, traces = plan_batch(probs, ids, args, local_rank, wrapper)
         recs += r
         results += list(zip(ids, result_lists(args.problem, traces, thr)))
     allr = gather_records(np.array(recs).reshape(-1, RECORD_LEN), world, rank, device="cuda")
@@ -275,7 +303,8 @@ def main():
         path = args.pickle_out
         if path == "auto":
             path = os.path.join("results", "evaluation", "3d" if args.problem == "random_3d" else "2d",
-                                "%s-%s-none-%d.pickle" % (args.problem, args.planner, len(cfgs)))
+                                "%s-%s%s-%s-%d.pickle" % (args.problem, args.planner[:-2] if args.planner.endswith("_c") else args.planner,
+                                                          "-c-bfs" if args.planner.endswith("_c") else "", args.neural_net, len(cfgs)))
         write_reference_pickle(path, cfgs, all_results)
     if rank == 0:
         solved = allr[allr[:, 1] > 0]

@@ -22,15 +22,15 @@ def checkpoint_path(root_dir, dim):
     return join(root_dir, "results/model_training/%s/checkpoints/best_%s.pth" % (tag, tag))
 
 
-def make_synthetic_checkpoint(path, seed=0, num_classes=2, calib_forwards=4, n_points=2048, dim=2):
+def make_synthetic_checkpoint(path, seed=0, num_classes=2, calib_forwards=4, n_points=2048, dim=2, device="cuda"):
     """Seeded random-init weights + BatchNorm statistics calibrated by a few train-mode forwards on random
     clouds, saved in the reference's checkpoint format (train_pointnet_pointnet2.py:266-272).  There are
     no trained weights without network access; plain random init predicts an empty
-    class and the planner cannot sample from it."""
+    class and the planner cannot sample from it.  The calibration forwards run on `device` (the point operators only
+    exist as HIP kernels; the CPU test-suite passes "cpu" with oracle/pointops_ref.py installed)."""
     import os
-    g = torch.Generator().manual_seed(seed)
     torch.manual_seed(seed)
-    model = get_model(num_classes)
+    model = get_model(num_classes).to(device)
     model.train()
     rs = np.random.RandomState(seed)
     with torch.no_grad():
@@ -43,7 +43,7 @@ def make_synthetic_checkpoint(path, seed=0, num_classes=2, calib_forwards=4, n_p
             gl = (np.linalg.norm(pc - pc[1], axis=1) < 10).astype(np.float32)
             feat = np.stack([s, gl, 1 - ((s + gl) > 0).astype(np.float32)], axis=-1)
             x = torch.from_numpy(np.concatenate([xyz, feat], axis=1).astype(np.float32)).permute(1, 0).unsqueeze(0)
-            model(x)
+            model(x.to(device))
     # un-trained weights put (almost) every point in one class and the planner cannot sample from an empty
     # prediction (the reference crashes in np.random.randint(0, 0), nirrt_star_png_2d.py:130): shift the class-1
     # bias so that about a third of the calibration points are labelled "path"
@@ -58,11 +58,12 @@ def make_synthetic_checkpoint(path, seed=0, num_classes=2, calib_forwards=4, n_p
             gl = (np.linalg.norm(pc - pc[1], axis=1) < 10).astype(np.float32)
             feat = np.stack([s, gl, 1 - ((s + gl) > 0).astype(np.float32)], axis=-1)
             x = torch.from_numpy(np.concatenate([pc_normalize(pc), feat], axis=1).astype(np.float32)).permute(1, 0).unsqueeze(0)
-            logp, _ = model(x)
-            gaps.append((logp[0, :, 1] - logp[0, :, 0]).numpy())
+            logp, _ = model(x.to(device))
+            gaps.append((logp[0, :, 1] - logp[0, :, 0]).cpu().numpy())
         model.conv2.bias[1] -= float(np.percentile(np.concatenate(gaps), 65))
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    torch.save({"epoch": 0, "class_avg_iou": 0.0, "model_state_dict": model.state_dict(), "optimizer_state_dict": {}}, path)
+    torch.save({"epoch": 0, "class_avg_iou": 0.0, "model_state_dict": {k: v.cpu() for k, v in model.state_dict().items()},
+                "optimizer_state_dict": {}}, path)
     return path
 
 
@@ -115,31 +116,67 @@ class PNGWrapper:
     def generate_connected_path_points(self, pc, x_start, x_goal, env_dict, neighbor_radius, max_trial_attempts,
                                        visualize=False, vis_folderpath="", token=""):
         """<= max_trial_attempts rounds of classify + BFS connectivity, re-seeding the start / goal masks at the
-        heuristic boundary point of the visited set, alternating start->goal and goal->start."""
-        has_path = False
-        path_pred_mask = np.zeros(len(pc)).astype(np.float32)
-        start_mask = get_point_cloud_mask_around_points(pc, x_start[np.newaxis].astype(np.float32), neighbor_radius)
-        goal_mask = get_point_cloud_mask_around_points(pc, x_goal[np.newaxis].astype(np.float32), neighbor_radius)
-        xs, xg = x_start.astype(np.float32), x_goal.astype(np.float32)
-        trial_i = -1
-        for trial_i in range(max_trial_attempts):
-            path_pred, _ = self.classify_path_points(pc, start_mask, goal_mask)
-            path_pred_mask = ((path_pred_mask + path_pred) > 0).astype(np.float32)
-            seeds = []
-            for a, b in ((xs, xg), (xg, xs)):
-                has_path, _, visited_mask = bfs_point_cloud_visualization(pc, path_pred_mask, a, b, neighbor_radius)
-                boundary_mask = get_boundary_mask(pc, visited_mask, 1 - path_pred_mask, neighbor_radius)
-                _, boundary_point, _ = select_heuristic_boundary_point(pc, boundary_mask, a, b)
-                if has_path:
-                    break
-                seeds.append(boundary_point)
-            if has_path:
+        heuristic boundary point of the visited set, alternating start->goal and goal->start
+        (pointnet2_wrapper_connect_bfs.py:76-240)."""
+        state = ConnectState(pc, x_start, x_goal, neighbor_radius)
+        for _ in range(max_trial_attempts):
+            path_pred, _ = self.classify_path_points(pc, state.start_mask, state.goal_mask)
+            if state.absorb(path_pred):
                 break
-            nxt = []
-            for cur, bp in zip((start_mask, goal_mask), seeds):
-                nxt.append(cur if bp is None else get_point_cloud_mask_around_points(pc, bp, neighbor_radius))
-            start_mask, goal_mask = nxt
-        return has_path, trial_i + 1, path_pred_mask
+        return state.has_path, state.trials, state.path_pred_mask
+
+    def generate_connected_path_points_batch(self, clouds, starts, goals, neighbor_radius, max_trial_attempts, fps_starts_for=None):
+        """neural connect for several clouds at once: round r classifies, in ONE forward per cloud size, every cloud that
+        is not connected yet.  Returns a list of (connection_success, num_png_runs, path_pred_mask) like the single call.
+        fps_starts_for(indices) -> the 4 FPS start tensors of a forward over those clouds (default: torch's CPU generator)."""
+        states = [ConnectState(pc, xs, xg, neighbor_radius) for pc, xs, xg in zip(clouds, starts, goals)]
+        for _ in range(max_trial_attempts):
+            open_ = [i for i, st in enumerate(states) if not st.has_path]
+            if not open_:
+                break
+            for size in sorted(set(len(clouds[i]) for i in open_)):
+                grp = [i for i in open_ if len(clouds[i]) == size]
+                pred, _ = self.classify_batch([clouds[i] for i in grp], [states[i].start_mask for i in grp],
+                                              [states[i].goal_mask for i in grp],
+                                              fps_starts=fps_starts_for(grp) if fps_starts_for else None)
+                for j, i in enumerate(grp):
+                    states[i].absorb(pred[j])
+        return [(st.has_path, st.trials, st.path_pred_mask) for st in states]
+
+
+class ConnectState:
+    """one cloud's progress through the neural-connect rounds: the union of the predictions so far, the start / goal masks
+    the NEXT classification uses, and whether start and goal are connected through predicted points yet"""
+
+    def __init__(self, pc, x_start, x_goal, neighbor_radius):
+        self.pc = pc
+        self.radius = neighbor_radius
+        self.xs = np.asarray(x_start).astype(np.float32)
+        self.xg = np.asarray(x_goal).astype(np.float32)
+        self.path_pred_mask = np.zeros(len(pc)).astype(np.float32)
+        self.start_mask = get_point_cloud_mask_around_points(pc, np.asarray(x_start)[np.newaxis].astype(np.float32), neighbor_radius)
+        self.goal_mask = get_point_cloud_mask_around_points(pc, np.asarray(x_goal)[np.newaxis].astype(np.float32), neighbor_radius)
+        self.has_path = False
+        self.trials = 0
+
+    def absorb(self, path_pred):
+        """take one classification result; True once start and goal are connected"""
+        self.trials += 1
+        self.path_pred_mask = ((self.path_pred_mask + path_pred) > 0).astype(np.float32)
+        seeds = []
+        for a, b in ((self.xs, self.xg), (self.xg, self.xs)):
+            has_path, _, visited_mask = bfs_point_cloud_visualization(self.pc, self.path_pred_mask, a, b, self.radius)
+            boundary_mask = get_boundary_mask(self.pc, visited_mask, 1 - self.path_pred_mask, self.radius)
+            _, boundary_point, _ = select_heuristic_boundary_point(self.pc, boundary_mask, a, b)
+            if has_path:
+                self.has_path = True
+                return True
+            seeds.append(boundary_point)
+        nxt = []
+        for cur, bp in zip((self.start_mask, self.goal_mask), seeds):
+            nxt.append(cur if bp is None else get_point_cloud_mask_around_points(self.pc, bp, self.radius))
+        self.start_mask, self.goal_mask = nxt
+        return False
 
 
 class PNGWrapper3D(PNGWrapper):

@@ -49,13 +49,19 @@ def _free_pixels_2d(point_cloud, binary_mask):
     return keep.nonzero()[0]
 
 
-def generate_rectangle_point_cloud(binary_mask, n_points, over_sample_scale=5):
-    """point_cloud_mask_utils.py:35-73 -> (n_points, 2)"""
+def rectangle_candidates(binary_mask, n_points, over_sample_scale=5, rng=None):
+    """the over-sampled free-space candidates the reference hands to open3d (point_cloud_mask_utils.py:35-68):
+    (m, 3) with z = 0.  `rng`: a numpy RandomState (default: the process-global legacy generator, like the reference)."""
+    rng = np.random if rng is None else rng
     h, w = binary_mask.shape
-    pc = np.random.uniform(low=[0, 0], high=[w, h], size=(n_points * over_sample_scale, 2))
+    pc = rng.uniform(low=[0, 0], high=[w, h], size=(n_points * over_sample_scale, 2))
     pc = pc[_free_pixels_2d(pc, binary_mask)]
-    pc3 = np.concatenate([pc, np.zeros((pc.shape[0], 1))], axis=1)
-    return farthest_point_down_sample(pc3, n_points)[:, :2]
+    return np.concatenate([pc, np.zeros((pc.shape[0], 1))], axis=1)
+
+
+def generate_rectangle_point_cloud(binary_mask, n_points, over_sample_scale=5, rng=None, device_id=0):
+    """point_cloud_mask_utils.py:35-73 -> (n_points, 2)"""
+    return farthest_point_down_sample(rectangle_candidates(binary_mask, n_points, over_sample_scale, rng), n_points, device_id)[:, :2]
 
 
 def _rotation_to_world_2d(start_point, goal_point, L):
@@ -67,8 +73,9 @@ def _rotation_to_world_2d(start_point, goal_point, L):
     return U @ np.diag([1.0, 1.0, np.linalg.det(U) * np.linalg.det(V_T.T)]) @ V_T
 
 
-def ellipsoid_point_cloud_sampling(start_point, goal_point, max_min_ratio, binary_mask, n_points=1000, n_raw_samples=10000):
-    """point_cloud_mask_utils.py:104-174 -> (<= n_points, 2)"""
+def ellipsoid_candidates(start_point, goal_point, max_min_ratio, binary_mask, n_raw_samples=10000, rng=None):
+    """candidates of the ellipse-restricted cloud before any down-sampling (point_cloud_mask_utils.py:104-168): (m, 2)"""
+    rng = np.random if rng is None else rng
     dx, dy = goal_point - start_point
     c_min = math.hypot(dx, dy)
     C = _rotation_to_world_2d(start_point, goal_point, c_min)
@@ -77,7 +84,7 @@ def ellipsoid_point_cloud_sampling(start_point, goal_point, max_min_ratio, binar
     eps = 1e-6 if c_max ** 2 - c_min ** 2 < 0 else 0
     r = [c_max / 2.0, math.sqrt(c_max ** 2 - c_min ** 2 + eps) / 2.0, math.sqrt(c_max ** 2 - c_min ** 2 + eps) / 2.0]
     L = np.diag(r)
-    samples = np.random.uniform(-1, 1, size=(n_raw_samples, 2))
+    samples = rng.uniform(-1, 1, size=(n_raw_samples, 2))
     samples = samples[np.linalg.norm(samples, axis=1) <= 1]
     samples = np.concatenate([samples, np.zeros((len(samples), 1))], axis=1)
     x_rand = np.dot(np.dot(C, L), samples.T).T + x_center
@@ -85,10 +92,16 @@ def ellipsoid_point_cloud_sampling(start_point, goal_point, max_min_ratio, binar
     pc = pc[_free_pixels_2d(pc, binary_mask)]
     h, w = binary_mask.shape
     in_range = (0 <= pc[:, 0]) & (pc[:, 0] <= w) & (0 <= pc[:, 1]) & (pc[:, 1] <= h)
-    pc = pc[in_range]
+    return pc[in_range]
+
+
+def ellipsoid_point_cloud_sampling(start_point, goal_point, max_min_ratio, binary_mask, n_points=1000, n_raw_samples=10000, rng=None,
+                                   device_id=0):
+    """point_cloud_mask_utils.py:104-174 -> (<= n_points, 2): down-sampled only if more than n_points candidates survive"""
+    pc = ellipsoid_candidates(start_point, goal_point, max_min_ratio, binary_mask, n_raw_samples, rng)
     if len(pc) > n_points:
         pc3 = np.concatenate([pc, np.zeros((pc.shape[0], 1))], axis=1)
-        pc = farthest_point_down_sample(pc3, n_points)[:, :2]
+        pc = farthest_point_down_sample(pc3, n_points, device_id)[:, :2]
     return pc
 
 
@@ -107,15 +120,21 @@ def _in_obstacles_3d(points, env, clearance):
     return inside
 
 
-def generate_rectangle_point_cloud_3d(env, n_points, over_sample_scale=5, use_open3d=True, clearance=0):
-    """point_cloud_mask_utils_3d.py:83-113"""
-    pc = np.random.uniform(
+def rectangle_candidates_3d(env, n_points, over_sample_scale=5, clearance=0, rng=None):
+    """point_cloud_mask_utils_3d.py:83-107: uniform over the (shrunken) box, obstacle points dropped -> (m, 3)"""
+    rng = np.random if rng is None else rng
+    pc = rng.uniform(
         low=(env.x_range[0] + clearance, env.y_range[0] + clearance, env.z_range[0] + clearance),
         high=(env.x_range[1] - clearance, env.y_range[1] - clearance, env.z_range[1] - clearance),
         size=(n_points * over_sample_scale, 3))
-    pc = pc[~_in_obstacles_3d(pc, env, clearance)]
+    return pc[~_in_obstacles_3d(pc, env, clearance)]
+
+
+def generate_rectangle_point_cloud_3d(env, n_points, over_sample_scale=5, use_open3d=True, clearance=0, rng=None, device_id=0):
+    """point_cloud_mask_utils_3d.py:83-113"""
+    pc = rectangle_candidates_3d(env, n_points, over_sample_scale, clearance, rng)
     if len(pc) > n_points:
-        pc = farthest_point_down_sample(pc, n_points)
+        pc = farthest_point_down_sample(pc, n_points, device_id)
     return pc
 
 
@@ -126,9 +145,9 @@ def _rotation_to_world_3d(x_start, x_goal, L):
     return U @ np.diag([1, 1, np.linalg.det(U) * np.linalg.det(V)]) @ V.T
 
 
-def ellipsoid_point_cloud_sampling_3d(start_point, goal_point, max_min_ratio, env, n_points=1000, n_raw_samples=10000,
-                                      clearance=0):
-    """point_cloud_mask_utils_3d.py:132-200"""
+def ellipsoid_candidates_3d(start_point, goal_point, max_min_ratio, env, n_raw_samples=10000, clearance=0, rng=None):
+    """point_cloud_mask_utils_3d.py:132-195: ellipsoid-restricted candidates before any down-sampling -> (m, 3)"""
+    rng = np.random if rng is None else rng
     c_min = np.linalg.norm(goal_point - start_point)
     C = _rotation_to_world_3d(start_point, goal_point, c_min)
     x_center = (start_point + goal_point) / 2.
@@ -138,15 +157,21 @@ def ellipsoid_point_cloud_sampling_3d(start_point, goal_point, max_min_ratio, en
     r[0] = c_max / 2
     r[1] = r[2] = np.sqrt(c_max ** 2 - c_min ** 2 + eps) / 2
     L = np.diag(r)
-    radius = np.random.uniform(0.0, 1.0, n_raw_samples)
-    theta = np.random.uniform(0, np.pi, n_raw_samples)
-    phi = np.random.uniform(0, 2 * np.pi, n_raw_samples)
+    radius = rng.uniform(0.0, 1.0, n_raw_samples)
+    theta = rng.uniform(0, np.pi, n_raw_samples)
+    phi = rng.uniform(0, 2 * np.pi, n_raw_samples)
     samples = np.array([radius * np.sin(theta) * np.cos(phi), radius * np.sin(theta) * np.sin(phi), radius * np.cos(theta)]).T
     pc = np.dot(np.dot(C, L), samples.T).T + x_center
     in_range = ((env.x_range[0] + clearance <= pc[:, 0]) & (pc[:, 0] <= env.x_range[1] - clearance) &
                 (env.y_range[0] + clearance <= pc[:, 1]) & (pc[:, 1] <= env.y_range[1] - clearance) &
                 (env.z_range[0] + clearance <= pc[:, 2]) & (pc[:, 2] <= env.z_range[1] - clearance))
-    pc = pc[in_range & ~_in_obstacles_3d(pc, env, clearance)]
+    return pc[in_range & ~_in_obstacles_3d(pc, env, clearance)]
+
+
+def ellipsoid_point_cloud_sampling_3d(start_point, goal_point, max_min_ratio, env, n_points=1000, n_raw_samples=10000,
+                                      clearance=0, rng=None, device_id=0):
+    """point_cloud_mask_utils_3d.py:132-200"""
+    pc = ellipsoid_candidates_3d(start_point, goal_point, max_min_ratio, env, n_raw_samples, clearance, rng)
     if len(pc) > n_points:
-        pc = farthest_point_down_sample(pc, n_points)
+        pc = farthest_point_down_sample(pc, n_points, device_id)
     return pc

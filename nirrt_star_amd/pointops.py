@@ -38,7 +38,8 @@ def _lib():
         L.nirrt_pn2_ball_query.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
         L.nirrt_pn2_three_nn.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         L.nirrt_fps_f64.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
-        for f in (L.nirrt_pn2_fps, L.nirrt_pn2_ball_query, L.nirrt_pn2_three_nn, L.nirrt_fps_f64):
+        L.nirrt_fps_f64_batch.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
+        for f in (L.nirrt_pn2_fps, L.nirrt_pn2_ball_query, L.nirrt_pn2_three_nn, L.nirrt_fps_f64, L.nirrt_fps_f64_batch):
             f.restype = C.c_int
         L._pn2_ready = True
     return L
@@ -105,3 +106,33 @@ def farthest_point_down_sample_f64(pts, num_samples, device_id=0):
     if rc != 0:
         raise _hip.NirrtError("nirrt_fps_f64 failed (%d)" % rc)
     return sel8.astype(bool)
+
+
+def farthest_point_down_sample_f64_batch(clouds, num_samples, device_id=0):
+    """several host clouds [(n_b, 3) f64] in ONE launch (one workgroup per cloud) -> list of bool masks; clouds that already
+    have num_samples points or fewer are kept whole"""
+    import numpy as np
+    from . import _hip
+    masks = [None] * len(clouds)
+    todo = [b for b, c in enumerate(clouds) if len(c) > num_samples]
+    for b, c in enumerate(clouds):
+        if len(c) <= num_samples:
+            masks[b] = np.ones(len(c), dtype=bool)
+    if not todo:
+        return masks
+    if _hip.device_count() <= 0:
+        for b in todo:
+            masks[b] = _cpu("farthest_point_down_sample_f64")(np.ascontiguousarray(clouds[b], dtype=np.float64), num_samples)
+        return masks
+    pts = np.ascontiguousarray(np.concatenate([np.asarray(clouds[b], dtype=np.float64) for b in todo], axis=0))
+    cnt = np.array([len(clouds[b]) for b in todo], dtype=np.int32)
+    ns = np.full(len(todo), int(num_samples), dtype=np.int32)
+    sel = np.zeros(len(pts), dtype=np.uint8)
+    rc = _lib().nirrt_fps_f64_batch(pts.ctypes.data, len(todo), cnt.ctypes.data, ns.ctypes.data, sel.ctypes.data, int(device_id))
+    if rc != 0:
+        raise _hip.NirrtError("nirrt_fps_f64_batch failed (%d)" % rc)
+    off = 0
+    for b, c in zip(todo, cnt):
+        masks[b] = sel[off:off + c].astype(bool)
+        off += int(c)
+    return masks

@@ -1,0 +1,41 @@
+"""One process of bench.py's cpu_baseline leg (TEST / MEASUREMENT INFRASTRUCTURE, see oracle/oracle.py): the C restatement of
+the reference loop (oracle/nirrt_oracle.c, incl. sampling from the problem's own seeded generators) on ONE host core, for
+the first --iters iterations of problem --pid of bench.py's batch.  Prints one JSON line {iters, seconds, n}."""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--algo", default="irrt")
+    ap.add_argument("--dim", type=int, default=2)
+    ap.add_argument("--world", default="b30")
+    ap.add_argument("--iters", type=int, default=20000)
+    ap.add_argument("--cap", type=int, default=50000)
+    ap.add_argument("--pid", type=int, default=0)
+    a = ap.parse_args()
+    import bench
+    from nirrt_star_amd import sampling
+    from oracle import oracle as orc
+    orc.build()
+    ns = SimpleNamespace(algo=a.algo, dim=a.dim, world=a.world, iters=a.iters, trees=1)
+    pr = bench.make_problem(ns, a.pid)
+    n_np, n_py = bench.word_budgets(ns)
+    npw, pyw = bench.problem_words(ns, a.pid, n_np, n_py)
+    o = orc.OracleTree(a.dim, a.cap, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env_dict"])
+    frame = sampling.informed_frame(pr["x_start"], pr["x_goal"])
+    t0 = time.perf_counter()
+    r = o.run_sampling(a.iters, npw, pyw, irrt=a.algo == "irrt", frame=frame)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"iters": int(r["iters_done"]), "seconds": dt, "n": int(o.n), "solutions": int(len(o.solutions))}))
+
+
+if __name__ == "__main__":
+    main()

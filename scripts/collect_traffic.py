@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""HBM-side traffic of the persistent kernel for ONE bench configuration, the way MI355X_MICROARCH.md prescribes:
+separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only), kernel-filtered, then
+    traffic_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+(FETCH_SIZE is in KiB and on gfx950 reports half of the bytes of wide reads - doubled as the guide says; WRITE_SIZE is
+uncalibrated).  Writes / updates profiles/r02_traffic.json: one entry per configuration key (bench.py config_key) with the
+raw counters, the date, the command and the kernel name, and copies the raw counter CSV rows next to it.
+
+    python scripts/collect_traffic.py [bench.py arguments, e.g. --trees 8192 --algo irrt]      (on the GPU box)
+"""
+import csv
+import datetime
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    bench_args = sys.argv[1:]
+    args = bench.parse(bench_args)
+    key = bench.config_key(args)
+    out_root = os.path.join(ROOT, "gpurun_out", "traffic_" + key)
+    os.makedirs(out_root, exist_ok=True)
+    prof_dir = os.path.join(ROOT, "profiles")
+    raw = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out_root, counter)
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--kernel-include-regex", "k_run_", "--output-format", "csv",
+               "-d", d, "-o", "bench", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-ttfs",
+               "--steps", "1", "--warmup", "0"] + bench_args
+        subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL)
+        rows = []
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                rows += [r for r in csv.DictReader(fh) if r["Counter_Name"] == counter and "k_run_" in r["Kernel_Name"]]
+        rows.sort(key=lambda r: -float(r["Counter_Value"]))   # the full launch dominates any short side launch
+        raw[counter] = rows[0]
+        with open(os.path.join(prof_dir, "r02_pmc_%s_%s.csv" % (key, counter)), "w") as fh:
+            w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
+    fetch, write = float(raw["FETCH_SIZE"]["Counter_Value"]), float(raw["WRITE_SIZE"]["Counter_Value"])
+    path = os.path.join(prof_dir, "r02_traffic.json")
+    tab = {"formula": "traffic_bytes = (2 * FETCH_SIZE_KiB + WRITE_SIZE_KiB) * 1024 (MI355X_MICROARCH.md, HBM section)", "entries": {}}
+    if os.path.exists(path):
+        with open(path) as fh:
+            tab = json.load(fh)
+    tab["entries"][key] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "traffic_bytes": (2 * fetch + write) * 1024,
+                           "kernel": raw["FETCH_SIZE"]["Kernel_Name"], "grid": raw["FETCH_SIZE"]["Grid_Size"],
+                           "workgroup": raw["FETCH_SIZE"]["Workgroup_Size"],
+                           "collected": datetime.date.today().isoformat(),
+                           "command": "rocprofv3 --pmc <C> --kernel-trace --kernel-include-regex k_run_ -- python bench.py "
+                                      "--no-cpu-baseline --no-ttfs --steps 1 --warmup 0 " + " ".join(bench_args)}
+    with open(path, "w") as fh:
+        json.dump(tab, fh, indent=1)
+    print(json.dumps(tab["entries"][key]))
+
+
+if __name__ == "__main__":
+    main()

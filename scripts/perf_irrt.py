@@ -43,9 +43,14 @@ print("B=%d iters=%d dim=%d %s: kernel %.1f ms -> %.0f it/s aggregate, %.0f it/s
 print("first-solution iteration: median %s  (min %d max %d); final c_best median %.2f; np_used mean %.0f py_used mean %.0f; alg GB/s %.1f"
       % (np.median(first), min(first), max(first), np.median(tr[:, -1]), res["np_used"].mean(), res["py_used"].mean(),
          res["scan_elems"].sum() * dim * 8 / 1e9 / (ms / 1e3)))
+st = res["stats"].astype(float)
+tot_it = st[:, 13].sum()
+print("per iteration: " + ", ".join("%s %.2f" % (n, st[:, j].sum() / tot_it) for j, n in enumerate(_hip.STAT_NAMES) if j not in (13, 14, 15) and st[:, j].sum() > 0))
+ts = (st[:, 15] - st[:, 14]) / 1e8
+print("per-tree seconds in the launch: mean %.3f median %.3f max %.3f; useful bytes/iter %.0f" % (ts.mean(), np.median(ts), ts.max(), _hip.useful_bytes(res["stats"], dim) / tot_it))
 pr_ = np.array([t.debug_prof() for t in trees]).sum(0).astype(float)
 if pr_.sum() > 0:
-    names = ["nearest", "steer+edge", "near", "choose", "cost(new)", "rewire", "goal/ingoal", "report", "N.scan", "N.gather", "N.fan", "N.compact", "rebuild", "(G.visit)", "(G.nearest)", "(G.order)", "L.draw", "L.iteration", "L.report", "L.other", "(G.setup)", "", "", ""]
+    names = ["nearest", "steer+edge", "query", "choose", "cost(new)", "rewire", "goal/ingoal", "report", "", "", "", "", "rebuild", "(Q.visit)", "(Q.nearest)", "(Q.finish)", "L.draw", "L.iteration", "L.report", "L.other", "(Q.setup)", "", "", ""]
     tot = pr_[16:20].sum() if pr_[16:20].sum() > 0 else pr_.sum()
     print("phase share: " + ", ".join("%s %.1f%%" % (n, 100 * v / tot) for n, v in zip(names, pr_) if v > 0),
           "| ticks/iter/tree %.0f (100MHz => %.1f us)" % (tot / done.sum(), tot / done.sum() / 100.0))

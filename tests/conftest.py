@@ -23,7 +23,7 @@ def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     out = {k: z[k] for k in z.files}
     for k in list(out):
-        if k == "env" or k.endswith("_env"):
+        if k == "env" or k.endswith("_env") or (k.startswith("env") and out[k].ndim == 0):
             out[k] = json.loads(str(out[k]))
     return out
 

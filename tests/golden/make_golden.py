@@ -282,7 +282,7 @@ def run_planner(name, algo, dim, world_kind, world_seed, pair, iters, seed, trac
     print("   %s: n=%d path_len=%.6f  (%.1fs)" % (name, n, float(arrays["path_len"]), time.time() - t0))
 
 
-def nirrt_fixture(name, dim, connect, world_seed, iters, seed):
+def nirrt_fixture(name, dim, connect, world_seed, iters, seed, random_after=None):
     """L3: reference NIRRT*-PNG[(C)] whole run with a deterministic fake wrapper (tests/conftest.py FakePNG)
     and OUR farthest-point restatement behind the open3d stub: pins update rule + sampling mix + RNG use."""
     sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
@@ -312,11 +312,16 @@ def nirrt_fixture(name, dim, connect, world_seed, iters, seed):
     planner.generate_random_node = rec
     np.random.seed(seed)
     random.seed(seed)
+    lst = np.zeros(0)
     with quiet():
-        planner.planning()
+        if random_after is None:
+            planner.planning()
+        else:   # planning_random (nirrt_star_png_2d.py:247-335): per-iteration best cost list
+            lst = np.array(planner.planning_random(random_after), dtype=np.float64)
     n = planner.num_vertices
     path = np.array(planner.path, dtype=np.float64).reshape(-1, dim) if len(planner.path) else np.zeros((0, dim))
     save(name, env=env_json(pr["env_dict"]), dim=np.array(dim), algo=np.array("nirrt_c" if connect else "nirrt"),
+         path_len_list=lst, iter_after_initial=np.array(-1 if random_after is None else random_after),
          seed=np.array(seed), iter_max=np.array(iters), step_len=np.array(float(STEP_LEN)), clearance=np.array(float(clearance)),
          search_radius=np.array(float(pr["search_radius"])), x_start=np.array(pr["x_start"], dtype=np.float64),
          x_goal=np.array(pr["x_goal"], dtype=np.float64), n=np.array(n), vertices=planner.vertices[:n].copy(),
@@ -326,33 +331,151 @@ def nirrt_fixture(name, dim, connect, world_seed, iters, seed):
     print("   %s: n=%d path_len=%.4f png calls %d (%.1fs)" % (name, n, float(planner.get_path_len(planner.path)), w.calls, time.time() - t0))
 
 
-def nrrt_fixture(name, dim, world_seed, iters, seed):
-    """NRRT*-PNG (RRT* + cloud sampling, no informed set) whole run with the fake wrapper (see nirrt_fixture)."""
+def nrrt_fixture(name, dim, world_seed, iters, seed, connect=False):
+    """NRRT*-PNG[(C)] (RRT* + cloud sampling, no informed set) whole run with the fake wrapper (see nirrt_fixture)."""
     sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
     from conftest import FakePNG
     if dim == 2:
-        from path_planning_classes.nrrt_star_png_2d import NRRTStarPNG2D as P
+        if connect:
+            from path_planning_classes.nrrt_star_png_c_2d import NRRTStarPNGC2D as P
+        else:
+            from path_planning_classes.nrrt_star_png_2d import NRRTStarPNG2D as P
     else:
-        from path_planning_classes_3d.nrrt_star_png_3d import NRRTStarPNG3D as P
+        if connect:
+            from path_planning_classes_3d.nrrt_star_png_c_3d import NRRTStarPNGC3D as P
+        else:
+            from path_planning_classes_3d.nrrt_star_png_3d import NRRTStarPNG3D as P
     pr, clearance = make_problem(dim, "b30", world_seed, 0)
     w = FakePNG(pr["x_start"], pr["x_goal"], 25.0 if dim == 2 else 8.0)
     common = [pr["x_start"], pr["x_goal"], STEP_LEN, pr["search_radius"], iters, pr["env_dict"], w]
     if dim == 2:
         common.append(pr["binary_mask"])
-    planner = P(*common, clearance, 2048, 5, 0.5)
+    planner = P(*common, clearance, 2048, 5, 0.5, 5) if connect else P(*common, clearance, 2048, 5, 0.5)
     np.random.seed(seed)
     random.seed(seed)
     with quiet():
         planner.planning()
     n = planner.num_vertices
     path = np.array(planner.path, dtype=np.float64).reshape(-1, dim) if len(planner.path) else np.zeros((0, dim))
-    save(name, env=env_json(pr["env_dict"]), dim=np.array(dim), algo=np.array("nrrt"), seed=np.array(seed), iter_max=np.array(iters),
+    save(name, env=env_json(pr["env_dict"]), dim=np.array(dim), algo=np.array("nrrt_c" if connect else "nrrt"), seed=np.array(seed), iter_max=np.array(iters),
          step_len=np.array(float(STEP_LEN)), clearance=np.array(float(clearance)), search_radius=np.array(float(pr["search_radius"])),
          x_start=np.array(pr["x_start"], dtype=np.float64), x_goal=np.array(pr["x_goal"], dtype=np.float64), n=np.array(n),
          vertices=planner.vertices[:n].copy(), parents=planner.vertex_parents[:n].astype(np.int64), path=path,
          path_len=np.array(float(planner.get_path_len(planner.path))), png_calls=np.array(w.calls),
          binary_mask=(pr["binary_mask"].astype(np.uint8) if dim == 2 else np.zeros(0, np.uint8)))
     print("   %s: n=%d path_len=%.4f png calls %d" % (name, n, float(planner.get_path_len(planner.path)), w.calls))
+
+
+def guidance_fixture():
+    """a18: the guidance-cloud functions of datasets/point_cloud_mask_utils.py:20-174 and
+    datasets_3d/point_cloud_mask_utils_3d.py:83-200 run by the reference itself with seeded generators: the candidate
+    set each call hands to open3d's farthest_point_down_sample (captured by the stub, refshim.FPS_CALLS), the returned
+    cloud (down-sampled by the repo's restatement behind the stub), the generator position afterwards, and
+    get_point_cloud_mask_around_points for one and for several centre points."""
+    from datasets.point_cloud_mask_utils import (ellipsoid_point_cloud_sampling, generate_rectangle_point_cloud,
+                                                  get_point_cloud_mask_around_points)
+    from datasets_3d.point_cloud_mask_utils_3d import ellipsoid_point_cloud_sampling_3d, generate_rectangle_point_cloud_3d
+    out = {}
+    pr, _ = make_problem(2, "b30", 3, 0)
+    mask = pr["binary_mask"]
+    xs, xg = np.array(pr["x_start"], dtype=np.float64), np.array(pr["x_goal"], dtype=np.float64)
+    out["env2"] = env_json(pr["env_dict"])
+    out["mask2"] = mask.astype(np.uint8)
+    out["xs2"], out["xg2"] = xs, xg
+
+    def capture(tag, fn, seed):
+        del refshim.FPS_CALLS[:]
+        np.random.seed(seed)
+        pc = fn()
+        out[tag + "_seed"] = np.array(seed)
+        out[tag + "_cloud"] = np.asarray(pc, dtype=np.float64)
+        out[tag + "_next"] = np.array(np.random.random_sample())     # where the global generator stands afterwards
+        out[tag + "_fps_calls"] = np.array(len(refshim.FPS_CALLS))
+        if refshim.FPS_CALLS:
+            out[tag + "_cand"] = refshim.FPS_CALLS[0][0]
+            out[tag + "_nsamp"] = np.array(refshim.FPS_CALLS[0][1])
+        return pc
+
+    rect = capture("rect2", lambda: generate_rectangle_point_cloud(mask, 2048, 5), 11)
+    for tag, ratio, seed in (("ell2_wide", 1.6, 12), ("ell2_mid", 1.15, 13), ("ell2_thin", 1.004, 14)):
+        capture(tag, lambda r=ratio: ellipsoid_point_cloud_sampling(xs, xg, r, mask, n_points=2048, n_raw_samples=10240), seed)
+        out[tag + "_ratio"] = np.array(ratio)
+    out["mask_start"] = get_point_cloud_mask_around_points(rect, xs[np.newaxis, :], 10)
+    out["mask_goal"] = get_point_cloud_mask_around_points(rect, xg[np.newaxis, :], 10)
+    line = xs + np.linspace(0, 1, 25)[:, None] * (xg - xs)
+    out["mask_line_pts"] = line
+    out["mask_line"] = get_point_cloud_mask_around_points(rect, line, 12.5)
+    out["mask_f32"] = get_point_cloud_mask_around_points(rect.astype(np.float32), xs[np.newaxis].astype(np.float32), 10)
+
+    np.random.seed(5)
+    pr3, _ = make_problem(3, "ref3d", 5, 0)
+    env3 = RefEnv3D(pr3["env_dict"])
+    xs3, xg3 = np.array(pr3["x_start"], dtype=np.float64), np.array(pr3["x_goal"], dtype=np.float64)
+    out["env3"] = env_json(pr3["env_dict"])
+    out["xs3"], out["xg3"] = xs3, xg3
+    capture("rect3", lambda: generate_rectangle_point_cloud_3d(env3, 2048, over_sample_scale=5), 21)
+    for tag, ratio, seed in (("ell3_wide", 1.5, 22), ("ell3_thin", 1.01, 23)):
+        capture(tag, lambda r=ratio: ellipsoid_point_cloud_sampling_3d(xs3, xg3, r, env3, n_points=2048, n_raw_samples=10240), seed)
+        out[tag + "_ratio"] = np.array(ratio)
+    save("guidance_clouds", **out)
+    print("   guidance_clouds: " + ", ".join("%s %s" % (k[:-6], out[k].shape) for k in out if k.endswith("_cloud")))
+
+
+def connect_fixture():
+    """a20: wrapper/utils/bfs_connect_heuristic.py:5-181 on saved clouds + PNGWrapper.generate_connected_path_points
+    (wrapper/pointnet_pointnet2/pointnet2_wrapper_connect_bfs.py:76-240) driven by a deterministic classifier that needs
+    several rounds: a point is "path" iff it lies within 28 of a point of the start or goal mask, so each round grows two
+    blobs from the seeds the heuristic picked."""
+    from datasets.point_cloud_mask_utils import generate_rectangle_point_cloud, get_point_cloud_mask_around_points
+    from wrapper.utils.bfs_connect_heuristic import (bfs_point_cloud_visualization, get_boundary_mask,
+                                                     select_heuristic_boundary_point)
+    from wrapper.pointnet_pointnet2.pointnet2_wrapper_connect_bfs import PNGWrapper as RefWrapper
+    out = {}
+    pr, _ = make_problem(2, "b30", 7, 1)
+    np.random.seed(31)
+    pc = generate_rectangle_point_cloud(pr["binary_mask"], 2048, 5).astype(np.float32)
+    xs, xg = np.array(pr["x_start"], dtype=np.float64), np.array(pr["x_goal"], dtype=np.float64)
+    out["pc"], out["xs"], out["xg"] = pc, xs, xg
+    out["env"] = env_json(pr["env_dict"])
+    # (1) the helpers on two masks: a corridor that connects start and goal, and two separate blobs
+    ab = (xg - xs).astype(np.float32)
+    tt = np.clip(((pc - xs.astype(np.float32)) @ ab) / (ab @ ab), 0, 1)
+    dline = np.linalg.norm(pc - (xs.astype(np.float32) + tt[:, None] * ab), axis=1)
+    corridor = (dline < 14).astype(np.float32)
+    blobs = ((np.linalg.norm(pc - xs.astype(np.float32), axis=1) < 35) | (np.linalg.norm(pc - xg.astype(np.float32), axis=1) < 35)).astype(np.float32)
+    for tag, pm in (("corridor", corridor), ("blobs", blobs)):
+        for dtag, a, b in (("sg", xs, xg), ("gs", xg, xs)):
+            has, line, vis = bfs_point_cloud_visualization(pc, pm, a.astype(np.float32), b.astype(np.float32), STEP_LEN)
+            bm = get_boundary_mask(pc, vis, 1 - pm, STEP_LEN)
+            bi, bp, heur = select_heuristic_boundary_point(pc, bm, a.astype(np.float32), b.astype(np.float32))
+            k = "%s_%s" % (tag, dtag)
+            out[k + "_mask"] = pm
+            out[k + "_has"] = np.array(bool(has))
+            out[k + "_line"] = np.zeros((0, 2), np.float32) if line is None else np.asarray(line, dtype=np.float32)
+            out[k + "_visited"] = np.asarray(vis, dtype=np.float32)
+            out[k + "_boundary"] = np.asarray(bm, dtype=np.float32)
+            out[k + "_bidx"] = np.array(-1 if bi is None else int(bi))
+            out[k + "_bpoint"] = np.zeros(2, np.float32) if bp is None else np.asarray(bp, dtype=np.float32)
+            out[k + "_heur"] = np.zeros(0) if heur is None else np.asarray(heur, dtype=np.float64)
+    # (2) the multi-round loop of the reference's wrapper class with the stub classifier (no weights involved)
+    calls = []
+
+    def classify(pc_, start_mask, goal_mask):
+        seeds = pc_[(np.asarray(start_mask) + np.asarray(goal_mask)) > 0]
+        d = np.linalg.norm(pc_[:, None] - seeds[None], axis=2).min(axis=1) if len(seeds) else np.full(len(pc_), np.inf)
+        calls.append((np.asarray(start_mask, dtype=np.float32).copy(), np.asarray(goal_mask, dtype=np.float32).copy()))
+        return (d < 28).astype(np.int64), (1.0 / (1.0 + d)).astype(np.float32)
+
+    w = object.__new__(RefWrapper)          # the stub replaces the network: no checkpoint is loaded
+    w.classify_path_points = classify
+    for tag, trials in (("loop5", 5), ("loop2", 2)):
+        del calls[:]
+        ok, runs, mask = w.generate_connected_path_points(pc, xs, xg, pr["env_dict"], STEP_LEN, trials)
+        out[tag + "_ok"], out[tag + "_runs"], out[tag + "_mask"] = np.array(bool(ok)), np.array(int(runs)), np.asarray(mask, dtype=np.float32)
+        out[tag + "_start_masks"] = np.stack([c[0] for c in calls])
+        out[tag + "_goal_masks"] = np.stack([c[1] for c in calls])
+        print("   connect %s: ok=%s runs=%d path points %d" % (tag, ok, runs, int(mask.sum())))
+    save("connect_ref", **out)
 
 
 def block_gap_fixture():
@@ -570,6 +693,11 @@ JOBS = {
     "dataset_ref": dataset_fixture,
     "blockgap_irrt_block": lambda: block_gap_run("blockgap_irrt_block", "irrt", "block", 137, 2001, 5000, percentage=0.1),
     "blockgap_rrt_gap": lambda: block_gap_run("blockgap_rrt_gap", "rrt", "gap", 250, 2002, 6000),
+    "guidance_clouds": guidance_fixture,
+    "connect_ref": connect_fixture,
+    "run_nrrtc2d_1500": lambda: nrrt_fixture("run_nrrtc2d_1500", 2, 13, 1500, 1013, connect=True),
+    "run_nrrtc3d_1500": lambda: nrrt_fixture("run_nrrtc3d_1500", 3, 7, 1500, 1007, connect=True),
+    "random_nirrt2d": lambda: nirrt_fixture("random_nirrt2d", 2, False, 14, 4000, 1014, random_after=300),
 }
 
 if __name__ == "__main__":

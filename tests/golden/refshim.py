@@ -5,8 +5,9 @@ on the GPU box imports this (``/root/reference`` does not exist there).
 
 * the reference has no ``__init__.py`` anywhere, and site-packages holds an unrelated
   ``datasets`` (HuggingFace) that shadows its ``datasets/`` namespace package -> pre-seed;
-* cv2 and open3d are not installed -> stubbed (open3d's FPS is replaced by a recorder, so
-  fixtures are defined downstream of the point cloud, SURVEY.md §8c);
+* cv2 and open3d are not installed -> stubbed.  open3d's farthest_point_down_sample is replaced by a RECORDER
+  (FPS_CALLS keeps every candidate set the reference hands to it - the fixtures pin those) followed by the
+  repo's restatement of the down-sampling (oracle/pointops_ref.py; parity of that one call is unpinned, SURVEY.md §8c);
 * never write bytecode into the reference tree.
 """
 import os
@@ -14,6 +15,7 @@ import sys
 import types
 
 REF = "/root/reference"
+FPS_CALLS = []   # (points (n, 3) float64 copy, num_samples) of every open3d farthest_point_down_sample call
 
 
 def install():
@@ -34,9 +36,12 @@ def install():
                 self.points = None
 
             def farthest_point_down_sample(self, num_samples):
-                from nirrt_star_amd.pointcloud import farthest_point_down_sample
+                import numpy as np
+                from oracle import pointops_ref
+                pts = np.ascontiguousarray(self.points, dtype=np.float64)
+                FPS_CALLS.append((pts.copy(), int(num_samples)))
                 out = _PC()
-                out.points = farthest_point_down_sample(self.points, num_samples)
+                out.points = pts[pointops_ref.farthest_point_down_sample_f64(pts, num_samples)] if num_samples < len(pts) else pts.copy()
                 return out
 
         o3d.geometry = types.SimpleNamespace(PointCloud=_PC)

@@ -8,10 +8,10 @@ import pytest
 from conftest import ROOT
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "nirrt_hip.h")).read()
+def _declared_symbols(header="nirrt_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(nirrt_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(nirrt_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -23,6 +23,10 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), "missing export %s" % s
     assert set(_hip.EXPORTS) == set(syms)
+    pn = _declared_symbols("nirrt_pointops.h")
+    assert len(pn) == 5
+    for s in pn:
+        assert hasattr(L, s), "missing export %s" % s
 
 
 def test_struct_layouts_match_header():
@@ -32,7 +36,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_hip.StepResult) == 8 + 16 + 16 + 8 + 24 + 8 + 8 + 8 + 8
     assert _hip.StepResult.c_best.offset == 72
     assert C.sizeof(_hip.Config) == 8 + 8 + 24 + 24 + 24 + 24 + 24 + 8 + 8 + 8 + 8
-    assert C.sizeof(_hip.RunArgs) == 8 + 8 + 8 * 13
+    assert C.sizeof(_hip.RunArgs) == 8 + 8 + 8 * 15
 
 
 def test_no_silent_cpu_fallback_without_device():

@@ -1,7 +1,12 @@
-"""CPU: the parts of bench.py that do not need a GPU (argument contract, synthetic problem set, word budgets)."""
+"""CPU: the parts of bench.py that do not need a GPU (argument contract, launcher, synthetic problem set, word budgets,
+CPU-baseline helper)."""
 import importlib.util
+import json
 import os
+import subprocess
 import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -18,10 +23,11 @@ def test_default_arguments_follow_the_driver_contract(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = b.parse()
     assert a.gpus == 1 and a.steps >= 1 and a.warmup >= 0
-    assert a.algo == "irrt" and a.dim == 2 and a.iters == 50000 and a.trees == 4096      # BASELINE.json configs[1], one tree per wave slot
+    assert a.algo == "irrt" and a.dim == 2 and a.iters == 50000 and a.trees >= 4096      # BASELINE.json configs[1], >= one tree per wave slot
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "2"])
     a = b.parse()
     assert (a.gpus, a.steps, a.warmup) == (8, 3, 2)
+    assert b.config_key(a) == "irrt_2d_b30_%dx50000" % a.trees
 
 
 def test_problem_set_is_disjoint_across_ranks_and_sized_like_the_survey(monkeypatch):
@@ -33,5 +39,55 @@ def test_problem_set_is_disjoint_across_ranks_and_sized_like_the_survey(monkeypa
     for p in p0:
         assert p["clearance"] == 3 and len(p["env_dict"]["circle_obstacles"]) == 30 and not p["env_dict"]["rectangle_obstacles"]
         assert tuple(p["env_dict"]["env_dims"]) == (224, 224) and p["search_radius"] > 0
+        assert all(8 <= c[2] <= 12 for c in p["env_dict"]["circle_obstacles"])
     n_np, n_py = b.word_budgets(a)
     assert n_np >= 2 * a.iters and n_py >= 4 * a.iters                                   # >= one SampleFree / unit-disk draw per iteration
+
+
+def test_primary_world_of_the_survey_has_large_circles_and_connected_start_goal(monkeypatch):
+    b = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--trees", "2", "--world", "b30r16"])
+    a = b.parse()
+    for p in b.make_problems(a, 0):
+        assert len(p["env_dict"]["circle_obstacles"]) == 30
+        assert all(16 <= c[2] <= 24 for c in p["env_dict"]["circle_obstacles"])
+
+
+def test_gpus_flag_spawns_that_many_ranks_and_prints_one_line():
+    """`python bench.py --gpus 2` with no launcher around it must become two ranks (gloo here: no GPU) and print ONE
+    JSON line with n_gpus = 2; the work of both ranks is in it."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--trees", "10",
+                        "--iters", "100"], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["work_all_ranks"] == 2 * 10 * 100 * 3
+
+
+def test_launcher_world_size_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       cwd=ROOT, env=env, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_cpu_baseline_process_runs_the_oracle_on_a_batch_problem():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--iters", "1500", "--pid", "3"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["iters"] == 1500 and d["seconds"] > 0 and 500 < d["n"] <= 1501
+
+
+def test_traffic_entry_is_used_only_for_the_exact_configuration(tmp_path, monkeypatch):
+    b = _bench()
+    tab = {"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", "entries": {"irrt_2d_b30_4096x50000": {"traffic_bytes": 5e13, "collected": "2026-09-28",
+                                                                                                    "kernel": "slim::k_run_sample<2>"}}}
+    f = tmp_path / "t.json"
+    f.write_text(json.dumps(tab))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--trees", "4096", "--traffic-file", str(f)])
+    t, src = b.measured_traffic(b.parse())
+    assert t == 5e13 and src["collected"] == "2026-09-28" and "FETCH_SIZE" in src["formula"]
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--trees", "2048", "--traffic-file", str(f)])
+    assert b.measured_traffic(b.parse()) == (None, None)

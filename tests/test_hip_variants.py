@@ -5,8 +5,8 @@ default bench of 4096 problems per GPU runs), `narrow` (128 threads) and `wide` 
 by batch size.  NIRRT_FORCE_VARIANT pins every launch (primitives, step kernel, persistent loops) to one of them, so
 the fixture / oracle comparisons of test_hip_parity / test_hip_sampling / test_hip_grid run whole under each.  On top:
 one launch of more than 2048 trees (the natural dispatch to `slim`) with trees compared against the oracle, and the
-suite once more against a build with tiny compile-time limits (parent chains longer than the LDS chain cache, ordering
-windows of 1024 vertices), loaded through NIRRT_HIP_SO in a child process.
+suite once more against a build with tiny compile-time limits (parent chains longer than the LDS chain cache, Near sets
+larger than the LDS stash), loaded through NIRRT_HIP_SO in a child process.
 
 Reference functions matched: rrt_star_2d.py:37-99, irrt_star_2d.py:42-97 (and the 3D twins)."""
 import os
@@ -145,8 +145,9 @@ def test_more_than_2048_trees_in_one_launch_against_the_oracle(oracle, irrt):
 
 
 def test_suite_against_the_small_limits_build():
-    """libnirrt_hip_small.so = same sources with -DCHAIN_MAX=8 -DGRID_BM_WORDS=32: parent chains longer than 8 edges take the
-    global-walk branches of wg_recost_subtree / the rewire leaf path, and the Near ordering runs in 1024-vertex windows.
+    """libnirrt_hip_small.so = same sources with -DCHAIN_MAX=8 -DNEAR_STASH=8: parent chains longer than 8 edges take the
+    global-walk branches of wg_recost_subtree / the rewire leaf path, and all but 8 members of a Near set live in the HBM
+    continuation of the stash.
     The fixture and oracle comparisons must not notice.  Run in a child interpreter because the library path is read
     once per process."""
     from nirrt_star_amd import build

@@ -50,7 +50,7 @@ def test_state_dict_layout_is_the_reference_one():
 def test_wrapper_roundtrip_cpu(tmp_path):
     """PNGWrapper on CPU with a synthetic checkpoint in the reference format: classify + neural connect run end to end."""
     from nirrt_star_amd import png_wrapper
-    ck = png_wrapper.make_synthetic_checkpoint(str(tmp_path / "results/model_training/pointnet2_2d/checkpoints/best_pointnet2_2d.pth"))
+    ck = png_wrapper.make_synthetic_checkpoint(str(tmp_path / "results/model_training/pointnet2_2d/checkpoints/best_pointnet2_2d.pth"), device="cpu")
     w = png_wrapper.PNGWrapper(root_dir=str(tmp_path), device="cpu")
     g = load_golden("pointnet2_ref")
     torch.manual_seed(0)
