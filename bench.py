@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.3 TB/s achievable)
-REF_PY = {"rrt": 153.0, "irrt": 43.0}  # reference numpy path in the survey container: context only
+REF_PY = {"rrt": 153.0, "irrt": 43.0, "nirrt": None, "nirrt_c": None}  # reference numpy path in the survey container: context only
 WORLDS = {"b30": "224x224, 30 circle obstacles r in [8, 12]", "b30r16": "224x224, 30 circle obstacles r in [16, 24], start / goal in one free component",
           "ref2d": "224x224, 8-12 rectangles (16-24) + 8-12 circles r in [16, 24]"}
 
@@ -56,7 +56,8 @@ def parse(argv=None):
     ap.add_argument("--trees", type=int, default=4096, help="problems per GPU per step (4096 = 16 one-wave workgroups per CU, all resident; more queue up behind them)")
     ap.add_argument("--iters", type=int, default=50000, help="planner iterations per problem (tree capacity)")
     ap.add_argument("--dim", type=int, default=2)
-    ap.add_argument("--algo", default="irrt", choices=["irrt", "rrt"])
+    ap.add_argument("--algo", default="irrt", choices=["irrt", "rrt", "nirrt", "nirrt_c"],
+                    help="nirrt / nirrt_c: NIRRT*-PNG[(C)] with PointNet++ guidance (BASELINE configs 3-4) through the batched driver")
     ap.add_argument("--world", default="b30", choices=sorted(WORLDS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20000, help="iterations each CPU-baseline process runs")
@@ -187,6 +188,8 @@ def main():
 
     from nirrt_star_amd import _hip, build, sampling
     build.build()
+    if args.algo.startswith("nirrt"):
+        return bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work)
 
     probs = make_problems(args, rank)
     D, B, iters = args.dim, args.trees, args.iters
@@ -283,6 +286,69 @@ def main():
             out["time_to_first_solution"] = time_to_first_solution(args, trees, np_tab, py_tab, flags)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
+    """NIRRT*-PNG[(C)] on B problems per GPU: the persistent loop returns to the host whenever trees need a new guidance cloud;
+    the due clouds are generated from each problem's own generator, down-sampled in one launch and classified in ONE
+    batched PointNet++ forward (nirrt_star_amd/batch.py).  The timed step therefore contains host work (cloud candidates,
+    word windows) and the network; `value` is still iterations of all trees / wall time."""
+    import torch
+    import torch.distributed as dist
+    from types import SimpleNamespace as NS
+    from nirrt_star_amd import _hip, batch, eval_sharded, sampling
+    D, B, iters = args.dim, args.trees, args.iters
+    probs = make_problems(args, rank)
+    wrapper = eval_sharded.make_wrapper(NS(root_dir=os.path.join(ROOT, "gpurun_out", "bench_ck")), D, "cuda:%d" % local_rank)
+    guidance = batch.Guidance(wrapper, D, 10, connect=args.algo == "nirrt_c", device_id=local_rank)
+    trees, frames = [], []
+    for pr in probs:
+        t = _hip.HipTree(D, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"], device_id=local_rank)
+        frames.append(sampling.informed_frame(pr["x_start"], pr["x_goal"]))
+        t.set_informed(*frames[-1])
+        trees.append(t)
+
+    def one_step():
+        for t in trees:
+            t.reset()
+        streams = [batch.ProblemStreams(1000 + pr["pid"]) for pr in probs]
+        return batch.run_batch(trees, streams, iters, _hip.F_IRRT, D, probs, guidance, frames, want_trace=False)
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    done, k_ms, launches = 0, [], []
+    f0, c0 = guidance.calls, guidance.clouds_classified
+    for _ in range(args.steps):
+        r = one_step()
+        done += int(r["iters_done"].sum())
+        k_ms.append(r["kernel_ms"])
+        launches.append(r["launches"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed_max, total_iters = reduce_time_and_work(elapsed, done)
+    if rank == 0:
+        st = r["stats"].astype(np.float64)
+        useful_b = _hip.useful_bytes(r["stats"], D)
+        out = {"metric": "RRT* iters/sec (50k-node tree), random_%dd" % D, "value": total_iters / elapsed_max, "unit": "iterations/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (tree) / f32 (PointNet++)", "data": "synthetic",
+               "config": {"workload": "%s_star -n pointnet2%s random_%dd, %d problems/GPU x %d iters, 2048-point guidance clouds, batched "
+                                      "PointNet++ refresh (synthetic weights), host-side cloud candidates inside the timed step"
+                                      % ("nirrt", " -c bfs" if args.algo == "nirrt_c" else "", D, B, iters),
+                          "key": config_key(args), "trees_per_gpu": B, "iters": iters, "dim": D,
+                          "launches_per_step": float(np.mean(launches)), "forwards_per_step": (guidance.calls - f0) / args.steps,
+                          "clouds_per_step": (guidance.clouds_classified - c0) / args.steps,
+                          "mean_final_vertices": float(np.mean([t.n for t in trees])), "failed": len(r["failed"])},
+               "roofline": {"bound": "hbm", "achieved": useful_b / (k_ms[-1] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": useful_b / (k_ms[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_run_sample<%d>" % D,
+                            "kernel_ms": float(np.mean(k_ms)), "kernel_share_of_step": float(np.mean(k_ms)) / (elapsed_max / args.steps * 1e3),
+                            "useful_bytes_per_step": useful_b, "near_members_per_iteration": float(st[:, 2].sum() / max(1.0, st[:, 13].sum()))}}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

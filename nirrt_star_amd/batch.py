@@ -144,7 +144,7 @@ class Guidance:
 
 
 def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, frames=None, want_trace=True, stop_first=False,
-              np_per_iter=None, py_per_iter=None, window=65536, init_clouds=True):
+              np_per_iter=None, py_per_iter=None, window=65536, init_clouds=True, pad=4096):
     """`iters` loop bodies for every tree of the batch (fewer for trees that stop: first solution with stop_first, full
     tree).  Returns dict(traces = per-tree best cost after each iteration, iters_done, kernel_ms, launches, stats).
     The per-tree generators in `streams` end up advanced by exactly what each tree consumed."""
@@ -171,8 +171,8 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
     active = list(range(B))
     while active:
         rem = remaining[active]
-        npw = [streams[i].peek_np((min(int(r), window) * np_per_iter + 4096) * int(grow[i])) for i, r in zip(active, rem)]
-        pyw = [streams[i].peek_py((min(int(r), window) * py_per_iter + 4096) * int(grow[i])) for i, r in zip(active, rem)] if need_py else None
+        npw = [streams[i].peek_np((min(int(r), window) * np_per_iter + pad) * int(grow[i])) for i, r in zip(active, rem)]
+        pyw = [streams[i].peek_py((min(int(r), window) * py_per_iter + pad) * int(grow[i])) for i, r in zip(active, rem)] if need_py else None
         r = _hip.run_sampling([trees[i] for i in active], int(rem.max()), npw, pyw, flags=run_flags, want_trace=want_trace,
                               iters_each=rem)
         kernel_ms += r["kernel_ms"]

@@ -29,7 +29,7 @@
 #include "../../include/nirrt_hip.h"
 
 #define MAX_OBS NIRRT_MAX_OBSTACLES
-#define LDS_POOL 896     // 8-byte LDS slots shared by the obstacle tables (4 per round + 6 per box obstacle) and the Near stash
+#define LDS_POOL 864     // 8-byte LDS slots shared by the obstacle tables (4 per round + 6 per box obstacle) and the Near stash
 #define OB_POOL NIRRT_OBSTACLE_POOL   // slots the obstacle tables may take (the rest, >= 256 entries, is the stash)
 #define SCAN_PAD 256     // extra elements allocated behind every per-vertex array (vector loads may overrun n)
 #define WALK_R 4         // parent chains chased concurrently per lane
@@ -38,7 +38,8 @@
 #endif
 #define GRID_MIN_VERTICES 2048   // smaller trees are visited whole (everything is "tail")
 #define GRID_REBUILD_EVERY 1024  // vertices appended behind the cell-ordered part before it is rebuilt
-#define GRID_RG_MAX 64           // rows of cells per query; larger boxes fall back to visiting the whole tree
+#define GRID_RG_MAX 64           // rows of cells per query (<= the smallest workgroup: one row per thread); larger boxes fall
+                                 // back to visiting the whole tree
 #ifndef NEAR_STASH
 #define NEAR_STASH LDS_POOL      // upper limit of Near members whose (index, bound) pair stays in LDS (the pool slots the
 #endif                           // obstacle tables leave free); the rest spills to nr_idx / nr_m.  Test builds set it to 8.
@@ -47,6 +48,9 @@
 #endif
 #ifndef LIST_U
 #define LIST_U 8                 // solution / goal-candidate list entries per lane and trip
+#endif
+#ifndef REWIRE_CAND
+#define REWIRE_CAND 64            // rewire candidates held in LDS (more: the stash is searched once per candidate instead)
 #endif
 #define GRID_N 1u                // range serves the Near query
 #define GRID_Q 2u                // range serves the nearest query
@@ -243,6 +247,8 @@ struct LdsData {
     unsigned char ob_list[2 * MAX_OBS];
     int rg_beg[GRID_RG_MAX], rg_len[GRID_RG_MAX];
     unsigned char rg_flag[GRID_RG_MAX];
+    int n_cand;                   // rewire: members whose stashed margin reaches cost(new)
+    int cand[REWIRE_CAND];
     long long stat[NSTAT];
 };
 template <int NT>
@@ -1014,7 +1020,7 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeDev &t, int n, co
     }
     // row `row` of box (c0, c1) -> slot range.  ball != nullptr: only the cells of the row that the ball (ball, rad)
     // can reach are kept (the corner cells of the box are dropped)
-    auto put_row = [&](int slot, const int (&c0)[3], const int (&c1)[3], int row, int flag, const double *ball, double rad) {
+    auto row_range = [&](const int (&c0)[3], const int (&c1)[3], int row, const double *ball, double rad, int &rb, int &rl) {
         const int ny_ = c1[1] - c0[1] + 1;
         const int cy = c0[1] + row % ny_, cz = c0[2] + row / ny_;
         int x0 = c0[0], x1 = c1[0];
@@ -1042,7 +1048,12 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeDev &t, int n, co
         const int base = (cz * G + cy) * G;
         int b = 0, e = 0;
         if (!empty) { b = t.g_start[base + x0]; e = t.g_start[base + x1 + 1]; }
-        s.rg_beg[slot] = b; s.rg_len[slot] = e - b; s.rg_flag[slot] = flag;
+        rb = b; rl = e - b;
+    };
+    auto put_row = [&](int slot, const int (&c0)[3], const int (&c1)[3], int row, int flag, const double *ball, double rad) {
+        int b, l;
+        row_range(c0, c1, row, ball, rad, b, l);
+        s.rg_beg[slot] = b; s.rg_len[slot] = l; s.rg_flag[slot] = flag;
     };
     int nb0[3] = {0, 0, 0}, nb1[3] = {0, 0, 0}, qb0[3] = {0, 0, 0}, qb1[3] = {0, 0, 0};
     int rowsN = 0, rowsQ = 0;
@@ -1078,8 +1089,18 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeDev &t, int n, co
             double d[3] = {pn[0] - px, pn[1] - py, D == 3 ? pn[D - 1] - pz : 0.};
             const double v = dist2<D>(d);
             if (v <= r2hi && id != new_idx) {
-                const double dj = dist_scan<D>(d);      // the reference's own distance: decides inside the band, and is d_j
-                if (v <= r2lo || dj <= r) {
+                // d_j: the reference's own distance (glibc hypot in 2D) decides inside the guard band and is what choose_parent
+                // adds - but it is only evaluated where it can matter: sqrt(v) is within 2 ulp of it, which settles every
+                // member that is not in the band and cannot reach this lane's best cost + dist so far
+                const double ds = __builtin_sqrt(v);
+                bool exact = D == 3;                    // 3D: dist_scan IS sqrt of this very sum
+                double dj = ds;
+                bool hit = v <= r2lo;
+                if (!hit) {
+                    if (!exact) { dj = dist_scan<D>(d); exact = true; }
+                    hit = dj <= r;
+                }
+                if (hit) {
                     bool col = false;
                     if (n_ob > 0) {
                         double vj[3] = {px, py, pz}, l0[3], l1[3];
@@ -1092,9 +1113,10 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeDev &t, int n, co
                     }
                     if (!col) {
                         member = true;
-                        const double c = pcost + dj;
+                        double c = pcost + dj;
+                        if (!exact && c <= cand * (1.0 + 0x1p-40)) c = pcost + dist_scan<D>(d);   // cand is always an exact value
                         if (c < cand || (c == cand && id < cj)) { cand = c; cj = id; }
-                        sm = pcost - dj;
+                        sm = pcost - ds;               // margin for rewire's search (tolerance there >> 2 ulp)
                     }
                 }
             }
@@ -1180,14 +1202,16 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeDev &t, int n, co
         brutes++;
         visit_records(0, fl_all);
     } else {
-        for (int row = tid; row < rowsN + rowsQ; row += NT) {
-            if (row < rowsN) put_row(row, nb0, nb1, row, GRID_N, pn, r);
-            else put_row(row, qb0, qb1, row - rowsN, GRID_Q, nullptr, 0.);
-        }
+        // the rows' slot ranges (two g_start loads per row; rowsN + rowsQ <= GRID_RG_MAX <= NT: one row per thread) are
+        // requested first, the tail is visited while they are in flight, then the range list goes to LDS
+        int rb = 0, rl = 0;
+        if (tid < rowsN) row_range(nb0, nb1, tid, pn, r, rb, rl);
+        else if (tid < rowsN + rowsQ) row_range(qb0, qb1, tid - rowsN, nullptr, 0., rb, rl);
+        PROF(20);
+        visit_records(ns, fl_all);
+        if (tid < rowsN + rowsQ) { s.rg_beg[tid] = rb; s.rg_len[tid] = rl; s.rg_flag[tid] = tid < rowsN ? GRID_N : GRID_Q; }
         if (tid == 0) s.rg_n = rowsN + rowsQ;
         __syncthreads();
-        PROF(20);
-        visit_records(ns, fl_all);   // the tail first (its loads do not wait on the range list)
         visit_ranges();
     }
     PROF(13);
@@ -1801,29 +1825,31 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 // before the search resumes.
                 const double thr = new_cost - (1e-10 + 1e-12 * new_cost);
                 const int k_lds = k < cap_lds ? k : cap_lds;
+                const int *ids = stash_ids(s);
+                // one pass over the stash (+ its spilled part) collects the members whose margin reaches cost(new): few
+                __syncthreads();
+                if (tid == 0) s.n_cand = 0;
+                __syncthreads();
+                for (int a = tid; a < k_lds; a += NT) {
+                    if (s.pool[s.stash_off + a] >= thr) {
+                        const int p = atomicAdd(&s.n_cand, 1);
+                        if (p < REWIRE_CAND) s.cand[p] = ids[a];
+                    }
+                }
+                for (int a = cap_lds + tid; a < k; a += NT) {   // spilled part (large Near sets only)
+                    if (t.nr_m[a - cap_lds] >= thr) {
+                        const int p = atomicAdd(&s.n_cand, 1);
+                        if (p < REWIRE_CAND) s.cand[p] = t.nr_idx[a - cap_lds];
+                    }
+                }
+                __syncthreads();
+                PROF(8);
+                const int n_cand = uni(s.n_cand);
+                const bool listed_all = n_cand <= REWIRE_CAND;
+                if (tid == 0) s.stat[ST_ROUNDS] += n_cand;
                 int last = -1;
-                for (;;) {
-                    int first = 0x7fffffff;
-                    const int *ids = stash_ids(s);
-                    for (int a = tid; a < k_lds; a += NT) {
-                        const int id = ids[a];
-                        if (id > last && id < first && s.pool[s.stash_off + a] >= thr) first = id;
-                    }
-                    for (int a = cap_lds + tid; a < k; a += NT) {   // spilled part (large Near sets only)
-                        const int id = t.nr_idx[a - cap_lds];
-                        if (id > last && id < first && t.nr_m[a - cap_lds] >= thr) first = id;
-                    }
-                    first = uni(block_min_int<NT>(s, first));
-                    if (first == 0x7fffffff) break;
-                    const int vj = first;
-                    last = vj;
-                    const VRec vr = t.vrec[vj];   // current cost + coordinates (same address in every lane)
-                    double d[D];
-                    d[0] = vr.x - node_new[0]; d[1] = vr.y - node_new[1];
-                    if (D == 3) d[D - 1] = vr.z - node_new[D - 1];
-                    const double dj = dist_scan<D>(d);
-                    if (tid == 0) s.stat[ST_ROUNDS] += 1;
-                    if (!(uni(vr.cost) > new_cost + dj)) continue;   // uniform
+                // the re-parenting of one member (thread 0) + re-costing of what hangs below it
+                auto rewire_one = [&](int vj, const double *d) {
                     if (tid == 0) {
                         // loads first (one round trip), then the stores
                         const bool leaf = t.first_child[vj] < 0;
@@ -1862,7 +1888,47 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                     }
                     n_rewired++;
                     __syncthreads();
+                    PROF(9);
                     if (!s.bc_i[7]) wg_recost_subtree<D, NT>(s, t, vj, new_idx);   // uniform
+                    PROF(10);
+                };
+                // every remaining candidate is re-tested in parallel with its CURRENT record; the lowest index that passes is
+                // re-parented, then the rest is looked at again (their costs may have dropped with the subtree just moved).
+                // More candidates than the list holds (all vertices on one line: the straight start-goal segment is free and the
+                // informed set has collapsed onto it - every downstream member ties with cost(new) + d_j up to rounding):
+                // the same, with the stash itself as the candidate list.
+                auto passes = [&](int id) -> bool {
+                    const VRec vr = t.vrec[id];
+                    double d[D];
+                    d[0] = vr.x - node_new[0]; d[1] = vr.y - node_new[1];
+                    if (D == 3) d[D - 1] = vr.z - node_new[D - 1];
+                    return vr.cost > new_cost + dist_scan<D>(d);
+                };
+                while (n_cand > 0) {
+                    int first = 0x7fffffff;
+                    if (listed_all) {
+                        for (int a = tid; a < n_cand; a += NT) {
+                            const int id = s.cand[a];
+                            if (id > last && id < first && passes(id)) first = id;
+                        }
+                    } else {
+                        for (int a = tid; a < k_lds; a += NT) {
+                            const int id = ids[a];
+                            if (id > last && id < first && s.pool[s.stash_off + a] >= thr && passes(id)) first = id;
+                        }
+                        for (int a = cap_lds + tid; a < k; a += NT) {
+                            const int id = t.nr_idx[a - cap_lds];
+                            if (id > last && id < first && t.nr_m[a - cap_lds] >= thr && passes(id)) first = id;
+                        }
+                    }
+                    first = uni(block_min_int<NT>(s, first));
+                    if (first == 0x7fffffff) break;
+                    last = first;
+                    const VRec vr = t.vrec[first];
+                    double d[D];
+                    d[0] = vr.x - node_new[0]; d[1] = vr.y - node_new[1];
+                    if (D == 3) d[D - 1] = vr.z - node_new[D - 1];
+                    rewire_one(first, d);
                 }
             }
             PROF(5);

@@ -81,7 +81,7 @@ def make_wrapper(args, dim, device):
 
 def _batch_setup(problems, pids, args, device_id, cap, wrapper):
     from . import _hip, batch, sampling
-    dim = 3 if args.problem == "random_3d" else 2
+    dim = 3 if getattr(args, "problem", "random_2d") == "random_3d" else 2
     planner = args.planner
     informed = planner in ("irrt_star", "nirrt_star", "nirrt_star_c")
     flags = _hip.F_IRRT if informed else _hip.F_GOAL_SCAN

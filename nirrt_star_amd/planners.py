@@ -57,6 +57,7 @@ class _HipPlanner:
             self.z_range = env.z_range
         self.path_planner_name = name
         self.mode = mode or self.default_mode
+        self.device_id = device_id
         self.tree = _hip.HipTree(D, iter_max, self.x_start, self.x_goal, step_len, search_radius, clearance, env,
                                  device_id=device_id)
         self.utils = _Utils(self)
@@ -167,10 +168,11 @@ class _HipPlanner:
         traces = []
         ms = 0.0
         need_py = D == 2 and (flags & _hip.F_IRRT)
+        grow = 1   # window multiplier: raised when not even ONE draw fitted into the words handed over
         while done_total < iters:
             left = iters - done_total
-            npw = sampling.peek_np_words(min(left, 65536) * D * 2 * (40 if (D == 3 and flags & _hip.F_IRRT) else 4) + 4096)
-            pyw = sampling.peek_py_words(min(left, 65536) * 16 + 4096) if need_py else None
+            npw = sampling.peek_np_words((min(left, 65536) * D * 2 * (40 if (D == 3 and flags & _hip.F_IRRT) else 4) + 4096) * grow)
+            pyw = sampling.peek_py_words((min(left, 65536) * 16 + 4096) * grow) if need_py else None
             res = _hip.run_sampling([self.tree], left, [npw], [pyw] if need_py else None, flags=flags, want_trace=want_trace)
             d = int(res["iters_done"][0])
             sampling.advance_np_words(int(res["np_used"][0]))
@@ -193,8 +195,15 @@ class _HipPlanner:
                 continue
             if st == 0 and d < left:   # STOP_FIRST fired
                 break
-            if d == 0 and st == _hip.E_STREAM and len(npw) > (1 << 24):
-                raise _hip.NirrtError("sampling cannot make progress (free space empty?)")
+            if d == 0 and st == _hip.E_STREAM:
+                # the very first draw of the launch exhausted the window (rejection sampling in a nearly full world):
+                # hand over a larger one next time instead of re-offering the same words for ever
+                grow *= 4
+                if grow > 1024:
+                    raise _hip.NirrtError("sampling cannot make progress: one draw needs more than %d generator words "
+                                          "(free space empty?)" % len(npw))
+            elif d > 0:
+                grow = 1
         self.last_kernel_ms = ms
         self._sync()
         return done_total, (np.concatenate(traces) if want_trace and traces else np.zeros(0))
@@ -553,15 +562,19 @@ class _NIRRTStarPNG(_IRRTStar):
         if self.dim == 2:
             if cmax < np.inf:
                 pc = pcu.ellipsoid_point_cloud_sampling(self.x_start, self.x_goal, cmax / cmin, self.binary_mask,
-                                                        self.pc_n_points, n_raw_samples=self.pc_n_points * self.pc_over_sample_scale)
+                                                        self.pc_n_points, n_raw_samples=self.pc_n_points * self.pc_over_sample_scale,
+                                                        device_id=self.device_id)
             else:
-                pc = pcu.generate_rectangle_point_cloud(self.binary_mask, self.pc_n_points, self.pc_over_sample_scale)
+                pc = pcu.generate_rectangle_point_cloud(self.binary_mask, self.pc_n_points, self.pc_over_sample_scale,
+                                                        device_id=self.device_id)
         else:
             if cmax < np.inf:
                 pc = pcu.ellipsoid_point_cloud_sampling_3d(self.x_start, self.x_goal, cmax / cmin, self.env, self.pc_n_points,
-                                                           n_raw_samples=self.pc_n_points * self.pc_over_sample_scale)
+                                                           n_raw_samples=self.pc_n_points * self.pc_over_sample_scale,
+                                                           device_id=self.device_id)
             else:
-                pc = pcu.generate_rectangle_point_cloud_3d(self.env, self.pc_n_points, over_sample_scale=self.pc_over_sample_scale)
+                pc = pcu.generate_rectangle_point_cloud_3d(self.env, self.pc_n_points, over_sample_scale=self.pc_over_sample_scale,
+                                                           device_id=self.device_id)
         if self.connect:
             _, n_runs, path_pred = self.png_wrapper.generate_connected_path_points(
                 pc.astype(np.float32), self.x_start, self.x_goal, self.env_dict, neighbor_radius=self.pc_neighbor_radius,
@@ -732,9 +745,10 @@ class _NRRTStarPNG(_RRTStar):
             self.path_point_cloud_pred = None
             return
         if self.dim == 2:
-            pc = pcu.generate_rectangle_point_cloud(self.binary_mask, self.pc_n_points, self.pc_over_sample_scale)
+            pc = pcu.generate_rectangle_point_cloud(self.binary_mask, self.pc_n_points, self.pc_over_sample_scale, device_id=self.device_id)
         else:
-            pc = pcu.generate_rectangle_point_cloud_3d(self.env, self.pc_n_points, over_sample_scale=self.pc_over_sample_scale)
+            pc = pcu.generate_rectangle_point_cloud_3d(self.env, self.pc_n_points, over_sample_scale=self.pc_over_sample_scale,
+                                                       device_id=self.device_id)
         if self.connect:
             _, _, path_pred = self.png_wrapper.generate_connected_path_points(
                 pc.astype(np.float32), self.x_start, self.x_goal, self.env_dict, neighbor_radius=self.pc_neighbor_radius,

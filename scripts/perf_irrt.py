@@ -50,7 +50,7 @@ ts = (st[:, 15] - st[:, 14]) / 1e8
 print("per-tree seconds in the launch: mean %.3f median %.3f max %.3f; useful bytes/iter %.0f" % (ts.mean(), np.median(ts), ts.max(), _hip.useful_bytes(res["stats"], dim) / tot_it))
 pr_ = np.array([t.debug_prof() for t in trees]).sum(0).astype(float)
 if pr_.sum() > 0:
-    names = ["nearest", "steer+edge", "query", "choose", "cost(new)", "rewire", "goal/ingoal", "report", "", "", "", "", "rebuild", "(Q.visit)", "(Q.nearest)", "(Q.finish)", "L.draw", "L.iteration", "L.report", "L.other", "(Q.setup)", "", "", ""]
+    names = ["nearest", "steer+edge", "query", "choose", "cost(new)", "rewire", "goal/ingoal", "report", "(R.collect)", "(R.rounds)", "(R.recost)", "", "rebuild", "(Q.visit)", "(Q.nearest)", "(Q.finish)", "L.draw", "L.iteration", "L.report", "L.other", "(Q.setup)", "", "", ""]
     tot = pr_[16:20].sum() if pr_[16:20].sum() > 0 else pr_.sum()
     print("phase share: " + ", ".join("%s %.1f%%" % (n, 100 * v / tot) for n, v in zip(names, pr_) if v > 0),
           "| ticks/iter/tree %.0f (100MHz => %.1f us)" % (tot / done.sum(), tot / done.sum() / 100.0))

@@ -66,3 +66,19 @@ class FakePNG:
                                        visualize=False, vis_folderpath="", token=""):
         pred, _ = self.classify_path_points(pc, None, None)
         return True, 1, pred.astype(np.float32)
+
+
+_CK_ROOTS = {}
+
+
+def synthetic_checkpoint_root(dim):
+    """root_dir with the seeded synthetic PointNet++ checkpoint of `dim` in the reference's layout, written the way
+    tests/golden/make_golden.py wrote the one the config3 / config4 fixtures were generated with (CPU calibration
+    forwards, oracle point operators)"""
+    import tempfile
+    from nirrt_star_amd import png_wrapper
+    if dim not in _CK_ROOTS:
+        root = tempfile.mkdtemp(prefix="nirrt_ck_")
+        png_wrapper.make_synthetic_checkpoint(png_wrapper.checkpoint_path(root, dim), seed=0, dim=dim, device="cpu")
+        _CK_ROOTS[dim] = root
+    return _CK_ROOTS[dim]

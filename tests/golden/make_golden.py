@@ -331,6 +331,78 @@ def nirrt_fixture(name, dim, connect, world_seed, iters, seed, random_after=None
     print("   %s: n=%d path_len=%.4f png calls %d (%.1fs)" % (name, n, float(planner.get_path_len(planner.path)), w.calls, time.time() - t0))
 
 
+def synthetic_checkpoint_root(dim):
+    """a scratch root_dir holding the seeded synthetic PointNet++ checkpoint in the reference's layout (there are no
+    trained weights offline): written by nirrt_star_amd.png_wrapper.make_synthetic_checkpoint on the CPU, which the
+    tests regenerate the same way on the GPU box (tests/conftest.py synthetic_checkpoint)"""
+    import tempfile
+    from nirrt_star_amd import pointops, png_wrapper
+    from oracle import pointops_ref
+    pointops.install_cpu_reference(pointops_ref)
+    root = tempfile.mkdtemp(prefix="nirrt_ck_")
+    png_wrapper.make_synthetic_checkpoint(png_wrapper.checkpoint_path(root, dim), seed=0, dim=dim, device="cpu")
+    return root
+
+
+def nirrt_real_fixture(name, dim, connect, world_seed, iters, seed):
+    """BASELINE configs 3 / 4 as composed in the reference: NIRRT*-PNG[(C)] with the reference's own PNGWrapper and
+    PointNet++ model (CPU, synthetic checkpoint), seeded numpy / python / torch generators.  Every network call is recorded
+    (cloud, masks, path_pred, path_score), so the GPU test can (L3) inject path_pred and demand the reference's tree, and
+    (L4) compare its own scores on the very same inputs."""
+    import torch
+    root = synthetic_checkpoint_root(dim)
+    if dim == 2:
+        from path_planning_classes.nirrt_star_png_2d import NIRRTStarPNG2D as P
+        from path_planning_classes.nirrt_star_png_c_2d import NIRRTStarPNGC2D as PC
+        from wrapper.pointnet_pointnet2.pointnet2_wrapper import PNGWrapper as W
+        from wrapper.pointnet_pointnet2.pointnet2_wrapper_connect_bfs import PNGWrapper as WC
+    else:
+        from path_planning_classes_3d.nirrt_star_png_3d import NIRRTStarPNG3D as P
+        from path_planning_classes_3d.nirrt_star_png_c_3d import NIRRTStarPNGC3D as PC
+        from wrapper_3d.pointnet_pointnet2.pointnet2_wrapper import PNGWrapper as W
+        from wrapper_3d.pointnet_pointnet2.pointnet2_wrapper_connect_bfs import PNGWrapper as WC
+    t0 = time.time()
+    pr, clearance = make_problem(dim, "b30", world_seed, 0)
+    with quiet():
+        w = (WC if connect else W)(root_dir=root, device="cpu")
+    calls = []
+    inner = w.classify_path_points
+
+    def classify(pc, start_mask, goal_mask):
+        pred, score = inner(pc, start_mask, goal_mask)
+        calls.append((np.asarray(pc, dtype=np.float32).copy(), np.asarray(start_mask, dtype=np.float32).copy(),
+                      np.asarray(goal_mask, dtype=np.float32).copy(), np.asarray(pred, dtype=np.int64).copy(),
+                      np.asarray(score, dtype=np.float32).copy()))
+        return pred, score
+
+    w.classify_path_points = classify
+    common = [pr["x_start"], pr["x_goal"], STEP_LEN, pr["search_radius"], iters, pr["env_dict"], w]
+    tail = [clearance, 2048, 5, 0.5, 0.9]
+    if dim == 2:
+        common.append(pr["binary_mask"])
+    planner = (PC(*common, *tail, 5) if connect else P(*common, *tail))
+    np.random.seed(seed)
+    random.seed(seed)
+    torch.manual_seed(seed)
+    with quiet():
+        planner.planning()
+    n = planner.num_vertices
+    path = np.array(planner.path, dtype=np.float64).reshape(-1, dim) if len(planner.path) else np.zeros((0, dim))
+    arrays = {}
+    for i, (pc, sm, gm, pred, score) in enumerate(calls):
+        arrays["call%d_pc" % i], arrays["call%d_start" % i], arrays["call%d_goal" % i] = pc, sm.astype(np.uint8), gm.astype(np.uint8)
+        arrays["call%d_pred" % i], arrays["call%d_score" % i] = pred.astype(np.uint8), score.astype(np.float16)
+    save(name, env=env_json(pr["env_dict"]), dim=np.array(dim), algo=np.array("nirrt_c" if connect else "nirrt"),
+         seed=np.array(seed), iter_max=np.array(iters), step_len=np.array(float(STEP_LEN)), clearance=np.array(float(clearance)),
+         search_radius=np.array(float(pr["search_radius"])), x_start=np.array(pr["x_start"], dtype=np.float64),
+         x_goal=np.array(pr["x_goal"], dtype=np.float64), n=np.array(n), vertices=planner.vertices[:n].copy(),
+         parents=planner.vertex_parents[:n].astype(np.int64), path=path, path_len=np.array(float(planner.get_path_len(planner.path))),
+         path_solutions=np.array(planner.path_solutions, dtype=np.int64), n_calls=np.array(len(calls)),
+         binary_mask=(pr["binary_mask"].astype(np.uint8) if dim == 2 else np.zeros(0, np.uint8)), **arrays)
+    print("   %s: n=%d path_len=%.4f network calls %d, path points per call %s (%.1fs)"
+          % (name, n, float(planner.get_path_len(planner.path)), len(calls), [int(c[3].sum()) for c in calls], time.time() - t0))
+
+
 def nrrt_fixture(name, dim, world_seed, iters, seed, connect=False):
     """NRRT*-PNG[(C)] (RRT* + cloud sampling, no informed set) whole run with the fake wrapper (see nirrt_fixture)."""
     sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
@@ -698,6 +770,9 @@ JOBS = {
     "run_nrrtc2d_1500": lambda: nrrt_fixture("run_nrrtc2d_1500", 2, 13, 1500, 1013, connect=True),
     "run_nrrtc3d_1500": lambda: nrrt_fixture("run_nrrtc3d_1500", 3, 7, 1500, 1007, connect=True),
     "random_nirrt2d": lambda: nirrt_fixture("random_nirrt2d", 2, False, 14, 4000, 1014, random_after=300),
+    # BASELINE configs 3 and 4 with the reference's own wrapper + PointNet++ (CPU, synthetic checkpoint)
+    "config3_nirrtc2d_real": lambda: nirrt_real_fixture("config3_nirrtc2d_real", 2, True, 15, 2500, 1015),
+    "config4_nirrt3d_real": lambda: nirrt_real_fixture("config4_nirrt3d_real", 3, False, 8, 2500, 1008),
 }
 
 if __name__ == "__main__":

@@ -145,9 +145,9 @@ def test_more_than_2048_trees_in_one_launch_against_the_oracle(oracle, irrt):
 
 
 def test_suite_against_the_small_limits_build():
-    """libnirrt_hip_small.so = same sources with -DCHAIN_MAX=8 -DNEAR_STASH=8: parent chains longer than 8 edges take the
-    global-walk branches of wg_recost_subtree / the rewire leaf path, and all but 8 members of a Near set live in the HBM
-    continuation of the stash.
+    """libnirrt_hip_small.so = same sources with -DCHAIN_MAX=8 -DNEAR_STASH=8 -DREWIRE_CAND=2: parent chains longer than 8
+    edges take the global-walk branches of wg_recost_subtree / the rewire leaf path, all but 8 members of a Near set live
+    in the HBM continuation of the stash, and more than 2 rewire candidates take the search-per-candidate path.
     The fixture and oracle comparisons must not notice.  Run in a child interpreter because the library path is read
     once per process."""
     from nirrt_star_amd import build

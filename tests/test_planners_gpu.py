@@ -192,23 +192,67 @@ def test_sharded_eval_batch_matches_planner_class():
         assert np.max(np.abs(res[np.isfinite(lst)] - lst[np.isfinite(lst)])) <= 1e-9
 
 
-@pytest.mark.parametrize("name", ["run_nrrt2d_1500", "run_nrrt3d_1500"])
+@pytest.mark.parametrize("name", ["run_nrrt2d_1500", "run_nrrt3d_1500", "run_nrrtc2d_1500", "run_nrrtc3d_1500"])
 def test_nrrt_png_against_reference_run(name):
-    """NRRT*-PNG: RRT* + point-cloud sampling, resident and host-loop modes"""
+    """NRRT*-PNG and NRRT*-PNG(C) (nrrt_star_png_2d.py:10-114, nrrt_star_png_c_2d.py, 3D twins):
+    RRT* + point-cloud sampling, resident and host-loop modes"""
     from nirrt_star_amd import planners
     g = load_golden(name)
     dim = int(g["dim"])
+    connect = str(g["algo"]) == "nrrt_c"
+    w = FakePNG(g["x_start"], g["x_goal"], 25.0 if dim == 2 else 8.0)
+    common = [tuple(g["x_start"]), tuple(g["x_goal"]), 10, float(g["search_radius"]), int(g["iter_max"]), g["env"], w]
+    if dim == 2:
+        common.append(g["binary_mask"].astype(np.float64))
     for mode in ("exact", "resident"):
-        w = FakePNG(g["x_start"], g["x_goal"], 25.0 if dim == 2 else 8.0)
-        common = [tuple(g["x_start"]), tuple(g["x_goal"]), 10, float(g["search_radius"]), int(g["iter_max"]), g["env"], w]
-        if dim == 2:
-            common.append(g["binary_mask"].astype(np.float64))
-        cls = planners.NRRTStarPNG2D if dim == 2 else planners.NRRTStarPNG3D
-        p = cls(*common, int(g["clearance"]), 2048, 5, 0.5, mode=mode)
+        w.calls = 0
+        if connect:
+            cls = planners.NRRTStarPNGC2D if dim == 2 else planners.NRRTStarPNGC3D
+            p = cls(*common, int(g["clearance"]), 2048, 5, 0.5, 5, mode=mode)
+        else:
+            cls = planners.NRRTStarPNG2D if dim == 2 else planners.NRRTStarPNG3D
+            p = cls(*common, int(g["clearance"]), 2048, 5, 0.5, mode=mode)
         _seed(g)
         p.planning()
         assert w.calls == int(g["png_calls"]) == 1
         _check_tree(p, g, exact=(mode == "exact" or dim == 3))
+
+
+def test_nirrt_planning_random_against_reference_run():
+    """NIRRT*-PNG planning_random (nirrt_star_png_2d.py:247-335): per-iteration best cost list and final tree"""
+    from nirrt_star_amd import planners
+    g = load_golden("random_nirrt2d")
+    w = FakePNG(g["x_start"], g["x_goal"], 25.0)
+    p = planners.NIRRTStarPNG2D(tuple(g["x_start"]), tuple(g["x_goal"]), 10, float(g["search_radius"]), int(g["iter_max"]), g["env"], w,
+                                g["binary_mask"].astype(np.float64), int(g["clearance"]), 2048, 5, 0.5, 0.9)
+    _seed(g)
+    lst = np.array(p.planning_random(int(g["iter_after_initial"])))
+    exp = g["path_len_list"]
+    assert len(lst) == len(exp) and np.array_equal(np.isinf(lst), np.isinf(exp))
+    m = np.isfinite(exp)
+    assert m.any() and np.max(np.abs(lst[m] - exp[m])) <= 1e-5
+    n = p.num_vertices
+    assert n == int(g["n"]) and np.array_equal(p.vertex_parents[:n], g["parents"]) and w.calls == int(g["png_calls"])
+
+
+def test_sharded_eval_batch_of_rrt_star_matches_planner_class():
+    """plan_batch with rrt_star (always SampleFree, in crowded worlds: r in [16, 24] circles) == the planner class; word
+    windows are refilled by the batch driver, and a tree that stops abnormally raises instead of being recorded as unsolved"""
+    from types import SimpleNamespace as NS
+    from nirrt_star_amd import eval_sharded as es, planners, worlds
+    args = NS(problem="random_2d", planner="rrt_star", iter_max=3000, iter_after_initial=150, step_len=10, clearance=3)
+    probs = [worlds.problem_2d(worlds.random_world_2d(60 + i, "b30", circle_radius_range=(16, 24)), 0) for i in range(3)]
+    pids = [21, 22, 23]
+    recs, traces = es.plan_batch(probs, pids, args, 0)
+    for pr, pid, tr in zip(probs, pids, traces):
+        p = planners.RRTStar2D(pr["x_start"], pr["x_goal"], 10, pr["search_radius"], 3150, pr["env"], 3)
+        np.random.seed(1000 + pid)
+        random.seed(1000 + pid)
+        lst = np.array(p.planning_random(150))
+        tr = np.asarray(tr)
+        assert len(tr) == len(lst) and np.array_equal(np.isinf(tr), np.isinf(lst))
+        fin = np.isfinite(lst)
+        assert np.max(np.abs(tr[fin] - lst[fin])) <= 1e-9 if fin.any() else True
 
 
 @pytest.mark.parametrize("name", ["blockgap_irrt_block", "blockgap_rrt_gap"])
@@ -245,7 +289,7 @@ def test_block_gap_batch_evaluation_is_segment_independent():
     thr = [p["best_path_len"] * 1.1 for p in probs]
     out = []
     for seg in (250, 3000):
-        args = SimpleNamespace(planner="irrt_star", iter_max=3000, step_len=10, clearance=3, segment=seg)
+        args = SimpleNamespace(problem="block", planner="irrt_star", iter_max=3000, step_len=10, clearance=3, segment=seg)
         out.append(np.array(E.plan_batch_block_gap(probs, list(range(6)), thr, args, 0)[0]))
     assert np.array_equal(out[0][:, [0, 1, 3]], out[1][:, [0, 1, 3]])          # ids, first-solution and stop iterations
     fin = np.isfinite(out[1][:, 4:])
