@@ -53,7 +53,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--trees", type=int, default=4096, help="problems per GPU per step (4096 = 16 one-wave workgroups per CU, all resident; more queue up behind them)")
+    ap.add_argument("--trees", type=int, default=8192, help="problems per GPU per step (4096 = 16 one-wave workgroups per CU, all resident; more queue up "
+                                                             "behind them and even out the heavy-tailed per-tree run times)")
     ap.add_argument("--iters", type=int, default=50000, help="planner iterations per problem (tree capacity)")
     ap.add_argument("--dim", type=int, default=2)
     ap.add_argument("--algo", default="irrt", choices=["irrt", "rrt", "nirrt", "nirrt_c"],
@@ -200,6 +201,15 @@ def main():
                          device_id=local_rank)
         t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
         trees.append(t)
+    # Launch order = dispatch order: trees whose straight start-goal segment is collision-free go first.  Their informed set
+    # collapses onto that segment (c_best -> c_min), Near sets grow to thousands of members and they run ~2x longer than the
+    # median tree, so they should not be the ones that start last (longest-processing-time-first, a host-side ordering of
+    # independent problems; the problems themselves and their seeds are untouched).
+    if args.algo == "irrt" and B > 1:
+        free_line = [not t.is_collision(pr["x_start"], pr["x_goal"]) for t, pr in zip(trees, probs)]
+        order = sorted(range(B), key=lambda b: (not free_line[b], b))
+        trees = [trees[b] for b in order]
+        probs = [probs[b] for b in order]
     # inputs: each problem's generator outputs (np.random.seed(s); random.seed(s)), resident in HBM
     n_np, n_py = word_budgets(args)
     py_stride = max(n_py, 1)

@@ -26,6 +26,17 @@ int nirrt_pn2_ball_query(const float *xyz, const float *new_xyz, int B, int N, i
  * distances ascending, idx DEVICE i64 (B, N, 3). */
 int nirrt_pn2_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S, float *dist, int64_t *idx, void *stream);
 
+/* One radius branch of PointNetSetAbstractionMsg.forward (pointnet2_utils.py:236-262) fused into one kernel on
+ * v_mfma_f32_16x16x4_f32 tiles: gather the K members of every centroid's group ([features, xyz - centroid], :247-250), three
+ * folded conv1x1+BatchNorm+ReLU layers, maximum over the members.  DEVICE pointers: feats f32 (B, N, C), xyz f32 (B, N, 3),
+ * new_xyz f32 (B, S, 3), gidx i64 (B, S, K) from nirrt_pn2_ball_query; w1t / w2t / w3t = the layers' weights TRANSPOSED
+ * (C_in x C_out row-major; w1t has cin_pad >= C + 3 rows, a multiple of 4, zero rows behind the real ones), b1 / b2 / b3
+ * their biases; C1, C2, C3 multiples of 16, C3 <= 128.  Writes out[b, s, out_off : out_off + C3] of out f32 (B, S, out_stride).
+ * Returns -3 (and does nothing) when the branch's weights + activation tiles exceed the 160 KB of LDS. */
+int nirrt_pn2_sa_mlp(const float *feats, const float *xyz, const float *new_xyz, const int64_t *gidx, int B, int N, int S, int K, int C,
+                     int cin_pad, const float *w1t, const float *b1, int C1, const float *w2t, const float *b2, int C2,
+                     const float *w3t, const float *b3, int C3, float *out, int out_stride, int out_off, void *stream);
+
 /* open3d PointCloud.farthest_point_down_sample as called by datasets/point_cloud_mask_utils.py:69-72,170-173 and
  * datasets_3d/point_cloud_mask_utils_3d.py:49-53,196-199 (un-vendored dependency, behaviour restated: start at point 0,
  * greedy max-min squared distance in float64, first maximum on ties).  HOST pointers: pts (N, 3) f64 row-major,

@@ -29,7 +29,9 @@
 #include "../../include/nirrt_hip.h"
 
 #define MAX_OBS NIRRT_MAX_OBSTACLES
+#ifndef LDS_POOL
 #define LDS_POOL 864     // 8-byte LDS slots shared by the obstacle tables (4 per round + 6 per box obstacle) and the Near stash
+#endif
 #define OB_POOL NIRRT_OBSTACLE_POOL   // slots the obstacle tables may take (the rest, >= 256 entries, is the stash)
 #define SCAN_PAD 256     // extra elements allocated behind every per-vertex array (vector loads may overrun n)
 #define WALK_R 4         // parent chains chased concurrently per lane
@@ -44,8 +46,9 @@
 #define NEAR_STASH LDS_POOL      // upper limit of Near members whose (index, bound) pair stays in LDS (the pool slots the
 #endif                           // obstacle tables leave free); the rest spills to nr_idx / nr_m.  Test builds set it to 8.
 #ifndef GRID_U
-#define GRID_U 4                 // slots per lane and trip of a grid visit
+#define GRID_U 2                 // slots per lane and trip of a grid visit (measured: 2 beats 4 by 12 %, 8 spills)
 #endif
+#define REBUILD_U 4               // vertices per lane and trip of an index rebuild
 #ifndef LIST_U
 #define LIST_U 8                 // solution / goal-candidate list entries per lane and trip
 #endif
@@ -920,18 +923,18 @@ __device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeDev &t, int n)
         if (D == 3) c += G * G * grid_cell_axis(t, 2, v.z);
         return c;
     };
-    for (int i0 = tid; i0 < n; i0 += NT * GRID_U) {
-        VRec v[GRID_U];
-        int cell[GRID_U], rk[GRID_U];
+    for (int i0 = tid; i0 < n; i0 += NT * REBUILD_U) {
+        VRec v[REBUILD_U];
+        int cell[REBUILD_U], rk[REBUILD_U];
 #pragma unroll
-        for (int u = 0; u < GRID_U; u++)
+        for (int u = 0; u < REBUILD_U; u++)
             if (i0 + u * NT < n) v[u] = t.vrec[i0 + u * NT];
 #pragma unroll
-        for (int u = 0; u < GRID_U; u++) cell[u] = i0 + u * NT < n ? cell_of(v[u]) : -1;
+        for (int u = 0; u < REBUILD_U; u++) cell[u] = i0 + u * NT < n ? cell_of(v[u]) : -1;
 #pragma unroll
-        for (int u = 0; u < GRID_U; u++) rk[u] = cell[u] >= 0 ? atomicAdd(&t.g_cnt[cell[u]], 1) : 0;
+        for (int u = 0; u < REBUILD_U; u++) rk[u] = cell[u] >= 0 ? atomicAdd(&t.g_cnt[cell[u]], 1) : 0;
 #pragma unroll
-        for (int u = 0; u < GRID_U; u++)
+        for (int u = 0; u < REBUILD_U; u++)
             if (cell[u] >= 0) t.g_rank[i0 + u * NT] = rk[u];
     }
     __syncthreads();
@@ -950,19 +953,19 @@ __device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeDev &t, int n)
     }
     if (tid == 0) t.g_start[nc] = n;
     __syncthreads();
-    for (int i0 = tid; i0 < n; i0 += NT * GRID_U) {
-        VRec v[GRID_U];
-        int rk[GRID_U], st[GRID_U];
+    for (int i0 = tid; i0 < n; i0 += NT * REBUILD_U) {
+        VRec v[REBUILD_U];
+        int rk[REBUILD_U], st[REBUILD_U];
 #pragma unroll
-        for (int u = 0; u < GRID_U; u++) {
+        for (int u = 0; u < REBUILD_U; u++) {
             const int i = i0 + u * NT;
             rk[u] = 0;
             if (i < n) { v[u] = t.vrec[i]; rk[u] = t.g_rank[i]; }
         }
 #pragma unroll
-        for (int u = 0; u < GRID_U; u++) st[u] = i0 + u * NT < n ? t.g_start[cell_of(v[u])] : 0;
+        for (int u = 0; u < REBUILD_U; u++) st[u] = i0 + u * NT < n ? t.g_start[cell_of(v[u])] : 0;
 #pragma unroll
-        for (int u = 0; u < GRID_U; u++) {
+        for (int u = 0; u < REBUILD_U; u++) {
             const int i = i0 + u * NT;
             if (i < n) {
                 const int sl = st[u] + rk[u];
@@ -976,6 +979,20 @@ __device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeDev &t, int n)
     }
     if (tid == 0) { t.g_ns = n; s.stat[ST_REBUILT] += n; }
     __syncthreads();
+}
+
+// sqrt to a few ulp (hardware reciprocal square root estimate + two coupled Newton steps, no special-case handling):
+// enough where a tolerance of 2^-40 follows; about a third of the instructions of the IEEE sequence
+__device__ __forceinline__ double sqrt_fast(double v)
+{
+    if (!(v > 0.)) return 0.;
+    const double y = __builtin_amdgcn_rsq(v);
+    double g = v * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    return __builtin_fma(g, r, g);
 }
 
 // result of the Near part of a query
@@ -1048,12 +1065,12 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeDev &t, int n, co
         const int base = (cz * G + cy) * G;
         int b = 0, e = 0;
         if (!empty) { b = t.g_start[base + x0]; e = t.g_start[base + x1 + 1]; }
-        rb = b; rl = e - b;
+        rb = b; rl = e;     // first slot / end slot: nothing is computed from the two loads here, so they stay in flight
     };
     auto put_row = [&](int slot, const int (&c0)[3], const int (&c1)[3], int row, int flag, const double *ball, double rad) {
-        int b, l;
-        row_range(c0, c1, row, ball, rad, b, l);
-        s.rg_beg[slot] = b; s.rg_len[slot] = l; s.rg_flag[slot] = flag;
+        int b, e;
+        row_range(c0, c1, row, ball, rad, b, e);
+        s.rg_beg[slot] = b; s.rg_len[slot] = e - b; s.rg_flag[slot] = flag;
     };
     int nb0[3] = {0, 0, 0}, nb1[3] = {0, 0, 0}, qb0[3] = {0, 0, 0}, qb1[3] = {0, 0, 0};
     int rowsN = 0, rowsQ = 0;
@@ -1092,7 +1109,7 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeDev &t, int n, co
                 // d_j: the reference's own distance (glibc hypot in 2D) decides inside the guard band and is what choose_parent
                 // adds - but it is only evaluated where it can matter: sqrt(v) is within 2 ulp of it, which settles every
                 // member that is not in the band and cannot reach this lane's best cost + dist so far
-                const double ds = __builtin_sqrt(v);
+                const double ds = sqrt_fast(v);
                 bool exact = D == 3;                    // 3D: dist_scan IS sqrt of this very sum
                 double dj = ds;
                 bool hit = v <= r2lo;
@@ -1167,24 +1184,30 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeDev &t, int n, co
         for (int i = 0; i < R; i++) total += s.rg_len[i];
         visited += total;
         vbytes += (long long)total * (8 * D + 12);
+        // a lane's flat offsets only grow (with u and with the trip), so its position in the range list is carried along
+        int rr = 0, r_lo = 0, r_hi = R > 0 ? s.rg_len[0] : 0, r_beg = R > 0 ? s.rg_beg[0] : 0;
+        unsigned r_flag = R > 0 ? (unsigned)s.rg_flag[0] : 0u;
         for (int f0 = 0; f0 < total; f0 += NT * GRID_U) {
             double px[GRID_U], py[GRID_U], pz[GRID_U], pc[GRID_U];
             int id[GRID_U];
             unsigned flag[GRID_U];
 #pragma unroll
             for (int u = 0; u < GRID_U; u++) {
-                int off = f0 + u * NT + tid;
+                const int off = f0 + u * NT + tid;
                 px[u] = 0.; py[u] = 0.; pz[u] = 0.; pc[u] = 0.; id[u] = 0;
                 flag[u] = 0u;
                 if (off < total) {
-                    int rr = 0, len = s.rg_len[0];
-                    while (off >= len) { off -= len; rr++; len = s.rg_len[rr]; }
-                    const int sl = s.rg_beg[rr] + off;
+                    while (off >= r_hi) {
+                        rr++;
+                        r_lo = r_hi;
+                        r_hi += s.rg_len[rr]; r_beg = s.rg_beg[rr]; r_flag = (unsigned)s.rg_flag[rr];
+                    }
+                    const int sl = r_beg + (off - r_lo);
                     px[u] = t.g_x[0][sl]; py[u] = t.g_x[1][sl];
                     if (D == 3) pz[u] = t.g_x[D - 1][sl];
                     pc[u] = t.g_cost[sl];
                     id[u] = t.g_idx[sl];
-                    flag[u] = (unsigned)s.rg_flag[rr];
+                    flag[u] = r_flag;
                 }
             }
 #pragma unroll
@@ -1209,7 +1232,7 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeDev &t, int n, co
         else if (tid < rowsN + rowsQ) row_range(qb0, qb1, tid - rowsN, nullptr, 0., rb, rl);
         PROF(20);
         visit_records(ns, fl_all);
-        if (tid < rowsN + rowsQ) { s.rg_beg[tid] = rb; s.rg_len[tid] = rl; s.rg_flag[tid] = tid < rowsN ? GRID_N : GRID_Q; }
+        if (tid < rowsN + rowsQ) { s.rg_beg[tid] = rb; s.rg_len[tid] = rl - rb; s.rg_flag[tid] = tid < rowsN ? GRID_N : GRID_Q; }
         if (tid == 0) s.rg_n = rowsN + rowsQ;
         __syncthreads();
         visit_ranges();
@@ -1761,6 +1784,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
             // the fused query: Near members of node_new (stash + choose_parent's argmin) and the next sample's nearest vertex
             NearResult nr;
             const int cap_lds = uni(s.stash_cap);
+            // (measured: reaching the query through a noinline call instead costs 25 % - the values alive around it get spilled)
             wg_query<D, NT>(s, t, n, node_new, inserted ? r_grown : r_same, new_idx, q_next, &next_ni, &nr, cap_lds);
             const int k = nr.k;
             alg += n;

@@ -374,3 +374,152 @@ extern "C" int nirrt_fps_f64(const double *pts, int N, int num_samples, unsigned
     if (N <= 0 || num_samples <= 0) return -1;
     return nirrt_fps_f64_batch(pts, 1, &N, &num_samples, sel, device_id);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Fused set-abstraction branch (PointNetSetAbstractionMsg.forward, pointnet2_utils.py:236-262, one radius): gather the K
+// grouped points of a centroid, run the three 1x1-conv + BatchNorm (folded: W, b) + ReLU layers and take the maximum over
+// the K members - without ever writing the grouped tensor (B, S, K, C_in) or an intermediate activation to HBM.
+//
+// One wave owns one group at a time; its rows are processed as 16-row tiles through v_mfma_f32_16x16x4_f32 (fp32 in,
+// fp32 accumulate - the reference computes in fp32):
+//     A (16 x 4)  lane l holds A[l % 16][l / 16]          activations, read from the wave's LDS tile
+//     B (4 x 16)  lane l holds B[l / 16][l % 16]          W^T, read from the workgroup's LDS copy of the weights
+//     D (16 x 16) lane l, register v holds D[4 * (l / 16) + v][l % 16]
+// Layer l: for every 16-column tile, acc = bias; acc += A[:, k0:k0+4] . W^T[k0:k0+4, tile] over k0; ReLU; the tile goes to the
+// other LDS activation buffer (layers 1, 2) or is reduced over its 16 rows in registers (layer 3: max over the 4 registers
+// of a lane, then over the 4 lane groups with two DPP-free shuffles) and written out.  Input rows are
+// [features of the member, xyz(member) - xyz(centroid)] (:247-250), zero-padded to a multiple of 4 channels.
+// ------------------------------------------------------------------------------------------------
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+#define SA_WAVES 4
+
+struct SaMlpArgs {
+    const float *feats;     // (B, N, C)
+    const float *xyz;       // (B, N, 3)
+    const float *new_xyz;   // (B, S, 3)
+    const long long *gidx;  // (B, S, K)
+    float *out;             // (B, S, out_stride) - this branch writes columns [out_off, out_off + C3)
+    const float *w1t, *b1, *w2t, *b2, *w3t, *b3;   // W^T row-major (C_in_pad x C1), (C1 x C2), (C2 x C3); biases
+    int B, N, S, K, C, Cin_pad, C1, C2, C3, out_stride, out_off;
+};
+
+__global__ __launch_bounds__(64 * SA_WAVES) void k_sa_mlp(SaMlpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float sa_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int Cin = a.Cin_pad, C1 = a.C1, C2 = a.C2, C3 = a.C3;
+    float *W1 = sa_lds;                       // Cin x C1
+    float *W2 = W1 + Cin * C1;                // C1 x C2
+    float *W3 = W2 + C1 * C2;                 // C2 x C3
+    float *Bs = W3 + C2 * C3;                 // C1 + C2 + C3 biases
+    const int sA = (Cin > C2 ? Cin : C2) + 1, sB = C1 + 1;      // row strides (odd: rows fall into different banks)
+    float *bufA = Bs + C1 + C2 + C3 + (size_t)w * 16 * (sA + sB);   // this wave's tiles: input / layer-2 output ...
+    float *bufB = bufA + 16 * sA;                                   // ... and layer-1 output
+    for (int i = tid; i < Cin * C1; i += 64 * SA_WAVES) W1[i] = a.w1t[i];
+    for (int i = tid; i < C1 * C2; i += 64 * SA_WAVES) W2[i] = a.w2t[i];
+    for (int i = tid; i < C2 * C3; i += 64 * SA_WAVES) W3[i] = a.w3t[i];
+    for (int i = tid; i < C1; i += 64 * SA_WAVES) Bs[i] = a.b1[i];
+    for (int i = tid; i < C2; i += 64 * SA_WAVES) Bs[C1 + i] = a.b2[i];
+    for (int i = tid; i < C3; i += 64 * SA_WAVES) Bs[C1 + C2 + i] = a.b3[i];
+    __syncthreads();
+    const int row = lane & 15, kq = lane >> 4;            // A / B operand coordinates of this lane
+    const long long groups = (long long)a.B * a.S;
+    const int CC = a.C + 3;
+    for (long long g = (long long)blockIdx.x * SA_WAVES + w; g < groups; g += (long long)gridDim.x * SA_WAVES) {
+        const int b = (int)(g / a.S);
+        const float *cen = a.new_xyz + g * 3;
+        const float cx = cen[0], cy = cen[1], cz = cen[2];
+        float best[8];                                     // running maxima of this lane's output columns (C3 <= 128)
+#pragma unroll
+        for (int i = 0; i < 8; i++) best[i] = -3.4e38f;
+        for (int r0 = 0; r0 < a.K; r0 += 16) {             // 16-row tiles of the group
+            // gather: element e of the tile = (row e / Cin, channel e % Cin); consecutive lanes read consecutive channels
+            for (int e = lane; e < 16 * Cin; e += 64) {
+                const int r = e / Cin, c = e - r * Cin;
+                float v = 0.f;
+                if (r0 + r < a.K && c < CC) {
+                    const long long idx = a.gidx[g * a.K + r0 + r];
+                    if (c < a.C) v = a.feats[((long long)b * a.N + idx) * a.C + c];
+                    else {
+                        const float p = a.xyz[((long long)b * a.N + idx) * 3 + (c - a.C)];
+                        v = p - (c - a.C == 0 ? cx : (c - a.C == 1 ? cy : cz));
+                    }
+                }
+                bufA[r * sA + c] = v;
+            }
+            // rows beyond K (K < 16 never happens in this network; K is 16 or 32) would be padding: keep them out of the max
+            // layer 1: bufA (16 x Cin) -> bufB (16 x C1)
+            for (int ct = 0; ct < C1; ct += 16) {
+                float4_t acc;
+                const float bias = Bs[ct + row];
+                acc[0] = bias; acc[1] = bias; acc[2] = bias; acc[3] = bias;
+                for (int k0 = 0; k0 < Cin; k0 += 4)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bufA[row * sA + k0 + kq], W1[(k0 + kq) * C1 + ct + row], acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; v++) bufB[(4 * kq + v) * sB + ct + row] = acc[v] > 0.f ? acc[v] : 0.f;
+            }
+            // layer 2: bufB (16 x C1) -> bufA (16 x C2)
+            for (int ct = 0; ct < C2; ct += 16) {
+                float4_t acc;
+                const float bias = Bs[C1 + ct + row];
+                acc[0] = bias; acc[1] = bias; acc[2] = bias; acc[3] = bias;
+                for (int k0 = 0; k0 < C1; k0 += 4)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bufB[row * sB + k0 + kq], W2[(k0 + kq) * C2 + ct + row], acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; v++) bufA[(4 * kq + v) * sA + ct + row] = acc[v] > 0.f ? acc[v] : 0.f;
+            }
+            // layer 3: bufA (16 x C2) -> maximum over the rows, per output column
+            for (int ct = 0, ci = 0; ct < C3; ct += 16, ci++) {
+                float4_t acc;
+                const float bias = Bs[C1 + C2 + ct + row];
+                acc[0] = bias; acc[1] = bias; acc[2] = bias; acc[3] = bias;
+                for (int k0 = 0; k0 < C2; k0 += 4)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bufA[row * sA + k0 + kq], W3[(k0 + kq) * C3 + ct + row], acc, 0, 0, 0);
+                float m = -3.4e38f;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const float x = acc[v] > 0.f ? acc[v] : 0.f;
+                    if (r0 + 4 * kq + v < a.K) m = x > m ? x : m;
+                }
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                best[ci] = fmaxf(best[ci], m);             // every lane now holds the column maximum of its `row` column
+            }
+        }
+        if (lane < 16) {
+            float *o = a.out + g * a.out_stride + a.out_off;
+            for (int ct = 0, ci = 0; ct < C3; ct += 16, ci++) o[ct + lane] = best[ci];
+        }
+    }
+}
+
+// One branch of a set-abstraction level.  DEVICE pointers; w*t are the folded weights TRANSPOSED (C_in x C_out, row-major), the
+// first with its C + 3 input rows padded with zero rows to cin_pad (a multiple of 4); C1, C2, C3 multiples of 16, C3 <= 128.
+// Needs 4 * (cin_pad * C1 + C1 * C2 + C2 * C3 + C1 + C2 + C3 + 4 * 16 * (max(cin_pad, C2) + C1 + 2)) bytes of LDS (<= 160 KB):
+// returns -3 when the level does not fit (the caller then uses library GEMMs).
+extern "C" int nirrt_pn2_sa_mlp(const float *feats, const float *xyz, const float *new_xyz, const int64_t *gidx, int B, int N, int S,
+                                int K, int C, int cin_pad, const float *w1t, const float *b1, int C1, const float *w2t, const float *b2,
+                                int C2, const float *w3t, const float *b3, int C3, float *out, int out_stride, int out_off, void *stream)
+{
+    if (C1 % 16 || C2 % 16 || C3 % 16 || C3 > 128 || cin_pad % 4 || cin_pad < C + 3 || K <= 0 || B <= 0 || S <= 0) return -1;
+    const int sA = (cin_pad > C2 ? cin_pad : C2) + 1, sB = C1 + 1;
+    const size_t lds = sizeof(float) * ((size_t)cin_pad * C1 + (size_t)C1 * C2 + (size_t)C2 * C3 + C1 + C2 + C3 +
+                                        (size_t)SA_WAVES * 16 * (sA + sB));
+    if (lds > 160 * 1024) return -3;
+    static size_t lds_max = 0;
+    if (lds > lds_max) {
+        if (hipFuncSetAttribute((const void *)k_sa_mlp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+        lds_max = lds;
+    }
+    SaMlpArgs a;
+    a.feats = feats; a.xyz = xyz; a.new_xyz = new_xyz; a.gidx = (const long long *)gidx; a.out = out;
+    a.w1t = w1t; a.b1 = b1; a.w2t = w2t; a.b2 = b2; a.w3t = w3t; a.b3 = b3;
+    a.B = B; a.N = N; a.S = S; a.K = K; a.C = C; a.Cin_pad = cin_pad; a.C1 = C1; a.C2 = C2; a.C3 = C3;
+    a.out_stride = out_stride; a.out_off = out_off;
+    const long long groups = (long long)B * S;
+    long long grid = (groups + SA_WAVES - 1) / SA_WAVES;
+    if (grid > 2048) grid = 2048;      // grid-stride over the groups: the weights are staged once per workgroup
+    hipLaunchKernelGGL(k_sa_mlp, dim3((unsigned)grid), dim3(64 * SA_WAVES), lds, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

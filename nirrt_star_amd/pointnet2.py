@@ -66,6 +66,13 @@ class SetAbstractionMSG(nn.Module):
 
     def fold(self):
         self._folded = [[_fold(c, b) for c, b in zip(cs, bs)] for cs, bs in zip(self.conv_blocks, self.bn_blocks)]
+        # the fused MFMA kernel (csrc/pointops.hip k_sa_mlp) takes the levels whose widths fit its tiles and whose weights fit
+        # the LDS (SA1, SA2); the others keep one library GEMM per layer
+        self._fused = None
+        dev = self._folded[0][0][0].device
+        if dev.type == "cuda":
+            c_in = self.conv_blocks[0][0].weight.shape[1]
+            self._fused = [pointops.sa_mlp_pack(layers, c_in, dev) for layers in self._folded]
 
     def forward(self, xyz, feats, fps_start=None):
         """xyz (B, N, 3), feats (B, N, C) -> new_xyz (B, S, 3), new_feats (B, S, sum C_out)"""
@@ -73,9 +80,19 @@ class SetAbstractionMSG(nn.Module):
         S = self.npoint
         fps_idx = pointops.farthest_point_sample(xyz, S, fps_start)            # (B, S)
         new_xyz = torch.gather(xyz, 1, fps_idx[..., None].expand(B, S, 3))
+        fused = getattr(self, "_fused", None) if (self._folded is not None and not self.training and xyz.is_cuda) else None
+        out_all, off = None, 0
+        if fused is not None:
+            out_all = torch.empty(B, S, sum(layers[-1][0].shape[0] for layers in self._folded), dtype=torch.float32, device=xyz.device)
         outs = []
         for bi, (radius, K) in enumerate(zip(self.radii, self.nsamples)):
             gidx = pointops.ball_query(radius, K, xyz, new_xyz)                # (B, S, K)
+            if fused is not None:
+                width = self._folded[bi][-1][0].shape[0]
+                if fused[bi] is not None and pointops.sa_mlp(feats, xyz, new_xyz, gidx, fused[bi], out_all, off):
+                    outs.append(None)
+                    off += width
+                    continue
             flat = gidx.reshape(B, S * K)
             g_xyz = torch.gather(xyz, 1, flat[..., None].expand(B, S * K, 3)).view(B, S, K, 3) - new_xyz[:, :, None, :]
             g_feat = torch.gather(feats, 1, flat[..., None].expand(B, S * K, feats.shape[-1])).view(B, S, K, -1)
@@ -90,7 +107,12 @@ class SetAbstractionMSG(nn.Module):
                 for conv, bn in zip(self.conv_blocks[bi], self.bn_blocks[bi]):
                     x = F.relu(bn(conv(x)))
                 x = x.max(dim=2)[0].permute(0, 2, 1)
+            if out_all is not None:
+                out_all[:, :, off:off + x.shape[-1]] = x
+                off += x.shape[-1]
             outs.append(x)
+        if out_all is not None:
+            return new_xyz, out_all, fps_idx
         return new_xyz, torch.cat(outs, dim=-1), fps_idx
 
 

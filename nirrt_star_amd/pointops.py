@@ -39,7 +39,10 @@ def _lib():
         L.nirrt_pn2_three_nn.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         L.nirrt_fps_f64.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
         L.nirrt_fps_f64_batch.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
-        for f in (L.nirrt_pn2_fps, L.nirrt_pn2_ball_query, L.nirrt_pn2_three_nn, L.nirrt_fps_f64, L.nirrt_fps_f64_batch):
+        L.nirrt_pn2_sa_mlp.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp,
+                                       C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]
+        for f in (L.nirrt_pn2_fps, L.nirrt_pn2_ball_query, L.nirrt_pn2_three_nn, L.nirrt_fps_f64, L.nirrt_fps_f64_batch,
+                  L.nirrt_pn2_sa_mlp):
             f.restype = C.c_int
         L._pn2_ready = True
     return L
@@ -92,6 +95,39 @@ def three_nn(xyz1, xyz2):
     _check(_lib().nirrt_pn2_three_nn(xyz1.contiguous().data_ptr(), xyz2.contiguous().data_ptr(), B, N, S, d.data_ptr(),
                                      i.data_ptr(), _stream(xyz1)), "three_nn")
     return d, i
+
+
+def sa_mlp_pack(layers, c_in, device):
+    """folded (W (C_out, C_in), b) triple of one set-abstraction branch -> what the fused kernel takes: W^T contiguous, the
+    first with its input rows zero-padded to a multiple of 4; None when the widths do not fit its 16-column MFMA tiles"""
+    if len(layers) != 3:
+        return None
+    widths = [w.shape[0] for w, _ in layers]
+    if any(c % 16 for c in widths) or widths[2] > 128:
+        return None
+    cin_pad = (c_in + 3) // 4 * 4
+    w1 = torch.zeros(cin_pad, widths[0], dtype=torch.float32, device=device)
+    w1[:c_in] = layers[0][0].t()
+    pack = [w1.contiguous(), layers[0][1].float().contiguous(), layers[1][0].t().float().contiguous(), layers[1][1].float().contiguous(),
+            layers[2][0].t().float().contiguous(), layers[2][1].float().contiguous()]
+    return {"t": pack, "cin_pad": cin_pad, "widths": widths}
+
+
+def sa_mlp(feats, xyz, new_xyz, gidx, pack, out, out_off):
+    """fused gather + 3 x (GEMM + bias + ReLU) + max over the K members of every group on MFMA tiles (k_sa_mlp): writes
+    out[:, :, out_off : out_off + C3]; False when the level's weights do not fit the LDS (caller falls back to library GEMMs)"""
+    B, N, C = feats.shape
+    S, K = gidx.shape[1], gidx.shape[2]
+    t = pack["t"]
+    c1, c2, c3 = pack["widths"]
+    rc = _lib().nirrt_pn2_sa_mlp(feats.contiguous().data_ptr(), xyz.contiguous().data_ptr(), new_xyz.contiguous().data_ptr(),
+                                 gidx.contiguous().data_ptr(), B, N, S, K, C, pack["cin_pad"], t[0].data_ptr(), t[1].data_ptr(), c1,
+                                 t[2].data_ptr(), t[3].data_ptr(), c2, t[4].data_ptr(), t[5].data_ptr(), c3, out.data_ptr(),
+                                 out.shape[2], out_off, _stream(feats))
+    if rc == -3:
+        return False
+    _check(rc, "sa_mlp")
+    return True
 
 
 def farthest_point_down_sample_f64(pts, num_samples, device_id=0):

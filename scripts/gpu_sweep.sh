@@ -10,9 +10,7 @@ run() {  # name, so, env...
   echo "== $name: $(grep -o 'kernel [0-9.]* ms' $OUT/$name.log) | $(grep 'per-tree seconds' $OUT/$name.log)"
 }
 run base libnirrt_hip.so
-run u2 libnirrt_hip_u2.so
-run u8 libnirrt_hip_u8.so
-run g256 libnirrt_hip.so NIRRT_GRID_G=256
-run rb512 libnirrt_hip.so NIRRT_GRID_REBUILD=512
-run g256rb512 libnirrt_hip.so NIRRT_GRID_G=256 NIRRT_GRID_REBUILD=512
-grep "per iteration" $OUT/base.log $OUT/g256.log $OUT/rb512.log
+run w5 libnirrt_hip_w5.so
+run prof libnirrt_hip_prof.so
+tail -1 $OUT/prof.log
+TREES=8192 run base8192 libnirrt_hip.so

@@ -86,7 +86,7 @@ def test_traffic_entry_is_used_only_for_the_exact_configuration(tmp_path, monkey
                                                                                                     "kernel": "slim::k_run_sample<2>"}}}
     f = tmp_path / "t.json"
     f.write_text(json.dumps(tab))
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--trees", "4096", "--traffic-file", str(f)])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--trees", "4096", "--traffic-file", str(f)])   # the entry's configuration
     t, src = b.measured_traffic(b.parse())
     assert t == 5e13 and src["collected"] == "2026-09-28" and "FETCH_SIZE" in src["formula"]
     monkeypatch.setattr(sys, "argv", ["bench.py", "--trees", "2048", "--traffic-file", str(f)])

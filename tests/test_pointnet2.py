@@ -126,3 +126,40 @@ def test_gpu_cloud_downsampling_equals_host_restatement():
     assert np.array_equal(pointcloud.farthest_point_down_sample(pts3, 2048), pts3[ref.farthest_point_down_sample_f64(pts3, 2048)])
     with pytest.raises(ValueError):
         pointcloud.farthest_point_down_sample(pts3[:10], 11)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [0, 1])
+def test_gpu_fused_mfma_set_abstraction_equals_library_gemms(level):
+    """k_sa_mlp (gather + 3 x (GEMM + bias + ReLU) + max over the group on v_mfma_f32_16x16x4_f32 tiles) vs the same branch as
+    torch gather / addmm / max, for both radii of SA1 and SA2 with B = 3 (fp32 both ways: only the summation order differs)"""
+    from nirrt_star_amd import pointops
+    g = load_golden("pointnet2_ref")
+    m = _model(g, "cuda").fold()
+    sa = (m.sa1, m.sa2)[level]
+    assert sa._fused is not None and all(p is not None for p in sa._fused)
+    torch.manual_seed(level)
+    B, N, C = 3, (2048, 1024)[level], (6, 96)[level]
+    xyz = torch.rand(B, N, 3, device="cuda")
+    feats = torch.randn(B, N, C, device="cuda")
+    S = sa.npoint
+    idx = pointops.farthest_point_sample(xyz, S, torch.tensor([0, 5, 9]))
+    new_xyz = torch.gather(xyz, 1, idx[..., None].expand(B, S, 3))
+    width = sum(layers[-1][0].shape[0] for layers in sa._folded)
+    out = torch.zeros(B, S, width, device="cuda")
+    off = 0
+    for bi, (radius, K) in enumerate(zip(sa.radii, sa.nsamples)):
+        gidx = pointops.ball_query(radius * (4 if level else 2), K, xyz, new_xyz)      # wider balls: groups with distinct members
+        assert pointops.sa_mlp(feats, xyz, new_xyz, gidx, sa._fused[bi], out, off)
+        flat = gidx.reshape(B, S * K)
+        g_xyz = torch.gather(xyz, 1, flat[..., None].expand(B, S * K, 3)).view(B, S, K, 3) - new_xyz[:, :, None, :]
+        g_feat = torch.gather(feats, 1, flat[..., None].expand(B, S * K, C)).view(B, S, K, C)
+        x = torch.cat([g_feat, g_xyz], dim=-1).reshape(B * S * K, -1)
+        for w, b in sa._folded[bi]:
+            x = torch.relu(torch.addmm(b, x, w.t()))
+        ref = x.view(B, S, K, -1).max(dim=2)[0]
+        c3 = ref.shape[-1]
+        got = out[:, :, off:off + c3]
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4), (level, bi, float((got - ref).abs().max()))
+        off += c3
+    torch.cuda.synchronize()
