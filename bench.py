@@ -64,6 +64,11 @@ def parse(argv=None):
     ap.add_argument("--cpu-iters", type=int, default=20000, help="iterations each CPU-baseline process runs")
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline processes (0 = min(host cores, 32))")
     ap.add_argument("--no-ttfs", action="store_true")
+    ap.add_argument("--pilot", type=int, default=5000,
+                    help="a step's iterations run as two launches: this many first, then the rest with the trees ordered by the Near-set "
+                         "size the pilot measured (largest first) and the largest on wider workgroups; 0 = one launch")
+    ap.add_argument("--wide-frac", type=float, default=0.01, help="share of the batch (largest Near sets in the pilot) run on 256 lanes")
+    ap.add_argument("--narrow-frac", type=float, default=0.03, help="next share of the batch run on 128 lanes")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "r02_traffic.json"),
                     help="PMC traffic table written by scripts/collect_traffic.py (an entry is used only if its key names this exact configuration)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group / timing protocol only, no GPU work (CPU test of --gpus N)")
@@ -201,15 +206,17 @@ def main():
                          device_id=local_rank)
         t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
         trees.append(t)
-    # Launch order = dispatch order: trees whose straight start-goal segment is collision-free go first.  Their informed set
-    # collapses onto that segment (c_best -> c_min), Near sets grow to thousands of members and they run ~2x longer than the
-    # median tree, so they should not be the ones that start last (longest-processing-time-first, a host-side ordering of
-    # independent problems; the problems themselves and their seeds are untouched).
+    # Scheduling of the independent problems (host side; problems, seeds and results are untouched).  Per-tree run times are
+    # heavy-tailed - a problem whose straight start-goal segment is free ends up with an informed set collapsed onto that segment,
+    # Near sets of thousands of members, and takes 2-3x the median - and a persistent launch lasts as long as its slowest tree.
+    # So a step runs as two launches: a pilot of `--pilot` iterations, then the rest with the trees in order of the Near-set size
+    # the pilot measured (rank correlation with the remaining run time: 0.93; launch order = dispatch order) and the largest 1 % /
+    # next 3 % on 256- / 128-lane workgroups (nirrt_run_args.lanes_hint: concurrent launch groups).  In the pilot, problems
+    # with a free start-goal segment go first.
+    first_order = list(range(B))
     if args.algo == "irrt" and B > 1:
         free_line = [not t.is_collision(pr["x_start"], pr["x_goal"]) for t, pr in zip(trees, probs)]
-        order = sorted(range(B), key=lambda b: (not free_line[b], b))
-        trees = [trees[b] for b in order]
-        probs = [probs[b] for b in order]
+        first_order = sorted(range(B), key=lambda b: (not free_line[b], b))
     # inputs: each problem's generator outputs (np.random.seed(s); random.seed(s)), resident in HBM
     n_np, n_py = word_budgets(args)
     py_stride = max(n_py, 1)
@@ -232,10 +239,42 @@ def main():
     torch.cuda.synchronize()
     del h_np, h_py
 
-    def one_step(want_trace=False):
-        for t in trees:
-            t.reset()
-        return _hip.run_sampling(trees, iters, np_tab, py_tab, flags=flags, want_trace=want_trace, on_device=True)
+    seg_len = [args.pilot, iters - args.pilot] if 0 < args.pilot < iters and B > 1 else [iters]
+    n_seg = len(seg_len)
+
+    def one_step():
+        """one pass of the loop over the whole batch = n_seg launches; returns the sums / last-launch views the report needs"""
+        _hip.reset_batch(trees)
+        used_np = np.zeros(B, dtype=np.int64)
+        used_py = np.zeros(B, dtype=np.int64)
+        order = list(first_order)
+        hint = None
+        tot = {"kernel_ms": 0.0, "stats": np.zeros((B, _hip.N_STATS), dtype=np.int64), "alg_elems": np.zeros(B, dtype=np.int64),
+               "iters_done": np.zeros(B, dtype=np.int64), "seconds": np.zeros(B), "wide": 0, "narrow": 0}
+        for si, n_it in enumerate(seg_len):
+            nt_s = [(np_tab[b][0] + 4 * int(used_np[b]), np_tab[b][1] - int(used_np[b])) for b in order]
+            pt_s = [(py_tab[b][0] + 4 * int(used_py[b]), py_tab[b][1] - int(used_py[b])) for b in order] if py_tab else None
+            r = _hip.run_sampling([trees[b] for b in order], n_it, nt_s, pt_s, flags=flags, on_device=True, lanes_hint=hint)
+            idx = np.asarray(order)
+            used_np[idx] += r["np_used"]
+            used_py[idx] += r["py_used"]
+            secs = (r["stats"][:, 15] - r["stats"][:, 14]) / 1e8
+            tot["kernel_ms"] += r["kernel_ms"]
+            tot["stats"][idx] += r["stats"]
+            tot["alg_elems"][idx] += r["alg_elems"]
+            tot["iters_done"][idx] += r["iters_done"]
+            tot["seconds"][idx] += secs
+            if si + 1 < n_seg and B > 1:
+                rank = np.argsort(-r["stats"][:, 2], kind="stable")      # positions in this launch, largest Near sets first
+                order = [order[j] for j in rank]
+                n_w, n_n = int(B * args.wide_frac), int(B * args.narrow_frac)
+                hint = np.zeros(B, dtype=np.int32)
+                hint[:n_w] = 256
+                hint[n_w:n_w + n_n] = 128
+                tot["wide"], tot["narrow"] = n_w, n_n
+                if not hint.any():
+                    hint = None
+        return tot
 
     for _ in range(args.warmup):
         one_step()
@@ -255,7 +294,7 @@ def main():
     n_sol = [len(trees[b].solutions) for b in range(0, B, max(1, B // 16))]
     short = int((r["iters_done"] < iters).sum())
     st = r["stats"].astype(np.float64)
-    tree_s = (st[:, 15] - st[:, 14]) / 1e8          # per-tree seconds inside the last launch (100 MHz device wall clock)
+    tree_s = r["seconds"]                           # per-tree seconds inside the launches of the last step (100 MHz device wall clock)
     elapsed_max, total_iters = reduce_time_and_work(elapsed, sum(done_iters))
     value = total_iters / elapsed_max
 
@@ -278,12 +317,13 @@ def main():
                        "key": config_key(args), "trees_per_gpu": B, "iters": iters, "dim": D, "step_len": 10,
                        "clearance": probs[0]["clearance"], "mean_final_vertices": float(np.mean(n_final)),
                        "mean_solutions_per_tree": float(np.mean(n_sol)), "trees_stopped_early": short,
+                       "launches_per_step": n_seg, "trees_on_256_lanes": r["wide"], "trees_on_128_lanes": r["narrow"],
                        "per_tree_seconds": {"mean": float(tree_s.mean()), "median": float(np.median(tree_s)), "max": float(tree_s.max())}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "wasted_traffic_ratio": (traffic / useful_b) if traffic else None,
-                         "kernel": "k_run_sample<%d>" % D, "kernel_ms": k_ms,
+                         "kernel": "k_run_sample<%d>" % D, "kernel_ms": k_ms, "kernel_ms_is": "sum of the step's %d launches (pilot + rest)" % n_seg if n_seg > 1 else "the step's launch",
                          "useful_bytes_per_launch": useful_b, "visited_index_bytes_per_launch": float(np.mean(visit_b)),
                          "per_iteration": {"visited_slots": per_it[0], "visit_bytes": per_it[1], "near_members": per_it[2],
                                            "members_spilled": per_it[3], "chain_records": per_it[4], "rewire_candidates": per_it[5],
@@ -323,8 +363,7 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
         trees.append(t)
 
     def one_step():
-        for t in trees:
-            t.reset()
+        _hip.reset_batch(trees)
         streams = [batch.ProblemStreams(1000 + pr["pid"]) for pr in probs]
         return batch.run_batch(trees, streams, iters, _hip.F_IRRT, D, probs, guidance, frames, want_trace=False)
 

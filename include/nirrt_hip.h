@@ -103,6 +103,9 @@ int nirrt_device_count(int *count);
 int nirrt_create(const nirrt_config *cfg, nirrt_tree **out);
 int nirrt_destroy(nirrt_tree *t);
 int nirrt_reset(nirrt_tree *t);
+/* the same for every tree of a batch (same device and dim) in ONE launch, one workgroup per tree: the planner objects of an
+ * evaluation set are single-use in the reference (demo_planning_2d.py:90); a benchmark step re-plans the same problems */
+int nirrt_reset_batch(nirrt_tree *const *trees, int32_t n_trees);
 /* test/bring-up helper: load a frozen tree (vertices (n,dim) f64, parents (n,) i64) */
 int nirrt_upload(nirrt_tree *t, int64_t n, const double *vertices, const int64_t *parents);
 /* `self.vertices[:n]`, `self.vertex_parents[:n]`, `self.num_vertices`; either pointer may be NULL */
@@ -203,6 +206,10 @@ typedef struct nirrt_run_args {
     const int64_t *iters_each; /* optional (n_trees,), sampling mode: tree i runs at most iters_each[i] <= iters iterations
                             (trees of one batch resumed after stopping at different iterations, e.g. NIRRT_E_CLOUD);
                             cost_trace rows stay `iters` long */
+    const int32_t *lanes_hint; /* optional (n_trees,), sampling mode: workgroup size wanted for tree i - 64, 128 or 256 lanes, 0 = the
+                            batch's default.  Trees with different sizes are launched as concurrent groups on their own streams:
+                            a tree known to be heavy (large Near sets) gets more lanes instead of holding up the launch on one
+                            wave.  Results never depend on it. */
 } nirrt_run_args;
 int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *args);
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "nirrt_last_error", "nirrt_device_count", "nirrt_create", "nirrt_destroy", "nirrt_reset", "nirrt_upload",
     "nirrt_download", "nirrt_num_vertices", "nirrt_nearest", "nirrt_collision_batch", "nirrt_points_in_obs",
     "nirrt_near", "nirrt_cost", "nirrt_search_goal_parent", "nirrt_best_solution", "nirrt_solutions",
-    "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed", "nirrt_debug_prof", "nirrt_set_cloud",
+    "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed", "nirrt_debug_prof", "nirrt_set_cloud", "nirrt_reset_batch",
 ]
 
 
@@ -58,7 +58,7 @@ class RunArgs(C.Structure):
                 ("py_used", C.POINTER(C.c_int64)), ("iters_done", C.POINTER(C.c_int64)),
                 ("status", C.POINTER(C.c_int32)), ("kernel_ms", C.POINTER(C.c_double)),
                 ("scan_elems", C.POINTER(C.c_int64)), ("alg_elems", C.POINTER(C.c_int64)),
-                ("stats", C.POINTER(C.c_int64)), ("iters_each", C.POINTER(C.c_int64))]
+                ("stats", C.POINTER(C.c_int64)), ("iters_each", C.POINTER(C.c_int64)), ("lanes_hint", C.POINTER(C.c_int32))]
 
 N_STATS = 20
 STAT_NAMES = ["visited", "visit_bytes", "members", "spilled", "hop_records", "rewire_candidates", "rewired", "recosted",
@@ -97,6 +97,7 @@ def load():
     L.nirrt_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.nirrt_destroy.argtypes = [vp]
     L.nirrt_reset.argtypes = [vp]
+    L.nirrt_reset_batch.argtypes = [C.POINTER(vp), C.c_int32]
     L.nirrt_upload.argtypes = [vp, C.c_int64, dp, ip]
     L.nirrt_download.argtypes = [vp, dp, ip, ip]
     L.nirrt_num_vertices.argtypes = [vp, ip]
@@ -319,6 +320,13 @@ class HipTree:
         return self._res
 
 
+def reset_batch(trees):
+    """all trees back to their single start vertex in one launch (one workgroup per tree)"""
+    nt = len(trees)
+    handles = (C.c_void_p * nt)(*[t.h for t in trees])
+    _check(load().nirrt_reset_batch(handles, nt))
+
+
 def run_replay(trees, samples, flags=0, want_trace=False, device_ptr=None, iters=None):
     """Device-resident loop over many trees with replayed samples (n_trees, iters, dim).
     `samples` is a host array, or pass device_ptr (int address of an (n_trees, iters, dim) f64
@@ -360,7 +368,7 @@ def run_replay(trees, samples, flags=0, want_trace=False, device_ptr=None, iters
             "alg_elems": alg, "stats": stats}
 
 
-def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=False, on_device=False, iters_each=None):
+def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=False, on_device=False, iters_each=None, lanes_hint=None):
     """Device-resident loop with in-kernel sampling.  np_words / py_words: per-tree uint32 arrays of
     raw MT19937 outputs (numpy legacy global stream / python `random`); with on_device=True they are
     per-tree (device_address, n_words) pairs of buffers already resident in HBM (e.g. slices of a
@@ -393,6 +401,11 @@ def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=Fals
         assert len(each) == nt
         keep.append(each)
         a.iters_each = _ip(each)
+    if lanes_hint is not None:     # per-tree workgroup size (0 / 64 / 128 / 256): heavy trees on wider workgroups, launched concurrently
+        hint = np.ascontiguousarray(lanes_hint, dtype=np.int32)
+        assert len(hint) == nt
+        keep.append(hint)
+        a.lanes_hint = hint.ctypes.data_as(C.POINTER(C.c_int32))
     a.samples = None
     a.np_words, a.n_np = table(np_words)
     if py_words is not None:

@@ -25,7 +25,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 # than the LDS chain cache, Near sets larger than the LDS stash) run in the parity suite (tests/test_hip_variants.py loads it
 # through NIRRT_HIP_SO).  Same sources, same flags, different -D limits.
 SO_SMALL = os.path.join(HERE, "libnirrt_hip_small.so")
-SMALL_FLAGS = ["-DCHAIN_MAX=8", "-DNEAR_STASH=8", "-DREWIRE_CAND=2"]
+SMALL_FLAGS = ["-DCHAIN_MAX=8", "-DNEAR_STASH=8"]
 
 
 def needs_build(so=SO):

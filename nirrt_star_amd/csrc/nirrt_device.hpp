@@ -30,7 +30,7 @@
 
 #define MAX_OBS NIRRT_MAX_OBSTACLES
 #ifndef LDS_POOL
-#define LDS_POOL 864     // 8-byte LDS slots shared by the obstacle tables (4 per round + 6 per box obstacle) and the Near stash
+#define LDS_POOL 800     // 8-byte LDS slots shared by the obstacle tables (4 per round + 6 per box obstacle) and the Near stash
 #endif
 #define OB_POOL NIRRT_OBSTACLE_POOL   // slots the obstacle tables may take (the rest, >= 256 entries, is the stash)
 #define SCAN_PAD 256     // extra elements allocated behind every per-vertex array (vector loads may overrun n)
@@ -51,9 +51,6 @@
 #define REBUILD_U 4               // vertices per lane and trip of an index rebuild
 #ifndef LIST_U
 #define LIST_U 8                 // solution / goal-candidate list entries per lane and trip
-#endif
-#ifndef REWIRE_CAND
-#define REWIRE_CAND 64            // rewire candidates held in LDS (more: the stash is searched once per candidate instead)
 #endif
 #define GRID_N 1u                // range serves the Near query
 #define GRID_Q 2u                // range serves the nearest query
@@ -84,7 +81,7 @@
 #define PROF(slot)                                                     \
     do {                                                               \
         long long now_ = wall_clock64();                               \
-        if (threadIdx.x == 0) const_cast<TreeDev &>(t).prof[slot] += now_ - prof_t0; \
+        if (threadIdx.x == 0) s.tree_g->prof[slot] += now_ - prof_t0; \
         prof_t0 = now_;                                                \
     } while (0)
 #else
@@ -135,7 +132,10 @@ struct __attribute__((aligned(32))) VRec {
     double cost;   // exact cost(v) of the CURRENT tree (see walk_chains / wg_recost_subtree)
 };
 
-struct TreeDev {
+// The part of a tree descriptor the loop body touches: copied into LDS when a kernel starts (hot_enter) and written back when
+// it ends (hot_leave), so that a pointer or a counter of the tree costs an LDS read instead of a dependent scalar load from HBM
+// (16 trees per CU x ~700 B of descriptor do not live in the scalar cache).
+struct TreeHot {
     double *c[3];   // SoA coordinates x[cap], y[cap], z[cap] (exact values, insertion order; download + exact fallback scans)
     Aux *aux;       // aux[cap]
     Hop4 *hop;      // hop[cap]: aux of the vertex and of its next three ancestors (kept in step with aux)
@@ -146,7 +146,6 @@ struct TreeDev {
     int n;          // num_vertices
     int dim;
     int status;     // sticky NIRRT_E_* code
-    long long stat[NSTAT];   // counters since creation / reset (ST_*); a launch reports the difference
     // continuation of the LDS Near stash (members beyond NEAR_STASH; the nirrt_near primitive puts all of them here)
     int *nr_idx;
     double *nr_m;
@@ -175,13 +174,10 @@ struct TreeDev {
     double step_len, clearance;
     double lo[3], hi[3];
     int n_round, n_box;
-    double rnd[MAX_OBS][4];  // cx, cy, cz, r
-    double box[MAX_OBS][6];  // x, y, z, w, h, d
     // informed sampling constants (IRRT*.init, irrt_star_2d.py:35-40 / irrt_star_3d.py:32-36)
     double c_min;
     double x_center[3];
     double CL_C[9];          // rotation-to-world matrix C, row-major 3x3
-    long long prof[24];      // NIRRT_PROFILE: wall_clock64 ticks (100 MHz) per phase
     // NIRRT* point-cloud guidance (nirrt_star_png_2d.py:99-130): predicted path points + policy scalars
     const double *pc;        // (pc_n, dim) row-major
     int pc_n;
@@ -208,6 +204,15 @@ struct TreeDev {
     double g_margin[3];      // slack added to every query box
 };
 
+// the whole descriptor in HBM: hot part first, then what only kernel prologues / epilogues and the host touch
+struct TreeDev : TreeHot {
+    long long stat[NSTAT];   // counters since creation / reset (ST_*); a launch reports the difference
+    double rnd[MAX_OBS][4];  // cx, cy, cz, r
+    double box[MAX_OBS][6];  // x, y, z, w, h, d
+    long long prof[24];      // NIRRT_PROFILE: wall_clock64 ticks (100 MHz) per phase
+};
+static_assert(sizeof(TreeHot) % 8 == 0, "hot_enter / hot_leave copy 8-byte words");
+
 // ------------------------------------------------------------------------------------------------
 // LDS working set of one workgroup
 // ------------------------------------------------------------------------------------------------
@@ -224,6 +229,8 @@ struct StreamState {
 // constant offsets (-mllvm -amdgpu-lower-module-lds-strategy=module) instead of looking its offset up per kernel.
 #define LDS_NW_MAX 4    // waves of the widest workgroup (256 threads)
 struct LdsData {
+    TreeHot hot;                  // this workgroup's copy of the descriptor's hot part (see TreeHot)
+    TreeDev *tree_g;              // the descriptor in HBM (counters, profile slots, obstacle tables)
     int n_round, n_box;
     int stash_off, stash_cap;     // first pool slot / number of slots of the Near stash
     // round obstacles (cx, cy, cz, r) first, then boxes (x, y, z, w, h, d), then the Near stash: stash_cap doubles
@@ -250,8 +257,8 @@ struct LdsData {
     unsigned char ob_list[2 * MAX_OBS];
     int rg_beg[GRID_RG_MAX], rg_len[GRID_RG_MAX];
     unsigned char rg_flag[GRID_RG_MAX];
-    int n_cand;                   // rewire: members whose stashed margin reaches cost(new)
-    int cand[REWIRE_CAND];
+    int n_cand;                   // rewire: members whose stashed margin reaches cost(new) (the stash is compacted to them)
+    int cand_listed;              // ... all of them are in the LDS list (else: the spilled part is searched per round)
     long long stat[NSTAT];
 };
 template <int NT>
@@ -613,7 +620,7 @@ __device__ __forceinline__ bool point_in_obs_wave(const Lds<NT> &s, const double
 
 // points_in_range: the range as one rectangle tested with clearance = -clearance (:330-351)
 template <int D>
-__device__ __forceinline__ bool point_in_range(const TreeDev &t, const double *p)
+__device__ __forceinline__ bool point_in_range(const TreeHot &t, const double *p)
 {
     double clr = -t.clearance;
     bool in = true;
@@ -663,12 +670,31 @@ __device__ __forceinline__ void stage_obstacles(Lds<NT> &s, const TreeDev &t)
     __syncthreads();
 }
 
-// add this launch's LDS counters to the descriptor (thread 0, end of a kernel)
-__device__ __forceinline__ void flush_stats(LdsData &s, TreeDev &t)
+// kernel prologue: stage the obstacle tables and the hot part of the descriptor; returns the LDS copy every device function
+// works on from here
+template <int NT>
+__device__ __forceinline__ TreeHot &hot_enter(Lds<NT> &s, TreeDev *tg)
 {
+    const long long *src = reinterpret_cast<const long long *>(static_cast<const TreeHot *>(tg));
+    long long *dst = reinterpret_cast<long long *>(&s.hot);
+    for (int i = threadIdx.x; i < (int)(sizeof(TreeHot) / 8); i += NT) dst[i] = src[i];
+    if (threadIdx.x == 0) s.tree_g = tg;
+    stage_obstacles<NT>(s, *tg);   // ends with a barrier
+    return s.hot;
+}
+
+// kernel epilogue: hot part back to HBM + this launch's LDS counters added to the descriptor's
+template <int NT>
+__device__ __forceinline__ void hot_leave(Lds<NT> &s)
+{
+    __syncthreads();
+    TreeDev *tg = s.tree_g;
+    const long long *src = reinterpret_cast<const long long *>(&s.hot);
+    long long *dst = reinterpret_cast<long long *>(static_cast<TreeHot *>(tg));
+    for (int i = threadIdx.x; i < (int)(sizeof(TreeHot) / 8); i += NT) dst[i] = src[i];
     if (threadIdx.x == 0)
         for (int i = 0; i < NSTAT; i++)
-            if (i != ST_T0 && i != ST_T1) t.stat[i] += s.stat[i];
+            if (i != ST_T0 && i != ST_T1) tg->stat[i] += s.stat[i];
 }
 
 // wave64 reductions without LDS traffic: four DPP steps (quad swaps, half-row and row mirrors) leave every 16-lane row
@@ -794,7 +820,7 @@ __device__ __forceinline__ int block_compact(Lds<NT> &s, bool keep, int &pos)
 // tree primitives (workgroup scope)
 // ------------------------------------------------------------------------------------------------
 template <int D>
-__device__ __forceinline__ void load_vertex(const TreeDev &t, int i, double *v)
+__device__ __forceinline__ void load_vertex(const TreeHot &t, int i, double *v)
 {
 #pragma unroll
     for (int k = 0; k < D; k++) v[k] = t.c[k][i];
@@ -802,7 +828,7 @@ __device__ __forceinline__ void load_vertex(const TreeDev &t, int i, double *v)
 
 // exact (reference-formula) nearest scan over the SoA coordinates; only used when a visit sees a near-tie
 template <int D, int NT>
-__device__ __noinline__ int wg_nearest_exact(Lds<NT> &s, const TreeDev &t, int n, const double *q)
+__device__ __noinline__ int wg_nearest_exact(Lds<NT> &s, const TreeHot &t, int n, const double *q)
 {
     double bd = __builtin_inf();
     int bi = 0x7fffffff;
@@ -863,7 +889,7 @@ __device__ __forceinline__ int wg_nearest_finish(Lds<NT> &s, double m1, int i1, 
 // cells, which extend to infinity.  The order inside a cell is whatever the atomics produce; no result depends on
 // it (minima are reduced as (value, index) pairs, rewire selects by index).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int grid_cell_axis(const TreeDev &t, int k, double x)
+__device__ __forceinline__ int grid_cell_axis(const TreeHot &t, int k, double x)
 {
     const double a = (x - t.lo[k]) * t.g_inv_h[k];
     const int G = t.g_G;
@@ -871,7 +897,7 @@ __device__ __forceinline__ int grid_cell_axis(const TreeDev &t, int k, double x)
 }
 
 template <int D>
-__device__ __forceinline__ void grid_box(const TreeDev &t, const double *p, double rad, int (&c0)[3], int (&c1)[3])
+__device__ __forceinline__ void grid_box(const TreeHot &t, const double *p, double rad, int (&c0)[3], int (&c1)[3])
 {
     c0[2] = 0; c1[2] = 0;
 #pragma unroll
@@ -913,7 +939,7 @@ __device__ __forceinline__ int block_excl_scan(Lds<NT> &s, int v, int &off)
 
 // counting sort of vertices [0, n) by cell into the float64 mirror.
 template <int D, int NT>
-__device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeDev &t, int n)
+__device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeHot &t, int n)
 {
     const int tid = threadIdx.x, nc = t.g_ncell, G = t.g_G;
     for (int c = tid; c < nc; c += NT) t.g_cnt[c] = 0;
@@ -1008,7 +1034,7 @@ struct NearResult {
 //                  stash: entries [0, lds_cap) in LDS, the rest in t.nr_idx / t.nr_m;
 //   q  != nullptr: *ni = argmin_i dist(q, v_i), lowest index on ties (np.argmin).
 template <int D, int NT>
-__device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeDev &t, int n, const double *pn, double r, int new_idx,
+__device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, const double *pn, double r, int new_idx,
                                          const double *q, int *ni, NearResult *nr, int lds_cap)
 {
     const int tid = threadIdx.x, lane = tid & 63, G = t.g_G;
@@ -1267,7 +1293,7 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeDev &t, int n, co
                 if (covered) {
                     result_ni = gi >= 0 ? gi : wg_nearest_exact<D, NT>(s, t, n, q);
                     if (tid == 0) {   // statistics only: no decision depends on it
-                        TreeDev &tw = const_cast<TreeDev &>(t);
+                        TreeHot &tw = const_cast<TreeHot &>(t);
                         tw.g_rho = 0.875 * tw.g_rho + 0.125 * __builtin_sqrt(g1);
                     }
                     break;
@@ -1315,7 +1341,7 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeDev &t, int n, co
 
 // nearest_neighbor: argmin_i dist(q, v_i), lowest index on ties (np.argmin)
 template <int D, int NT>
-__device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, const double *q)
+__device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeHot &t, int n, const double *q)
 {
     int ni = -1;
     wg_query<D, NT>(s, t, n, nullptr, 0., -1, q, &ni, nullptr, 0);
@@ -1327,7 +1353,7 @@ __device__ __forceinline__ int wg_nearest(Lds<NT> &s, const TreeDev &t, int n, c
 // idx[r] <= 0: inactive slot (the root costs 0).  A chain stops early when it reaches `stop_at` (> 0):
 // the caller then continues the very same left-to-right sum with the cached tail of that vertex.
 template <int D>
-__device__ __forceinline__ int walk_chains(const TreeDev &t, int (&idx)[WALK_R], double (&acc)[WALK_R], int stop_at)
+__device__ __forceinline__ int walk_chains(const TreeHot &t, int (&idx)[WALK_R], double (&acc)[WALK_R], int stop_at)
 {
     int guard = t.cap + 1, nrec = 0;
     for (;;) {
@@ -1357,7 +1383,7 @@ __device__ __forceinline__ int walk_chains(const TreeDev &t, int (&idx)[WALK_R],
 
 // single chain
 template <int D>
-__device__ __forceinline__ double walk_cost(const TreeDev &t, int i)
+__device__ __forceinline__ double walk_cost(const TreeHot &t, int i)
 {
     double acc = 0.;
     int guard = t.cap + 1;
@@ -1370,7 +1396,7 @@ __device__ __forceinline__ double walk_cost(const TreeDev &t, int i)
 }
 
 // child-list maintenance (one thread)
-__device__ __forceinline__ void link_child(TreeDev &t, int v, int p)
+__device__ __forceinline__ void link_child(TreeHot &t, int v, int p)
 {
     int f = t.first_child[p];
     t.next_sib[v] = f;
@@ -1378,7 +1404,7 @@ __device__ __forceinline__ void link_child(TreeDev &t, int v, int p)
     if (f >= 0) t.prev_sib[f] = v;
     t.first_child[p] = v;
 }
-__device__ __forceinline__ void unlink_child(TreeDev &t, int v, int p)
+__device__ __forceinline__ void unlink_child(TreeHot &t, int v, int p)
 {
     int nx = t.next_sib[v], pv = t.prev_sib[v];
     if (pv >= 0) t.next_sib[pv] = nx; else t.first_child[p] = nx;
@@ -1392,9 +1418,16 @@ __device__ __forceinline__ void unlink_child(TreeDev &t, int v, int p)
 // there and finished from s.chainE, the edge-length sequence through -> root recorded this iteration
 // - the same additions in the same order as a full walk.  The cost lands in the vertex's record and, for vertices
 // of the cell-ordered part of the index, in the mirror slot the Near visits read.
+// rewire's candidate list lives where the Near stash was: ids in the stash's index area, one state byte per entry in its
+// (dead) margin area: bit 0 = passes the reference's test with its current cost, bit 1 = cost changed since it was tested
+#define CAND_PASS 1u
+#define CAND_DIRTY 2u
+__device__ __forceinline__ unsigned char *cand_state(LdsData &s) { return reinterpret_cast<unsigned char *>(&s.pool[s.stash_off]); }
+
 template <int D, int NT>
-__device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v, int through)
+__device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v, int through, int n_list = 0)
 {
+    // n_list > 0: re-costed vertices that are on rewire's candidate list (first n_list stash ids) are marked for re-testing
     const int tid = threadIdx.x;
     const int ns = uni(t.g_ns);
     __syncthreads();
@@ -1456,6 +1489,11 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v,
                 const unsigned char li = t.listed[who[r]];
                 if (li & 1) t.sol_dirty = 1;
                 if (li & 2) t.gc_dirty = 1;
+                if (n_list > 0) {
+                    const int *ids = stash_ids(s);
+                    for (int a = 0; a < n_list; a++)
+                        if (ids[a] == who[r]) cand_state(s)[a] = CAND_DIRTY;
+                }
             }
         }
     }
@@ -1467,7 +1505,7 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeDev &t, int v,
 
 // record the edge-length sequence new_idx -> root in LDS and return cost(new_idx) (thread 0 walks; uniform result)
 template <int D, int NT>
-__device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeDev &t, int new_idx)
+__device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeHot &t, int new_idx)
 {
     if (threadIdx.x == 0) {
         double acc = 0.;
@@ -1496,7 +1534,7 @@ __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeDev &t, 
 
 // steer (new_state).  2D: rrt_star_2d.py:67-78, device atan2/cos/sin; 3D: rrt_star_3d.py:67-78, IEEE only.
 template <int D>
-__device__ __forceinline__ void steer(const TreeDev &t, const double *from, const double *to, double *out)
+__device__ __forceinline__ void steer(const TreeHot &t, const double *from, const double *to, double *out)
 {
     double d[D];
 #pragma unroll
@@ -1531,7 +1569,7 @@ __device__ __forceinline__ bool wg_collision(const Lds<NT> &s, const double *a, 
 // find_near_neighbors as a primitive (nirrt_near): every member index goes to t.nr_idx[0, k) in visiting order (the host
 // sorts them ascending, which is the reference's np.where order); returns k.
 template <int D, int NT>
-__device__ __forceinline__ int wg_near_list(Lds<NT> &s, TreeDev &t, int n, const double *node_new, int new_idx)
+__device__ __forceinline__ int wg_near_list(Lds<NT> &s, TreeHot &t, int n, const double *node_new, int new_idx)
 {
     NearResult nr;
     wg_query<D, NT>(s, t, n, node_new, t.near_r[n], new_idx, nullptr, nullptr, &nr, 0);
@@ -1542,7 +1580,7 @@ __device__ __forceinline__ int wg_near_list(Lds<NT> &s, TreeDev &t, int n, const
 // The costs come from the exact cache; the argmin is only redone when a listed vertex was re-costed (sol_dirty),
 // a solution appended in between competes with the standing minimum (strict <, so the first minimum stays).
 template <int D, int NT>
-__device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double &c_best, int &x_best, bool want_x = true)
+__device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeHot &t, double &c_best, int &x_best, bool want_x = true)
 {
     const int tid = threadIdx.x;
     const int ns = t.n_sol;
@@ -1578,7 +1616,7 @@ __device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeDev &t, double 
 
 // append a solution (InGoalRegion true).  Uniform; thread 0 writes.
 template <int D, int NT>
-__device__ __forceinline__ void wg_append_solution(Lds<NT> &s, TreeDev &t, int idx, const double *v)
+__device__ __forceinline__ void wg_append_solution(Lds<NT> &s, TreeHot &t, int idx, const double *v)
 {
     if (threadIdx.x == 0) {
         if (t.n_sol < t.cap_sol) {
@@ -1604,7 +1642,7 @@ __device__ __forceinline__ void wg_append_solution(Lds<NT> &s, TreeDev &t, int i
 
 // search_goal_parent (rrt_star_2d.py:101-117) over the maintained candidate list + path length
 template <int D, int NT>
-__device__ __forceinline__ void wg_goal_parent(Lds<NT> &s, TreeDev &t, int &gp, double &path_len)
+__device__ __forceinline__ void wg_goal_parent(Lds<NT> &s, TreeHot &t, int &gp, double &path_len)
 {
     const int tid = threadIdx.x;
     const int ng = t.n_gc;
@@ -1660,7 +1698,7 @@ __device__ __forceinline__ void wg_goal_parent(Lds<NT> &s, TreeDev &t, int &gp, 
 // bookkeeping when a vertex (idx, coordinates v) joined the tree: RRT* goal-candidate list.
 // Block-uniform control flow; `v` identical in all threads; cost[idx] must be final.
 template <int D, int NT>
-__device__ __forceinline__ void wg_goal_candidate(Lds<NT> &s, TreeDev &t, int idx, const double *v)
+__device__ __forceinline__ void wg_goal_candidate(Lds<NT> &s, TreeHot &t, int idx, const double *v)
 {
     double d[D];
 #pragma unroll
@@ -1691,7 +1729,7 @@ __device__ __forceinline__ void wg_goal_candidate(Lds<NT> &s, TreeDev &t, int id
 //   else      : node_in = node_rand
 // ------------------------------------------------------------------------------------------------
 template <int D, int NT>
-__device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const double *node_in, bool host_steer,
+__device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const double *node_in, bool host_steer,
                                              int nearest_in, unsigned flags, nirrt_step_result *res,
                                              int pref_ni = -1, const double *q_next = nullptr)
 {
@@ -1849,28 +1887,43 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 // before the search resumes.
                 const double thr = new_cost - (1e-10 + 1e-12 * new_cost);
                 const int k_lds = k < cap_lds ? k : cap_lds;
-                const int *ids = stash_ids(s);
-                // one pass over the stash (+ its spilled part) collects the members whose margin reaches cost(new): few
+                int *ids = stash_ids(s);
+                unsigned char *state = cand_state(s);
+                const int list_cap = cap_lds;   // the LDS part always fits (it shrinks in place); spilled candidates may not
+                // The stash is compacted IN PLACE to the candidates - the members whose margin reaches cost(new), few unless the
+                // tree is degenerate; candidates from the spilled part are appended while there is room.  (One trip = read a
+                // slice, barrier, write: a write lands at or below the slice just read.)
                 __syncthreads();
-                if (tid == 0) s.n_cand = 0;
+                if (tid == 0) { s.n_cand = 0; s.cand_listed = 1; }
                 __syncthreads();
-                for (int a = tid; a < k_lds; a += NT) {
-                    if (s.pool[s.stash_off + a] >= thr) {
+                for (int base = 0; base < k_lds; base += NT) {
+                    const int a = base + tid;
+                    const bool c = a < k_lds && s.pool[s.stash_off + a] >= thr;
+                    const int id = a < k_lds ? ids[a] : 0;
+                    __syncthreads();
+                    if (c) {
                         const int p = atomicAdd(&s.n_cand, 1);
-                        if (p < REWIRE_CAND) s.cand[p] = ids[a];
+                        if (p < list_cap) ids[p] = id; else s.cand_listed = 0;
                     }
+                    __syncthreads();
                 }
                 for (int a = cap_lds + tid; a < k; a += NT) {   // spilled part (large Near sets only)
                     if (t.nr_m[a - cap_lds] >= thr) {
                         const int p = atomicAdd(&s.n_cand, 1);
-                        if (p < REWIRE_CAND) s.cand[p] = t.nr_idx[a - cap_lds];
+                        if (p < list_cap) ids[p] = t.nr_idx[a - cap_lds]; else s.cand_listed = 0;
                     }
                 }
                 __syncthreads();
                 PROF(8);
                 const int n_cand = uni(s.n_cand);
-                const bool listed_all = n_cand <= REWIRE_CAND;
+                // every candidate on the list: the margins are dead now, their bytes hold the candidates' state.  Not all on the
+                // list (more candidates than the stash has room for): the LDS part cannot be trusted to be complete ->
+                // every round re-tests the spilled stash too (slow, rare).
+                const bool listed_all = uni(s.cand_listed) != 0;
+                const int n_list = n_cand < list_cap ? n_cand : list_cap;
+                for (int a = tid; a < n_list; a += NT) state[a] = CAND_DIRTY;
                 if (tid == 0) s.stat[ST_ROUNDS] += n_cand;
+                __syncthreads();
                 int last = -1;
                 // the re-parenting of one member (thread 0) + re-costing of what hangs below it
                 auto rewire_one = [&](int vj, const double *d) {
@@ -1913,14 +1966,12 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                     n_rewired++;
                     __syncthreads();
                     PROF(9);
-                    if (!s.bc_i[7]) wg_recost_subtree<D, NT>(s, t, vj, new_idx);   // uniform
+                    if (!s.bc_i[7]) wg_recost_subtree<D, NT>(s, t, vj, new_idx, n_list);   // uniform
                     PROF(10);
                 };
-                // every remaining candidate is re-tested in parallel with its CURRENT record; the lowest index that passes is
-                // re-parented, then the rest is looked at again (their costs may have dropped with the subtree just moved).
-                // More candidates than the list holds (all vertices on one line: the straight start-goal segment is free and the
-                // informed set has collapsed onto it - every downstream member ties with cost(new) + d_j up to rounding):
-                // the same, with the stash itself as the candidate list.
+                // Candidates are tested in parallel against their CURRENT records, and tested again only after their cost changed
+                // (a re-costed vertex marks itself on the list): the lowest index that passes is re-parented, its subtree re-costed,
+                // and the next round looks at what is left.  Sequential round trips = vertices actually rewired + 1.
                 auto passes = [&](int id) -> bool {
                     const VRec vr = t.vrec[id];
                     double d[D];
@@ -1930,16 +1981,15 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
                 };
                 while (n_cand > 0) {
                     int first = 0x7fffffff;
-                    if (listed_all) {
-                        for (int a = tid; a < n_cand; a += NT) {
-                            const int id = s.cand[a];
-                            if (id > last && id < first && passes(id)) first = id;
+                    for (int a = tid; a < n_list; a += NT) {
+                        const int id = ids[a];
+                        if (id > last) {
+                            unsigned st = state[a];
+                            if (st & CAND_DIRTY) { st = passes(id) ? CAND_PASS : 0u; state[a] = (unsigned char)st; }
+                            if ((st & CAND_PASS) && id < first) first = id;
                         }
-                    } else {
-                        for (int a = tid; a < k_lds; a += NT) {
-                            const int id = ids[a];
-                            if (id > last && id < first && s.pool[s.stash_off + a] >= thr && passes(id)) first = id;
-                        }
+                    }
+                    if (!listed_all) {   // candidates that found no room on the list: straight from the spilled stash, every round
                         for (int a = cap_lds + tid; a < k; a += NT) {
                             const int id = t.nr_idx[a - cap_lds];
                             if (id > last && id < first && t.nr_m[a - cap_lds] >= thr && passes(id)) first = id;
@@ -1987,7 +2037,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeDev &t, const doubl
 
 // end-of-iteration report shared by the step kernel and the persistent loops
 template <int D, int NT>
-__device__ __forceinline__ void wg_report(Lds<NT> &s, TreeDev &t, unsigned flags, double &cb, int &xb, bool want_x = true)
+__device__ __forceinline__ void wg_report(Lds<NT> &s, TreeHot &t, unsigned flags, double &cb, int &xb, bool want_x = true)
 {
     cb = __builtin_inf();
     xb = -1;

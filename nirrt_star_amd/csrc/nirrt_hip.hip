@@ -107,6 +107,8 @@ namespace slim {
 #define NT_WIDE NIRRT_NT_WIDE
 #define NT_SLIM 64
 static_assert(NT_WIDE / 64 <= LDS_NW_MAX && NT_NARROW / 64 <= LDS_NW_MAX, "LdsData reduction slots: raise LDS_NW_MAX");
+static_assert(offsetof(TreeHot, pc) > offsetof(TreeHot, CL_C) && offsetof(TreeHot, g_x) > offsetof(TreeHot, c_update),
+              "nirrt_set_informed / nirrt_set_cloud patch contiguous field ranges of the descriptor");
 static_assert(sizeof(LdsData) <= 10240, "LdsData must fit 16 times into a CU's 160 KB of LDS (16 one-wave trees per CU)");
 // nirrt_run: batches larger than the 2048 workgroup slots of the 128-thread kernels run one wave per tree (16 trees per
 // CU with 10 KB of LDS): measured on 4096 problems 12.8 vs 10.9 M it/s (IRRT*), 39.0 vs 26.3 M it/s (RRT*); at 2048
@@ -196,6 +198,7 @@ struct nirrt_tree {
     hipStream_t stream;
     TreeDev host;    // host mirror of the descriptor (pointers are device pointers)
     TreeDev *dev;    // descriptor in HBM
+    TreeDev **self_dev;   // one-element device array holding `dev` (kernels take arrays of descriptors)
     double *near_r;  // device table
     Scratch *scratch;      // pinned host memory
     Scratch *scratch_dev;  // device alias of the same memory
@@ -283,29 +286,50 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
         if (b) (void)hipFree(b);
     if (t->pc_dev) (void)hipFree(t->pc_dev);
     if (t->dev) (void)hipFree(t->dev);
+    if (t->self_dev) (void)hipFree(t->self_dev);
     if (t->scratch) (void)hipHostFree(t->scratch);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
     return NIRRT_OK;
 }
 
-extern "C" int nirrt_reset(nirrt_tree *t)
+static void host_mirror_reset(nirrt_tree *t)
 {
-    if (!t) return NIRRT_E_ARG;
-    HIPCHK(hipSetDevice(t->device));
-    for (int k = 0; k < t->dim; k++)
-        HIPCHK(hipMemcpyAsync(t->host.c[k], &t->cfg.x_start[k], sizeof(double), hipMemcpyHostToDevice, t->stream));
-    HIPCHK(hipMemsetAsync(t->host.aux, 0, sizeof(Aux) * (size_t)(t->cap + SCAN_PAD), t->stream));  // parent 0, elen 0, mark 0
     t->host.n = 1;
     t->last_n = 1;
     t->host.n_sol = 0;
     t->host.n_gc = 0;
     t->host.status = 0;
     for (int i = 0; i < NSTAT; i++) t->host.stat[i] = 0;
-    int rc = push_desc(t);
-    if (rc) return rc;
-    DISPATCH_DIM(t, k_init, 1, t->dev);
+}
+
+extern "C" int nirrt_reset(nirrt_tree *t)
+{
+    if (!t) return NIRRT_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    host_mirror_reset(t);
+    DISPATCH_DIM(t, k_init, 1, (TreeDev *const *)t->self_dev, 1);   // back to the single start vertex, on the device
     return sync_check(t);
+}
+
+/* all trees of a batch back to their single start vertex in ONE launch (one workgroup per tree) */
+extern "C" int nirrt_reset_batch(nirrt_tree *const *trees, int32_t n_trees)
+{
+    if (!trees || n_trees <= 0) return NIRRT_E_ARG;
+    nirrt_tree *t0 = trees[0];
+    for (int i = 0; i < n_trees; i++)
+        if (!trees[i] || trees[i]->device != t0->device || trees[i]->dim != t0->dim) { g_err = "nirrt_reset_batch: all trees must share device and dim"; return NIRRT_E_ARG; }
+    HIPCHK(hipSetDevice(t0->device));
+    for (int i = 1; i < n_trees; i++) HIPCHK(hipStreamSynchronize(trees[i]->stream));
+    std::vector<TreeDev *> ptrs((size_t)n_trees);
+    for (int i = 0; i < n_trees; i++) { ptrs[(size_t)i] = trees[i]->dev; host_mirror_reset(trees[i]); }
+    TreeDev **d_ptrs = nullptr;
+    HIPCHK(hipMalloc(&d_ptrs, sizeof(TreeDev *) * (size_t)n_trees));
+    HIPCHK(hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(TreeDev *) * (size_t)n_trees, hipMemcpyHostToDevice, t0->stream));
+    DISPATCH_DIM(t0, k_init, n_trees, (TreeDev *const *)d_ptrs, 1);
+    int rc = sync_check(t0);
+    (void)hipFree(d_ptrs);
+    return rc;
 }
 
 extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
@@ -340,7 +364,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     t->cap = (int)(cfg->iter_max + 1);
     t->device = cfg->device_id;
     t->stream = nullptr;
-    t->dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->pc_dev = nullptr;
+    t->dev = nullptr; t->self_dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->pc_dev = nullptr;
     const int D = t->dim;
     auto fail = [&](int rc) { nirrt_destroy(t); return rc; };
 #define HIPCHK_T(expr)                                                                        \
@@ -404,6 +428,8 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     HIPCHK_T(hipMalloc(&h.g_cnt, sizeof(int) * (size_t)h.g_ncell));
     HIPCHK_T(hipMalloc(&h.g_rank, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&t->dev, sizeof(TreeDev)));
+    HIPCHK_T(hipMalloc(&t->self_dev, sizeof(TreeDev *)));
+    HIPCHK_T(hipMemcpy(t->self_dev, &t->dev, sizeof(TreeDev *), hipMemcpyHostToDevice));
     HIPCHK_T(hipHostMalloc((void **)&t->scratch, sizeof(Scratch), hipHostMallocMapped));
     HIPCHK_T(hipHostGetDevicePointer((void **)&t->scratch_dev, t->scratch, 0));
     // Near radius table with the host libm (the reference's math.sqrt/math.log/float pow):
@@ -440,7 +466,10 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     h.c_min = 0.;
     for (int k = 0; k < 9; k++) h.CL_C[k] = (k % 4 == 0) ? 1. : 0.;
     h.pc = nullptr; h.pc_n = 0; h.pad2 = 0; h.pc_rate = 0.; h.pc_ratio = 0.; h.c_update = std::numeric_limits<double>::infinity();
-    int rc = nirrt_reset(t);
+    for (int k = 0; k < D; k++) HIPCHK_T(hipMemset(h.c[k], 0, sizeof(double)));
+    h.n = 1;
+    int rc = push_desc(t);
+    if (!rc) rc = nirrt_reset(t);
     if (rc) return fail(rc);
     *out = t;
     return NIRRT_OK;
@@ -485,7 +514,7 @@ extern "C" int nirrt_upload(nirrt_tree *t, int64_t n, const double *vertices, co
     t->host.status = 0;
     int rc = push_desc(t);
     if (rc) return rc;
-    DISPATCH_DIM(t, k_init, 1, t->dev);
+    DISPATCH_DIM(t, k_init, 1, (TreeDev *const *)t->self_dev, 0);
     return sync_check(t);
 }
 
@@ -682,7 +711,7 @@ extern "C" int nirrt_set_informed(nirrt_tree *t, double c_min, const double *x_c
     t->host.c_min = c_min;
     for (int k = 0; k < 3; k++) t->host.x_center[k] = k < t->dim ? x_center[k] : 0.;
     for (int k = 0; k < 9; k++) t->host.CL_C[k] = C[k];
-    const size_t off = offsetof(TreeDev, c_min), end = offsetof(TreeDev, prof);   // c_min, x_center, CL_C
+    const size_t off = offsetof(TreeHot, c_min), end = offsetof(TreeHot, pc);   // c_min, x_center, CL_C
     HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, end - off, hipMemcpyHostToDevice, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     return NIRRT_OK;
@@ -704,21 +733,38 @@ extern "C" int nirrt_set_cloud(nirrt_tree *t, int64_t n, const double *pts, doub
     t->host.pc_rate = sample_rate;
     t->host.pc_ratio = update_cost_ratio;
     t->host.c_update = c_update;
-    const size_t off = offsetof(TreeDev, pc), end = offsetof(TreeDev, g_x);   // pc, pc_n, pc_rate, pc_ratio, c_update
+    const size_t off = offsetof(TreeHot, pc), end = offsetof(TreeHot, g_x);   // pc, pc_n, pc_rate, pc_ratio, c_update
     HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, end - off, hipMemcpyHostToDevice, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     return NIRRT_OK;
 }
 
-// per-tree counters of one launch: the descriptor accumulates since reset, a launch reports the difference
-static void report_stats(const nirrt_run_args *a, int i, const TreeDev &after, const long long *before)
+// {n, status, stat[NSTAT]} of every tree of a batch in one array: one small kernel + one copy instead of a descriptor
+// read per tree (8192 trees per launch in the bench)
+#define COLLECT_W (NSTAT + 2)
+__global__ void k_collect(TreeDev *const *trees, int n, long long *out)
 {
-    if (a->scan_elems) a->scan_elems[i] = after.stat[ST_VISITED] - before[ST_VISITED];
-    if (a->alg_elems) a->alg_elems[i] = after.stat[ST_ALG] - before[ST_ALG];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const TreeDev *t = trees[i];
+        long long *o = out + (size_t)i * COLLECT_W;
+        o[0] = t->n;
+        o[1] = t->status;
+        for (int j = 0; j < NSTAT; j++) o[2 + j] = t->stat[j];
+    }
+}
+
+// per-tree counters of one launch: the descriptor accumulates since reset, a launch reports the difference
+// (after / before: rows of k_collect)
+static void report_stats(const nirrt_run_args *a, int i, const long long *after, const long long *before)
+{
+    const long long *sa = after + 2, *sb = before + 2;
+    if (a->scan_elems) a->scan_elems[i] = sa[ST_VISITED] - sb[ST_VISITED];
+    if (a->alg_elems) a->alg_elems[i] = sa[ST_ALG] - sb[ST_ALG];
     if (a->stats) {
-        for (int j = 0; j < NSTAT; j++) a->stats[(size_t)i * NSTAT + j] = after.stat[j] - before[j];
-        a->stats[(size_t)i * NSTAT + ST_T0] = after.stat[ST_T0];
-        a->stats[(size_t)i * NSTAT + ST_T1] = after.stat[ST_T1];
+        for (int j = 0; j < NSTAT; j++) a->stats[(size_t)i * NSTAT + j] = sa[j] - sb[j];
+        a->stats[(size_t)i * NSTAT + ST_T0] = sa[ST_T0];
+        a->stats[(size_t)i * NSTAT + ST_T1] = sa[ST_T1];
     }
 }
 
@@ -749,13 +795,35 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         if (e == hipSuccess) to_free.push_back(*out);
         return e;
     };
-    std::vector<TreeDev *> ptrs((size_t)n_trees);
-    std::vector<long long> stat0((size_t)n_trees * NSTAT, 0);
-    for (int i = 0; i < n_trees; i++) {
-        ptrs[(size_t)i] = trees[i]->dev;
-        HIPCHK_R(hipMemcpy(&stat0[(size_t)i * NSTAT], (char *)trees[i]->dev + offsetof(TreeDev, stat), sizeof(long long) * NSTAT,
-                           hipMemcpyDeviceToHost));
+    // Launch groups.  By default the whole batch runs on one kernel instantiation (run_variant).  With lanes_hint the
+    // caller asks for wider workgroups for some trees (64 / 128 / 256 lanes): the batch is split into up to three groups,
+    // each launched on its own stream at the same time - a tree that is known to be heavy (its Near sets will be large) gets
+    // more lanes instead of holding up the launch on one wave.  perm[j] = index of the tree at launch position j.
+    long long n_hi = 0;
+    for (int i = 0; i < n_trees; i++) n_hi = std::max(n_hi, trees[i]->last_n);
+    const Variant v_all = run_variant(n_trees, a->flags, n_hi, a->iters);
+    std::vector<Variant> want((size_t)n_trees, v_all);
+    if (a->lanes_hint && forced_variant() == V_AUTO) {
+        for (int i = 0; i < n_trees; i++) {
+            const int h = a->lanes_hint[i];
+            if (h == 64) want[(size_t)i] = V_SLIM; else if (h == 128) want[(size_t)i] = V_NARROW; else if (h == 256) want[(size_t)i] = V_WIDE;
+            else if (h != 0) { g_err = "nirrt_run: lanes_hint[i] must be 0, 64, 128 or 256"; return NIRRT_E_ARG; }
+        }
     }
+    std::vector<int> perm;
+    perm.reserve((size_t)n_trees);
+    struct Group { Variant v; int b0, b1; hipStream_t st; hipEvent_t e0, e1; };
+    std::vector<Group> groups;
+    for (Variant v : {V_WIDE, V_NARROW, V_SLIM}) {   // widest first: those are the long-running trees
+        const int b0 = (int)perm.size();
+        for (int i = 0; i < n_trees; i++)
+            if (want[(size_t)i] == v) perm.push_back(i);
+        if ((int)perm.size() > b0) groups.push_back(Group{v, b0, (int)perm.size(), trees[perm[(size_t)b0]]->stream, nullptr, nullptr});
+    }
+    bool identity = true;
+    for (int j = 0; j < n_trees; j++) identity = identity && perm[(size_t)j] == j;
+    std::vector<TreeDev *> ptrs((size_t)n_trees);
+    for (int j = 0; j < n_trees; j++) ptrs[(size_t)j] = trees[perm[(size_t)j]]->dev;
     // word streams -> device (one slab per generator) unless they already live there
     std::vector<const unsigned *> npp((size_t)n_trees), pyp((size_t)n_trees, nullptr);
     std::vector<long long> nnp((size_t)n_trees), npy((size_t)n_trees, 0);
@@ -766,16 +834,17 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         std::vector<const unsigned *> &dst = pass == 0 ? npp : pyp;
         std::vector<long long> &dn = pass == 0 ? nnp : npy;
         size_t total = 0;
-        for (int i = 0; i < n_trees; i++) { dn[(size_t)i] = cnt[i]; total += (size_t)cnt[i]; }
+        for (int j = 0; j < n_trees; j++) { dn[(size_t)j] = cnt[perm[(size_t)j]]; total += (size_t)dn[(size_t)j]; }
         if (a->inputs_on_device) {
-            for (int i = 0; i < n_trees; i++) dst[(size_t)i] = src[i];
+            for (int j = 0; j < n_trees; j++) dst[(size_t)j] = src[perm[(size_t)j]];
         } else {
             unsigned *slab = nullptr;
             HIPCHK_R(dalloc(sizeof(unsigned) * total, (void **)&slab));
             size_t off = 0;
-            for (int i = 0; i < n_trees; i++) {
+            for (int j = 0; j < n_trees; j++) {
+                const int i = perm[(size_t)j];
                 if (cnt[i] > 0) HIPCHK_R(hipMemcpyAsync(slab + off, src[i], sizeof(unsigned) * (size_t)cnt[i], hipMemcpyHostToDevice, st));
-                dst[(size_t)i] = slab + off;
+                dst[(size_t)j] = slab + off;
                 off += (size_t)cnt[i];
             }
         }
@@ -804,53 +873,71 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
     long long *d_each = nullptr;
     if (a->iters_each) {
         std::vector<long long> each(nt);
-        for (int i = 0; i < n_trees; i++) {
-            if (a->iters_each[i] < 0 || a->iters_each[i] > a->iters) { g_err = "nirrt_run: iters_each[i] must be in [0, iters]"; cleanup(); return NIRRT_E_ARG; }
-            each[(size_t)i] = a->iters_each[i];
+        for (int j = 0; j < n_trees; j++) {
+            const long long e = a->iters_each[perm[(size_t)j]];
+            if (e < 0 || e > a->iters) { g_err = "nirrt_run: iters_each[i] must be in [0, iters]"; cleanup(); return NIRRT_E_ARG; }
+            each[(size_t)j] = e;
         }
         HIPCHK_R(dalloc(sizeof(long long) * nt, (void **)&d_each));
-        HIPCHK_R(hipMemcpy(d_each, each.data(), sizeof(long long) * nt, hipMemcpyHostToDevice));
+        HIPCHK_R(hipMemcpyAsync(d_each, each.data(), sizeof(long long) * nt, hipMemcpyHostToDevice, st));
     }
-    RunSampleDev rd;
-    rd.iters_each = d_each;
-    rd.flags = a->flags; rd.pad = 0; rd.iters = a->iters;
-    rd.np_words = d_npp; rd.n_np = d_nnp; rd.py_words = a->py_words ? d_pyp : nullptr; rd.n_py = d_npy;
-    rd.np_used = d_npu; rd.py_used = d_pyu; rd.cost_trace = d_trace; rd.iters_done = d_done; rd.stop_code = d_stop;
-    hipEvent_t e0, e1;
-    HIPCHK_R(hipEventCreate(&e0));
-    HIPCHK_R(hipEventCreate(&e1));
-    HIPCHK_R(hipEventRecord(e0, st));
-    long long n_hi = 0;
-    for (int i = 0; i < n_trees; i++) n_hi = std::max(n_hi, trees[i]->last_n);
-    LAUNCH_V(run_variant(n_trees, a->flags, n_hi, a->iters), D, k_run_sample, n_trees, st, (TreeDev *const *)d_ptrs, rd);
-    HIPCHK_R(hipEventRecord(e1, st));
-    HIPCHK_R(hipGetLastError());
+    long long *d_col = nullptr;   // k_collect rows before / after the launch
+    HIPCHK_R(dalloc(sizeof(long long) * 2 * nt * COLLECT_W, (void **)&d_col));
+    hipLaunchKernelGGL(k_collect, dim3((n_trees + 255) / 256), dim3(256), 0, st, (TreeDev *const *)d_ptrs, n_trees, d_col);
+    HIPCHK_R(hipStreamSynchronize(st));   // inputs in place before any group's stream starts
+    for (Group &g : groups) {
+        RunSampleDev rd;
+        const int o = g.b0;
+        rd.iters_each = d_each ? d_each + o : nullptr;
+        rd.flags = a->flags; rd.pad = 0; rd.iters = a->iters;
+        rd.np_words = d_npp + o; rd.n_np = d_nnp + o; rd.py_words = a->py_words ? d_pyp + o : nullptr; rd.n_py = d_npy + o;
+        rd.np_used = d_npu + o; rd.py_used = d_pyu + o; rd.cost_trace = d_trace ? d_trace + (size_t)o * (size_t)a->iters : nullptr;
+        rd.iters_done = d_done + o; rd.stop_code = d_stop + o;
+        HIPCHK_R(hipEventCreate(&g.e0));
+        HIPCHK_R(hipEventCreate(&g.e1));
+        HIPCHK_R(hipEventRecord(g.e0, g.st));
+        LAUNCH_V(g.v, D, k_run_sample, g.b1 - g.b0, g.st, (TreeDev *const *)(d_ptrs + o), rd);
+        HIPCHK_R(hipEventRecord(g.e1, g.st));
+        HIPCHK_R(hipGetLastError());
+    }
+    float ms_max = 0.f;
+    for (Group &g : groups) {
+        HIPCHK_R(hipStreamSynchronize(g.st));
+        float ms = 0.f;
+        HIPCHK_R(hipEventElapsedTime(&ms, g.e0, g.e1));
+        ms_max = std::max(ms_max, ms);
+        (void)hipEventDestroy(g.e0);
+        (void)hipEventDestroy(g.e1);
+    }
+    if (a->kernel_ms) *a->kernel_ms = ms_max;   // the groups start together: the longest one is the launch's device time
+    hipLaunchKernelGGL(k_collect, dim3((n_trees + 255) / 256), dim3(256), 0, st, (TreeDev *const *)d_ptrs, n_trees, d_col + nt * COLLECT_W);
+    std::vector<long long> col(2 * nt * COLLECT_W);
+    HIPCHK_R(hipMemcpyAsync(col.data(), d_col, sizeof(long long) * col.size(), hipMemcpyDeviceToHost, st));
     HIPCHK_R(hipStreamSynchronize(st));
-    float ms = 0.f;
-    HIPCHK_R(hipEventElapsedTime(&ms, e0, e1));
-    if (a->kernel_ms) *a->kernel_ms = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     std::vector<long long> done(nt), npu(nt), pyu(nt);
     std::vector<int> stop(nt);
     HIPCHK_R(hipMemcpy(done.data(), d_done, sizeof(long long) * nt, hipMemcpyDeviceToHost));
     HIPCHK_R(hipMemcpy(npu.data(), d_npu, sizeof(long long) * nt, hipMemcpyDeviceToHost));
     HIPCHK_R(hipMemcpy(pyu.data(), d_pyu, sizeof(long long) * nt, hipMemcpyDeviceToHost));
     HIPCHK_R(hipMemcpy(stop.data(), d_stop, sizeof(int) * nt, hipMemcpyDeviceToHost));
-    if (a->cost_trace) HIPCHK_R(hipMemcpy(a->cost_trace, d_trace, sizeof(double) * nt * (size_t)a->iters, hipMemcpyDeviceToHost));
+    if (a->cost_trace) {
+        if (identity) HIPCHK_R(hipMemcpy(a->cost_trace, d_trace, sizeof(double) * nt * (size_t)a->iters, hipMemcpyDeviceToHost));
+        else
+            for (int j = 0; j < n_trees; j++)
+                HIPCHK_R(hipMemcpy(a->cost_trace + (size_t)perm[(size_t)j] * (size_t)a->iters, d_trace + (size_t)j * (size_t)a->iters,
+                                   sizeof(double) * (size_t)a->iters, hipMemcpyDeviceToHost));
+    }
     int rc_all = NIRRT_OK;
-    for (int i = 0; i < n_trees; i++) {
-        a->iters_done[i] = done[(size_t)i];
-        a->np_used[i] = npu[(size_t)i];
-        a->py_used[i] = pyu[(size_t)i];
-        if (a->status) a->status[i] = stop[(size_t)i];
-        {
-            TreeDev tmp;
-            HIPCHK_R(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
-            report_stats(a, i, tmp, &stat0[(size_t)i * NSTAT]);
-            trees[i]->last_n = tmp.n;
-        }
-        if (stop[(size_t)i] == NIRRT_E_CAPACITY) rc_all = NIRRT_E_CAPACITY;
+    for (int j = 0; j < n_trees; j++) {
+        const int i = perm[(size_t)j];
+        a->iters_done[i] = done[(size_t)j];
+        a->np_used[i] = npu[(size_t)j];
+        a->py_used[i] = pyu[(size_t)j];
+        if (a->status) a->status[i] = stop[(size_t)j];
+        const long long *before = &col[(size_t)j * COLLECT_W], *after = &col[(nt + (size_t)j) * COLLECT_W];
+        report_stats(a, i, after, before);
+        trees[i]->last_n = after[0];
+        if (stop[(size_t)j] == NIRRT_E_CAPACITY) rc_all = NIRRT_E_CAPACITY;
     }
     cleanup();
     return rc_all;   // NIRRT_E_STREAM is reported per tree in status[] (the caller refills and resumes)
@@ -891,15 +978,14 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
     long long *d_done = nullptr;
     size_t sbytes = sizeof(double) * (size_t)n_trees * (size_t)a->iters * D;
     HIPCHK(hipMalloc(&d_ptrs, sizeof(TreeDev *) * (size_t)n_trees));
-    std::vector<long long> stat0((size_t)n_trees * NSTAT, 0);
-    for (int i = 0; i < n_trees; i++)
-        HIPCHK(hipMemcpy(&stat0[(size_t)i * NSTAT], (char *)trees[i]->dev + offsetof(TreeDev, stat), sizeof(long long) * NSTAT,
-                         hipMemcpyDeviceToHost));
+    long long *d_col = nullptr;
+    HIPCHK(hipMalloc(&d_col, sizeof(long long) * 2 * (size_t)n_trees * COLLECT_W));
     if (a->inputs_on_device) d_samples = const_cast<double *>(a->samples);
     else HIPCHK(hipMalloc(&d_samples, sbytes ? sbytes : 8));
     HIPCHK(hipMalloc(&d_done, sizeof(long long) * (size_t)n_trees));
     if (a->cost_trace) HIPCHK(hipMalloc(&d_trace, sizeof(double) * (size_t)n_trees * (size_t)a->iters));
     HIPCHK(hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(TreeDev *) * (size_t)n_trees, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_collect, dim3((n_trees + 255) / 256), dim3(256), 0, st, (TreeDev *const *)d_ptrs, n_trees, d_col);
     if (!a->inputs_on_device) HIPCHK(hipMemcpyAsync(d_samples, a->samples, sbytes, hipMemcpyHostToDevice, st));
     RunDev rd;
     rd.flags = a->flags; rd.pad = 0; rd.iters = a->iters; rd.samples = d_samples; rd.cost_trace = d_trace; rd.iters_done = d_done;
@@ -918,6 +1004,11 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
     if (a->kernel_ms) *a->kernel_ms = ms;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    hipLaunchKernelGGL(k_collect, dim3((n_trees + 255) / 256), dim3(256), 0, st, (TreeDev *const *)d_ptrs, n_trees, d_col + (size_t)n_trees * COLLECT_W);
+    std::vector<long long> col(2 * (size_t)n_trees * COLLECT_W);
+    HIPCHK(hipMemcpyAsync(col.data(), d_col, sizeof(long long) * col.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(d_col);
     std::vector<long long> done((size_t)n_trees);
     HIPCHK(hipMemcpy(done.data(), d_done, sizeof(long long) * (size_t)n_trees, hipMemcpyDeviceToHost));
     if (a->cost_trace)
@@ -927,12 +1018,11 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
         if (a->iters_done) a->iters_done[i] = done[(size_t)i];
         if (a->np_used) a->np_used[i] = 0;
         if (a->py_used) a->py_used[i] = 0;
-        TreeDev tmp;
-        HIPCHK(hipMemcpy(&tmp, trees[i]->dev, sizeof(TreeDev), hipMemcpyDeviceToHost));
-        if (a->status) a->status[i] = tmp.status;
-        trees[i]->last_n = tmp.n;
-        report_stats(a, i, tmp, &stat0[(size_t)i * NSTAT]);
-        if (tmp.status) rc_all = tmp.status;
+        const long long *before = &col[(size_t)i * COLLECT_W], *after = &col[((size_t)n_trees + (size_t)i) * COLLECT_W];
+        if (a->status) a->status[i] = (int)after[1];
+        trees[i]->last_n = after[0];
+        report_stats(a, i, after, before);
+        if (after[1]) rc_all = (int)after[1];
     }
     (void)hipFree(d_ptrs);
     if (!a->inputs_on_device) (void)hipFree(d_samples);

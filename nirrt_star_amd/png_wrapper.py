@@ -79,6 +79,9 @@ class PNGWrapper:
         checkpoint = torch.load(model_filepath, map_location=torch.device(device), weights_only=False)
         self.model.load_state_dict(checkpoint['model_state_dict'])
         self.model = self.model.eval().fold()
+        # one-cloud forwards are launch-bound (~150 small kernels): replayed from a HIP graph per cloud size
+        self.use_graph = torch.device(device).type == "cuda"
+        self._graphs = {}
         print("PointNet++ wrapper%s is initialized." % ("" if self.dim == 2 else " 3d"))
 
     @staticmethod
@@ -103,10 +106,45 @@ class PNGWrapper:
         the device once, and only the two result rows per cloud come back."""
         x = np.stack([self.network_input(c, s, g) for c, s, g in zip(clouds, start_masks, goal_masks)], axis=0)
         with torch.no_grad():
-            logp, _ = self.model(torch.from_numpy(x).to(self.device), fps_starts=fps_starts)   # (B, N, classes)
+            if x.shape[0] == 1 and getattr(self, "use_graph", False):
+                logp = self._graph_forward(x, fps_starts)
+            else:
+                logp, _ = self.model(torch.from_numpy(x).to(self.device), fps_starts=fps_starts)   # (B, N, classes)
             pred = logp.argmax(dim=2)
             score = torch.softmax(logp, dim=2)[:, :, 1]
             return pred.cpu().numpy(), score.cpu().numpy()
+
+    def _graph_forward(self, x, fps_starts):
+        """B = 1: the forward of a cloud of this size captured once into a HIP graph (static input / start-index buffers) and
+        replayed.  The FPS start indices are drawn here, on the CPU generator and in the order the model itself would draw them
+        (pointnet2_utils.py:77: one torch.randint per set-abstraction level), and copied into the graph's buffers."""
+        n = x.shape[2]
+        if fps_starts is None:
+            fps_starts = [torch.randint(0, m, (1,), dtype=torch.long) for m in (n, 1024, 256, 64)]
+        g = self._graphs.get(n)
+        if g is None:
+            g = {"x": torch.zeros(1, 6, n, device=self.device), "st": [torch.zeros(1, dtype=torch.long, device=self.device) for _ in range(4)]}
+            try:
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self.model(g["x"], fps_starts=g["st"])
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                g["graph"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g["graph"]):
+                    g["out"], _ = self.model(g["x"], fps_starts=g["st"])
+            except Exception as e:   # capture not possible in this environment: plain launches from now on
+                print("PointNet++ wrapper: HIP graph capture failed (%s); using plain launches." % e)
+                self.use_graph = False
+                logp, _ = self.model(torch.from_numpy(x).to(self.device), fps_starts=fps_starts)
+                return logp
+            self._graphs[n] = g
+        g["x"].copy_(torch.from_numpy(x))
+        for dst, src in zip(g["st"], fps_starts):
+            dst.copy_(src)
+        g["graph"].replay()
+        return g["out"]
 
     def classify_path_points(self, pc, start_mask, goal_mask):
         """reference signature (pointnet2_wrapper.py:43-63): one cloud -> (path_pred (N,), path_score (N,))"""

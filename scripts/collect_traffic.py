@@ -40,10 +40,13 @@ def main():
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
                 rows += [r for r in csv.DictReader(fh) if r["Counter_Name"] == counter and "k_run_" in r["Kernel_Name"]]
-        rows.sort(key=lambda r: -float(r["Counter_Value"]))   # the full launch dominates any short side launch
-        raw[counter] = rows[0]
+        rows.sort(key=lambda r: -float(r["Counter_Value"]))
+        # one step = several launches (segments x workgroup-size groups): the step's traffic is the sum over all of them
+        raw[counter] = dict(rows[0], Counter_Value=str(sum(float(r["Counter_Value"]) for r in rows)), dispatches=str(len(rows)))
         with open(os.path.join(prof_dir, "r02_pmc_%s_%s.csv" % (key, counter)), "w") as fh:
-            w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+            keep = ["Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count",
+                    "SGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+            w = csv.DictWriter(fh, fieldnames=keep, extrasaction="ignore")
             w.writeheader()
             w.writerows(rows)
     fetch, write = float(raw["FETCH_SIZE"]["Counter_Value"]), float(raw["WRITE_SIZE"]["Counter_Value"])
@@ -53,8 +56,8 @@ def main():
         with open(path) as fh:
             tab = json.load(fh)
     tab["entries"][key] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "traffic_bytes": (2 * fetch + write) * 1024,
-                           "kernel": raw["FETCH_SIZE"]["Kernel_Name"], "grid": raw["FETCH_SIZE"]["Grid_Size"],
-                           "workgroup": raw["FETCH_SIZE"]["Workgroup_Size"],
+                           "kernel": "k_run_sample<%d> (slim / narrow / wide instantiations)" % args.dim,
+                           "dispatches_summed": int(raw["FETCH_SIZE"]["dispatches"]),
                            "collected": datetime.date.today().isoformat(),
                            "command": "rocprofv3 --pmc <C> --kernel-trace --kernel-include-regex k_run_ -- python bench.py "
                                       "--no-cpu-baseline --no-ttfs --steps 1 --warmup 0 " + " ".join(bench_args)}

@@ -10,7 +10,5 @@ run() {  # name, so, env...
   echo "== $name: $(grep -o 'kernel [0-9.]* ms' $OUT/$name.log) | $(grep 'per-tree seconds' $OUT/$name.log)"
 }
 run base libnirrt_hip.so
-run w5 libnirrt_hip_w5.so
 run prof libnirrt_hip_prof.so
 tail -1 $OUT/prof.log
-TREES=8192 run base8192 libnirrt_hip.so

@@ -8,7 +8,11 @@ from nirrt_star_amd import _hip, sampling
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
-pids = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else list(range(B))
+if len(sys.argv) > 3 and "-" in sys.argv[3]:
+    lo, hi = sys.argv[3].split("-")
+    pids = list(range(int(lo), int(hi) + 1))
+else:
+    pids = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else list(range(B))
 a = SimpleNamespace(algo="irrt", dim=2, world="b30", iters=iters, trees=len(pids))
 n_np, n_py = bench.word_budgets(a)
 trees, npw, pyw, cache = [], [], [], {}

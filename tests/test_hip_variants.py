@@ -144,10 +144,41 @@ def test_more_than_2048_trees_in_one_launch_against_the_oracle(oracle, irrt):
         t.close()
 
 
+def test_lanes_hint_groups_run_concurrently_and_change_nothing():
+    """nirrt_run_args.lanes_hint: trees of one call split into 256- / 128- / 64-lane groups launched side by side; every
+    output lands at its tree's own index and equals the un-hinted run"""
+    from nirrt_star_amd import _hip, sampling, worlds
+    iters, B = 4000, 7
+    outs = []
+    for hint in (None, [0, 256, 128, 64, 0, 256, 128]):
+        trees, npw, pyw = [], [], []
+        for b in range(B):
+            pr = worlds.problem_2d(worlds.random_world_2d(80 + b, "b30"), 0)
+            t = _hip.HipTree(2, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], 3.0, pr["env"])
+            t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
+            trees.append(t)
+            rs = np.random.RandomState(900 + b)
+            npw.append(rs.randint(0, 1 << 32, size=iters * 8 + 4096, dtype=np.uint32))
+            pyw.append(rs.randint(0, 1 << 32, size=iters * 16 + 4096, dtype=np.uint32))
+        each = [iters, iters - 7, iters, 1234, iters, iters, 77]
+        r = _hip.run_sampling(trees, iters, npw, pyw, flags=_hip.F_IRRT, want_trace=True, iters_each=each, lanes_hint=hint)
+        assert list(r["iters_done"]) == each and not r["status"].any()
+        outs.append((r, [t.download() for t in trees], [list(t.solutions) for t in trees]))
+        for t in trees:
+            t.close()
+    (ra, da, sa), (rb, db, sb) = outs
+    assert np.array_equal(ra["np_used"], rb["np_used"]) and np.array_equal(ra["py_used"], rb["py_used"])
+    for b in range(B):
+        assert np.array_equal(da[b][1], db[b][1]) and np.array_equal(da[b][0], db[b][0]) and sa[b] == sb[b]
+        n_it = int(ra["iters_done"][b])
+        assert np.array_equal(ra["cost_trace"][b, :n_it], rb["cost_trace"][b, :n_it])
+    assert np.array_equal(ra["stats"][:, 13], rb["stats"][:, 13])
+
+
 def test_suite_against_the_small_limits_build():
-    """libnirrt_hip_small.so = same sources with -DCHAIN_MAX=8 -DNEAR_STASH=8 -DREWIRE_CAND=2: parent chains longer than 8
-    edges take the global-walk branches of wg_recost_subtree / the rewire leaf path, all but 8 members of a Near set live
-    in the HBM continuation of the stash, and more than 2 rewire candidates take the search-per-candidate path.
+    """libnirrt_hip_small.so = same sources with -DCHAIN_MAX=8 -DNEAR_STASH=8: parent chains longer than 8 edges take the
+    global-walk branches of wg_recost_subtree / the rewire leaf path, all but 8 members of a Near set live in the HBM
+    continuation of the stash, and rewire candidates beyond the 8 list slots are searched there every round.
     The fixture and oracle comparisons must not notice.  Run in a child interpreter because the library path is read
     once per process."""
     from nirrt_star_amd import build
