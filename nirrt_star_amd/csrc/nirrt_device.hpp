@@ -36,7 +36,7 @@
 #define SCAN_PAD 256     // extra elements allocated behind every per-vertex array (vector loads may overrun n)
 #define WALK_R 4         // parent chains chased concurrently per lane
 #ifndef CHAIN_MAX
-#define CHAIN_MAX 96     // LDS slots for the new->root edge-length sequence (deeper chains fall back to global walks)
+#define CHAIN_MAX 96     // LDS slots for the new->root edge-length sequence (deeper chains continue in HBM, t.chain_g)
 #endif
 #define GRID_MIN_VERTICES 2048   // smaller trees are visited whole (everything is "tail")
 #define GRID_REBUILD_EVERY 1024  // vertices appended behind the cell-ordered part before it is rebuilt
@@ -142,6 +142,7 @@ struct TreeHot {
     VRec *vrec;     // vrec[cap]: coordinates + exact cost, insertion order (random access AND the tail of the index)
     int *first_child, *next_sib, *prev_sib;   // child lists (-1 = none); the root is nobody's child
     int *bfs_q;     // scratch queue for subtree traversals
+    double *chain_g;   // edge lengths of the chain new -> root beyond the first CHAIN_MAX (which live in LDS)
     int cap;
     int n;          // num_vertices
     int dim;
@@ -245,7 +246,7 @@ struct LdsData {
     int bc_i[8];
     // edge lengths along the chain new -> root of the current iteration (every vertex re-costed in this
     // iteration hangs below `new`, so its walk ends with exactly this sequence)
-    int chain_len;          // entries valid in chainE, or -1 if the chain is longer than CHAIN_MAX
+    int chain_len;          // edges on the chain new -> root: the first CHAIN_MAX lengths in chainE, the rest in t.chain_g
     double chainE[CHAIN_MAX];
     // grid queries: slot ranges of the cell-ordered mirror to visit (rows of cells)
     int rg_n, hit_cnt;
@@ -1418,6 +1419,15 @@ __device__ __forceinline__ void unlink_child(TreeHot &t, int v, int p)
 // there and finished from s.chainE, the edge-length sequence through -> root recorded this iteration
 // - the same additions in the same order as a full walk.  The cost lands in the vertex's record and, for vertices
 // of the cell-ordered part of the index, in the mirror slot the Near visits read.
+// finish a cost walk that has reached `new`: add the recorded edge lengths new -> root, in that order (LDS part, then HBM part)
+__device__ __forceinline__ double chain_finish(const LdsData &s, const TreeHot &t, double acc, int clen)
+{
+    const int n_lds = clen < CHAIN_MAX ? clen : CHAIN_MAX;
+    for (int i = 0; i < n_lds; i++) acc += s.chainE[i];
+    for (int i = CHAIN_MAX; i < clen; i++) acc += t.chain_g[i];
+    return acc;
+}
+
 // rewire's candidate list lives where the Near stash was: ids in the stash's index area, one state byte per entry in its
 // (dead) margin area: bit 0 = passes the reference's test with its current cost, bit 1 = cost changed since it was tested
 #define CAND_PASS 1u
@@ -1472,14 +1482,10 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v,
 #pragma unroll
         for (int r = 0; r < WALK_R; r++) slot[r] = (who[r] >= 0 && who[r] < ns) ? t.pos[who[r]] : -1;
         const int clen = s.chain_len;
-        const int stop_at = clen >= 0 ? through : -1;
-        nrec += walk_chains<D>(t, idx, acc, stop_at);
-        if (clen >= 0) {
+        nrec += walk_chains<D>(t, idx, acc, through);
 #pragma unroll
-            for (int r = 0; r < WALK_R; r++) {
-                if (who[r] >= 0 && idx[r] == through)
-                    for (int i = 0; i < clen; i++) acc[r] += s.chainE[i];
-            }
+        for (int r = 0; r < WALK_R; r++) {
+            if (who[r] >= 0 && idx[r] == through) acc[r] = chain_finish(s, t, acc[r], clen);
         }
 #pragma unroll
         for (int r = 0; r < WALK_R; r++) {
@@ -1503,7 +1509,7 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v,
     __syncthreads();
 }
 
-// record the edge-length sequence new_idx -> root in LDS and return cost(new_idx) (thread 0 walks; uniform result)
+// record the edge-length sequence new_idx -> root (LDS + HBM continuation) and return cost(new_idx) (thread 0 walks; uniform result)
 template <int D, int NT>
 __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeHot &t, int new_idx)
 {
@@ -1517,13 +1523,13 @@ __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeHot &t, 
             for (int j = 0; j < 4; j++) {
                 if (i > 0) {
                     acc += h.e[j];
-                    if (len < CHAIN_MAX) s.chainE[len] = h.e[j];
+                    if (len < CHAIN_MAX) s.chainE[len] = h.e[j]; else t.chain_g[len] = h.e[j];
                     len++;
                     i = h.a[j];
                 }
             }
         }
-        s.chain_len = len <= CHAIN_MAX ? len : -1;
+        s.chain_len = len;
         s.bc_d[6] = acc;
         s.stat[ST_HOPREC] += nrec;
     }
@@ -1950,10 +1956,10 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                         // recorded chain new -> root, the same additions in the same order as a walk
                         const int clen = s.chain_len;
                         int fast = 0;
-                        if (leaf && clen >= 0) {
+                        if (leaf) {
                             double acc = 0.;
                             acc += el;
-                            for (int i = 0; i < clen; i++) acc += s.chainE[i];
+                            acc = chain_finish(s, t, acc, clen);
                             t.vrec[vj].cost = acc;
                             if (slot >= 0) t.g_cost[slot] = acc;
                             if (li & 1) t.sol_dirty = 1;

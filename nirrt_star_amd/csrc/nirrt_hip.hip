@@ -279,7 +279,7 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     TreeDev &h = t->host;
-    void *bufs[] = {h.c[0], h.c[1], h.c[2], h.aux, h.vrec, h.first_child, h.next_sib, h.prev_sib, h.bfs_q,
+    void *bufs[] = {h.c[0], h.c[1], h.c[2], h.aux, h.vrec, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.chain_g,
                     h.nr_idx, h.nr_m, h.sol, h.sol_line, h.gc_idx, h.gc_dist, h.gc_col,
                     h.g_x[0], h.g_x[1], h.g_x[2], h.g_cost, h.g_idx, h.pos, h.g_start, h.g_cnt, h.g_rank, h.hop, h.listed, t->near_r};
     for (void *b : bufs)
@@ -391,6 +391,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     HIPCHK_T(hipMalloc(&h.next_sib, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.prev_sib, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.bfs_q, sizeof(int) * np));
+    HIPCHK_T(hipMalloc(&h.chain_g, sizeof(double) * np));
     HIPCHK_T(hipMalloc(&h.nr_idx, sizeof(int) * np));
     HIPCHK_T(hipMalloc(&h.nr_m, sizeof(double) * np));
     h.cap = t->cap;
