@@ -17,8 +17,11 @@ DEPS = SOURCES + [os.path.join(CSRC, "nirrt_device.hpp"), os.path.join(CSRC, "ni
                   os.path.join(os.path.dirname(HERE), "include", "nirrt_hip.h")]
 # one module-wide LDS object at the same address in every kernel: the non-inlined loop-body functions then address it
 # with constant offsets instead of a per-kernel offset-table lookup (see LdsData in csrc/nirrt_device.hpp)
+# -fno-optimize-sibling-calls: keeps LLVM from marking the calls of the loop-body functions `tail`; only then does its
+# inter-procedural register allocation drop the callee-saved saves of those local functions (48 VGPRs = 12.8 KB of
+# scratch written and read back per wave and iteration otherwise - a quarter of the kernel's measured HBM writes).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-mllvm", "-amdgpu-lower-module-lds-strategy=module"]
+         "-fno-optimize-sibling-calls", "-mllvm", "-amdgpu-lower-module-lds-strategy=module"]
 
 
 # Test-only second build with tiny compile-time limits, so that the overflow paths of the loop body (parent chains longer

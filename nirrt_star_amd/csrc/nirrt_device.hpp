@@ -249,7 +249,7 @@ struct LdsData {
     int chain_len;          // edges on the chain new -> root: the first CHAIN_MAX lengths in chainE, the rest in t.chain_g
     double chainE[CHAIN_MAX];
     // grid queries: slot ranges of the cell-ordered mirror to visit (rows of cells)
-    int rg_n, hit_cnt;
+    int rg_n, hit_cnt, mem_cnt;   // query: ranges listed, members stashed, members seen
     // constants of the samplers (copied from the descriptor once per kernel)
     double k_lo[3], k_hi[3], k_clr, k_cmin, k_xc[3], k_CLC[9];
     Hop4 hop_new;                 // copy of hop[new_idx] of the current iteration (thread 0 reads it when re-parenting)
@@ -1027,6 +1027,7 @@ struct NearResult {
     int k;          // members: collision-free vertices within r of node_new other than new_idx
     double cand;    // min over members of cost(j) + dist(j, new)   (inf if none)
     int cj;         // its vertex index, lowest index on ties (np.argmin over the ascending neighbour list)
+    int n_stash;    // members on the stash (<= k): those whose margin cost - dist exceeds the caller's floor
 };
 
 // ONE fused query (find_near_neighbors rrt_star_2d.py:125-144 + choose_parent's argmin :80-90 + the nearest_neighbor
@@ -1036,7 +1037,8 @@ struct NearResult {
 //   q  != nullptr: *ni = argmin_i dist(q, v_i), lowest index on ties (np.argmin).
 template <int D, int NT>
 __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, const double *pn, double r, int new_idx,
-                                         const double *q, int *ni, NearResult *nr, int lds_cap)
+                                         const double *q, int *ni, NearResult *nr, int lds_cap,
+                                         double floor_m = -__builtin_inf())
 {
     const int tid = threadIdx.x, lane = tid & 63, G = t.g_G;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1048,7 +1050,7 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, co
     int revisits = 0, brutes = 0;
     PROF_DECL
     __syncthreads();
-    if (tid == 0) { s.ob_n = 0; s.hit_cnt = 0; }
+    if (tid == 0) { s.ob_n = 0; s.hit_cnt = 0; s.mem_cnt = 0; }
     __syncthreads();
     // obstacles whose inflated box meets the box of the Near ball: a segment new -> v_j (|v_j - new| <= r per axis)
     // can only pass the AABB prefilter of those.  Same comparisons as seg_aabb_pass, on a superset of every segment's box.
@@ -1168,13 +1170,18 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, co
         return member;
     };
     // members of one trip slot -> stash positions (wave ballot + one LDS atomic per wave); every lane of the wave is here
+    // Only members whose margin exceeds floor_m are kept: the caller passes a lower bound of cost(new), below which
+    // rewire's test cannot pass (wg_iteration); the others are merely counted.
+    int n_mem = 0;   // members seen by this wave
     auto stash = [&](bool member, int id, double sm) {
-        const unsigned long long mk = __ballot(member);
+        n_mem += __popcll(__ballot(member));
+        const bool keep = member && sm > floor_m;
+        const unsigned long long mk = __ballot(keep);
         if (mk) {
             int base = 0;
             if (lane == 0) base = atomicAdd(&s.hit_cnt, __popcll(mk));
             base = __builtin_amdgcn_readfirstlane(base);
-            if (member) {
+            if (keep) {
                 const int p = base + __popcll(mk & lt);
                 if (p < lds_cap) stash_put(s, p, id, sm);
                 else { t.nr_idx[p - lds_cap] = id; t.nr_m[p - lds_cap] = sm; }
@@ -1323,17 +1330,19 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, co
     }
     PROF(14);
     if (wantN) {
-        block_argmin<NT>(s, cand, cj);   // lexicographic (value, index): np.argmin's first minimum of the ascending list
+        if (lane == 0 && n_mem) atomicAdd(&s.mem_cnt, n_mem);
+        block_argmin<NT>(s, cand, cj);   // lexicographic (value, index): np.argmin's first minimum of the ascending list (barriers inside)
         nr->cand = uni(cand);
         nr->cj = uni(cj);
-        nr->k = uni(s.hit_cnt);
+        nr->k = uni(s.mem_cnt);
+        nr->n_stash = uni(s.hit_cnt);
     }
     if (tid == 0) {
         s.stat[ST_VISITED] += visited; s.stat[ST_VISIT_B] += vbytes; s.stat[ST_REVISITS] += revisits; s.stat[ST_BRUTE] += brutes;
         if (wantN) {
-            const int k = s.hit_cnt;
-            s.stat[ST_MEMBERS] += k;
-            if (k > lds_cap) s.stat[ST_SPILLED] += k - lds_cap;
+            const int ks = s.hit_cnt;
+            s.stat[ST_MEMBERS] += s.mem_cnt;
+            if (ks > lds_cap) s.stat[ST_SPILLED] += ks - lds_cap;
         }
     }
     __syncthreads();
@@ -1829,8 +1838,19 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
             NearResult nr;
             const int cap_lds = uni(s.stash_cap);
             // (measured: reaching the query through a noinline call instead costs 25 % - the values alive around it get spilled)
-            wg_query<D, NT>(s, t, n, node_new, inserted ? r_grown : r_same, new_idx, q_next, &next_ni, &nr, cap_lds);
-            const int k = nr.k;
+            // Rewire can only re-parent a member j with cost(j) - d_j > cost(new) (rrt_star_2d.py:95), and cost(new) - a sum of
+            // edge lengths along a polyline root -> new, each within an ulp - is at least the straight distance root -> new
+            // up to 1e-13 relative.  Members whose margin stays below that floor are counted but not kept: in a converged
+            // tree (costs close to straight-line distances: exactly the problems with thousands of Near members) that is
+            // nearly all of them, and the stash stays inside LDS.
+            double d_root[D];
+#pragma unroll
+            for (int kk = 0; kk < D; kk++) d_root[kk] = node_new[kk] - t.start[kk];
+            const double lb_new = __builtin_sqrt(dist2<D>(d_root));
+            const double floor_m = lb_new - (1e-9 + 1e-11 * lb_new);
+            wg_query<D, NT>(s, t, n, node_new, inserted ? r_grown : r_same, new_idx, q_next, &next_ni, &nr, cap_lds, floor_m);
+            const int k = nr.k;            // Near members
+            const int ks = nr.n_stash;     // ... of which on the stash
             alg += n;
             PROF(2);
             int reparented = 0, n_rewired = 0;
@@ -1884,7 +1904,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                 }
             }
             PROF(4);
-            if (k > 0) {
+            if (ks > 0) {
                 // rewire (rrt_star_2d.py:92-99), sequential semantics: members in ascending index order, each tested with
                 // its CURRENT cost.  Costs only ever drop during a rewire pass, so a member can only pass
                 // `cost(j) > cost(new) + d_j` if its stashed margin cost(j) - d_j (visit time, rounding ~1e-13) reaches
@@ -1892,7 +1912,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                 // record is read afresh and the reference's test decides; a re-parented vertex's subtree is re-costed
                 // before the search resumes.
                 const double thr = new_cost - (1e-10 + 1e-12 * new_cost);
-                const int k_lds = k < cap_lds ? k : cap_lds;
+                const int k_lds = ks < cap_lds ? ks : cap_lds;
                 int *ids = stash_ids(s);
                 unsigned char *state = cand_state(s);
                 const int list_cap = cap_lds;   // the LDS part always fits (it shrinks in place); spilled candidates may not
@@ -1913,7 +1933,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                     }
                     __syncthreads();
                 }
-                for (int a = cap_lds + tid; a < k; a += NT) {   // spilled part (large Near sets only)
+                for (int a = cap_lds + tid; a < ks; a += NT) {   // spilled part (large Near sets only)
                     if (t.nr_m[a - cap_lds] >= thr) {
                         const int p = atomicAdd(&s.n_cand, 1);
                         if (p < list_cap) ids[p] = t.nr_idx[a - cap_lds]; else s.cand_listed = 0;
@@ -1996,7 +2016,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                         }
                     }
                     if (!listed_all) {   // candidates that found no room on the list: straight from the spilled stash, every round
-                        for (int a = cap_lds + tid; a < k; a += NT) {
+                        for (int a = cap_lds + tid; a < ks; a += NT) {
                             const int id = t.nr_idx[a - cap_lds];
                             if (id > last && id < first && t.nr_m[a - cap_lds] >= thr && passes(id)) first = id;
                         }

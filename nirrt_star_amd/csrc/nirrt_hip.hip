@@ -82,6 +82,12 @@ __shared__ LdsData g_lds;   // see LdsData in nirrt_device.hpp
 #ifndef NIRRT_WAVES_PER_EU
 #define NIRRT_WAVES_PER_EU 4   // second __launch_bounds__ argument of the persistent kernels (register budget 512 / this)
 #endif
+#ifndef NIRRT_BODY_ATTR
+#define NIRRT_BODY_ATTR __noinline__   // loop body of the persistent kernels: a real call (see iteration_call)
+#endif
+#ifndef NIRRT_DRAW_ATTR
+#define NIRRT_DRAW_ATTR __noinline__
+#endif
 #ifndef NIRRT_NT_NARROW
 #define NIRRT_NT_NARROW 128
 #endif
@@ -199,7 +205,8 @@ struct nirrt_tree {
     TreeDev host;    // host mirror of the descriptor (pointers are device pointers)
     TreeDev *dev;    // descriptor in HBM
     TreeDev **self_dev;   // one-element device array holding `dev` (kernels take arrays of descriptors)
-    double *near_r;  // device table
+    void *arena;     // ONE device allocation holding every per-tree array, the descriptor and the Near-radius table
+    double *near_r;  // device table (inside the arena)
     Scratch *scratch;      // pinned host memory
     Scratch *scratch_dev;  // device alias of the same memory
     double *pc_dev;        // guidance cloud (nirrt_set_cloud)
@@ -278,15 +285,8 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     if (!t) return NIRRT_OK;
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
-    TreeDev &h = t->host;
-    void *bufs[] = {h.c[0], h.c[1], h.c[2], h.aux, h.vrec, h.first_child, h.next_sib, h.prev_sib, h.bfs_q, h.chain_g,
-                    h.nr_idx, h.nr_m, h.sol, h.sol_line, h.gc_idx, h.gc_dist, h.gc_col,
-                    h.g_x[0], h.g_x[1], h.g_x[2], h.g_cost, h.g_idx, h.pos, h.g_start, h.g_cnt, h.g_rank, h.hop, h.listed, t->near_r};
-    for (void *b : bufs)
-        if (b) (void)hipFree(b);
+    if (t->arena) (void)hipFree(t->arena);
     if (t->pc_dev) (void)hipFree(t->pc_dev);
-    if (t->dev) (void)hipFree(t->dev);
-    if (t->self_dev) (void)hipFree(t->self_dev);
     if (t->scratch) (void)hipHostFree(t->scratch);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
@@ -364,7 +364,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     t->cap = (int)(cfg->iter_max + 1);
     t->device = cfg->device_id;
     t->stream = nullptr;
-    t->dev = nullptr; t->self_dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->pc_dev = nullptr;
+    t->arena = nullptr; t->dev = nullptr; t->self_dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->pc_dev = nullptr;
     const int D = t->dim;
     auto fail = [&](int rc) { nirrt_destroy(t); return rc; };
 #define HIPCHK_T(expr)                                                                        \
@@ -379,36 +379,48 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     HIPCHK_T(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     TreeDev &h = t->host;
     const size_t np = (size_t)t->cap + SCAN_PAD;   // padded element count of every per-vertex array
-    for (int k = 0; k < D; k++) {
-        HIPCHK_T(hipMalloc(&h.c[k], sizeof(double) * np));
-        HIPCHK_T(hipMemset(h.c[k], 0, sizeof(double) * np));
-    }
-    HIPCHK_T(hipMalloc(&h.aux, sizeof(Aux) * np));
-    HIPCHK_T(hipMalloc(&h.hop, sizeof(Hop4) * np));
-    HIPCHK_T(hipMemset(h.hop, 0, sizeof(Hop4) * np));
-    HIPCHK_T(hipMalloc(&h.vrec, sizeof(VRec) * np));
-    HIPCHK_T(hipMalloc(&h.first_child, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.next_sib, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.prev_sib, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.bfs_q, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.chain_g, sizeof(double) * np));
-    HIPCHK_T(hipMalloc(&h.nr_idx, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.nr_m, sizeof(double) * np));
-    h.cap = t->cap;
-    h.dim = D;
-    h.cap_sol = t->cap;
-    HIPCHK_T(hipMalloc(&h.sol, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.sol_line, sizeof(double) * np));
-    HIPCHK_T(hipMalloc(&h.gc_idx, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.gc_dist, sizeof(double) * np));
-    HIPCHK_T(hipMalloc(&h.gc_col, np));
-    HIPCHK_T(hipMalloc(&h.listed, np));
-    HIPCHK_T(hipMalloc(&t->near_r, sizeof(double) * (size_t)(t->cap + 1)));
     // uniform-grid index: 256^2 / 16^3 cells over the range box (2D, measured at the bench configuration: 256^2 visits
     // 12 % fewer slots than 128^2 and is 5 % faster)
     h.g_G = D == 2 ? 256 : 16;
     if (const char *e = std::getenv("NIRRT_GRID_G")) h.g_G = std::min(D == 2 ? 256 : 40, std::max(1, std::atoi(e)));
     h.g_ncell = D == 2 ? h.g_G * h.g_G : h.g_G * h.g_G * h.g_G;
+    // One allocation per tree (~12 MB at 50k vertices in 2D), carved into its arrays: a workgroup's scattered accesses then
+    // fall into half a dozen 2 MB pages instead of ~35 separately placed buffers of 50 - 2400 KB (address translation, not
+    // HBM, is what a latency-bound chase across 8192 such trees pays for).  Arrays the loop body touches every iteration
+    // come first, next to each other.
+    {
+        struct Piece { void **dst; size_t bytes; };
+        std::vector<Piece> pieces;
+        auto want = [&](auto **dst, size_t count) { pieces.push_back({(void **)dst, sizeof(**dst) * count}); };
+        want(&t->dev, 1);
+        want(&t->self_dev, 1);
+        want(&t->near_r, (size_t)t->cap + 1);
+        want(&h.vrec, np);
+        want(&h.hop, np);
+        want(&h.aux, np);
+        want(&h.first_child, np); want(&h.next_sib, np); want(&h.prev_sib, np);
+        for (int k = 0; k < D; k++) want(&h.g_x[k], np);
+        want(&h.g_cost, np); want(&h.g_idx, np); want(&h.pos, np);
+        want(&h.g_start, (size_t)h.g_ncell + 1);
+        want(&h.listed, np);
+        want(&h.sol, np); want(&h.sol_line, np);
+        want(&h.gc_idx, np); want(&h.gc_dist, np); want(&h.gc_col, np);
+        want(&h.nr_idx, np); want(&h.nr_m, np);
+        want(&h.bfs_q, np); want(&h.chain_g, np);
+        want(&h.g_cnt, (size_t)h.g_ncell); want(&h.g_rank, np);
+        for (int k = 0; k < D; k++) want(&h.c[k], np);
+        const size_t A = 256;
+        size_t total = 0;
+        for (const Piece &pc : pieces) total += (pc.bytes + A - 1) / A * A;
+        HIPCHK_T(hipMalloc(&t->arena, total));
+        size_t off = 0;
+        for (const Piece &pc : pieces) { *pc.dst = (char *)t->arena + off; off += (pc.bytes + A - 1) / A * A; }
+    }
+    for (int k = 0; k < D; k++) HIPCHK_T(hipMemset(h.c[k], 0, sizeof(double) * np));
+    HIPCHK_T(hipMemset(h.hop, 0, sizeof(Hop4) * np));
+    h.cap = t->cap;
+    h.dim = D;
+    h.cap_sol = t->cap;
     h.g_ns = 0;
     h.g_rho = 0.;
     h.g_min = GRID_MIN_VERTICES;
@@ -421,15 +433,6 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         h.g_inv_h[k] = (double)h.g_G / ext;
         h.g_margin[k] = ext / (double)h.g_G / 256.0;
     }
-    for (int k = 0; k < D; k++) HIPCHK_T(hipMalloc(&h.g_x[k], sizeof(double) * np));
-    HIPCHK_T(hipMalloc(&h.g_cost, sizeof(double) * np));
-    HIPCHK_T(hipMalloc(&h.g_idx, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.pos, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&h.g_start, sizeof(int) * (size_t)(h.g_ncell + 1)));
-    HIPCHK_T(hipMalloc(&h.g_cnt, sizeof(int) * (size_t)h.g_ncell));
-    HIPCHK_T(hipMalloc(&h.g_rank, sizeof(int) * np));
-    HIPCHK_T(hipMalloc(&t->dev, sizeof(TreeDev)));
-    HIPCHK_T(hipMalloc(&t->self_dev, sizeof(TreeDev *)));
     HIPCHK_T(hipMemcpy(t->self_dev, &t->dev, sizeof(TreeDev *), hipMemcpyHostToDevice));
     HIPCHK_T(hipHostMalloc((void **)&t->scratch, sizeof(Scratch), hipHostMallocMapped));
     HIPCHK_T(hipHostGetDevicePointer((void **)&t->scratch_dev, t->scratch, 0));

@@ -63,6 +63,11 @@ def main():
                                       "--no-cpu-baseline --no-ttfs --steps 1 --warmup 0 " + " ".join(bench_args)}
     with open(path, "w") as fh:
         json.dump(tab, fh, indent=1)
+    # gpurun merges back gpurun_out/ only: leave copies of what went into profiles/ there
+    import shutil
+    shutil.copy(path, out_root)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        shutil.copy(os.path.join(prof_dir, "r02_pmc_%s_%s.csv" % (key, counter)), out_root)
     print(json.dumps(tab["entries"][key]))
 
 
