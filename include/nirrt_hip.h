@@ -202,7 +202,10 @@ typedef struct nirrt_run_args {
                             [8] solution / goal-candidate list entries re-evaluated, [9] vertices inserted,
                             [10] vertices passed through index rebuilds, [11] widened nearest visits,
                             [12] whole-tree visits, [13] iterations, [14] / [15] device wall clock (100 MHz ticks)
-                            when the tree's loop started / ended, [16] = alg_elems, [17..19] reserved */
+                            when the tree's loop started / ended, [16] = alg_elems, [17] sampling mode: bit pattern (IEEE double) of
+                            the best cost on the tree when its loop ended - what a NIRRT_E_CLOUD stop compared with
+                            update_cost_ratio * c_update, so that the host needs no extra launch per stopped tree -
+                            [18..19] reserved */
     const int64_t *iters_each; /* optional (n_trees,), sampling mode: tree i runs at most iters_each[i] <= iters iterations
                             (trees of one batch resumed after stopping at different iterations, e.g. NIRRT_E_CLOUD);
                             cost_trace rows stay `iters` long */

@@ -63,7 +63,7 @@ class RunArgs(C.Structure):
 N_STATS = 20
 STAT_NAMES = ["visited", "visit_bytes", "members", "spilled", "hop_records", "rewire_candidates", "rewired", "recosted",
               "list_entries", "inserted", "rebuilt", "revisits", "whole_tree_visits", "iterations", "t0_ticks", "t1_ticks",
-              "alg_elems", "r17", "r18", "r19"]
+              "alg_elems", "c_best_bits", "r18", "r19"]
 
 
 def useful_bytes(stats, dim):
@@ -170,6 +170,7 @@ class HipTree:
         self.L = L
         self.dim = int(dim)
         self.iter_max = int(iter_max)
+        self.device_id = int(device_id)
         rnd, box, lo, hi = obstacle_tables(env, self.dim)
         self._keep = (rnd, box)
         cfg = Config()

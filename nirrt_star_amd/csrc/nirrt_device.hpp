@@ -72,6 +72,7 @@
 #define ST_ITERS 13
 #define ST_T0 14         // wall_clock64 (100 MHz) when the tree's loop started / ended
 #define ST_T1 15
+#define ST_CBEST 17      // bit pattern of the best cost when a sampling loop ended (absolute, like T0 / T1; what NIRRT* compared with ratio * c_update)
 #define ST_ALG 16        // vertices the REFERENCE algorithm scans for the same iterations: n per nearest_neighbor + n per find_near_neighbors
 #define NSTAT NIRRT_N_STATS
 

@@ -196,6 +196,7 @@ struct Scratch {  // pinned, device-visible result slots
     double d[4];
 };
 
+#define PC_OWN_POINTS 4096   // guidance-cloud points that fit the per-tree arena (pc_n_points is 2048 in the reference's configs)
 struct nirrt_tree {
     nirrt_config cfg;
     int dim;
@@ -209,7 +210,8 @@ struct nirrt_tree {
     double *near_r;  // device table (inside the arena)
     Scratch *scratch;      // pinned host memory
     Scratch *scratch_dev;  // device alias of the same memory
-    double *pc_dev;        // guidance cloud (nirrt_set_cloud)
+    double *pc_dev;        // guidance cloud (nirrt_set_cloud): pc_own (inside the arena, PC_OWN_POINTS points) or an allocation of its own
+    double *pc_own;
     long long last_n;      // num_vertices as of the last call that reported it (kernel-variant choice only)
 };
 
@@ -285,8 +287,8 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     if (!t) return NIRRT_OK;
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
+    if (t->pc_dev && t->pc_dev != t->pc_own) (void)hipFree(t->pc_dev);
     if (t->arena) (void)hipFree(t->arena);
-    if (t->pc_dev) (void)hipFree(t->pc_dev);
     if (t->scratch) (void)hipHostFree(t->scratch);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
@@ -364,7 +366,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     t->cap = (int)(cfg->iter_max + 1);
     t->device = cfg->device_id;
     t->stream = nullptr;
-    t->arena = nullptr; t->dev = nullptr; t->self_dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->pc_dev = nullptr;
+    t->arena = nullptr; t->pc_own = nullptr; t->dev = nullptr; t->self_dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->pc_dev = nullptr;
     const int D = t->dim;
     auto fail = [&](int rc) { nirrt_destroy(t); return rc; };
 #define HIPCHK_T(expr)                                                                        \
@@ -395,6 +397,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         want(&t->dev, 1);
         want(&t->self_dev, 1);
         want(&t->near_r, (size_t)t->cap + 1);
+        want(&t->pc_own, (size_t)PC_OWN_POINTS * 3);
         want(&h.vrec, np);
         want(&h.hop, np);
         want(&h.aux, np);
@@ -726,10 +729,14 @@ extern "C" int nirrt_set_cloud(nirrt_tree *t, int64_t n, const double *pts, doub
 {
     if (!t || n < 0 || (n > 0 && !pts)) return NIRRT_E_ARG;
     HIPCHK(hipSetDevice(t->device));
-    if (t->pc_dev) { (void)hipFree(t->pc_dev); t->pc_dev = nullptr; }
+    // a refresh replaces the cloud of a stopped tree: the usual 2048-point clouds live in the tree's arena (no allocation,
+    // no implicit device synchronisation of hipFree per refresh - a batch refreshes thousands of clouds per run)
+    if (t->pc_dev && t->pc_dev != t->pc_own) (void)hipFree(t->pc_dev);
+    t->pc_dev = nullptr;
     if (n > 0) {
-        HIPCHK(hipMalloc(&t->pc_dev, sizeof(double) * (size_t)n * t->dim));
-        HIPCHK(hipMemcpy(t->pc_dev, pts, sizeof(double) * (size_t)n * t->dim, hipMemcpyHostToDevice));
+        if (n <= PC_OWN_POINTS) t->pc_dev = t->pc_own;
+        else HIPCHK(hipMalloc(&t->pc_dev, sizeof(double) * (size_t)n * t->dim));
+        HIPCHK(hipMemcpyAsync(t->pc_dev, pts, sizeof(double) * (size_t)n * t->dim, hipMemcpyHostToDevice, t->stream));
     }
     t->host.pc = t->pc_dev;
     t->host.pc_n = (int)n;
@@ -769,6 +776,7 @@ static void report_stats(const nirrt_run_args *a, int i, const long long *after,
         for (int j = 0; j < NSTAT; j++) a->stats[(size_t)i * NSTAT + j] = sa[j] - sb[j];
         a->stats[(size_t)i * NSTAT + ST_T0] = sa[ST_T0];
         a->stats[(size_t)i * NSTAT + ST_T1] = sa[ST_T1];
+        a->stats[(size_t)i * NSTAT + ST_CBEST] = sa[ST_CBEST];
     }
 }
 

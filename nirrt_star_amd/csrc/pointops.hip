@@ -3,6 +3,7 @@
 // torch code (pointnet_pointnet2/models/pointnet2_utils.py): farthest_point_sample :65-86,
 // query_ball_point :89-109 (with square_distance :21-42), 3-NN of PointNetFeaturePropagation :295-299.
 // float32 arithmetic, -ffp-contract=off; the dot products of square_distance are a forward FMA chain.
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -323,6 +324,10 @@ __global__ __launch_bounds__(FPS_NT) void k_fps_f64(const double *__restrict__ b
     }
 }
 
+struct FpsScratch { void *p = nullptr; size_t cap = 0; };
+static std::mutex g_fps_mu;
+static FpsScratch g_fps_scratch[16];
+
 // Down-sampling of n_clouds clouds in ONE launch (one workgroup each).  Host pointers in / out: pts = the clouds' (cnt[b], 3)
 // row-major f64 points back to back, sel = their keep-bytes back to back (1 = kept), num_samples[b] < cnt[b].
 extern "C" int nirrt_fps_f64_batch(const double *pts, int n_clouds, const int *cnt, const int *num_samples, unsigned char *sel,
@@ -339,15 +344,26 @@ extern "C" int nirrt_fps_f64_batch(const double *pts, int n_clouds, const int *c
     }
     double *h = (double *)malloc(sizeof(double) * 3 * (size_t)total);
     for (long long i = 0; i < total; i++) { h[i] = pts[3 * i]; h[total + i] = pts[3 * i + 1]; h[2 * total + i] = pts[3 * i + 2]; }
-    double *d = nullptr;
-    unsigned char *ds = nullptr;
-    long long *d_off = nullptr;
-    int *d_cnt = nullptr, *d_ns = nullptr;
+    // device scratch: ONE grow-only allocation per device, kept between calls - a batch run refreshes clouds while the
+    // other half of the batch is inside a persistent launch, and hipFree would wait for that launch
+    const size_t a256 = 255;
+    const size_t b_pts = (sizeof(double) * 3 * (size_t)total + a256) & ~a256, b_sel = ((size_t)total + a256) & ~a256;
+    const size_t b_off = (sizeof(long long) * (size_t)n_clouds + a256) & ~a256, b_int = (sizeof(int) * (size_t)n_clouds + a256) & ~a256;
+    const size_t need = b_pts + b_sel + b_off + 2 * b_int;
     int rc = 0;
-    if (hipMalloc(&d, sizeof(double) * 3 * (size_t)total) != hipSuccess || hipMalloc(&ds, (size_t)total) != hipSuccess ||
-        hipMalloc(&d_off, sizeof(long long) * (size_t)n_clouds) != hipSuccess || hipMalloc(&d_cnt, sizeof(int) * (size_t)n_clouds) != hipSuccess ||
-        hipMalloc(&d_ns, sizeof(int) * (size_t)n_clouds) != hipSuccess)
-        rc = -2;
+    std::lock_guard<std::mutex> hold(g_fps_mu);
+    FpsScratch &sc = g_fps_scratch[device_id & 15];
+    if (sc.cap < need) {
+        if (sc.p) (void)hipFree(sc.p);
+        sc.p = nullptr; sc.cap = 0;
+        const size_t want = need + need / 2;
+        if (hipMalloc(&sc.p, want) == hipSuccess) sc.cap = want; else rc = -2;
+    }
+    char *base = (char *)sc.p;
+    double *d = (double *)base;
+    unsigned char *ds = (unsigned char *)(base + b_pts);
+    long long *d_off = (long long *)(base + b_pts + b_sel);
+    int *d_cnt = (int *)(base + b_pts + b_sel + b_off), *d_ns = (int *)(base + b_pts + b_sel + b_off + b_int);
     if (!rc && (hipMemcpy(d, h, sizeof(double) * 3 * (size_t)total, hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy(d_off, h_off, sizeof(long long) * (size_t)n_clouds, hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy(d_cnt, cnt, sizeof(int) * (size_t)n_clouds, hipMemcpyHostToDevice) != hipSuccess ||
@@ -360,11 +376,6 @@ extern "C" int nirrt_fps_f64_batch(const double *pts, int n_clouds, const int *c
     }
     free(h);
     free(h_off);
-    if (d) (void)hipFree(d);
-    if (ds) (void)hipFree(ds);
-    if (d_off) (void)hipFree(d_off);
-    if (d_cnt) (void)hipFree(d_cnt);
-    if (d_ns) (void)hipFree(d_ns);
     return rc;
 }
 

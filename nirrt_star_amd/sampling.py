@@ -15,6 +15,9 @@ import random
 import numpy as np
 
 
+_SCRATCH = np.random.RandomState(0)   # carrier of a copied python-generator state (peek_py_words)
+
+
 def peek_np_words(n):
     """next n raw MT19937 outputs of numpy's global RandomState, without consuming them"""
     st = np.random.get_state()
@@ -33,10 +36,11 @@ def peek_py_words(n):
     n = int(n)
     if n == 0:
         return np.zeros(0, dtype=np.uint32)
-    st = random.getstate()
-    bits = random.getrandbits(32 * n)  # filled least-significant word first, one output per word
-    random.setstate(st)
-    return np.frombuffer(bits.to_bytes(4 * n, "little"), dtype="<u4").astype(np.uint32)
+    # getrandbits(32 n) would be n consecutive outputs, least-significant word first; the same MT19937 state inside a numpy
+    # RandomState yields them 3-4x faster than building (and splitting) a multi-megabit Python integer
+    st = random.getstate()[1]
+    _SCRATCH.set_state(("MT19937", np.array(st[:624], dtype=np.uint32), int(st[624])))
+    return _SCRATCH.randint(0, 1 << 32, size=n, dtype=np.uint32)
 
 
 def advance_py_words(n):

@@ -1,0 +1,25 @@
+#!/bin/bash
+# NIRRT* batch: two half-batches pipelined (refresh of one overlaps the launch of the other), faster word generation,
+# clouds inside the tree arena, FPS scratch kept
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/r02ad
+mkdir -p $OUT
+cd $R
+timeout 900 python -m pytest tests/test_nirrt_batch_gpu.py tests/test_batch_driver_gpu.py  -m gpu -x -q 2>&1 | tail -3
+run() {
+  name=$1; shift
+  timeout 900 python bench.py --no-cpu-baseline --no-ttfs --steps 1 --warmup 0 "$@" > $OUT/$name.json 2> $OUT/$name.err
+  python - <<PY
+import json
+try:
+    d=json.loads(open('$OUT/$name.json').read().strip().splitlines()[-1])
+    print("$name", d['config'].get('host_seconds_last_step'), d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline'].get('kernel_share_of_step'), d['config'].get('launches_per_step'), d['config'].get('clouds_per_step'), d['config'].get('failed'))
+except Exception as e:
+    print("$name failed", e)
+PY
+  tail -3 $OUT/$name.err | grep -v amdgpu.ids
+}
+run nirrt2d_1024 --algo nirrt --trees 1024
+run nirrt2d_4096 --algo nirrt --trees 4096
+run nirrt3d_512 --algo nirrt --dim 3 --trees 512
+exit 0
