@@ -115,7 +115,14 @@ def word_budgets(args):
     if args.algo == "rrt":
         return it * D * 2 * 4 + 4096, 0          # four SampleFree attempts per iteration (crowded worlds reject 2 of 3)
     if D == 2:
-        return it * 12 + 4096, it * 14 + 4096    # SampleFree until the first solution, then python-random unit disk
+        # SampleFree (4 words per attempt) until the first solution, then python-random unit disk.  In the r in [16, 24] worlds
+        # only ~39 % of the range is free (10 words per sample, 14 in the most crowded ones) and a tree without a solution
+        # keeps drawing that way for the whole run
+        # ... and once it has one, the informed sampler's unit-disk points (5.1 python words each) are rejected at the same
+        # rate: 13 words per sample on average, 18+ in the most crowded worlds (measured: 17 % of the trees ran out of a
+        # 14-word budget, having done 82 % of their iterations on average)
+        crowded = getattr(args, "world", "b30") == "b30r16"
+        return it * (24 if crowded else 12) + 4096, it * (48 if crowded else 14) + 4096
     return it * 6 * 40 + 4096, 0                 # 3D informed sampling stays on the numpy stream
 
 

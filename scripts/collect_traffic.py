@@ -40,6 +40,8 @@ def main():
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
                 rows += [r for r in csv.DictReader(fh) if r["Counter_Name"] == counter and "k_run_" in r["Kernel_Name"]]
+        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            os.remove(f)   # ~18 MB per pass (every copy / fill / init kernel of the set-up): gpurun merges back at most 64 MiB
         rows.sort(key=lambda r: -float(r["Counter_Value"]))
         # one step = several launches (segments x workgroup-size groups): the step's traffic is the sum over all of them
         raw[counter] = dict(rows[0], Counter_Value=str(sum(float(r["Counter_Value"]) for r in rows)), dispatches=str(len(rows)))

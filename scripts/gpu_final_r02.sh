@@ -7,10 +7,13 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_r02
 rm -rf $OUT; mkdir -p $OUT
 cd $R
+if [ -z "$SKIP_TESTS" ]; then
 timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -4 > $OUT/pytest_gpu.txt
 cat $OUT/pytest_gpu.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 > $OUT/smoke.txt
 cat $OUT/smoke.txt
+rm -rf $R/gpurun_out/test_* $R/gpurun_out/bench_ck    # checkpoints written by the suite: not results
+fi
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python $R/bench.py --steps 2 --warmup 1 > $OUT/bench_irrt2d.json 2> $OUT/bench_irrt2d.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_irrt2d -o bench -- python $R/bench.py --no-cpu-baseline --no-ttfs --steps 1 --warmup 0 > $OUT/bench_irrt2d_profiled.json 2>> $OUT/err.log
@@ -24,7 +27,8 @@ timeout 900 python $R/bench.py --algo nirrt --trees 4096 --iters 50000 --steps 1
 timeout 900 python $R/bench.py --algo nirrt --dim 3 --trees 512 --iters 50000 --steps 1 --warmup 0 > $OUT/bench_nirrt3d.json 2>> $OUT/err.log
 find $OUT -name '*kernel_trace.csv' -size +1M -delete
 find $OUT -name '*.db' -delete
-cp -r $R/gpurun_out/traffic_* $OUT/ 2>/dev/null
+find $R/gpurun_out -name '*kernel_trace.csv' -size +1M -delete
+du -sh $R/gpurun_out
 ls $OUT | head -40
 tail -5 $OUT/err.log
 exit 0
