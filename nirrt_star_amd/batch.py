@@ -14,6 +14,7 @@ What the host does between launches:
 Reference loop being batched: eval_planning_2d.py:83-136 calling planning_random / planning of nirrt_star_png_2d.py:56-174,
 247-335, nirrt_star_png_c_2d.py:52-87 (+ the 3D twins).
 """
+import os
 import random
 
 import numpy as np
@@ -266,7 +267,7 @@ class Guidance:
 
 
 def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, frames=None, want_trace=True, stop_first=False,
-              np_per_iter=None, py_per_iter=None, window=65536, init_clouds=True, pad=4096, overlap_min=1024):
+              np_per_iter=None, py_per_iter=None, window=65536, init_clouds=True, pad=4096, overlap_min=None):
     """`iters` loop bodies for every tree of the batch (fewer for trees that stop: first solution with stop_first, full
     tree).  Returns dict(traces = per-tree best cost after each iteration, iters_done, kernel_ms, launches, stats).
     The per-tree generators in `streams` end up advanced by exactly what each tree consumed."""
@@ -360,6 +361,8 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
     # overlaps the other half's launch.  Trees are independent and draw from their own generators: the split changes no result.
     # A launch lasts as long as its slowest tree, so two half launches take longer than one whole: measured on 2D problems the
     # split pays from ~2048 trees (4096: 3.0 vs 2.8 M it/s; 1024: 1.7 vs 2.2).
+    if overlap_min is None:
+        overlap_min = int(os.environ.get("NIRRT_BATCH_OVERLAP_MIN", "1024"))   # trees per half; tests set 1
     n_groups = 2 if (png and B >= 2 * overlap_min) else 1
     groups = [list(range(g, B, n_groups)) for g in range(n_groups)]
     futures = [None] * n_groups
