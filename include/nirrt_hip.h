@@ -106,7 +106,8 @@ int nirrt_reset(nirrt_tree *t);
 /* the same for every tree of a batch (same device and dim) in ONE launch, one workgroup per tree: the planner objects of an
  * evaluation set are single-use in the reference (demo_planning_2d.py:90); a benchmark step re-plans the same problems */
 int nirrt_reset_batch(nirrt_tree *const *trees, int32_t n_trees);
-/* test/bring-up helper: load a frozen tree (vertices (n,dim) f64, parents (n,) i64) */
+/* test/bring-up helper: load a frozen tree (vertices (n,dim) f64, parents (n,) i64); vertex 0 must be x_start - the tree is
+ * rooted at the start state like the reference's (rrt_base_2d.py:27) - else NIRRT_E_ARG */
 int nirrt_upload(nirrt_tree *t, int64_t n, const double *vertices, const int64_t *parents);
 /* `self.vertices[:n]`, `self.vertex_parents[:n]`, `self.num_vertices`; either pointer may be NULL */
 int nirrt_download(nirrt_tree *t, double *vertices, int64_t *parents, int64_t *n);

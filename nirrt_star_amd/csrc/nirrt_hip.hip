@@ -499,6 +499,10 @@ extern "C" int nirrt_upload(nirrt_tree *t, int64_t n, const double *vertices, co
     if (!t || !vertices || !parents || n < 1 || n > t->cap) { g_err = "bad upload arguments"; return NIRRT_E_ARG; }
     HIPCHK(hipSetDevice(t->device));
     const int D = t->dim;
+    // the tree is rooted at the start state (RRTBase.__init__: vertices[0] = x_start, rrt_base_2d.py:27): the loop body
+    // relies on it (cost(v) >= |v - x_start|, the floor of the Near stash), so a frozen tree with another root is refused
+    for (int k = 0; k < D; k++)
+        if (vertices[k] != t->cfg.x_start[k]) { g_err = "nirrt_upload: vertex 0 must be x_start (the tree is rooted at the start state)"; return NIRRT_E_ARG; }
     std::vector<double> col((size_t)n);
     for (int k = 0; k < D; k++) {
         for (int64_t i = 0; i < n; i++) col[(size_t)i] = vertices[i * D + k];
