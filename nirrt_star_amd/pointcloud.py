@@ -37,16 +37,26 @@ def get_point_cloud_mask_around_points(point_cloud, points, neighbor_radius=3):
 
 
 def _free_pixels_2d(point_cloud, binary_mask):
-    """keep points whose 4 surrounding pixels (clipped to the image) are all free"""
+    """keep points whose 4 surrounding pixels (clipped to the image) are all free (point_cloud_mask_utils.py:52-62: the
+    product of binary_mask[clip(y + dy), clip(x + dx)] over dx, dy in {0, 1} is non-zero).  One table look-up per point: the
+    edge-replicated mask is reduced to "this 2 x 2 block is free" once (entry [iy, ix] stands for the clipped pixel pairs
+    (iy - 1, iy) x (ix - 1, ix)), which is the same set of four pixels for every integer position, inside the image or not."""
     h, w = binary_mask.shape
+    P = np.empty((h + 2, w + 2), dtype=bool)
+    P[1:-1, 1:-1] = binary_mask != 0
+    P[0, 1:-1] = P[1, 1:-1]
+    P[-1, 1:-1] = P[-2, 1:-1]
+    P[:, 0] = P[:, 1]
+    P[:, -1] = P[:, -2]
+    block_free = P[:-1, :-1] & P[:-1, 1:] & P[1:, :-1] & P[1:, 1:]      # (h + 1, w + 1)
     pix = point_cloud.astype(int)
-    keep = np.ones(len(pix))
-    for dx in (0, 1):
-        for dy in (0, 1):
-            px = np.clip(pix[:, 0] + dx, 0, w - 1)
-            py = np.clip(pix[:, 1] + dy, 0, h - 1)
-            keep = keep * binary_mask[py, px]
-    return keep.nonzero()[0]
+    ix = pix[:, 0] + 1
+    np.maximum(ix, 0, out=ix)
+    np.minimum(ix, w, out=ix)
+    iy = pix[:, 1] + 1
+    np.maximum(iy, 0, out=iy)
+    np.minimum(iy, h, out=iy)
+    return np.flatnonzero(block_free.ravel()[iy * (w + 1) + ix])
 
 
 def rectangle_candidates(binary_mask, n_points, over_sample_scale=5, rng=None):
@@ -54,9 +64,13 @@ def rectangle_candidates(binary_mask, n_points, over_sample_scale=5, rng=None):
     (m, 3) with z = 0.  `rng`: a numpy RandomState (default: the process-global legacy generator, like the reference)."""
     rng = np.random if rng is None else rng
     h, w = binary_mask.shape
-    pc = rng.uniform(low=[0, 0], high=[w, h], size=(n_points * over_sample_scale, 2))
-    pc = pc[_free_pixels_2d(pc, binary_mask)]
-    return np.concatenate([pc, np.zeros((pc.shape[0], 1))], axis=1)
+    # rng.uniform(low=[0, 0], high=[w, h], size=(m, 2)) of the reference = 0 + (high - low) * random_sample, element by element
+    # in C order: the same doubles, without the array-argument path of the legacy generator
+    pc = rng.random_sample((n_points * over_sample_scale, 2)) * np.array([float(w), float(h)])
+    keep = _free_pixels_2d(pc, binary_mask)
+    out = np.zeros((len(keep), 3))
+    out[:, :2] = pc[keep]
+    return out
 
 
 def generate_rectangle_point_cloud(binary_mask, n_points, over_sample_scale=5, rng=None, device_id=0):
