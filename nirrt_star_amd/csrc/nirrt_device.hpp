@@ -13,7 +13,8 @@
 //     band and for every member.  Members are not stored as a list: the visit keeps the running
 //     argmin of cost + dist for choose_parent and leaves (index, cost - dist) pairs in an LDS stash (spilling to
 //     HBM only beyond the stash capacity), from which rewire later picks, in ascending index order, the few members
-//     that can pass `cost(j) > cost(new) + dist`.
+//     that can pass `cost(j) > cost(new) + dist`.  Only members whose margin cost - dist exceeds the straight
+//     distance root -> new (a lower bound of cost(new)) are kept: the others cannot pass that test.
 //   * cost(v) is the reference's leaf->root sum (math.hypot per edge, added in that order).  It is kept
 //     EXACT in a per-vertex cache: a walk chases one 48-byte record per FOUR hops, and a re-parented
 //     vertex has its whole subtree (child / sibling links) re-walked right away, so every cost the loop
