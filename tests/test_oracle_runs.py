@@ -55,3 +55,52 @@ def test_near_sets_match_trace(oracle):
             idx = t.near(np.array(r.node_new[: t.dim]), r.new_idx)
             assert np.array_equal(idx, g["trace_near_idx"][lo:hi])
     t.close()
+
+
+@pytest.mark.parametrize("name", ["run_irrt2d_3000", "run_rrt2d_3000", "run_irrt3d_3000", "run_rrt3d_3000"])
+def test_rewired_vertices_lie_above_the_straight_line_floor(oracle, name):
+    """The device loop keeps a Near member for rewire only if cost(j) - dist(j, new) exceeds |new - x_start| - (1e-9 + 1e-11 |.|)
+    (csrc/nirrt_device.hpp, wg_iteration: cost(new) is a polyline length root -> new, hence at least the straight distance).
+    On the reference runs: every vertex the reference's rewire (rrt_star_2d.py:92-99) re-parented had a margin above that
+    floor when its iteration started.  The bound itself is tight - in the converged IRRT* run re-parented vertices sit
+    EXACTLY on it (collinear chains along the start-goal line: margin - |new - x_start| = 0, median 1.4e-7) - so what the
+    tolerance has to absorb is rounding only: no margin falls below the exact bound by more than 1e-10, a tenth of it."""
+    g = load_golden(name)
+    irrt = str(g["algo"]) == "irrt"
+    samples = g["samples"]
+    root = np.asarray(g["x_start"], dtype=np.float64)
+    # pass 1: which vertices does each iteration re-parent under its new vertex?
+    t = make_oracle_tree(oracle, g)
+    rewired = {}
+    for k, q in enumerate(samples):
+        n0 = t.n
+        before = t.parents[:n0].copy()
+        r = t.step(q, irrt)
+        if r.n_rewired:
+            after = t.parents[:n0]
+            moved = np.flatnonzero(after != before)
+            moved = moved[after[moved] == r.new_idx]
+            assert len(moved) >= 1
+            rewired[k] = (int(r.new_idx), moved.copy())
+    t.close()
+    assert len(rewired) > 50
+    # pass 2: their margins at the start of that iteration
+    t = make_oracle_tree(oracle, g)
+    worst, worst_exact = np.inf, np.inf
+    for k, q in enumerate(samples):
+        if k in rewired:
+            new_idx, moved = rewired[k]
+            costs = [t.cost(int(j)) for j in moved]
+            pos = t.vertices[moved].copy()
+        t.step(q, irrt)
+        if k in rewired:
+            new = t.vertices[new_idx]
+            lb = float(np.sqrt(np.sum((new - root) ** 2)))
+            floor = lb - (1e-9 + 1e-11 * lb)
+            for c, p in zip(costs, pos):
+                margin = c - float(np.sqrt(np.sum((p - new) ** 2)))
+                worst = min(worst, margin - floor)
+                worst_exact = min(worst_exact, margin - lb)
+    t.close()
+    assert worst > 0.0, "a re-parented vertex would have been dropped: margin - floor = %g" % worst
+    assert worst_exact >= -1e-10, "margin below the exact bound by %g" % -worst_exact
