@@ -61,6 +61,7 @@ class RunArgs(C.Structure):
                 ("stats", C.POINTER(C.c_int64)), ("iters_each", C.POINTER(C.c_int64)), ("lanes_hint", C.POINTER(C.c_int32))]
 
 N_STATS = 20
+ST_ITERS, ST_T0, ST_T1, ST_CBEST = 13, 14, 15, 17   # slots 14 / 15 / 17 are absolute values of a launch, the rest are deltas
 STAT_NAMES = ["visited", "visit_bytes", "members", "spilled", "hop_records", "rewire_candidates", "rewired", "recosted",
               "list_entries", "inserted", "rebuilt", "revisits", "whole_tree_visits", "iterations", "t0_ticks", "t1_ticks",
               "alg_elems", "c_best_bits", "r18", "r19"]

@@ -200,6 +200,13 @@ class Guidance:
         (nirrt_star_png_2d.py:132-145), otherwise the ellipse / ellipsoid-restricted one (:146-160)"""
         import time
         from . import pointops
+        if self.rate == 0:
+            # update_point_cloud returns at once when pc_sample_rate == 0 (nirrt_star_png_2d.py:121-124): no candidates are
+            # drawn (the problem's generators stay where they are), no forward; the trees only get the policy scalars
+            empty = np.zeros((0, self.dim))
+            for i in due:
+                trees[i].set_cloud(empty, 0.0, self.ratio, c_best[i])
+            return {i: (empty, np.zeros(0, dtype=np.int64)) for i in due}
         t0 = time.perf_counter()
         cands = []
         for i in due:
@@ -324,7 +331,14 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
                 traces[i].append(tr.copy())
                 c_best[i] = tr[-1]
             remaining[i] -= d
+            # delta slots add up; T0 / T1 (device clocks) and the best-cost bit pattern are absolute values of the launch:
+            # first T0, last T1, last best cost
+            first_launch = stats[i, _hip.ST_ITERS] == 0 and stats[i, _hip.ST_T0] == 0
+            keep_t0 = stats[i, _hip.ST_T0]
             stats[i] += r["stats"][j]
+            stats[i, _hip.ST_T0] = r["stats"][j, _hip.ST_T0] if first_launch else keep_t0
+            stats[i, _hip.ST_T1] = r["stats"][j, _hip.ST_T1]
+            stats[i, _hip.ST_CBEST] = r["stats"][j, _hip.ST_CBEST]
             st = int(r["status"][j])
             if st == _hip.E_CLOUD:
                 # the cost the stopped kernel compared with ratio * c_update (find_best_path_solution), handed back with the

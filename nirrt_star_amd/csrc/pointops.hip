@@ -518,11 +518,9 @@ extern "C" int nirrt_pn2_sa_mlp(const float *feats, const float *xyz, const floa
     const size_t lds = sizeof(float) * ((size_t)cin_pad * C1 + (size_t)C1 * C2 + (size_t)C2 * C3 + C1 + C2 + C3 +
                                         (size_t)SA_WAVES * 16 * (sA + sB));
     if (lds > 160 * 1024) return -3;
-    static size_t lds_max = 0;
-    if (lds > lds_max) {
-        if (hipFuncSetAttribute((const void *)k_sa_mlp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-        lds_max = lds;
-    }
+    // the attribute belongs to the CURRENT device's copy of the kernel (a process may drive several GPUs): set on every call,
+    // it is a host-side table write
+    if (hipFuncSetAttribute((const void *)k_sa_mlp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
     SaMlpArgs a;
     a.feats = feats; a.xyz = xyz; a.new_xyz = new_xyz; a.gidx = (const long long *)gidx; a.out = out;
     a.w1t = w1t; a.b1 = b1; a.w2t = w2t; a.b2 = b2; a.w3t = w3t; a.b3 = b3;

@@ -12,7 +12,7 @@ on MI355X:
     libnirrt_hip.so (nirrt_star_amd/csrc/pointops.hip): FPS is one persistent workgroup per cloud
     instead of ~1360 dependent torch launches; ball query is a first-K-in-index-order scan instead of an
     O(N log N) sort.  The model therefore runs on 'cuda' only (pointops raises on CPU tensors; the test
-    suite installs oracle/pointops_ref.py for its CPU runs).
+    suite replaces the pointops functions from tests/conftest.py for its CPU runs).
 
 Semantics kept from the reference: FPS starts at torch.randint(0, N) drawn from the CPU generator
 (pointnet2_utils.py:77); ball query = first K indices in ascending order with squared distance

@@ -1,9 +1,9 @@
 """Point operators of the PointNet++ guidance net: hand-written HIP kernels of libnirrt_hip.so (csrc/pointops.hip),
 launched on the current torch stream.
 
-ONE implementation: tensors must live on the GPU; the library being absent, or a CPU tensor, is an error.  (The CPU
-test-suite and the fixture generator install `oracle/pointops_ref.py` through `install_cpu_reference` - that module is
-test infrastructure and is never imported from the package.)
+ONE implementation: tensors must live on the GPU; the library being absent, a host without a visible GPU, or a CPU
+tensor is an error.  There is no hook for another implementation in this module: the CPU test-suite replaces these
+functions from the outside (tests/conftest.py monkeypatches the module attributes on a host without a GPU).
 
 Semantics (reference pointnet_pointnet2/models/pointnet2_utils.py): farthest_point_sample :65-86 with the start index
 drawn by torch.randint on the CPU generator, query_ball_point :89-109 (first K indices in ascending order, padded with
@@ -13,20 +13,17 @@ import ctypes as C
 
 import torch
 
-_CPU_REF = None
-
-
-def install_cpu_reference(module):
-    """route CPU tensors to `module` (tests / fixture generation only); None removes it again"""
-    global _CPU_REF
-    _CPU_REF = module
-
-
-def _cpu(name):
-    if _CPU_REF is None:
+def _need_cuda(name, t):
+    if not t.is_cuda:
         raise RuntimeError("nirrt_star_amd.pointops.%s got a CPU tensor: the package only has the HIP kernels "
-                           "(move the model / cloud to 'cuda'); CPU references live in oracle/pointops_ref.py" % name)
-    return getattr(_CPU_REF, name)
+                           "(move the model / cloud to 'cuda')" % name)
+
+
+def _need_device(name):
+    from . import _hip
+    if _hip.device_count() <= 0:
+        raise RuntimeError("nirrt_star_amd.pointops.%s needs a visible MI355X: the down-sampling only exists as a HIP "
+                           "kernel (k_fps_f64), there is no CPU path" % name)
 
 
 def _lib():
@@ -62,8 +59,7 @@ def farthest_point_sample(xyz, npoint, start=None):
     B, N, _ = xyz.shape
     if start is None:
         start = torch.randint(0, N, (B,), dtype=torch.long)
-    if not xyz.is_cuda:
-        return _cpu("farthest_point_sample")(xyz, npoint, start)
+    _need_cuda("farthest_point_sample", xyz)
     start = start.to(xyz.device)
     xyz = xyz.contiguous().float()
     out = torch.empty(B, npoint, dtype=torch.long, device=xyz.device)
@@ -73,8 +69,7 @@ def farthest_point_sample(xyz, npoint, start=None):
 
 def ball_query(radius, nsample, xyz, new_xyz):
     """first `nsample` indices in ascending order within `radius` of each query, padded with the first -> (B, S, K) long"""
-    if not xyz.is_cuda:
-        return _cpu("ball_query")(radius, nsample, xyz, new_xyz)
+    _need_cuda("ball_query", xyz)
     B, N, _ = xyz.shape
     S = new_xyz.shape[1]
     out = torch.empty(B, S, nsample, dtype=torch.long, device=xyz.device)
@@ -86,8 +81,7 @@ def ball_query(radius, nsample, xyz, new_xyz):
 
 def three_nn(xyz1, xyz2):
     """3 nearest coarse points per fine point -> (squared distances (B, N, 3), indices (B, N, 3))"""
-    if not xyz1.is_cuda:
-        return _cpu("three_nn")(xyz1, xyz2)
+    _need_cuda("three_nn", xyz1)
     B, N, _ = xyz1.shape
     S = xyz2.shape[1]
     d = torch.empty(B, N, 3, dtype=torch.float32, device=xyz1.device)
@@ -135,8 +129,7 @@ def farthest_point_down_sample_f64(pts, num_samples, device_id=0):
     import numpy as np
     from . import _hip
     n = len(pts)
-    if _hip.device_count() <= 0:
-        return _cpu("farthest_point_down_sample_f64")(pts, num_samples)
+    _need_device("farthest_point_down_sample_f64")
     sel8 = np.zeros(n, dtype=np.uint8)
     rc = _lib().nirrt_fps_f64(pts.ctypes.data, n, int(num_samples), sel8.ctypes.data, int(device_id))
     if rc != 0:
@@ -156,10 +149,7 @@ def farthest_point_down_sample_f64_batch(clouds, num_samples, device_id=0):
             masks[b] = np.ones(len(c), dtype=bool)
     if not todo:
         return masks
-    if _hip.device_count() <= 0:
-        for b in todo:
-            masks[b] = _cpu("farthest_point_down_sample_f64")(np.ascontiguousarray(clouds[b], dtype=np.float64), num_samples)
-        return masks
+    _need_device("farthest_point_down_sample_f64_batch")
     pts = np.ascontiguousarray(np.concatenate([np.asarray(clouds[b], dtype=np.float64) for b in todo], axis=0))
     cnt = np.array([len(clouds[b]) for b in todo], dtype=np.int32)
     ns = np.full(len(todo), int(num_samples), dtype=np.int32)

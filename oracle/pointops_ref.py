@@ -1,9 +1,10 @@
 """CPU references of the point operators (TEST INFRASTRUCTURE ONLY - see oracle/oracle.py).
 
 The product package (nirrt_star_amd.pointops / pointcloud) has ONE implementation of these operators, the HIP kernels
-of csrc/pointops.hip, and raises on CPU tensors.  The CPU test-suite, the fixture generator (tests/golden/make_golden.py)
-and the GPU tests that compare "HIP vs plain torch / numpy" install this module through
-`nirrt_star_amd.pointops.install_cpu_reference(oracle.pointops_ref)`; only then are CPU tensors routed here.
+of csrc/pointops.hip, and raises on CPU tensors; it offers no hook for another one.  The CPU test-suite and the fixture
+generator (tests/golden/make_golden.py) replace the package's module attributes from the OUTSIDE with `patched(pointops)`
+below (tests/conftest.py: for the whole session on a host without a GPU; on a GPU box only around the CPU calibration of the
+synthetic checkpoint, so a CPU tensor that reaches the operators inside a `-m gpu` test raises).
 
 Restated from the reference, plain torch ops in fp32 / numpy in fp64:
   square_distance          pointnet_pointnet2/models/pointnet2_utils.py:21-42
@@ -66,3 +67,50 @@ def farthest_point_down_sample_f64(pts, num_samples):
         np.minimum(dist, d, out=dist)
         far = int(np.argmax(dist))
     return sel
+
+
+def farthest_point_down_sample_f64_batch(clouds, num_samples, device_id=0):
+    masks = []
+    for c in clouds:
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        masks.append(np.ones(len(c), dtype=bool) if len(c) <= num_samples else farthest_point_down_sample_f64(c, num_samples))
+    return masks
+
+
+def cpu_operators():
+    """name -> CPU stand-in with the signature of the nirrt_star_amd.pointops function of that name"""
+    def fps(xyz, npoint, start=None):
+        if start is None:
+            start = torch.randint(0, xyz.shape[1], (xyz.shape[0],), dtype=torch.long)
+        return farthest_point_sample(xyz, npoint, start)
+    return {"farthest_point_sample": fps, "ball_query": ball_query, "three_nn": three_nn,
+            "farthest_point_down_sample_f64": lambda pts, num_samples, device_id=0: farthest_point_down_sample_f64(pts, num_samples),
+            "farthest_point_down_sample_f64_batch": farthest_point_down_sample_f64_batch}
+
+
+class patched:
+    """`with patched(nirrt_star_amd.pointops):` - the module's operators are the CPU stand-ins inside the block.
+    `patched(module).start()` leaves them in place (CPU-only test sessions, fixture generation)."""
+
+    def __init__(self, module):
+        self.module = module
+        self.saved = None
+
+    def start(self):
+        if self.saved is None:
+            ops = cpu_operators()
+            self.saved = {k: getattr(self.module, k) for k in ops}
+            for k, f in ops.items():
+                setattr(self.module, k, f)
+        return self
+
+    def stop(self):
+        if self.saved is not None:
+            for k, f in self.saved.items():
+                setattr(self.module, k, f)
+            self.saved = None
+
+    __enter__ = start
+
+    def __exit__(self, *exc):
+        self.stop()

@@ -13,10 +13,19 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
-    # the package has only the HIP point operators; CPU tensors (CPU tests, fixtures) go to the oracle's torch / numpy ones
-    from nirrt_star_amd import pointops
-    from oracle import pointops_ref
-    pointops.install_cpu_reference(pointops_ref)
+    # The package has only the HIP point operators and no hook for others.  On a host WITHOUT a GPU (the CPU suite) the
+    # module's functions are replaced from here by the oracle's torch / numpy ones for the whole session; on a GPU box
+    # nothing is replaced, so a CPU tensor that reaches the operators inside a `-m gpu` test raises (the one explicit
+    # exception is the CPU calibration of the synthetic checkpoint, synthetic_checkpoint_root below).
+    if not _gpu_visible():
+        from nirrt_star_amd import pointops
+        from oracle import pointops_ref
+        pointops_ref.patched(pointops).start()
+
+
+def _gpu_visible():
+    import torch
+    return torch.cuda.is_available()
 
 
 def load_golden(name):
@@ -78,7 +87,10 @@ def synthetic_checkpoint_root(dim):
     import tempfile
     from nirrt_star_amd import png_wrapper
     if dim not in _CK_ROOTS:
+        from nirrt_star_amd import pointops
+        from oracle import pointops_ref
         root = tempfile.mkdtemp(prefix="nirrt_ck_")
-        png_wrapper.make_synthetic_checkpoint(png_wrapper.checkpoint_path(root, dim), seed=0, dim=dim, device="cpu")
+        with pointops_ref.patched(pointops):   # the fixtures' weights were calibrated by CPU forwards: same here, explicitly
+            png_wrapper.make_synthetic_checkpoint(png_wrapper.checkpoint_path(root, dim), seed=0, dim=dim, device="cpu")
         _CK_ROOTS[dim] = root
     return _CK_ROOTS[dim]

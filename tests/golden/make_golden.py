@@ -338,7 +338,7 @@ def synthetic_checkpoint_root(dim):
     import tempfile
     from nirrt_star_amd import pointops, png_wrapper
     from oracle import pointops_ref
-    pointops.install_cpu_reference(pointops_ref)
+    pointops_ref.patched(pointops).start()
     root = tempfile.mkdtemp(prefix="nirrt_ck_")
     png_wrapper.make_synthetic_checkpoint(png_wrapper.checkpoint_path(root, dim), seed=0, dim=dim, device="cpu")
     return root
