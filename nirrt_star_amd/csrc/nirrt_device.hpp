@@ -29,6 +29,41 @@
 
 #include "../../include/nirrt_hip.h"
 
+// Tree arrays live in HBM: the device code addresses them through address-space-1 ("global") pointers, so that the
+// compiler emits global_load / global_store (vmcnt only) instead of flat_* instructions - a flat access also counts on
+// lgkmcnt, i.e. every wait for an LDS read would wait for the loads in flight as well.  Host code (and the descriptor as
+// stored in HBM) uses plain pointers of the same size: TreeHotH is the storage type, TreeHot the device's view of it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GAS __attribute__((address_space(1)))
+#else
+#define GAS
+#endif
+template <typename T> struct gp_plain { typedef T *type; };
+template <typename T> struct gp_global { typedef GAS T *type; };
+
+// whole-record loads / stores through a global pointer (16-byte pieces; the records are 16 / 32 / 48 bytes)
+typedef unsigned nirrt_v4u __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ T ldg(const GAS T *p)
+{
+    static_assert(sizeof(T) % 16 == 0, "records are multiples of 16 bytes");
+    T out;
+    const GAS nirrt_v4u *g = (const GAS nirrt_v4u *)p;
+    nirrt_v4u *o = (nirrt_v4u *)&out;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) o[i] = g[i];
+    return out;
+}
+template <typename T>
+__device__ __forceinline__ void stg(GAS T *p, const T &v)
+{
+    static_assert(sizeof(T) % 16 == 0, "records are multiples of 16 bytes");
+    GAS nirrt_v4u *g = (GAS nirrt_v4u *)p;
+    const nirrt_v4u *o = (const nirrt_v4u *)&v;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) g[i] = o[i];
+}
+
 #define MAX_OBS NIRRT_MAX_OBSTACLES
 #ifndef LDS_POOL
 #define LDS_POOL 800     // 8-byte LDS slots shared by the obstacle tables (4 per round + 6 per box obstacle) and the Near stash
@@ -137,41 +172,42 @@ struct __attribute__((aligned(32))) VRec {
 // The part of a tree descriptor the loop body touches: copied into LDS when a kernel starts (hot_enter) and written back when
 // it ends (hot_leave), so that a pointer or a counter of the tree costs an LDS read instead of a dependent scalar load from HBM
 // (16 trees per CU x ~700 B of descriptor do not live in the scalar cache).
-struct TreeHot {
-    double *c[3];   // SoA coordinates x[cap], y[cap], z[cap] (exact values, insertion order; download + exact fallback scans)
-    Aux *aux;       // aux[cap]
-    Hop4 *hop;      // hop[cap]: aux of the vertex and of its next three ancestors (kept in step with aux)
-    VRec *vrec;     // vrec[cap]: coordinates + exact cost, insertion order (random access AND the tail of the index)
-    int *first_child, *next_sib, *prev_sib;   // child lists (-1 = none); the root is nobody's child
-    int *bfs_q;     // scratch queue for subtree traversals
-    double *chain_g;   // edge lengths of the chain new -> root beyond the first CHAIN_MAX (which live in LDS)
+template <template <typename> class P>
+struct TreeHotT {
+    typename P<double>::type c[3];   // SoA coordinates x[cap], y[cap], z[cap] (exact values, insertion order; download + exact fallback scans)
+    typename P<Aux>::type aux;       // aux[cap]
+    typename P<Hop4>::type hop;      // hop[cap]: aux of the vertex and of its next three ancestors (kept in step with aux)
+    typename P<VRec>::type vrec;     // vrec[cap]: coordinates + exact cost, insertion order (random access AND the tail of the index)
+    typename P<int>::type first_child, next_sib, prev_sib;   // child lists (-1 = none); the root is nobody's child
+    typename P<int>::type bfs_q;     // scratch queue for subtree traversals
+    typename P<double>::type chain_g;   // edge lengths of the chain new -> root beyond the first CHAIN_MAX (which live in LDS)
     int cap;
     int n;          // num_vertices
     int dim;
     int status;     // sticky NIRRT_E_* code
     // continuation of the LDS Near stash (members beyond NEAR_STASH; the nirrt_near primitive puts all of them here)
-    int *nr_idx;
-    double *nr_m;
+    typename P<int>::type nr_idx;
+    typename P<double>::type nr_m;
     // IRRT*: path_solutions (goal-parent indices, duplicates allowed) + cached costs
-    int *sol;
-    double *sol_line;   // Line(v, goal) of each solution vertex (static)
+    typename P<int>::type sol;
+    typename P<double>::type sol_line;   // Line(v, goal) of each solution vertex (static)
     int n_sol;
     int cap_sol;
     int sol_dirty;   // some parent changed since sol_best was computed
     int sol_best;    // argmin position in sol[] (first minimum), -1 if none
     double sol_best_cost;
     // RRT*: vertices within step_len of the goal (ascending index), distance, segment test result
-    int *gc_idx;
-    double *gc_dist;
-    unsigned char *gc_col;
-    unsigned char *listed;   // per vertex: bit 0 = in sol[], bit 1 = in gc_idx[] (a re-costed listed vertex invalidates the cached best)
+    typename P<int>::type gc_idx;
+    typename P<double>::type gc_dist;
+    typename P<unsigned char>::type gc_col;
+    typename P<unsigned char>::type listed;   // per vertex: bit 0 = in sol[], bit 1 = in gc_idx[] (a re-costed listed vertex invalidates the cached best)
     int n_gc;
     int gc_dirty;
     int gc_best;
     int pad1;
     double gc_best_cost;
     // Near radius r(n), tabulated on the host with glibc (rrt_star_2d.py:133, rrt_star_3d.py:134)
-    const double *near_r;
+    typename P<const double>::type near_r;
     // problem constants
     double start[3], goal[3];
     double step_len, clearance;
@@ -182,20 +218,20 @@ struct TreeHot {
     double x_center[3];
     double CL_C[9];          // rotation-to-world matrix C, row-major 3x3
     // NIRRT* point-cloud guidance (nirrt_star_png_2d.py:99-130): predicted path points + policy scalars
-    const double *pc;        // (pc_n, dim) row-major
+    typename P<const double>::type pc;        // (pc_n, dim) row-major
     int pc_n;
     int pad2;
     double pc_rate;          // pc_sample_rate
     double pc_ratio;         // pc_update_cost_ratio
     double c_update;         // best cost at the last cloud refresh (inf before the first solution)
     // uniform-grid index (see "uniform-grid index" below): float64 mirror of vertices [0, g_ns) ordered by cell
-    double *g_x[3];          // coordinates by slot
-    double *g_cost;          // exact cost(v) by slot, kept in step with vrec[v].cost
-    int *g_idx;              // vertex index by slot
-    int *pos;                // slot of vertex i (valid for i < g_ns)
-    int *g_start;            // g_start[c] .. g_start[c+1]: slots of cell c inside [0, g_ns); g_ncell + 1 entries
-    int *g_cnt;              // rebuild scratch: per-cell counters
-    int *g_rank;             // rebuild scratch: rank of vertex i inside its cell
+    typename P<double>::type g_x[3];          // coordinates by slot
+    typename P<double>::type g_cost;          // exact cost(v) by slot, kept in step with vrec[v].cost
+    typename P<int>::type g_idx;              // vertex index by slot
+    typename P<int>::type pos;                // slot of vertex i (valid for i < g_ns)
+    typename P<int>::type g_start;            // g_start[c] .. g_start[c+1]: slots of cell c inside [0, g_ns); g_ncell + 1 entries
+    typename P<int>::type g_cnt;              // rebuild scratch: per-cell counters
+    typename P<int>::type g_rank;             // rebuild scratch: rank of vertex i inside its cell
     int g_ns;                // vertices covered by the cell-ordered part (0: index not built yet)
     int g_G;                 // cells per axis
     int g_ncell;             // g_G ^ dim
@@ -206,15 +242,17 @@ struct TreeHot {
     double g_inv_h[3];       // cells per unit length, per axis
     double g_margin[3];      // slack added to every query box
 };
+using TreeHotH = TreeHotT<gp_plain>;    // as stored in HBM and as the host fills it in
+using TreeHot = TreeHotT<gp_global>;    // the device code's view (same layout)
 
 // the whole descriptor in HBM: hot part first, then what only kernel prologues / epilogues and the host touch
-struct TreeDev : TreeHot {
+struct TreeDev : TreeHotH {
     long long stat[NSTAT];   // counters since creation / reset (ST_*); a launch reports the difference
     double rnd[MAX_OBS][4];  // cx, cy, cz, r
     double box[MAX_OBS][6];  // x, y, z, w, h, d
     long long prof[24];      // NIRRT_PROFILE: wall_clock64 ticks (100 MHz) per phase
 };
-static_assert(sizeof(TreeHot) % 8 == 0, "hot_enter / hot_leave copy 8-byte words");
+static_assert(sizeof(TreeHot) % 8 == 0 && sizeof(TreeHot) == sizeof(TreeHotH), "hot_enter / hot_leave copy 8-byte words");
 
 // ------------------------------------------------------------------------------------------------
 // LDS working set of one workgroup
@@ -222,7 +260,7 @@ static_assert(sizeof(TreeHot) % 8 == 0, "hot_enter / hot_leave copy 8-byte words
 // Generator state of one tree between draws: stream positions and the 64-word windows (see WordStream in
 // nirrt_hip.hip) live in LDS, so the persistent loop carries no sampler registers across the loop-body call.
 struct StreamState {
-    const unsigned *w;
+    const GAS unsigned *w;
     long long n, pos, base;
     unsigned buf[64];
 };
@@ -678,7 +716,7 @@ __device__ __forceinline__ void stage_obstacles(Lds<NT> &s, const TreeDev &t)
 template <int NT>
 __device__ __forceinline__ TreeHot &hot_enter(Lds<NT> &s, TreeDev *tg)
 {
-    const long long *src = reinterpret_cast<const long long *>(static_cast<const TreeHot *>(tg));
+    const long long *src = reinterpret_cast<const long long *>(static_cast<const TreeHotH *>(tg));
     long long *dst = reinterpret_cast<long long *>(&s.hot);
     for (int i = threadIdx.x; i < (int)(sizeof(TreeHot) / 8); i += NT) dst[i] = src[i];
     if (threadIdx.x == 0) s.tree_g = tg;
@@ -693,7 +731,7 @@ __device__ __forceinline__ void hot_leave(Lds<NT> &s)
     __syncthreads();
     TreeDev *tg = s.tree_g;
     const long long *src = reinterpret_cast<const long long *>(&s.hot);
-    long long *dst = reinterpret_cast<long long *>(static_cast<TreeHot *>(tg));
+    long long *dst = reinterpret_cast<long long *>(static_cast<TreeHotH *>(tg));
     for (int i = threadIdx.x; i < (int)(sizeof(TreeHot) / 8); i += NT) dst[i] = src[i];
     if (threadIdx.x == 0)
         for (int i = 0; i < NSTAT; i++)
@@ -957,11 +995,11 @@ __device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeHot &t, int n)
         int cell[REBUILD_U], rk[REBUILD_U];
 #pragma unroll
         for (int u = 0; u < REBUILD_U; u++)
-            if (i0 + u * NT < n) v[u] = t.vrec[i0 + u * NT];
+            if (i0 + u * NT < n) v[u] = ldg(&t.vrec[i0 + u * NT]);
 #pragma unroll
         for (int u = 0; u < REBUILD_U; u++) cell[u] = i0 + u * NT < n ? cell_of(v[u]) : -1;
 #pragma unroll
-        for (int u = 0; u < REBUILD_U; u++) rk[u] = cell[u] >= 0 ? atomicAdd(&t.g_cnt[cell[u]], 1) : 0;
+        for (int u = 0; u < REBUILD_U; u++) rk[u] = cell[u] >= 0 ? __hip_atomic_fetch_add(&t.g_cnt[cell[u]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
 #pragma unroll
         for (int u = 0; u < REBUILD_U; u++)
             if (cell[u] >= 0) t.g_rank[i0 + u * NT] = rk[u];
@@ -989,7 +1027,7 @@ __device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeHot &t, int n)
         for (int u = 0; u < REBUILD_U; u++) {
             const int i = i0 + u * NT;
             rk[u] = 0;
-            if (i < n) { v[u] = t.vrec[i]; rk[u] = t.g_rank[i]; }
+            if (i < n) { v[u] = ldg(&t.vrec[i]); rk[u] = t.g_rank[i]; }
         }
 #pragma unroll
         for (int u = 0; u < REBUILD_U; u++) st[u] = i0 + u * NT < n ? t.g_start[cell_of(v[u])] : 0;
@@ -1200,7 +1238,7 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, co
 #pragma unroll
             for (int u = 0; u < GRID_U; u++) {
                 const int i = f0 + u * NT + tid;
-                if (i < n) v[u] = t.vrec[i];
+                if (i < n) v[u] = ldg(&t.vrec[i]);
             }
 #pragma unroll
             for (int u = 0; u < GRID_U; u++) {
@@ -1376,7 +1414,7 @@ __device__ __forceinline__ int walk_chains(const TreeHot &t, int (&idx)[WALK_R],
         Hop4 h[WALK_R];
 #pragma unroll
         for (int r = 0; r < WALK_R; r++)
-            if (idx[r] > 0 && idx[r] != stop_at) { h[r] = t.hop[idx[r]]; nrec++; }
+            if (idx[r] > 0 && idx[r] != stop_at) { h[r] = ldg(&t.hop[idx[r]]); nrec++; }
 #pragma unroll
         for (int r = 0; r < WALK_R; r++) {
             if (idx[r] > 0 && idx[r] != stop_at) {
@@ -1400,7 +1438,7 @@ __device__ __forceinline__ double walk_cost(const TreeHot &t, int i)
     double acc = 0.;
     int guard = t.cap + 1;
     while (i > 0 && guard-- > 0) {
-        Aux a = t.aux[i];
+        Aux a = ldg(&t.aux[i]);
         acc += a.elen;
         i = a.parent;
     }
@@ -1461,12 +1499,12 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v,
             int c = t.first_child[u];
             // hop[v] was refreshed by the caller; the records of the next three levels mention v's edge too
             Hop4 hu;
-            if (level < 3 && c >= 0) hu = t.hop[u];
+            if (level < 3 && c >= 0) hu = ldg(&t.hop[u]);
             while (c >= 0) {
                 int pos = atomicAdd(&s.bc_i[4], 1);
                 t.bfs_q[pos] = c;
                 if (level < 3) {   // entry 0 of the child's record (its own edge) is unchanged
-                    Hop4 &hc = t.hop[c];
+                    GAS Hop4 &hc = t.hop[c];
                     hc.e[1] = hu.e[0]; hc.e[2] = hu.e[1]; hc.e[3] = hu.e[2];
                     hc.a[1] = hu.a[0]; hc.a[2] = hu.a[1]; hc.a[3] = hu.a[2];
                 }
@@ -1528,7 +1566,7 @@ __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeHot &t, 
         double acc = 0.;
         int i = new_idx, len = 0, guard = t.cap + 1, nrec = 0;
         while (i > 0 && guard-- > 0) {
-            const Hop4 h = t.hop[i];
+            const Hop4 h = ldg(&t.hop[i]);
             nrec++;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1775,7 +1813,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
     ni = uni(ni);
     // coordinates and exact cost of the nearest vertex in one 32-byte record; the Near radii the iteration can need
     // (tree size unchanged for a "same point", + 1 otherwise) ride along in the same round trip
-    const VRec vnear = t.vrec[ni];
+    const VRec vnear = ldg(&t.vrec[ni]);
     const double r_same = t.near_r[n], r_grown = t.near_r[n + 1 <= t.cap ? n + 1 : n];
     nearest[0] = vnear.x; nearest[1] = vnear.y;
     if (D == 3) nearest[D - 1] = vnear.z;
@@ -1798,7 +1836,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
         bool inserted = false;
         if (dup) {
             new_idx = ni;
-            if (tid == 0) s.hop_new = t.hop[ni];   // only thread 0 reads it back
+            if (tid == 0) s.hop_new = ldg(&t.hop[ni]);   // only thread 0 reads it back
 #pragma unroll
             for (int k = 0; k < D; k++) node_new[k] = nearest[k];
         } else if (n >= t.cap) {
@@ -1808,18 +1846,18 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
             new_idx = n;
             if (tid == 0) {
                 // loads first (one round trip), then the stores
-                const Hop4 hp = t.hop[ni];
+                const Hop4 hp = ldg(&t.hop[ni]);
                 const int fc_ni = t.first_child[ni];
 #pragma unroll
                 for (int k = 0; k < D; k++) t.c[k][new_idx] = node_new[k];
                 Aux a;
                 a.elen = edge_new; a.parent = ni; a.pad = 0;
-                t.aux[new_idx] = a;
+                stg(&t.aux[new_idx], a);
                 s.hop_new = hop_shift(hp, edge_new, ni);
-                t.hop[new_idx] = s.hop_new;
+                stg(&t.hop[new_idx], s.hop_new);
                 VRec vr;
                 vr.x = node_new[0]; vr.y = node_new[1]; vr.z = D == 3 ? node_new[D - 1] : 0.; vr.cost = 0.;
-                t.vrec[new_idx] = vr;   // also its entry in the tail of the index
+                stg(&t.vrec[new_idx], vr);   // also its entry in the tail of the index
                 t.first_child[new_idx] = -1;
                 // link_child(new_idx, ni) with the head read above; new's own links are remembered for a re-parenting
                 t.next_sib[new_idx] = fc_ni;
@@ -1866,8 +1904,8 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
             if (reparented) {
                 if (tid == 0) {
                     // loads first (one round trip), then the stores
-                    const VRec vb = t.vrec[best_parent];
-                    const Hop4 hp = t.hop[best_parent];
+                    const VRec vb = ldg(&t.vrec[best_parent]);
+                    const Hop4 hp = ldg(&t.hop[best_parent]);
                     const int fc_bp = t.first_child[best_parent];
                     int old_p, nx, pv;
                     if (dup) { old_p = t.aux[new_idx].parent; nx = t.next_sib[new_idx]; pv = t.prev_sib[new_idx]; }
@@ -1882,7 +1920,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                     t.aux[new_idx].parent = best_parent;
                     t.aux[new_idx].elen = el;
                     s.hop_new = hop_shift(hp, el, best_parent);
-                    t.hop[new_idx] = s.hop_new;
+                    stg(&t.hop[new_idx], s.hop_new);
                     // link under the new parent; if that is the old parent again (its Near distance can beat the steer
                     // edge by an ulp) the head read above may be new_idx itself: use the list as the unlink left it
                     const int head = (best_parent == old_p && pv < 0) ? nx : fc_bp;
@@ -1967,7 +2005,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                         if (nx >= 0) t.prev_sib[nx] = pv;
                         t.aux[vj].parent = new_idx;
                         t.aux[vj].elen = el;
-                        t.hop[vj] = hop_shift(s.hop_new, el, new_idx);
+                        stg(&t.hop[vj], hop_shift(s.hop_new, el, new_idx));
                         const int head = (old_p == new_idx && pv < 0) ? nx : fc_new;   // vj may already hang under new ("same point")
                         t.next_sib[vj] = head;
                         t.prev_sib[vj] = -1;
@@ -2001,7 +2039,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                 // (a re-costed vertex marks itself on the list): the lowest index that passes is re-parented, its subtree re-costed,
                 // and the next round looks at what is left.  Sequential round trips = vertices actually rewired + 1.
                 auto passes = [&](int id) -> bool {
-                    const VRec vr = t.vrec[id];
+                    const VRec vr = ldg(&t.vrec[id]);
                     double d[D];
                     d[0] = vr.x - node_new[0]; d[1] = vr.y - node_new[1];
                     if (D == 3) d[D - 1] = vr.z - node_new[D - 1];
@@ -2026,7 +2064,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                     first = uni(block_min_int<NT>(s, first));
                     if (first == 0x7fffffff) break;
                     last = first;
-                    const VRec vr = t.vrec[first];
+                    const VRec vr = ldg(&t.vrec[first]);
                     double d[D];
                     d[0] = vr.x - node_new[0]; d[1] = vr.y - node_new[1];
                     if (D == 3) d[D - 1] = vr.z - node_new[D - 1];

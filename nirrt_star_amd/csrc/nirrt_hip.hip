@@ -29,7 +29,7 @@ struct RunDev {
 // lane i keeps word base+i of a 64-word window in a register, a word is fetched with v_readlane, and the window is
 // refilled with one coalesced load when the position leaves it (so a draw costs no memory round trip most of the time).
 struct WordStream {
-    const unsigned *w;
+    const GAS unsigned *w;
     long long n, pos;
     long long base;   // first word of the window, -1: nothing loaded
     unsigned reg;     // this lane's word of the window
@@ -113,7 +113,7 @@ namespace slim {
 #define NT_WIDE NIRRT_NT_WIDE
 #define NT_SLIM 64
 static_assert(NT_WIDE / 64 <= LDS_NW_MAX && NT_NARROW / 64 <= LDS_NW_MAX, "LdsData reduction slots: raise LDS_NW_MAX");
-static_assert(offsetof(TreeHot, pc) > offsetof(TreeHot, CL_C) && offsetof(TreeHot, g_x) > offsetof(TreeHot, c_update),
+static_assert(offsetof(TreeHotH, pc) > offsetof(TreeHotH, CL_C) && offsetof(TreeHotH, g_x) > offsetof(TreeHotH, c_update),
               "nirrt_set_informed / nirrt_set_cloud patch contiguous field ranges of the descriptor");
 static_assert(sizeof(LdsData) <= 10240, "LdsData must fit 16 times into a CU's 160 KB of LDS (16 one-wave trees per CU)");
 // nirrt_run: batches larger than the 2048 workgroup slots of the 128-thread kernels run one wave per tree (16 trees per
@@ -722,7 +722,7 @@ extern "C" int nirrt_set_informed(nirrt_tree *t, double c_min, const double *x_c
     t->host.c_min = c_min;
     for (int k = 0; k < 3; k++) t->host.x_center[k] = k < t->dim ? x_center[k] : 0.;
     for (int k = 0; k < 9; k++) t->host.CL_C[k] = C[k];
-    const size_t off = offsetof(TreeHot, c_min), end = offsetof(TreeHot, pc);   // c_min, x_center, CL_C
+    const size_t off = offsetof(TreeHotH, c_min), end = offsetof(TreeHotH, pc);   // c_min, x_center, CL_C
     HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, end - off, hipMemcpyHostToDevice, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     return NIRRT_OK;
@@ -748,7 +748,7 @@ extern "C" int nirrt_set_cloud(nirrt_tree *t, int64_t n, const double *pts, doub
     t->host.pc_rate = sample_rate;
     t->host.pc_ratio = update_cost_ratio;
     t->host.c_update = c_update;
-    const size_t off = offsetof(TreeHot, pc), end = offsetof(TreeHot, g_x);   // pc, pc_n, pc_rate, pc_ratio, c_update
+    const size_t off = offsetof(TreeHotH, pc), end = offsetof(TreeHotH, g_x);   // pc, pc_n, pc_rate, pc_ratio, c_update
     HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, end - off, hipMemcpyHostToDevice, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     return NIRRT_OK;
