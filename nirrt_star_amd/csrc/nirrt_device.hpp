@@ -64,6 +64,16 @@ __device__ __forceinline__ void stg(GAS T *p, const T &v)
     for (unsigned i = 0; i < sizeof(T) / 16; i++) g[i] = o[i];
 }
 
+#ifndef NIRRT_WAVES_PER_EU
+#define NIRRT_WAVES_PER_EU 4   // second __launch_bounds__ argument of the persistent kernels (register budget 512 / this)
+#endif
+// Out-of-line device functions (NIRRT_FN) get their register budget from the kernels that reach them: the compiler gives a
+// callee the union of its callers' waves-per-EU ranges, so EVERY kernel of the library carries the same second launch
+// bound - one kernel without it would lift the limit for the shared callees, and with them for every kernel that calls them
+// `static`: internal linkage makes the definition exact, which is what lets the inter-procedural register allocation use
+// the callee's real clobber set at the call sites (a template's linkonce_odr body "may be replaced" and counts as unknown)
+#define NIRRT_FN static __noinline__
+
 #define MAX_OBS NIRRT_MAX_OBSTACLES
 #ifndef LDS_POOL
 #define LDS_POOL 800     // 8-byte LDS slots shared by the obstacle tables (4 per round + 6 per box obstacle) and the Near stash
@@ -169,15 +179,21 @@ struct __attribute__((aligned(32))) VRec {
     double cost;   // exact cost(v) of the CURRENT tree (see walk_chains / wg_recost_subtree)
 };
 
+// one slot of the grid index (see "uniform-grid index"): what a query needs about a vertex, in one 32-byte record
+struct __attribute__((aligned(32))) GSlot {
+    double x, y;
+    double cost;   // exact cost(v), kept in step with vrec[v].cost
+    double w;      // 2D: the vertex index (integer bit pattern in the low word); 3D: z (the index is in g_idx[slot])
+};
+
 // The part of a tree descriptor the loop body touches: copied into LDS when a kernel starts (hot_enter) and written back when
 // it ends (hot_leave), so that a pointer or a counter of the tree costs an LDS read instead of a dependent scalar load from HBM
 // (16 trees per CU x ~700 B of descriptor do not live in the scalar cache).
 template <template <typename> class P>
 struct TreeHotT {
-    typename P<double>::type c[3];   // SoA coordinates x[cap], y[cap], z[cap] (exact values, insertion order; download + exact fallback scans)
     typename P<Aux>::type aux;       // aux[cap]
     typename P<Hop4>::type hop;      // hop[cap]: aux of the vertex and of its next three ancestors (kept in step with aux)
-    typename P<VRec>::type vrec;     // vrec[cap]: coordinates + exact cost, insertion order (random access AND the tail of the index)
+    typename P<VRec>::type vrec;     // vrec[cap]: coordinates + exact cost by vertex index (random access, download)
     typename P<int>::type first_child, next_sib, prev_sib;   // child lists (-1 = none); the root is nobody's child
     typename P<int>::type bfs_q;     // scratch queue for subtree traversals
     typename P<double>::type chain_g;   // edge lengths of the chain new -> root beyond the first CHAIN_MAX (which live in LDS)
@@ -224,11 +240,11 @@ struct TreeHotT {
     double pc_rate;          // pc_sample_rate
     double pc_ratio;         // pc_update_cost_ratio
     double c_update;         // best cost at the last cloud refresh (inf before the first solution)
-    // uniform-grid index (see "uniform-grid index" below): float64 mirror of vertices [0, g_ns) ordered by cell
-    typename P<double>::type g_x[3];          // coordinates by slot
-    typename P<double>::type g_cost;          // exact cost(v) by slot, kept in step with vrec[v].cost
-    typename P<int>::type g_idx;              // vertex index by slot
-    typename P<int>::type pos;                // slot of vertex i (valid for i < g_ns)
+    // uniform-grid index (see "uniform-grid index" below): one 32-byte record per SLOT - slots [0, g_ns) hold vertices
+    // [0, g_ns) ordered by cell, slots [g_ns, n) the vertices appended since (slot i = vertex i): a query streams slot ranges only
+    typename P<GSlot>::type g_rec;            // coordinates + exact cost(v) (kept in step with vrec[v].cost) + index (2D) / z (3D)
+    typename P<int>::type g_idx;              // 3D: vertex index by slot
+    typename P<int>::type pos;                // slot of vertex i (valid for i < g_ns; slot i otherwise)
     typename P<int>::type g_start;            // g_start[c] .. g_start[c+1]: slots of cell c inside [0, g_ns); g_ncell + 1 entries
     typename P<int>::type g_cnt;              // rebuild scratch: per-cell counters
     typename P<int>::type g_rank;             // rebuild scratch: rank of vertex i inside its cell
@@ -296,14 +312,19 @@ struct LdsData {
     int new_next, new_fc;         // thread 0: next sibling of the vertex inserted this iteration / head of its child list
     int ob_n;                     // obstacles whose inflated box meets the Near ball's box
     unsigned char ob_list[2 * MAX_OBS];
-    int rg_beg[GRID_RG_MAX], rg_len[GRID_RG_MAX];
-    unsigned char rg_flag[GRID_RG_MAX];
+    int rg_beg[GRID_RG_MAX + 1], rg_len[GRID_RG_MAX + 1];   // + 1: the appended vertices [g_ns, n)
+    unsigned char rg_flag[GRID_RG_MAX + 4];
+    struct {                      // arguments / results of wg_query_fn
+        double pn[3], q[3], r, floor_m, cand;
+        int n, want, new_idx, lds_cap, ni, cj;
+    } qa;
     int n_cand;                   // rewire: members whose stashed margin reaches cost(new) (the stash is compacted to them)
     int cand_listed;              // ... all of them are in the LDS list (else: the spilled part is searched per round)
     long long stat[NSTAT];
 };
 template <int NT>
 using Lds = LdsData;   // the per-instantiation name the device functions use
+__shared__ LdsData g_lds;   // the one LDS object of the library (see above); out-of-line helpers address it directly
 
 
 // ------------------------------------------------------------------------------------------------
@@ -344,7 +365,7 @@ __device__ __forceinline__ double hypot_np(double x, double y)
 
 // CPython 3.10 Modules/mathmodule.c vector_norm() on (x, y[, z]); z == 0 contributes exact zeros,
 // so the 2-argument call is the same code with z = 0.
-__device__ __noinline__ double hypot_py3(double x0, double x1, double x2, int nd)
+NIRRT_FN __device__ double hypot_py3(double x0, double x1, double x2, int nd)
 {
     const double T27 = 134217729.0;
     double vec[3] = {fabs(x0), fabs(x1), fabs(x2)};
@@ -864,21 +885,73 @@ template <int D>
 __device__ __forceinline__ void load_vertex(const TreeHot &t, int i, double *v)
 {
 #pragma unroll
-    for (int k = 0; k < D; k++) v[k] = t.c[k][i];
+    for (int k = 0; k < D; k++) v[k] = k == 0 ? t.vrec[i].x : (k == 1 ? t.vrec[i].y : t.vrec[i].z);
 }
 
-// exact (reference-formula) nearest scan over the SoA coordinates; only used when a visit sees a near-tie
-template <int D, int NT>
-__device__ __noinline__ int wg_nearest_exact(Lds<NT> &s, const TreeHot &t, int n, const double *q)
+// slot record helpers (GSlot: x, y, cost, w; w = the vertex index in 2D, z in 3D - there the index sits in g_idx[])
+template <int D>
+__device__ __forceinline__ GSlot slot_make(const double *v, double cost, int id)
 {
+    GSlot g;
+    g.x = v[0]; g.y = v[1];
+    g.cost = cost;
+    g.w = D == 3 ? v[D - 1] : __longlong_as_double((long long)id);
+    return g;
+}
+typedef double nirrt_v2d __attribute__((ext_vector_type(2)));
+typedef unsigned nirrt_v3u __attribute__((ext_vector_type(3)));
+// the fields of slot sl, fetched with loads whose every register is used (x, y: 16 bytes; 2D: cost + index 12 bytes;
+// 3D: cost + z 16 bytes and the index word) - a wider load with a dead lane would let the register allocator recycle that
+// lane and wait for the load right after issuing it
+template <int D>
+__device__ __forceinline__ void slot_load(const TreeHot &t, int sl, double &x, double &y, double &z, double &c, int &id)
+{
+    const GAS char *p = (const GAS char *)(t.g_rec + sl);
+    const nirrt_v2d xy = *(const GAS nirrt_v2d *)p;
+    x = xy.x; y = xy.y;
+    if (D == 2) {
+        const nirrt_v3u b = *(const GAS nirrt_v3u *)(p + 16);
+        c = __longlong_as_double(((long long)b.y << 32) | (long long)b.x);
+        id = (int)b.z;
+        z = 0.;
+    } else {
+        const nirrt_v2d cz = *(const GAS nirrt_v2d *)(p + 16);
+        c = cz.x; z = cz.y;
+        id = t.g_idx[sl];
+    }
+}
+
+// out-of-line forms of the rare, long paths of a visit (one copy each in the code; the visit loop stays compact)
+NIRRT_FN __device__ double hypot_np_cold(double x, double y) { return hypot_np(x, y); }
+template <int D>
+__device__ __forceinline__ double dist_scan_cold(double dx, double dy, double dz)
+{
+    if (D == 2) return hypot_np_cold(dx, dy);
+    return __builtin_sqrt(dx * dx + dy * dy + dz * dz);
+}
+// exact segment test against obstacle #o of the LDS tables
+template <int D>
+NIRRT_FN __device__ bool seg_obstacle_cold(int o, double ax, double ay, double az, double bx, double by, double bz)
+{
+    const double a[3] = {ax, ay, az}, b[3] = {bx, by, bz};
+    return seg_obstacle<D, 64>(g_lds, o, a, b, g_lds.k_clr);
+}
+
+// exact (reference-formula) nearest scan over every slot; only used when a visit sees a near-tie
+template <int D, int NT>
+NIRRT_FN __device__ int wg_nearest_exact(int n, double q0, double q1, double q2)
+{
+    Lds<NT> &s = g_lds;
+    const TreeHot &t = g_lds.hot;
     double bd = __builtin_inf();
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < n; i += NT) {
-        double d[D];
-#pragma unroll
-        for (int k = 0; k < D; k++) d[k] = q[k] - t.c[k][i];
+    for (int sl = threadIdx.x; sl < n; sl += NT) {
+        double gx, gy, gz, gc;
+        int id;
+        slot_load<D>(t, sl, gx, gy, gz, gc, id);
+        double d[3] = {q0 - gx, q1 - gy, D == 3 ? q2 - gz : 0.};
         double h = dist_scan<D>(d);
-        if (h < bd) { bd = h; bi = i; }
+        if (h < bd || (h == bd && id < bi)) { bd = h; bi = id; }
     }
     block_argmin<NT>(s, bd, bi);
     return bi;
@@ -921,14 +994,14 @@ __device__ __forceinline__ int wg_nearest_finish(Lds<NT> &s, double m1, int i1, 
 
 // ------------------------------------------------------------------------------------------------
 // uniform-grid index.  The reference scans every vertex for nearest_neighbor and find_near_neighbors; the
-// answers only depend on the vertices inside a small ball around the query, so large trees keep a float64 mirror
-// of their vertices ordered by cell of a G^D grid over the range box (g_x / g_cost / g_idx [0, g_ns), rebuilt by
-// a counting sort every GRID_REBUILD_EVERY insertions); vertices [g_ns, n) - the tail - are read from their
-// records vrec[] in insertion order.  A query visits the rows of cells (contiguous slot ranges) that intersect its
-// box plus the tail.  Completeness: cell(x) is monotone in x per axis, so every vertex within `rad` of p (per axis)
-// lies in a cell of grid_box(p, rad) (g_margin is slack on top); vertices outside the range box fall into border
-// cells, which extend to infinity.  The order inside a cell is whatever the atomics produce; no result depends on
-// it (minima are reduced as (value, index) pairs, rewire selects by index).
+// answers only depend on the vertices inside a small ball around the query, so every vertex has a 32-byte SLOT record
+// (coordinates, exact cost, index): slots [0, g_ns) hold vertices [0, g_ns) ordered by cell of a G^D grid over the range
+// box (rebuilt by a counting sort every GRID_REBUILD_EVERY insertions), slots [g_ns, n) the vertices appended since, in
+// insertion order.  A query visits the rows of cells (contiguous slot ranges) that intersect its box plus the appended
+// range - ONE loop over a list of slot ranges.  Completeness: cell(x) is monotone in x per axis, so every vertex within
+// `rad` of p (per axis) lies in a cell of grid_box(p, rad) (g_margin is slack on top); vertices outside the range box
+// fall into border cells, which extend to infinity.  The order inside a cell is whatever the atomics produce; no result
+// depends on it (minima are reduced as (value, index) pairs, rewire selects by index).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int grid_cell_axis(const TreeHot &t, int k, double x)
 {
@@ -978,10 +1051,12 @@ __device__ __forceinline__ int block_excl_scan(Lds<NT> &s, int v, int &off)
     return tot;
 }
 
-// counting sort of vertices [0, n) by cell into the float64 mirror.
+// counting sort of vertices [0, n) by cell into the slot records (one 32-byte store per vertex + its pos[] entry)
 template <int D, int NT>
-__device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeHot &t, int n)
+NIRRT_FN __device__ void wg_grid_rebuild(int n)
 {
+    Lds<NT> &s = g_lds;
+    TreeHot &t = g_lds.hot;
     const int tid = threadIdx.x, nc = t.g_ncell, G = t.g_G;
     for (int c = tid; c < nc; c += NT) t.g_cnt[c] = 0;
     __syncthreads();
@@ -999,7 +1074,8 @@ __device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeHot &t, int n)
 #pragma unroll
         for (int u = 0; u < REBUILD_U; u++) cell[u] = i0 + u * NT < n ? cell_of(v[u]) : -1;
 #pragma unroll
-        for (int u = 0; u < REBUILD_U; u++) rk[u] = cell[u] >= 0 ? __hip_atomic_fetch_add(&t.g_cnt[cell[u]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+        for (int u = 0; u < REBUILD_U; u++)
+            rk[u] = cell[u] >= 0 ? __hip_atomic_fetch_add(&t.g_cnt[cell[u]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
 #pragma unroll
         for (int u = 0; u < REBUILD_U; u++)
             if (cell[u] >= 0) t.g_rank[i0 + u * NT] = rk[u];
@@ -1036,10 +1112,9 @@ __device__ __forceinline__ void wg_grid_rebuild(Lds<NT> &s, TreeHot &t, int n)
             const int i = i0 + u * NT;
             if (i < n) {
                 const int sl = st[u] + rk[u];
-                t.g_x[0][sl] = v[u].x; t.g_x[1][sl] = v[u].y;
-                if (D == 3) t.g_x[D - 1][sl] = v[u].z;
-                t.g_cost[sl] = v[u].cost;
-                t.g_idx[sl] = i;
+                const double xyz[3] = {v[u].x, v[u].y, v[u].z};
+                stg(&t.g_rec[sl], slot_make<D>(xyz, v[u].cost, i));
+                if (D == 3) t.g_idx[sl] = i;
                 t.pos[i] = sl;
             }
         }
@@ -1070,27 +1145,45 @@ struct NearResult {
     int n_stash;    // members on the stash (<= k): those whose margin cost - dist exceeds the caller's floor
 };
 
+// one visited slot in registers
+struct SlotRegs {
+    double x, y, z, c;
+    int id;
+    unsigned fl;
+};
+
 // ONE fused query (find_near_neighbors rrt_star_2d.py:125-144 + choose_parent's argmin :80-90 + the nearest_neighbor
 // rrt_base_2d.py:94-107 of another point):
 //   pn != nullptr: Near set of pn with radius r on the current tree -> *nr; member (index, bound) pairs go to the
 //                  stash: entries [0, lds_cap) in LDS, the rest in t.nr_idx / t.nr_m;
 //   q  != nullptr: *ni = argmin_i dist(q, v_i), lowest index on ties (np.argmin).
+// Structure: a list of slot ranges in LDS is visited by ONE loop (GRID_U slots per lane and trip, the next trip's records
+// requested before the current trip is evaluated); the list is first the appended vertices [g_ns, n) - visited while the
+// g_start words of the cell rows are in flight -, then the rows, then (nearest only) whatever a widened box adds.
+// The query is a real call with its arguments and results in LDS (s.qa): its loops then get a register allocation of their
+// own instead of sharing the file with everything the loop body keeps alive around them (which spilled into those loops).
 template <int D, int NT>
-__device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, const double *pn, double r, int new_idx,
-                                         const double *q, int *ni, NearResult *nr, int lds_cap,
-                                         double floor_m = -__builtin_inf())
+NIRRT_FN __device__ void wg_query_fn()
 {
+    Lds<NT> &s = g_lds;
+    const TreeHot &t = g_lds.hot;
     const int tid = threadIdx.x, lane = tid & 63, G = t.g_G;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    __syncthreads();   // s.qa is in place
+    if (tid == 0) { s.ob_n = 0; s.hit_cnt = 0; s.mem_cnt = 0; }
     const int ns = uni(t.g_ns);
-    const bool wantN = pn != nullptr, wantQ = q != nullptr;
+    const int n = uni(s.qa.n);
+    const bool wantN = (uni(s.qa.want) & 1) != 0, wantQ = (uni(s.qa.want) & 2) != 0;
+    // everything the loop compares with is the same in every lane: scalar registers
+    const double r = uni(s.qa.r), floor_m = uni(s.qa.floor_m);
+    const int new_idx = uni(s.qa.new_idx), lds_cap = uni(s.qa.lds_cap);
     const double r2 = r * r, r2lo = r2 * BAND_LO, r2hi = r2 * BAND_HI;
-    const double clr = s.k_clr;
-    long long visited = 0, vbytes = 0;
+    const double pnx = uni(s.qa.pn[0]), pny = uni(s.qa.pn[1]), pnz = D == 3 ? uni(s.qa.pn[2]) : 0.;
+    const double qx = uni(s.qa.q[0]), qy = uni(s.qa.q[1]), qz = D == 3 ? uni(s.qa.q[2]) : 0.;
+    const double pnv[3] = {pnx, pny, pnz}, qv[3] = {qx, qy, qz};
+    long long visited = 0;
     int revisits = 0, brutes = 0;
     PROF_DECL
-    __syncthreads();
-    if (tid == 0) { s.ob_n = 0; s.hit_cnt = 0; s.mem_cnt = 0; }
     __syncthreads();
     // obstacles whose inflated box meets the box of the Near ball: a segment new -> v_j (|v_j - new| <= r per axis)
     // can only pass the AABB prefilter of those.  Same comparisons as seg_aabb_pass, on a superset of every segment's box.
@@ -1100,7 +1193,7 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, co
             const double rb = r * (1.0 + 1e-9);
             double l0[3], l1[3];
 #pragma unroll
-            for (int c = 0; c < D; c++) { l0[c] = pn[c] - rb; l1[c] = pn[c] + rb; }
+            for (int c = 0; c < D; c++) { l0[c] = pnv[c] - rb; l1[c] = pnv[c] + rb; }
             if (seg_aabb_pass<D, NT>(s, o, l0, l1)) s.ob_list[atomicAdd(&s.ob_n, 1)] = (unsigned char)o;
         }
     }
@@ -1136,45 +1229,56 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, co
         if (!empty) { b = t.g_start[base + x0]; e = t.g_start[base + x1 + 1]; }
         rb = b; rl = e;     // first slot / end slot: nothing is computed from the two loads here, so they stay in flight
     };
-    auto put_row = [&](int slot, const int (&c0)[3], const int (&c1)[3], int row, int flag, const double *ball, double rad) {
-        int b, e;
-        row_range(c0, c1, row, ball, rad, b, e);
-        s.rg_beg[slot] = b; s.rg_len[slot] = e - b; s.rg_flag[slot] = flag;
-    };
     int nb0[3] = {0, 0, 0}, nb1[3] = {0, 0, 0}, qb0[3] = {0, 0, 0}, qb1[3] = {0, 0, 0};
     int rowsN = 0, rowsQ = 0;
     // whole-tree visit: no index yet, or a box of more rows than the range list holds (never the case for the Near
-    // radius of an indexed tree): every vertex is read from its record
+    // radius of an indexed tree)
     bool brute = ns == 0;
     if (!brute) {
-        if (wantN) { grid_box<D>(t, pn, r, nb0, nb1); rowsN = grid_rows(nb0, nb1); }
+        if (wantN) { grid_box<D>(t, pnv, r, nb0, nb1); rowsN = grid_rows(nb0, nb1); }
         if (wantQ) {
             // first guess: the cells within 1.5x the typical nearest distance seen so far (the cell of q itself at first)
-            grid_box<D>(t, q, 1.5 * t.g_rho, qb0, qb1);
+            grid_box<D>(t, qv, 1.5 * t.g_rho, qb0, qb1);
             rowsQ = grid_rows(qb0, qb1);
         }
         if (rowsN + rowsQ > GRID_RG_MAX) brute = true;
+    }
+    const unsigned fl_all = (wantN ? GRID_N : 0u) | (wantQ ? GRID_Q : 0u);
+    // the rows' slot ranges (two g_start loads per row; rowsN + rowsQ <= GRID_RG_MAX <= NT: one row per thread) are
+    // requested now and consumed after the first pass of the loop
+    int rb = 0, rl = 0;
+    if (!brute) {
+        if (tid < rowsN) row_range(nb0, nb1, tid, pnv, r, rb, rl);
+        else if (tid < rowsN + rowsQ) row_range(qb0, qb1, tid - rowsN, nullptr, 0., rb, rl);
+    }
+    if (tid == 0) {
+        const int beg = brute ? 0 : ns;
+        s.rg_beg[0] = beg; s.rg_len[0] = n - beg; s.rg_flag[0] = (unsigned char)fl_all; s.rg_n = 1;
     }
     double m1 = __builtin_inf(), m2 = __builtin_inf();   // nearest: smallest / second-smallest squared distance of this lane
     int i1 = 0x7fffffff;
     double cand = __builtin_inf();                        // Near: this lane's best cost + dist
     int cj = 0x7fffffff;
+    int n_mem = 0;                                        // members seen by this wave
     __syncthreads();
     const int n_ob = wantN ? uni(s.ob_n) : 0;
-    // one visited vertex (coordinates, exact cost, index) of a range flagged fl; true = Near member (sm = cost - dist, what
-    // rewire compares with cost(new) later: members of a dense, well optimised tree sit within 1e-5 of that threshold by the
-    // dozen, so the margin is kept in full float64)
-    auto process = [&](double px, double py, double pz, double pcost, int id, unsigned fl, double &sm) -> bool {
-        if (fl & GRID_Q) {
-            double d[3] = {q[0] - px, q[1] - py, D == 3 ? q[D - 1] - pz : 0.};
-            const double wv = dist2<D>(d);
-            if (wv < m1 || (wv == m1 && id < i1)) { m2 = m1; m1 = wv; i1 = id; } else if (wv < m2) m2 = wv;
+    if (brute) brutes++;
+    PROF(20);
+    // one visited slot; true = Near member (sm = cost - dist, what rewire compares with cost(new) later: members of a dense,
+    // well optimised tree sit within 1e-5 of that threshold by the dozen, so the margin is kept in full float64)
+    auto process = [&](const SlotRegs &p, double &sm) -> bool {
+        if (p.fl & GRID_Q) {
+            const double dx = qx - p.x, dy = qy - p.y;
+            double wv = dx * dx + dy * dy;
+            if (D == 3) { const double dz = qz - p.z; wv = wv + dz * dz; }
+            if (wv < m1 || (wv == m1 && p.id < i1)) { m2 = m1; m1 = wv; i1 = p.id; } else if (wv < m2) m2 = wv;
         }
         bool member = false;
-        if (fl & GRID_N) {
-            double d[3] = {pn[0] - px, pn[1] - py, D == 3 ? pn[D - 1] - pz : 0.};
-            const double v = dist2<D>(d);
-            if (v <= r2hi && id != new_idx) {
+        if (p.fl & GRID_N) {
+            const double dx = pnx - p.x, dy = pny - p.y, dz = D == 3 ? pnz - p.z : 0.;
+            double v = dx * dx + dy * dy;
+            if (D == 3) v = v + dz * dz;
+            if (v <= r2hi && p.id != new_idx) {
                 // d_j: the reference's own distance (glibc hypot in 2D) decides inside the guard band and is what choose_parent
                 // adds - but it is only evaluated where it can matter: sqrt(v) is within 2 ulp of it, which settles every
                 // member that is not in the band and cannot reach this lane's best cost + dist so far
@@ -1183,36 +1287,35 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, co
                 double dj = ds;
                 bool hit = v <= r2lo;
                 if (!hit) {
-                    if (!exact) { dj = dist_scan<D>(d); exact = true; }
+                    if (!exact) { dj = dist_scan_cold<D>(dx, dy, dz); exact = true; }
                     hit = dj <= r;
                 }
                 if (hit) {
                     bool col = false;
                     if (n_ob > 0) {
-                        double vj[3] = {px, py, pz}, l0[3], l1[3];
-#pragma unroll
-                        for (int c = 0; c < D; c++) { l0[c] = fmin(pn[c], vj[c]); l1[c] = fmax(pn[c], vj[c]); }
+                        double l0[3], l1[3];
+                        l0[0] = fmin(pnx, p.x); l1[0] = fmax(pnx, p.x); l0[1] = fmin(pny, p.y); l1[1] = fmax(pny, p.y);
+                        if (D == 3) { l0[D - 1] = fmin(pnz, p.z); l1[D - 1] = fmax(pnz, p.z); }
                         for (int j = 0; j < n_ob && !col; j++) {
                             const int o = s.ob_list[j];
-                            if (seg_aabb_pass<D, NT>(s, o, l0, l1)) col = seg_obstacle<D, NT>(s, o, pn, vj, clr);
+                            if (seg_aabb_pass<D, NT>(s, o, l0, l1)) col = seg_obstacle_cold<D>(o, pnx, pny, pnz, p.x, p.y, D == 3 ? p.z : 0.);
                         }
                     }
                     if (!col) {
                         member = true;
-                        double c = pcost + dj;
-                        if (!exact && c <= cand * (1.0 + 0x1p-40)) c = pcost + dist_scan<D>(d);   // cand is always an exact value
-                        if (c < cand || (c == cand && id < cj)) { cand = c; cj = id; }
-                        sm = pcost - ds;               // margin for rewire's search (tolerance there >> 2 ulp)
+                        double c = p.c + dj;
+                        if (!exact && c <= cand * (1.0 + 0x1p-40)) c = p.c + dist_scan_cold<D>(dx, dy, dz);   // cand is always an exact value
+                        if (c < cand || (c == cand && p.id < cj)) { cand = c; cj = p.id; }
+                        sm = p.c - ds;               // margin for rewire's search (tolerance there >> 2 ulp)
                     }
                 }
             }
         }
         return member;
     };
-    // members of one trip slot -> stash positions (wave ballot + one LDS atomic per wave); every lane of the wave is here
+    // members of one trip slot -> stash positions (wave ballot + one LDS atomic per wave); every lane of the wave is here.
     // Only members whose margin exceeds floor_m are kept: the caller passes a lower bound of cost(new), below which
     // rewire's test cannot pass (wg_iteration); the others are merely counted.
-    int n_mem = 0;   // members seen by this wave
     auto stash = [&](bool member, int id, double sm) {
         n_mem += __popcll(__ballot(member));
         const bool keep = member && sm > floor_m;
@@ -1228,157 +1331,128 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, co
             }
         }
     };
-    // vertices [beg, n) straight from their records (the tail of the index, or the whole tree); uniform trip counts,
-    // GRID_U records per lane and trip, all loads issued before the first use
-    auto visit_records = [&](int beg, unsigned fl) {
-        visited += n - beg;
-        vbytes += (long long)(n - beg) * (long long)sizeof(VRec);
-        for (int f0 = beg; f0 < n; f0 += NT * GRID_U) {
-            VRec v[GRID_U];
-#pragma unroll
-            for (int u = 0; u < GRID_U; u++) {
-                const int i = f0 + u * NT + tid;
-                if (i < n) v[u] = ldg(&t.vrec[i]);
-            }
-#pragma unroll
-            for (int u = 0; u < GRID_U; u++) {
-                if (f0 + u * NT < n) {   // uniform
-                    const int i = f0 + u * NT + tid;
-                    double sm = 0.;
-                    const bool member = i < n ? process(v[u].x, v[u].y, v[u].z, v[u].cost, i, fl, sm) : false;
-                    if (fl & GRID_N) stash(member, i, sm);
-                }
-            }
-        }
-    };
-    // the slot ranges in s.rg_* from the cell-ordered mirror
-    auto visit_ranges = [&]() {
-        const int R = uni(s.rg_n);
-        int total = 0;
-        for (int i = 0; i < R; i++) total += s.rg_len[i];
-        visited += total;
-        vbytes += (long long)total * (8 * D + 12);
-        // a lane's flat offsets only grow (with u and with the trip), so its position in the range list is carried along
-        int rr = 0, r_lo = 0, r_hi = R > 0 ? s.rg_len[0] : 0, r_beg = R > 0 ? s.rg_beg[0] : 0;
-        unsigned r_flag = R > 0 ? (unsigned)s.rg_flag[0] : 0u;
-        for (int f0 = 0; f0 < total; f0 += NT * GRID_U) {
-            double px[GRID_U], py[GRID_U], pz[GRID_U], pc[GRID_U];
-            int id[GRID_U];
-            unsigned flag[GRID_U];
-#pragma unroll
-            for (int u = 0; u < GRID_U; u++) {
-                const int off = f0 + u * NT + tid;
-                px[u] = 0.; py[u] = 0.; pz[u] = 0.; pc[u] = 0.; id[u] = 0;
-                flag[u] = 0u;
-                if (off < total) {
+    int stage = brute ? 2 : 0;   // 0: the appended range is being visited, the rows come next; 1: rows visited; 2: nearest widening / whole tree
+    int pass = 0;
+    double ring = 0.;
+    int result_ni = -1;
+#pragma nounroll
+    for (;;) {
+        // ---------------- visit the ranges listed in s.rg_* ----------------
+        {
+            const int R = uni(s.rg_n);
+            int total = 0;
+            for (int i = 0; i < R; i++) total += s.rg_len[i];
+            total = uni(total);
+            visited += total;
+            // a lane's flat offsets only grow (with u and with the trip), so its position in the range list is carried along
+            int rr = 0, r_lo = 0, r_hi = s.rg_len[0], r_beg = s.rg_beg[0];
+            unsigned r_flag = (unsigned)s.rg_flag[0];
+            // the loads are issued unconditionally (lanes past the end read slot 0 and get flag 0): a load behind a branch would
+            // make the number of loads in flight unknown to the wait-count insertion, which then waits for all of them
+            auto fetch = [&](int off, SlotRegs &o) {
+                const bool live = off < total;
+                if (live) {
                     while (off >= r_hi) {
                         rr++;
                         r_lo = r_hi;
                         r_hi += s.rg_len[rr]; r_beg = s.rg_beg[rr]; r_flag = (unsigned)s.rg_flag[rr];
                     }
-                    const int sl = r_beg + (off - r_lo);
-                    px[u] = t.g_x[0][sl]; py[u] = t.g_x[1][sl];
-                    if (D == 3) pz[u] = t.g_x[D - 1][sl];
-                    pc[u] = t.g_cost[sl];
-                    id[u] = t.g_idx[sl];
-                    flag[u] = r_flag;
                 }
-            }
+                const int sl = live ? r_beg + (off - r_lo) : 0;
+                slot_load<D>(t, sl, o.x, o.y, o.z, o.c, o.id);
+                o.fl = live ? r_flag : 0u;
+            };
+            SlotRegs cur[GRID_U], nxt[GRID_U];
 #pragma unroll
-            for (int u = 0; u < GRID_U; u++) {
-                if (f0 + u * NT < total) {   // uniform
-                    double sm = 0.;
-                    const bool member = flag[u] ? process(px[u], py[u], pz[u], pc[u], id[u], flag[u], sm) : false;
-                    if (wantN) stash(member, id[u], sm);
+            for (int u = 0; u < GRID_U; u++) fetch(u * NT + tid, cur[u]);
+#pragma nounroll
+            for (int f0 = 0; f0 < total; f0 += NT * GRID_U) {
+#pragma unroll
+                for (int u = 0; u < GRID_U; u++) fetch(f0 + NT * GRID_U + u * NT + tid, nxt[u]);   // (past the end: dummy loads)
+#pragma unroll
+                for (int u = 0; u < GRID_U; u++) {
+                    if (f0 + u * NT < total) {   // uniform
+                        double sm = 0.;
+                        const bool member = cur[u].fl ? process(cur[u], sm) : false;
+                        if (wantN) stash(member, cur[u].id, sm);
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < GRID_U; u++) cur[u] = nxt[u];
             }
         }
-    };
-    const unsigned fl_all = (wantN ? GRID_N : 0u) | (wantQ ? GRID_Q : 0u);
-    if (brute) {
-        brutes++;
-        visit_records(0, fl_all);
-    } else {
-        // the rows' slot ranges (two g_start loads per row; rowsN + rowsQ <= GRID_RG_MAX <= NT: one row per thread) are
-        // requested first, the tail is visited while they are in flight, then the range list goes to LDS
-        int rb = 0, rl = 0;
-        if (tid < rowsN) row_range(nb0, nb1, tid, pn, r, rb, rl);
-        else if (tid < rowsN + rowsQ) row_range(qb0, qb1, tid - rowsN, nullptr, 0., rb, rl);
-        PROF(20);
-        visit_records(ns, fl_all);
-        if (tid < rowsN + rowsQ) { s.rg_beg[tid] = rb; s.rg_len[tid] = rl - rb; s.rg_flag[tid] = tid < rowsN ? GRID_N : GRID_Q; }
-        if (tid == 0) s.rg_n = rowsN + rowsQ;
-        __syncthreads();
-        visit_ranges();
-    }
-    PROF(13);
-    int result_ni = -1;
-    if (wantQ) {
+        if (stage == 0) {
+            // the rows of cells: the range list goes to LDS now (their g_start words have had the first pass to arrive)
+            __syncthreads();
+            if (tid < rowsN + rowsQ) { s.rg_beg[tid] = rb; s.rg_len[tid] = rl - rb; s.rg_flag[tid] = tid < rowsN ? GRID_N : GRID_Q; }
+            if (tid == 0) s.rg_n = rowsN + rowsQ;
+            __syncthreads();
+            stage = 1;
+            PROF(13);
+            if (rowsN + rowsQ > 0) continue;
+        }
+        if (!wantQ) break;
         // widen the box until it provably contains the nearest vertex: nothing found -> one more ring of cells (twice),
         // something found -> the box of the ball through the winner's distance (then final)
-        double ring = 0.;
-        for (int pass = 0;; pass++) {   // uniform
-            double g1;
-            const int gi = wg_nearest_finish<D, NT>(s, m1, i1, m2, &g1);
-            if (brute) {   // the whole tree was visited
-                result_ni = gi >= 0 ? gi : wg_nearest_exact<D, NT>(s, t, n, q);
+        double g1;
+        const int gi = wg_nearest_finish<D, NT>(s, m1, i1, m2, &g1);
+        if (brute) {   // the whole tree was visited
+            result_ni = gi >= 0 ? gi : wg_nearest_exact<D, NT>(n, qx, qy, qz);
+            break;
+        }
+        int eb0[3], eb1[3];
+        if (g1 == __builtin_inf()) {
+            double h = 0.;
+#pragma unroll
+            for (int k = 0; k < D; k++) h = fmax(h, 1.0 / t.g_inv_h[k]);
+            ring += h;
+            grid_box<D>(t, qv, ring, eb0, eb1);
+        } else {
+            // every vertex that could beat (or tie with) the winner lies within its distance of q
+            const double rad = __builtin_sqrt(g1 * BAND_HI) * (1.0 + 1e-9);
+            grid_box<D>(t, qv, rad, eb0, eb1);
+            bool covered = true;
+#pragma unroll
+            for (int k = 0; k < D; k++) covered = covered && eb0[k] >= qb0[k] && eb1[k] <= qb1[k];
+            if (covered) {
+                result_ni = gi >= 0 ? gi : wg_nearest_exact<D, NT>(n, qx, qy, qz);
+                if (tid == 0) {   // statistics only: no decision depends on it
+                    TreeHot &tw = const_cast<TreeHot &>(t);
+                    tw.g_rho = 0.875 * tw.g_rho + 0.125 * __builtin_sqrt(g1);
+                }
                 break;
             }
-            int eb0[3], eb1[3];
-            if (g1 == __builtin_inf()) {
-                double h = 0.;
-#pragma unroll
-                for (int k = 0; k < D; k++) h = fmax(h, 1.0 / t.g_inv_h[k]);
-                ring += h;
-                grid_box<D>(t, q, ring, eb0, eb1);
-            } else {
-                // every vertex that could beat (or tie with) the winner lies within its distance of q
-                const double rad = __builtin_sqrt(g1 * BAND_HI) * (1.0 + 1e-9);
-                grid_box<D>(t, q, rad, eb0, eb1);
-                bool covered = true;
-#pragma unroll
-                for (int k = 0; k < D; k++) covered = covered && eb0[k] >= qb0[k] && eb1[k] <= qb1[k];
-                if (covered) {
-                    result_ni = gi >= 0 ? gi : wg_nearest_exact<D, NT>(s, t, n, q);
-                    if (tid == 0) {   // statistics only: no decision depends on it
-                        TreeHot &tw = const_cast<TreeHot &>(t);
-                        tw.g_rho = 0.875 * tw.g_rho + 0.125 * __builtin_sqrt(g1);
-                    }
-                    break;
-                }
-            }
-            const int rowsE = grid_rows(eb0, eb1);
-            // another visit, nearest only, with a fresh reduction (a vertex seen twice would look like its own runner-up)
-            m1 = __builtin_inf(); m2 = __builtin_inf(); i1 = 0x7fffffff;
-            if (rowsE > GRID_RG_MAX || pass >= 3 || (g1 == __builtin_inf() && pass >= 2)) {
-                brute = true;
-                brutes++;
-                visit_records(0, GRID_Q);
-                continue;
-            }
+        }
+        const int rowsE = grid_rows(eb0, eb1);
+        // another visit, nearest only, with a fresh reduction (a vertex seen twice would look like its own runner-up)
+        m1 = __builtin_inf(); m2 = __builtin_inf(); i1 = 0x7fffffff;
+        __syncthreads();
+        if (rowsE > GRID_RG_MAX || pass >= 3 || (g1 == __builtin_inf() && pass >= 2)) {
+            brute = true;
+            brutes++;
+            if (tid == 0) { s.rg_beg[0] = 0; s.rg_len[0] = n; s.rg_flag[0] = GRID_Q; s.rg_n = 1; }
+        } else {
             revisits++;
-            __syncthreads();
-            for (int row = tid; row < rowsE; row += NT) put_row(row, eb0, eb1, row, GRID_Q, nullptr, 0.);
-            if (tid == 0) s.rg_n = rowsE;
-            __syncthreads();
+            int eb = 0, el = 0;
+            if (tid < rowsE) row_range(eb0, eb1, tid, nullptr, 0., eb, el);
+            if (tid < rowsE) { s.rg_beg[tid] = eb; s.rg_len[tid] = el - eb; s.rg_flag[tid] = GRID_Q; }
+            if (tid == 0) { s.rg_beg[rowsE] = ns; s.rg_len[rowsE] = n - ns; s.rg_flag[rowsE] = GRID_Q; s.rg_n = rowsE + 1; }
 #pragma unroll
             for (int k = 0; k < 3; k++) { qb0[k] = eb0[k]; qb1[k] = eb1[k]; }
-            visit_records(ns, GRID_Q);
-            visit_ranges();
         }
-        *ni = result_ni;
+        __syncthreads();
+        stage = 2;
+        pass++;
     }
     PROF(14);
     if (wantN) {
         if (lane == 0 && n_mem) atomicAdd(&s.mem_cnt, n_mem);
         block_argmin<NT>(s, cand, cj);   // lexicographic (value, index): np.argmin's first minimum of the ascending list (barriers inside)
-        nr->cand = uni(cand);
-        nr->cj = uni(cj);
-        nr->k = uni(s.mem_cnt);
-        nr->n_stash = uni(s.hit_cnt);
     }
     if (tid == 0) {
-        s.stat[ST_VISITED] += visited; s.stat[ST_VISIT_B] += vbytes; s.stat[ST_REVISITS] += revisits; s.stat[ST_BRUTE] += brutes;
+        s.qa.ni = result_ni;
+        s.qa.cand = cand; s.qa.cj = cj;
+        s.stat[ST_VISITED] += visited; s.stat[ST_VISIT_B] += visited * (D == 3 ? 36 : 32); s.stat[ST_REVISITS] += revisits; s.stat[ST_BRUTE] += brutes;
         if (wantN) {
             const int ks = s.hit_cnt;
             s.stat[ST_MEMBERS] += s.mem_cnt;
@@ -1387,6 +1461,27 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, co
     }
     __syncthreads();
     PROF(15);
+}
+
+template <int D, int NT>
+__device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, const double *pn, double r, int new_idx,
+                                         const double *q, int *ni, NearResult *nr, int lds_cap,
+                                         double floor_m = -__builtin_inf())
+{
+    if (threadIdx.x == 0) {   // the arguments are the same in every thread
+        s.qa.n = n; s.qa.want = (pn ? 1 : 0) | (q ? 2 : 0);
+        s.qa.r = r; s.qa.floor_m = floor_m; s.qa.new_idx = new_idx; s.qa.lds_cap = lds_cap;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s.qa.pn[k] = (pn && k < D) ? pn[k] : 0.; s.qa.q[k] = (q && k < D) ? q[k] : 0.; }
+    }
+    wg_query_fn<D, NT>();   // barriers at both ends
+    if (ni) *ni = uni(s.qa.ni);
+    if (nr) {
+        nr->cand = uni(s.qa.cand);
+        nr->cj = uni(s.qa.cj);
+        nr->k = uni(s.mem_cnt);
+        nr->n_stash = uni(s.hit_cnt);
+    }
 }
 
 // nearest_neighbor: argmin_i dist(q, v_i), lowest index on ties (np.argmin)
@@ -1529,7 +1624,7 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v,
             acc[r] = 0.;
         }
 #pragma unroll
-        for (int r = 0; r < WALK_R; r++) slot[r] = (who[r] >= 0 && who[r] < ns) ? t.pos[who[r]] : -1;
+        for (int r = 0; r < WALK_R; r++) slot[r] = (who[r] >= 0 && who[r] < ns) ? t.pos[who[r]] : who[r];   // appended vertices: slot = index
         const int clen = s.chain_len;
         nrec += walk_chains<D>(t, idx, acc, through);
 #pragma unroll
@@ -1540,7 +1635,7 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v,
         for (int r = 0; r < WALK_R; r++) {
             if (who[r] >= 0) {
                 t.vrec[who[r]].cost = acc[r];
-                if (slot[r] >= 0) t.g_cost[slot[r]] = acc[r];
+                t.g_rec[slot[r]].cost = acc[r];
                 const unsigned char li = t.listed[who[r]];
                 if (li & 1) t.sol_dirty = 1;
                 if (li & 2) t.gc_dirty = 1;
@@ -1797,7 +1892,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
     long long alg = host_steer ? 0 : n;
     PROF_DECL
     // keep the cell-ordered part of the grid index within GRID_REBUILD_EVERY vertices of the tree
-    if (n >= t.g_min && n - t.g_ns >= t.g_every) wg_grid_rebuild<D, NT>(s, t, n);   // uniform
+    if (n >= t.g_min && n - t.g_ns >= t.g_every) wg_grid_rebuild<D, NT>(n);   // uniform
     PROF(12);
     int ni;
     double node_new[D], nearest[D];
@@ -1848,8 +1943,6 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                 // loads first (one round trip), then the stores
                 const Hop4 hp = ldg(&t.hop[ni]);
                 const int fc_ni = t.first_child[ni];
-#pragma unroll
-                for (int k = 0; k < D; k++) t.c[k][new_idx] = node_new[k];
                 Aux a;
                 a.elen = edge_new; a.parent = ni; a.pad = 0;
                 stg(&t.aux[new_idx], a);
@@ -1857,7 +1950,9 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                 stg(&t.hop[new_idx], s.hop_new);
                 VRec vr;
                 vr.x = node_new[0]; vr.y = node_new[1]; vr.z = D == 3 ? node_new[D - 1] : 0.; vr.cost = 0.;
-                stg(&t.vrec[new_idx], vr);   // also its entry in the tail of the index
+                stg(&t.vrec[new_idx], vr);
+                stg(&t.g_rec[new_idx], slot_make<D>(node_new, 0., new_idx));   // its slot (appended vertices: slot = index)
+                if (D == 3) t.g_idx[new_idx] = new_idx;
                 t.first_child[new_idx] = -1;
                 // link_child(new_idx, ni) with the head read above; new's own links are remembered for a re-parenting
                 t.next_sib[new_idx] = fc_ni;
@@ -1940,7 +2035,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                 if (dup) {
                     if (reparented) wg_recost_subtree<D, NT>(s, t, new_idx, new_idx);
                 } else {
-                    if (tid == 0) t.vrec[new_idx].cost = new_cost;
+                    if (tid == 0) { t.vrec[new_idx].cost = new_cost; t.g_rec[new_idx].cost = new_cost; }
                 }
             }
             PROF(4);
@@ -1998,7 +2093,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                         const bool leaf = t.first_child[vj] < 0;
                         const int old_p = t.aux[vj].parent, nx = t.next_sib[vj], pv = t.prev_sib[vj];
                         const unsigned char li = t.listed[vj];
-                        const int slot = vj < t.g_ns ? t.pos[vj] : -1;
+                        const int slot = vj < t.g_ns ? t.pos[vj] : vj;
                         const int fc_new = dup ? t.first_child[new_idx] : s.new_fc;   // a fresh vertex's child list lives in LDS
                         const double el = hypot_py<D>(d);
                         if (pv >= 0) t.next_sib[pv] = nx; else t.first_child[old_p] = nx;
@@ -2021,7 +2116,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                             acc += el;
                             acc = chain_finish(s, t, acc, clen);
                             t.vrec[vj].cost = acc;
-                            if (slot >= 0) t.g_cost[slot] = acc;
+                            t.g_rec[slot].cost = acc;
                             if (li & 1) t.sol_dirty = 1;
                             if (li & 2) t.gc_dirty = 1;
                             fast = 1;

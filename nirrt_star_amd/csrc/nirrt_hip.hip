@@ -77,11 +77,7 @@ struct RunSampleDev {
 //          256 was best while the O(n) scans dominated);
 //   wide   256 threads: one or a few trees - measured for one 50k-iteration problem: IRRT* 2.10 s (128 threads 2.66 s,
 //          1024 threads 2.24 s), RRT* 1.4x faster than with 1024 threads, which had been best for the scans.
-__shared__ LdsData g_lds;   // see LdsData in nirrt_device.hpp
 
-#ifndef NIRRT_WAVES_PER_EU
-#define NIRRT_WAVES_PER_EU 4   // second __launch_bounds__ argument of the persistent kernels (register budget 512 / this)
-#endif
 #ifndef NIRRT_BODY_ATTR
 #define NIRRT_BODY_ATTR __noinline__   // loop body of the persistent kernels: a real call (see iteration_call)
 #endif
@@ -113,7 +109,7 @@ namespace slim {
 #define NT_WIDE NIRRT_NT_WIDE
 #define NT_SLIM 64
 static_assert(NT_WIDE / 64 <= LDS_NW_MAX && NT_NARROW / 64 <= LDS_NW_MAX, "LdsData reduction slots: raise LDS_NW_MAX");
-static_assert(offsetof(TreeHotH, pc) > offsetof(TreeHotH, CL_C) && offsetof(TreeHotH, g_x) > offsetof(TreeHotH, c_update),
+static_assert(offsetof(TreeHotH, pc) > offsetof(TreeHotH, CL_C) && offsetof(TreeHotH, g_rec) > offsetof(TreeHotH, c_update),
               "nirrt_set_informed / nirrt_set_cloud patch contiguous field ranges of the descriptor");
 static_assert(sizeof(LdsData) <= 10240, "LdsData must fit 16 times into a CU's 160 KB of LDS (16 one-wave trees per CU)");
 // nirrt_run: batches larger than the 2048 workgroup slots of the 128-thread kernels run one wave per tree (16 trees per
@@ -402,8 +398,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         want(&h.hop, np);
         want(&h.aux, np);
         want(&h.first_child, np); want(&h.next_sib, np); want(&h.prev_sib, np);
-        for (int k = 0; k < D; k++) want(&h.g_x[k], np);
-        want(&h.g_cost, np); want(&h.g_idx, np); want(&h.pos, np);
+        want(&h.g_rec, np); want(&h.g_idx, np); want(&h.pos, np);
         want(&h.g_start, (size_t)h.g_ncell + 1);
         want(&h.listed, np);
         want(&h.sol, np); want(&h.sol_line, np);
@@ -411,7 +406,6 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         want(&h.nr_idx, np); want(&h.nr_m, np);
         want(&h.bfs_q, np); want(&h.chain_g, np);
         want(&h.g_cnt, (size_t)h.g_ncell); want(&h.g_rank, np);
-        for (int k = 0; k < D; k++) want(&h.c[k], np);
         const size_t A = 256;
         size_t total = 0;
         for (const Piece &pc : pieces) total += (pc.bytes + A - 1) / A * A;
@@ -419,7 +413,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         size_t off = 0;
         for (const Piece &pc : pieces) { *pc.dst = (char *)t->arena + off; off += (pc.bytes + A - 1) / A * A; }
     }
-    for (int k = 0; k < D; k++) HIPCHK_T(hipMemset(h.c[k], 0, sizeof(double) * np));
+    HIPCHK_T(hipMemset(h.vrec, 0, sizeof(VRec) * np));
     HIPCHK_T(hipMemset(h.hop, 0, sizeof(Hop4) * np));
     h.cap = t->cap;
     h.dim = D;
@@ -473,7 +467,6 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     h.c_min = 0.;
     for (int k = 0; k < 9; k++) h.CL_C[k] = (k % 4 == 0) ? 1. : 0.;
     h.pc = nullptr; h.pc_n = 0; h.pad2 = 0; h.pc_rate = 0.; h.pc_ratio = 0.; h.c_update = std::numeric_limits<double>::infinity();
-    for (int k = 0; k < D; k++) HIPCHK_T(hipMemset(h.c[k], 0, sizeof(double)));
     h.n = 1;
     int rc = push_desc(t);
     if (!rc) rc = nirrt_reset(t);
@@ -503,10 +496,13 @@ extern "C" int nirrt_upload(nirrt_tree *t, int64_t n, const double *vertices, co
     // relies on it (cost(v) >= |v - x_start|, the floor of the Near stash), so a frozen tree with another root is refused
     for (int k = 0; k < D; k++)
         if (vertices[k] != t->cfg.x_start[k]) { g_err = "nirrt_upload: vertex 0 must be x_start (the tree is rooted at the start state)"; return NIRRT_E_ARG; }
-    std::vector<double> col((size_t)n);
-    for (int k = 0; k < D; k++) {
-        for (int64_t i = 0; i < n; i++) col[(size_t)i] = vertices[i * D + k];
-        HIPCHK(hipMemcpy(t->host.c[k], col.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    {   // coordinates go straight into the per-vertex records (k_init fills in the costs and the slot records)
+        std::vector<VRec> rec((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            VRec &r = rec[(size_t)i];
+            r.x = vertices[i * D]; r.y = vertices[i * D + 1]; r.z = D == 3 ? vertices[i * D + 2] : 0.; r.cost = 0.;
+        }
+        HIPCHK(hipMemcpy(t->host.vrec, rec.data(), sizeof(VRec) * (size_t)n, hipMemcpyHostToDevice));
     }
     std::vector<Aux> ax((size_t)n);
     for (int64_t i = 0; i < n; i++) {
@@ -537,10 +533,12 @@ extern "C" int nirrt_download(nirrt_tree *t, double *vertices, int64_t *parents,
     if (rc) return rc;
     const int D = t->dim;
     if (vertices) {
-        std::vector<double> col((size_t)n);
-        for (int k = 0; k < D; k++) {
-            HIPCHK(hipMemcpy(col.data(), t->host.c[k], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
-            for (int64_t i = 0; i < n; i++) vertices[i * D + k] = col[(size_t)i];
+        std::vector<VRec> rec((size_t)n);
+        HIPCHK(hipMemcpy(rec.data(), t->host.vrec, sizeof(VRec) * (size_t)n, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; i++) {
+            const VRec &r = rec[(size_t)i];
+            vertices[i * D] = r.x; vertices[i * D + 1] = r.y;
+            if (D == 3) vertices[i * D + 2] = r.z;
         }
     }
     if (parents) {
@@ -748,7 +746,7 @@ extern "C" int nirrt_set_cloud(nirrt_tree *t, int64_t n, const double *pts, doub
     t->host.pc_rate = sample_rate;
     t->host.pc_ratio = update_cost_ratio;
     t->host.c_update = c_update;
-    const size_t off = offsetof(TreeHotH, pc), end = offsetof(TreeHotH, g_x);   // pc, pc_n, pc_rate, pc_ratio, c_update
+    const size_t off = offsetof(TreeHotH, pc), end = offsetof(TreeHotH, g_rec);   // pc, pc_n, pc_rate, pc_ratio, c_update
     HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, end - off, hipMemcpyHostToDevice, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     return NIRRT_OK;
