@@ -64,6 +64,8 @@ __device__ __forceinline__ void stg(GAS T *p, const T &v)
     for (unsigned i = 0; i < sizeof(T) / 16; i++) g[i] = o[i];
 }
 
+struct Hop4;
+struct Topo;
 #ifndef NIRRT_WAVES_PER_EU
 #define NIRRT_WAVES_PER_EU 4   // second __launch_bounds__ argument of the persistent kernels (register budget 512 / this)
 #endif
@@ -150,12 +152,6 @@ __device__ __forceinline__ double uni(double v)
 // ------------------------------------------------------------------------------------------------
 // per-tree state in HBM
 // ------------------------------------------------------------------------------------------------
-struct __attribute__((aligned(16))) Aux {
-    double elen;  // math.hypot(v - v_parent): the term cost() adds for this vertex (0 for the root)
-    int parent;
-    int pad;
-};
-
 // four hops of the parent chain in one 48-byte record: a cost() walk needs one memory round trip per FOUR edges.
 // e[j] / a[j] = length / upper end of the j-th edge above the vertex; beyond the root the entries are (0, 0), and
 // adding 0.0 to the (non-negative) running sum leaves it bit-identical, so a walk may run over the end of the chain.
@@ -164,6 +160,10 @@ struct __attribute__((aligned(16))) Hop4 {
     int a[4];
 };
 
+// the hop part (first 48 bytes) of a vertex's record
+__device__ __forceinline__ Hop4 ld_hop(const GAS Topo *p) { return ldg(reinterpret_cast<const GAS Hop4 *>(p)); }
+__device__ __forceinline__ void st_hop(GAS Topo *p, const Hop4 &h) { stg(reinterpret_cast<GAS Hop4 *>(p), h); }
+
 __device__ __forceinline__ Hop4 hop_shift(const Hop4 &p, double e0, int a0)
 {
     Hop4 r;
@@ -171,6 +171,16 @@ __device__ __forceinline__ Hop4 hop_shift(const Hop4 &p, double e0, int a0)
     r.a[0] = a0; r.a[1] = p.a[0]; r.a[2] = p.a[1]; r.a[3] = p.a[2];
     return r;
 }
+
+// Everything about a vertex's place in the tree in ONE 64-byte record (one sector): the four hops above it (a[0] = its
+// parent, e[0] = math.hypot(v - v_parent), the term cost() adds for this vertex; 0 for the root), its child-list links and
+// its list-membership flags.  A cost walk, a re-parenting and a subtree traversal each touch one record per vertex.
+struct __attribute__((aligned(64))) Topo {
+    double e[4];
+    int a[4];
+    int fc, ns, ps;   // first child, next / previous sibling (-1 = none); the root is nobody's child
+    int flags;        // bit 0 = in sol[], bit 1 = in gc_idx[] (a re-costed listed vertex invalidates the cached best)
+};
 
 // random-access twin of a vertex: one 32-byte record (half a 64-byte sector) holds everything the O(k) phases
 // need about a Near candidate - coordinates and the exact cost(v) - so a candidate costs ONE sector read
@@ -191,10 +201,8 @@ struct __attribute__((aligned(32))) GSlot {
 // (16 trees per CU x ~700 B of descriptor do not live in the scalar cache).
 template <template <typename> class P>
 struct TreeHotT {
-    typename P<Aux>::type aux;       // aux[cap]
-    typename P<Hop4>::type hop;      // hop[cap]: aux of the vertex and of its next three ancestors (kept in step with aux)
+    typename P<Topo>::type topo;     // topo[cap]: parent chain (4 hops), child-list links, flags
     typename P<VRec>::type vrec;     // vrec[cap]: coordinates + exact cost by vertex index (random access, download)
-    typename P<int>::type first_child, next_sib, prev_sib;   // child lists (-1 = none); the root is nobody's child
     typename P<int>::type bfs_q;     // scratch queue for subtree traversals
     typename P<double>::type chain_g;   // edge lengths of the chain new -> root beyond the first CHAIN_MAX (which live in LDS)
     int cap;
@@ -216,7 +224,6 @@ struct TreeHotT {
     typename P<int>::type gc_idx;
     typename P<double>::type gc_dist;
     typename P<unsigned char>::type gc_col;
-    typename P<unsigned char>::type listed;   // per vertex: bit 0 = in sol[], bit 1 = in gc_idx[] (a re-costed listed vertex invalidates the cached best)
     int n_gc;
     int gc_dirty;
     int gc_best;
@@ -1509,7 +1516,7 @@ __device__ __forceinline__ int walk_chains(const TreeHot &t, int (&idx)[WALK_R],
         Hop4 h[WALK_R];
 #pragma unroll
         for (int r = 0; r < WALK_R; r++)
-            if (idx[r] > 0 && idx[r] != stop_at) { h[r] = ldg(&t.hop[idx[r]]); nrec++; }
+            if (idx[r] > 0 && idx[r] != stop_at) { h[r] = ld_hop(&t.topo[idx[r]]); nrec++; }
 #pragma unroll
         for (int r = 0; r < WALK_R; r++) {
             if (idx[r] > 0 && idx[r] != stop_at) {
@@ -1533,9 +1540,8 @@ __device__ __forceinline__ double walk_cost(const TreeHot &t, int i)
     double acc = 0.;
     int guard = t.cap + 1;
     while (i > 0 && guard-- > 0) {
-        Aux a = ldg(&t.aux[i]);
-        acc += a.elen;
-        i = a.parent;
+        acc += t.topo[i].e[0];
+        i = t.topo[i].a[0];
     }
     return acc;
 }
@@ -1543,26 +1549,19 @@ __device__ __forceinline__ double walk_cost(const TreeHot &t, int i)
 // child-list maintenance (one thread)
 __device__ __forceinline__ void link_child(TreeHot &t, int v, int p)
 {
-    int f = t.first_child[p];
-    t.next_sib[v] = f;
-    t.prev_sib[v] = -1;
-    if (f >= 0) t.prev_sib[f] = v;
-    t.first_child[p] = v;
+    int f = t.topo[p].fc;
+    t.topo[v].ns = f;
+    t.topo[v].ps = -1;
+    if (f >= 0) t.topo[f].ps = v;
+    t.topo[p].fc = v;
 }
 __device__ __forceinline__ void unlink_child(TreeHot &t, int v, int p)
 {
-    int nx = t.next_sib[v], pv = t.prev_sib[v];
-    if (pv >= 0) t.next_sib[pv] = nx; else t.first_child[p] = nx;
-    if (nx >= 0) t.prev_sib[nx] = pv;
+    int nx = t.topo[v].ns, pv = t.topo[v].ps;
+    if (pv >= 0) t.topo[pv].ns = nx; else t.topo[p].fc = nx;
+    if (nx >= 0) t.topo[nx].ps = pv;
 }
 
-// vertex v was just re-parented (aux[v] already updated, child lists already relinked): refresh the
-// exact cost of v and of every vertex below it.  Breadth-first over the child lists into bfs_q, then
-// one leaf->root walk per collected vertex (WALK_R chains per lane).  Every such walk passes through
-// `through` (= new_idx, the vertex they were all just hung under): it is chased in memory only up to
-// there and finished from s.chainE, the edge-length sequence through -> root recorded this iteration
-// - the same additions in the same order as a full walk.  The cost lands in the vertex's record and, for vertices
-// of the cell-ordered part of the index, in the mirror slot the Near visits read.
 // finish a cost walk that has reached `new`: add the recorded edge lengths new -> root, in that order (LDS part, then HBM part)
 __device__ __forceinline__ double chain_finish(const LdsData &s, const TreeHot &t, double acc, int clen)
 {
@@ -1573,37 +1572,46 @@ __device__ __forceinline__ double chain_finish(const LdsData &s, const TreeHot &
 }
 
 // rewire's candidate list lives where the Near stash was: ids in the stash's index area, one state byte per entry in its
-// (dead) margin area: bit 0 = passes the reference's test with its current cost, bit 1 = cost changed since it was tested
-#define CAND_PASS 1u
-#define CAND_DIRTY 2u
+// (dead) margin area
+#define CAND_PASS 1u      // passes the reference's test with its current cost
+#define CAND_DIRTY 2u     // cost changed since it was tested (by a re-parenting the reference performs BEFORE this member's turn)
+#define CAND_BLOCKED 4u   // passes, but a passing ancestor with a lower index is re-parented first: tested again afterwards
+#define CAND_DONE 8u      // re-parented in this pass
 __device__ __forceinline__ unsigned char *cand_state(LdsData &s) { return reinterpret_cast<unsigned char *>(&s.pool[s.stash_off]); }
 
+// Vertices were just re-parented under `through` (records and child lists already relinked): refresh the exact cost of
+// everything below them.  The queue t.bfs_q[0, n_src) holds the re-parented vertices ("sources"; t.g_rank[] the source each
+// queue entry descends from), s.bc_i[4] = n_src.  Breadth-first over the child lists, then one leaf->root walk per collected
+// vertex from queue position walk_from on (WALK_R chains per lane).  Every such walk passes through `through` (= new_idx,
+// the vertex they were all just hung under): it is chased in memory only up to there and finished from s.chainE, the
+// edge-length sequence through -> root recorded this iteration - the same additions in the same order as a full walk.
+// The cost lands in the vertex's record and in its slot record.  n_list > 0: a re-costed vertex that is on rewire's candidate
+// list (first n_list stash ids) is marked for re-testing if its source has the LOWER index (the reference re-parents that
+// source before the member's turn; a source with a higher index comes after it and must not change the member's test).
 template <int D, int NT>
-__device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v, int through, int n_list = 0)
+__device__ __forceinline__ void wg_recost_queue(Lds<NT> &s, TreeHot &t, int n_src, int walk_from, int through, int n_list)
 {
-    // n_list > 0: re-costed vertices that are on rewire's candidate list (first n_list stash ids) are marked for re-testing
     const int tid = threadIdx.x;
     const int ns = uni(t.g_ns);
-    __syncthreads();
-    if (tid == 0) { t.bfs_q[0] = v; s.bc_i[4] = 1; }
-    __syncthreads();
-    int head = 0, tail = 1, level = 0;
+    int head = 0, tail = n_src, level = 0;
     while (head < tail) {   // one BFS level per trip; uniform
         for (int i = head + tid; i < tail; i += NT) {
             const int u = t.bfs_q[i];
-            int c = t.first_child[u];
-            // hop[v] was refreshed by the caller; the records of the next three levels mention v's edge too
+            const int su = t.g_rank[i];
+            int c = t.topo[u].fc;
+            // the records of the three levels below a re-parented vertex mention its edge too
             Hop4 hu;
-            if (level < 3 && c >= 0) hu = ldg(&t.hop[u]);
+            if (level < 3 && c >= 0) hu = ld_hop(&t.topo[u]);
             while (c >= 0) {
                 int pos = atomicAdd(&s.bc_i[4], 1);
                 t.bfs_q[pos] = c;
+                t.g_rank[pos] = su;
+                GAS Topo &hc = t.topo[c];
                 if (level < 3) {   // entry 0 of the child's record (its own edge) is unchanged
-                    GAS Hop4 &hc = t.hop[c];
                     hc.e[1] = hu.e[0]; hc.e[2] = hu.e[1]; hc.e[3] = hu.e[2];
                     hc.a[1] = hu.a[0]; hc.a[2] = hu.a[1]; hc.a[3] = hu.a[2];
                 }
-                c = t.next_sib[c];
+                c = hc.ns;
             }
         }
         __syncthreads();
@@ -1613,13 +1621,14 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v,
         __syncthreads();
     }
     int nrec = 0;
-    for (int base = 0; base < tail; base += NT * WALK_R) {
-        int idx[WALK_R], who[WALK_R], slot[WALK_R];
+    for (int base = walk_from; base < tail; base += NT * WALK_R) {
+        int idx[WALK_R], who[WALK_R], slot[WALK_R], src[WALK_R];
         double acc[WALK_R];
 #pragma unroll
         for (int r = 0; r < WALK_R; r++) {
             int i = base + r * NT + tid;
             who[r] = i < tail ? t.bfs_q[i] : -1;
+            src[r] = i < tail ? t.g_rank[i] : 0;
             idx[r] = who[r];
             acc[r] = 0.;
         }
@@ -1636,13 +1645,13 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v,
             if (who[r] >= 0) {
                 t.vrec[who[r]].cost = acc[r];
                 t.g_rec[slot[r]].cost = acc[r];
-                const unsigned char li = t.listed[who[r]];
+                const int li = t.topo[who[r]].flags;
                 if (li & 1) t.sol_dirty = 1;
                 if (li & 2) t.gc_dirty = 1;
-                if (n_list > 0) {
+                if (n_list > 0 && src[r] < who[r]) {
                     const int *ids = stash_ids(s);
                     for (int a = 0; a < n_list; a++)
-                        if (ids[a] == who[r]) cand_state(s)[a] = CAND_DIRTY;
+                        if (ids[a] == who[r] && !(cand_state(s)[a] & CAND_DONE)) cand_state(s)[a] = CAND_DIRTY;
                 }
             }
         }
@@ -1653,15 +1662,27 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v,
     __syncthreads();
 }
 
-// record the edge-length sequence new_idx -> root (LDS + HBM continuation) and return cost(new_idx) (thread 0 walks; uniform result)
+// one re-parented vertex v: its own cost and everything below it
+template <int D, int NT>
+__device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v, int through, int n_list = 0)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) { t.bfs_q[0] = v; t.g_rank[0] = v; s.bc_i[4] = 1; }
+    __syncthreads();
+    wg_recost_queue<D, NT>(s, t, 1, 0, through, n_list);
+}
+
+// record the edge-length sequence new_idx -> root (LDS + HBM continuation) and return cost(new_idx) (thread 0 walks; uniform
+// result).  The first record of the chain is s.hop_new (thread 0 has just written or read it).
 template <int D, int NT>
 __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeHot &t, int new_idx)
 {
     if (threadIdx.x == 0) {
         double acc = 0.;
         int i = new_idx, len = 0, guard = t.cap + 1, nrec = 0;
+        Hop4 h = s.hop_new;
         while (i > 0 && guard-- > 0) {
-            const Hop4 h = ldg(&t.hop[i]);
+            if (nrec > 0) h = ld_hop(&t.topo[i]);
             nrec++;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1675,7 +1696,7 @@ __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeHot &t, 
         }
         s.chain_len = len;
         s.bc_d[6] = acc;
-        s.stat[ST_HOPREC] += nrec;
+        s.stat[ST_HOPREC] += nrec > 0 ? nrec - 1 : 0;
     }
     __syncthreads();
     double c = s.bc_d[6];
@@ -1777,7 +1798,7 @@ __device__ __forceinline__ void wg_append_solution(Lds<NT> &s, TreeHot &t, int i
             double line = hypot_py<D>(d);
             t.sol[q] = idx;
             t.sol_line[q] = line;
-            t.listed[idx] |= 1;
+            t.topo[idx].flags |= 1;
             if (!t.sol_dirty) {
                 double c = t.vrec[idx].cost + line;
                 if (q == 0 || c < t.sol_best_cost) { t.sol_best = q; t.sol_best_cost = c; }
@@ -1836,7 +1857,7 @@ __device__ __forceinline__ void wg_goal_parent(Lds<NT> &s, TreeHot &t, int &gp, 
             for (int k = 0; k < D; k++) { d[k] = prev[k] - v[k]; prev[k] = v[k]; }
             len += norm_axis<D>(d);
             if (i == 0 || guard-- <= 0) break;
-            i = t.aux[i].parent;
+            i = t.topo[i].a[0];
         }
         s.bc_d[7] = len;
     }
@@ -1861,7 +1882,7 @@ __device__ __forceinline__ void wg_goal_candidate(Lds<NT> &s, TreeHot &t, int id
             int q = t.n_gc;
             t.gc_idx[q] = idx;
             t.gc_dist[q] = h;
-            t.listed[idx] |= 2;
+            t.topo[idx].flags |= 2;
             t.gc_col[q] = col ? 1 : 0;
             if (!t.gc_dirty) {
                 double c = col ? __builtin_inf() : t.vrec[idx].cost + h;
@@ -1908,7 +1929,9 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
     ni = uni(ni);
     // coordinates and exact cost of the nearest vertex in one 32-byte record; the Near radii the iteration can need
     // (tree size unchanged for a "same point", + 1 otherwise) ride along in the same round trip
+    // ... and so does the vertex's tree record (parent chain + head of its child list: what an insertion under it needs)
     const VRec vnear = ldg(&t.vrec[ni]);
+    const Topo tnear = ldg(&t.topo[ni]);
     const double r_same = t.near_r[n], r_grown = t.near_r[n + 1 <= t.cap ? n + 1 : n];
     nearest[0] = vnear.x; nearest[1] = vnear.y;
     if (D == 3) nearest[D - 1] = vnear.z;
@@ -1931,7 +1954,7 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
         bool inserted = false;
         if (dup) {
             new_idx = ni;
-            if (tid == 0) s.hop_new = ldg(&t.hop[ni]);   // only thread 0 reads it back
+            if (tid == 0) s.hop_new = *reinterpret_cast<const Hop4 *>(&tnear);   // only thread 0 reads it back
 #pragma unroll
             for (int k = 0; k < D; k++) node_new[k] = nearest[k];
         } else if (n >= t.cap) {
@@ -1940,25 +1963,23 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
         } else {
             new_idx = n;
             if (tid == 0) {
-                // loads first (one round trip), then the stores
-                const Hop4 hp = ldg(&t.hop[ni]);
-                const int fc_ni = t.first_child[ni];
-                Aux a;
-                a.elen = edge_new; a.parent = ni; a.pad = 0;
-                stg(&t.aux[new_idx], a);
+                // (the nearest vertex's record arrived with its coordinates: stores only)
+                const Hop4 hp = *reinterpret_cast<const Hop4 *>(&tnear);
+                const int fc_ni = tnear.fc;
                 s.hop_new = hop_shift(hp, edge_new, ni);
-                stg(&t.hop[new_idx], s.hop_new);
+                Topo tn;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { tn.e[j] = s.hop_new.e[j]; tn.a[j] = s.hop_new.a[j]; }
+                // link_child(new_idx, ni) with the head read above; new's own links are remembered for a re-parenting
+                tn.fc = -1; tn.ns = fc_ni; tn.ps = -1; tn.flags = 0;
+                stg(&t.topo[new_idx], tn);
                 VRec vr;
                 vr.x = node_new[0]; vr.y = node_new[1]; vr.z = D == 3 ? node_new[D - 1] : 0.; vr.cost = 0.;
                 stg(&t.vrec[new_idx], vr);
                 stg(&t.g_rec[new_idx], slot_make<D>(node_new, 0., new_idx));   // its slot (appended vertices: slot = index)
                 if (D == 3) t.g_idx[new_idx] = new_idx;
-                t.first_child[new_idx] = -1;
-                // link_child(new_idx, ni) with the head read above; new's own links are remembered for a re-parenting
-                t.next_sib[new_idx] = fc_ni;
-                t.prev_sib[new_idx] = -1;
-                if (fc_ni >= 0) t.prev_sib[fc_ni] = new_idx;
-                t.first_child[ni] = new_idx;
+                if (fc_ni >= 0) t.topo[fc_ni].ps = new_idx;
+                t.topo[ni].fc = new_idx;
                 s.new_next = fc_ni;
                 s.new_fc = -1;
                 t.n = n + 1;
@@ -2000,29 +2021,28 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                 if (tid == 0) {
                     // loads first (one round trip), then the stores
                     const VRec vb = ldg(&t.vrec[best_parent]);
-                    const Hop4 hp = ldg(&t.hop[best_parent]);
-                    const int fc_bp = t.first_child[best_parent];
+                    const Topo tb = ldg(&t.topo[best_parent]);
+                    const Hop4 hp = *reinterpret_cast<const Hop4 *>(&tb);
+                    const int fc_bp = tb.fc;
                     int old_p, nx, pv;
-                    if (dup) { old_p = t.aux[new_idx].parent; nx = t.next_sib[new_idx]; pv = t.prev_sib[new_idx]; }
+                    if (dup) { old_p = tnear.a[0]; nx = tnear.ns; pv = tnear.ps; }   // new_idx == ni: its record is at hand
                     else { old_p = ni; nx = s.new_next; pv = -1; }   // just inserted at the head of ni's children
                     double d[D];
                     d[0] = node_new[0] - vb.x; d[1] = node_new[1] - vb.y;
                     if (D == 3) d[D - 1] = node_new[D - 1] - vb.z;
                     const double el = hypot_py<D>(d);
                     // unlink from the old parent
-                    if (pv >= 0) t.next_sib[pv] = nx; else t.first_child[old_p] = nx;
-                    if (nx >= 0) t.prev_sib[nx] = pv;
-                    t.aux[new_idx].parent = best_parent;
-                    t.aux[new_idx].elen = el;
+                    if (pv >= 0) t.topo[pv].ns = nx; else t.topo[old_p].fc = nx;
+                    if (nx >= 0) t.topo[nx].ps = pv;
                     s.hop_new = hop_shift(hp, el, best_parent);
-                    stg(&t.hop[new_idx], s.hop_new);
+                    st_hop(&t.topo[new_idx], s.hop_new);
                     // link under the new parent; if that is the old parent again (its Near distance can beat the steer
                     // edge by an ulp) the head read above may be new_idx itself: use the list as the unlink left it
                     const int head = (best_parent == old_p && pv < 0) ? nx : fc_bp;
-                    t.next_sib[new_idx] = head;
-                    t.prev_sib[new_idx] = -1;
-                    if (head >= 0) t.prev_sib[head] = new_idx;
-                    t.first_child[best_parent] = new_idx;
+                    t.topo[new_idx].ns = head;
+                    t.topo[new_idx].ps = -1;
+                    if (head >= 0) t.topo[head].ps = new_idx;
+                    t.topo[best_parent].fc = new_idx;
                     s.new_next = head;
                 }
                 __syncthreads();
@@ -2086,26 +2106,26 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                 if (tid == 0) s.stat[ST_ROUNDS] += n_cand;
                 __syncthreads();
                 int last = -1;
+                if (dup && tid == 0) s.new_fc = tnear.fc;   // head of an existing vertex's child list (a fresh vertex's is in LDS already)
+                // ---- sequential path (more candidates than the list holds / tiny stash) ----
                 // the re-parenting of one member (thread 0) + re-costing of what hangs below it
                 auto rewire_one = [&](int vj, const double *d) {
                     if (tid == 0) {
                         // loads first (one round trip), then the stores
-                        const bool leaf = t.first_child[vj] < 0;
-                        const int old_p = t.aux[vj].parent, nx = t.next_sib[vj], pv = t.prev_sib[vj];
-                        const unsigned char li = t.listed[vj];
+                        const bool leaf = t.topo[vj].fc < 0;
+                        const int old_p = t.topo[vj].a[0], nx = t.topo[vj].ns, pv = t.topo[vj].ps;
+                        const int li = t.topo[vj].flags;
                         const int slot = vj < t.g_ns ? t.pos[vj] : vj;
-                        const int fc_new = dup ? t.first_child[new_idx] : s.new_fc;   // a fresh vertex's child list lives in LDS
+                        const int fc_new = s.new_fc;   // head of new's child list: kept in LDS during the pass
                         const double el = hypot_py<D>(d);
-                        if (pv >= 0) t.next_sib[pv] = nx; else t.first_child[old_p] = nx;
-                        if (nx >= 0) t.prev_sib[nx] = pv;
-                        t.aux[vj].parent = new_idx;
-                        t.aux[vj].elen = el;
-                        stg(&t.hop[vj], hop_shift(s.hop_new, el, new_idx));
+                        if (pv >= 0) t.topo[pv].ns = nx; else t.topo[old_p].fc = nx;
+                        if (nx >= 0) t.topo[nx].ps = pv;
+                        st_hop(&t.topo[vj], hop_shift(s.hop_new, el, new_idx));
                         const int head = (old_p == new_idx && pv < 0) ? nx : fc_new;   // vj may already hang under new ("same point")
-                        t.next_sib[vj] = head;
-                        t.prev_sib[vj] = -1;
-                        if (head >= 0) t.prev_sib[head] = vj;
-                        t.first_child[new_idx] = vj;
+                        t.topo[vj].ns = head;
+                        t.topo[vj].ps = -1;
+                        if (head >= 0) t.topo[head].ps = vj;
+                        t.topo[new_idx].fc = vj;
                         s.new_fc = vj;
                         // a leaf (the common case) has nothing below it: its new cost is its edge followed by the
                         // recorded chain new -> root, the same additions in the same order as a walk
@@ -2140,6 +2160,159 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                     if (D == 3) d[D - 1] = vr.z - node_new[D - 1];
                     return vr.cost > new_cost + dist_scan<D>(d);
                 };
+                // ---- batched rounds -----------------------------------------------------------------------------------------
+                // The reference's loop (rrt_star_2d.py:92-99) re-parents in ascending index order, each member tested with its
+                // CURRENT cost; a re-parenting changes the costs of exactly the vertices below the re-parented one.  So a passing
+                // member whose ancestors hold no passing member of LOWER index is tested with the cost the reference will see at
+                // its turn, whatever happens to the others: all such members of a round are re-parented TOGETHER (they all end up
+                // as children of `new`; child order carries no meaning), their subtrees are re-costed in ONE multi-source
+                // traversal, and only members that sit below a lower-index source are tested again.  Rounds = longest chain of
+                // such dependencies + 1 (usually 1-2) instead of one round per re-parented vertex.
+                const bool batch_ok = listed_all && cap_lds >= 128;   // (room for the relink chunk behind the state bytes; small test builds take the sequential path)
+                if (batch_ok) {
+                    int *ch_v = reinterpret_cast<int *>(state + ((cap_lds + 7) & ~7)), *ch_pv = ch_v + 64, *ch_nx = ch_v + 128;
+                    const int lane = tid & 63;
+                    const bool single = n_list <= 64;   // every candidate has its own lane of wave 0: records stay in registers across the phases
+                    const int ns_ = uni(t.g_ns);
+                    const double bound = new_cost - (1e-9 + 1e-11 * new_cost);   // an ancestor that passes costs more than cost(new)
+                    const int clen = s.chain_len;
+                    VRec vr;
+                    Topo tp;
+                    int slot = 0;
+                    for (;;) {
+                        __syncthreads();
+                        if (tid == 0) { s.bc_i[5] = 0; s.bc_i[4] = 0; s.bc_i[7] = 0; }
+                        __syncthreads();
+                        // phase A: test what changed
+                        for (int base = 0; base < n_list; base += NT) {
+                            const int a = base + tid;
+                            if (a < n_list) {
+                                unsigned st = state[a];
+                                if (st & CAND_DIRTY) {
+                                    const int id = ids[a];
+                                    vr = ldg(&t.vrec[id]);
+                                    if (single) { tp = ldg(&t.topo[id]); slot = id < ns_ ? t.pos[id] : id; }
+                                    const double dx = vr.x - node_new[0], dy = vr.y - node_new[1], dz = D == 3 ? vr.z - node_new[D - 1] : 0.;
+                                    st = vr.cost > new_cost + dist_scan_cold<D>(dx, dy, dz) ? CAND_PASS : 0u;
+                                    state[a] = (unsigned char)st;
+                                }
+                                if (st & CAND_PASS) atomicAdd(&s.bc_i[5], 1);
+                            }
+                        }
+                        __syncthreads();
+                        if (uni(s.bc_i[5]) == 0) break;
+                        // phase B: a passing member with a passing ancestor of lower index waits for that one
+                        for (int base = 0; base < n_list; base += NT) {
+                            const int a = base + tid;
+                            if (a < n_list && state[a] == CAND_PASS) {
+                                const int id = ids[a];
+                                Hop4 h;
+                                double cst;
+                                if (single) { h = *reinterpret_cast<const Hop4 *>(&tp); cst = vr.cost; }
+                                else { h = ld_hop(&t.topo[id]); cst = t.vrec[id].cost; }
+                                bool blocked = false, stop = false;
+                                for (int guard = 0; guard <= t.cap && !stop; guard++) {
+#pragma unroll
+                                    for (int j = 0; j < 4; j++) {
+                                        if (!stop) {
+                                            const int anc = h.a[j];
+                                            cst -= h.e[j];   // ~ cost(anc)
+                                            if (anc <= 0 || cst < bound) stop = true;
+                                            else if (anc < id) {
+                                                for (int b = 0; b < n_list; b++)
+                                                    if (ids[b] == anc && (state[b] & CAND_PASS)) { blocked = true; stop = true; }
+                                            }
+                                        }
+                                    }
+                                    if (!stop) h = ld_hop(&t.topo[h.a[3]]);
+                                }
+                                if (blocked) state[a] = (unsigned char)(CAND_PASS | CAND_BLOCKED);
+                            }
+                        }
+                        __syncthreads();
+                        // phase C: re-parent the others, 64 at a time (wave 0): unlink (runs of adjacent siblings resolved in LDS),
+                        // new records + costs, then the whole chunk is pushed onto new's child list
+                        for (int base = 0; base < n_list; base += 64) {
+                            const int a = base + tid;
+                            const bool mine = tid < 64 && a < n_list && state[a] == CAND_PASS;
+                            int v = -1, pv = -1, nx = -1, old_p = -1, fc = -1, flg = 0;
+                            if (mine) {
+                                v = ids[a];
+                                if (!single) { vr = ldg(&t.vrec[v]); tp = ldg(&t.topo[v]); slot = v < ns_ ? t.pos[v] : v; }
+                                pv = tp.ps; nx = tp.ns; old_p = tp.a[0]; fc = tp.fc; flg = tp.flags;
+                            }
+                            if (tid < 64) { ch_v[tid] = v; ch_pv[tid] = pv; ch_nx[tid] = nx; }
+                            __syncthreads();
+                            double el = 0.;
+                            if (mine) {
+                                auto find = [&](int x) -> int {
+                                    int r = -1;
+                                    for (int j = 0; j < 64; j++) if (ch_v[j] == x) r = j;
+                                    return r;
+                                };
+                                if (pv < 0 || find(pv) < 0) {   // first of a run of chunk members that are adjacent siblings
+                                    int after = nx;
+                                    while (after >= 0) {
+                                        const int j = find(after);
+                                        if (j < 0) break;
+                                        after = ch_nx[j];
+                                    }
+                                    if (pv >= 0) t.topo[pv].ns = after;
+                                    else if (old_p == new_idx) s.new_fc = after;   // head of new's own list (kept in LDS until the push)
+                                    else t.topo[old_p].fc = after;
+                                    if (after >= 0) t.topo[after].ps = pv;
+                                }
+                                double d[D];
+                                d[0] = vr.x - node_new[0]; d[1] = vr.y - node_new[1];
+                                if (D == 3) d[D - 1] = vr.z - node_new[D - 1];
+                                el = hypot_py<D>(d);
+                                // cost: its edge followed by the recorded chain new -> root, the same additions in the same order as a walk
+                                double acc = 0.;
+                                acc += el;
+                                acc = chain_finish(s, t, acc, clen);
+                                t.vrec[v].cost = acc;
+                                t.g_rec[slot].cost = acc;
+                                if (flg & 1) t.sol_dirty = 1;
+                                if (flg & 2) t.gc_dirty = 1;
+                                state[a] = (unsigned char)CAND_DONE;
+                            }
+                            __syncthreads();
+                            if (tid < 64) {
+                                const unsigned long long m = __ballot(mine);
+                                if (m) {
+                                    const int old_head = s.new_fc;
+                                    if (mine) {
+                                        const unsigned long long above = lane == 63 ? 0ull : (m & ~((2ull << lane) - 1ull));
+                                        const unsigned long long below = m & ((1ull << lane) - 1ull);
+                                        const int succ = above ? ch_v[__ffsll((long long)above) - 1] : old_head;
+                                        const int pred = below ? ch_v[63 - __clzll((long long)below)] : -1;
+                                        // hop part + sibling links; the child-list head of v stays as it is in memory (a chunk member that
+                                        // was v's first child has just updated it)
+                                        st_hop(&t.topo[v], hop_shift(s.hop_new, el, new_idx));
+                                        t.topo[v].ns = succ;
+                                        t.topo[v].ps = pred;
+                                        if (!above && old_head >= 0) t.topo[old_head].ps = v;
+                                        if (!below) { s.new_fc = v; t.topo[new_idx].fc = v; }
+                                        if (fc >= 0) {   // something hangs below it
+                                            const int qp = atomicAdd(&s.bc_i[4], 1);
+                                            t.bfs_q[qp] = v;
+                                            t.g_rank[qp] = v;
+                                        }
+                                    }
+                                    if (lane == 0) { s.bc_i[7] += __popcll(m); s.stat[ST_REWIRED] += __popcll(m); }
+                                }
+                            }
+                            __syncthreads();
+                        }
+                        PROF(9);
+                        n_rewired += uni(s.bc_i[7]);
+                        const int n_src = uni(s.bc_i[4]);
+                        if (n_src > 0) wg_recost_queue<D, NT>(s, t, n_src, n_src, new_idx, n_list);   // uniform
+                        for (int a = tid; a < n_list; a += NT)
+                            if (state[a] & CAND_BLOCKED) state[a] = (unsigned char)CAND_DIRTY;
+                        PROF(10);
+                    }
+                } else
                 while (n_cand > 0) {
                     int first = 0x7fffffff;
                     for (int a = tid; a < n_list; a += NT) {

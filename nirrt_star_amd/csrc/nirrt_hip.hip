@@ -202,7 +202,9 @@ struct nirrt_tree {
     TreeDev host;    // host mirror of the descriptor (pointers are device pointers)
     TreeDev *dev;    // descriptor in HBM
     TreeDev **self_dev;   // one-element device array holding `dev` (kernels take arrays of descriptors)
-    void *arena;     // ONE device allocation holding every per-tree array, the descriptor and the Near-radius table
+    void *arena;     // ONE device range holding every per-tree array, the descriptor and the Near-radius table
+    size_t arena_bytes;
+    bool arena_pooled;   // carved out of a pool chunk (see ArenaPool) / an allocation of its own
     double *near_r;  // device table (inside the arena)
     Scratch *scratch;      // pinned host memory
     Scratch *scratch_dev;  // device alias of the same memory
@@ -278,13 +280,63 @@ static int push_desc(nirrt_tree *t)
     return NIRRT_OK;
 }
 
+// Tree arenas come out of large device chunks (NIRRT_POOL_CHUNK_MB, default 4096; 0 = one hipMalloc per tree): thousands of
+// separately mapped 12 MB allocations cost one address-translation entry per 2 MB each, while a few multi-GB chunks are
+// mapped with large fragments - the loop is a latency-bound chase across ~100 GB of trees, and translation misses are part of
+// every round trip.  Bump allocation inside a chunk, exact-size free lists per device (trees of one batch have one size);
+// chunks stay with the process.
+#include <map>
+#include <mutex>
+namespace {
+struct ArenaPool {
+    std::mutex mu;
+    struct Chunk { char *base; size_t size, used; };
+    std::map<int, std::vector<Chunk>> chunks;                       // per device
+    std::map<std::pair<int, size_t>, std::vector<void *>> free_list;   // (device, bytes) -> arenas handed back
+    static size_t chunk_bytes()
+    {
+        const char *e = std::getenv("NIRRT_POOL_CHUNK_MB");
+        const long long mb = (e && *e) ? std::atoll(e) : 4096;
+        return mb <= 0 ? 0 : (size_t)mb << 20;
+    }
+    // returns nullptr when pooling is off or the request is small / larger than a chunk (the caller then uses hipMalloc)
+    void *take(int device, size_t bytes)
+    {
+        const size_t cb = chunk_bytes();
+        if (cb == 0 || bytes < ((size_t)1 << 20) || bytes > cb) return nullptr;
+        std::lock_guard<std::mutex> g(mu);
+        auto &fl = free_list[{device, bytes}];
+        if (!fl.empty()) { void *p = fl.back(); fl.pop_back(); return p; }
+        const size_t A = (size_t)2 << 20;   // arenas start on 2 MB boundaries
+        const size_t need = (bytes + A - 1) / A * A;
+        auto &cs = chunks[device];
+        if (cs.empty() || cs.back().used + need > cs.back().size) {
+            void *b = nullptr;
+            if (hipMalloc(&b, cb) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            cs.push_back(Chunk{(char *)b, cb, 0});
+        }
+        Chunk &c = cs.back();
+        void *p = c.base + c.used;
+        c.used += need;
+        return p;
+    }
+    void give(int device, size_t bytes, void *p)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        free_list[{device, bytes}].push_back(p);
+    }
+};
+ArenaPool g_pool;
+}
+
 extern "C" int nirrt_destroy(nirrt_tree *t)
 {
     if (!t) return NIRRT_OK;
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     if (t->pc_dev && t->pc_dev != t->pc_own) (void)hipFree(t->pc_dev);
-    if (t->arena) (void)hipFree(t->arena);
+    if (t->arena && t->arena_pooled) g_pool.give(t->device, t->arena_bytes, t->arena);
+    else if (t->arena) (void)hipFree(t->arena);
     if (t->scratch) (void)hipHostFree(t->scratch);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
@@ -362,7 +414,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     t->cap = (int)(cfg->iter_max + 1);
     t->device = cfg->device_id;
     t->stream = nullptr;
-    t->arena = nullptr; t->pc_own = nullptr; t->dev = nullptr; t->self_dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->pc_dev = nullptr;
+    t->arena = nullptr; t->arena_bytes = 0; t->arena_pooled = false; t->pc_own = nullptr; t->dev = nullptr; t->self_dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->pc_dev = nullptr;
     const int D = t->dim;
     auto fail = [&](int rc) { nirrt_destroy(t); return rc; };
 #define HIPCHK_T(expr)                                                                        \
@@ -395,12 +447,9 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         want(&t->near_r, (size_t)t->cap + 1);
         want(&t->pc_own, (size_t)PC_OWN_POINTS * 3);
         want(&h.vrec, np);
-        want(&h.hop, np);
-        want(&h.aux, np);
-        want(&h.first_child, np); want(&h.next_sib, np); want(&h.prev_sib, np);
+        want(&h.topo, np);
         want(&h.g_rec, np); want(&h.g_idx, np); want(&h.pos, np);
         want(&h.g_start, (size_t)h.g_ncell + 1);
-        want(&h.listed, np);
         want(&h.sol, np); want(&h.sol_line, np);
         want(&h.gc_idx, np); want(&h.gc_dist, np); want(&h.gc_col, np);
         want(&h.nr_idx, np); want(&h.nr_m, np);
@@ -409,12 +458,15 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         const size_t A = 256;
         size_t total = 0;
         for (const Piece &pc : pieces) total += (pc.bytes + A - 1) / A * A;
-        HIPCHK_T(hipMalloc(&t->arena, total));
+        t->arena_bytes = total;
+        t->arena = g_pool.take(t->device, total);
+        t->arena_pooled = t->arena != nullptr;
+        if (!t->arena) HIPCHK_T(hipMalloc(&t->arena, total));
         size_t off = 0;
         for (const Piece &pc : pieces) { *pc.dst = (char *)t->arena + off; off += (pc.bytes + A - 1) / A * A; }
     }
     HIPCHK_T(hipMemset(h.vrec, 0, sizeof(VRec) * np));
-    HIPCHK_T(hipMemset(h.hop, 0, sizeof(Hop4) * np));
+    HIPCHK_T(hipMemset(h.topo, 0, sizeof(Topo) * np));
     h.cap = t->cap;
     h.dim = D;
     h.cap_sol = t->cap;
@@ -504,16 +556,16 @@ extern "C" int nirrt_upload(nirrt_tree *t, int64_t n, const double *vertices, co
         }
         HIPCHK(hipMemcpy(t->host.vrec, rec.data(), sizeof(VRec) * (size_t)n, hipMemcpyHostToDevice));
     }
-    std::vector<Aux> ax((size_t)n);
+    std::vector<Topo> ax((size_t)n);   // each vertex's own edge (e[0], a[0]); k_init derives the rest of the records
+    std::memset(ax.data(), 0, sizeof(Topo) * (size_t)n);
     for (int64_t i = 0; i < n; i++) {
         if (parents[i] < 0 || parents[i] >= n) { g_err = "parent index out of range"; return NIRRT_E_ARG; }
         double d[3] = {0., 0., 0.};
         for (int k = 0; k < D; k++) d[k] = vertices[i * D + k] - vertices[parents[i] * D + k];
-        ax[(size_t)i].elen = i == 0 ? 0. : host_hypot_py(D, d);
-        ax[(size_t)i].parent = (int)parents[i];
-        ax[(size_t)i].pad = 0;
+        ax[(size_t)i].e[0] = i == 0 ? 0. : host_hypot_py(D, d);
+        ax[(size_t)i].a[0] = (int)parents[i];
     }
-    HIPCHK(hipMemcpy(t->host.aux, ax.data(), sizeof(Aux) * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t->host.topo, ax.data(), sizeof(Topo) * (size_t)n, hipMemcpyHostToDevice));
     t->host.n = (int)n;
     t->last_n = n;
     t->host.n_sol = 0;
@@ -542,9 +594,9 @@ extern "C" int nirrt_download(nirrt_tree *t, double *vertices, int64_t *parents,
         }
     }
     if (parents) {
-        std::vector<Aux> ax((size_t)n);
-        HIPCHK(hipMemcpy(ax.data(), t->host.aux, sizeof(Aux) * (size_t)n, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < n; i++) parents[i] = ax[(size_t)i].parent;
+        std::vector<Topo> ax((size_t)n);
+        HIPCHK(hipMemcpy(ax.data(), t->host.topo, sizeof(Topo) * (size_t)n, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; i++) parents[i] = ax[(size_t)i].a[0];
     }
     if (n_out) *n_out = n;
     return NIRRT_OK;
