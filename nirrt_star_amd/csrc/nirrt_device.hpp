@@ -325,6 +325,13 @@ struct LdsData {
         double pn[3], q[3], r, floor_m, cand;
         int n, want, new_idx, lds_cap, ni, cj;
     } qa;
+    struct {                      // state of the loop body handed from phase to phase (it_extend / it_connect / it_book)
+        double node_in[3], node_new[3], edge_new, cost_ni, r_query;
+        long long alg;
+        nirrt_step_result *res;
+        unsigned flags;
+        int host_steer, ni, pref_ni, collided, new_idx, n, dup, inserted, dup_parent, dup_ns, dup_ps, dup_fc, k, reparented, n_rewired;
+    } it;
     int n_cand;                   // rewire: members whose stashed margin reaches cost(new) (the stash is compacted to them)
     int cand_listed;              // ... all of them are in the LDS list (else: the spilled part is searched per round)
     long long stat[NSTAT];
@@ -936,6 +943,13 @@ __device__ __forceinline__ double dist_scan_cold(double dx, double dy, double dz
     if (D == 2) return hypot_np_cold(dx, dy);
     return __builtin_sqrt(dx * dx + dy * dy + dz * dz);
 }
+// cost(j) + d(j, p) with the reference's distance, from vertex j's record (the same doubles its slot record holds)
+template <int D>
+NIRRT_FN __device__ double near_exact_cold(int j, double px, double py, double pz)
+{
+    const VRec v = ldg(&g_lds.hot.vrec[j]);
+    return v.cost + dist_scan_cold<D>(px - v.x, py - v.y, D == 3 ? pz - v.z : 0.);
+}
 // exact segment test against obstacle #o of the LDS tables
 template <int D>
 NIRRT_FN __device__ bool seg_obstacle_cold(int o, double ax, double ay, double az, double bx, double by, double bz)
@@ -1264,7 +1278,9 @@ NIRRT_FN __device__ void wg_query_fn()
     }
     double m1 = __builtin_inf(), m2 = __builtin_inf();   // nearest: smallest / second-smallest squared distance of this lane
     int i1 = 0x7fffffff;
-    double cand = __builtin_inf();                        // Near: this lane's best cost + dist
+    // Near: this lane's best cost + dist (ba: by sqrt(v) until b_exact, then the reference's value) and its index
+    double ba = __builtin_inf();
+    bool b_exact = false;
     int cj = 0x7fffffff;
     int n_mem = 0;                                        // members seen by this wave
     __syncthreads();
@@ -1273,50 +1289,63 @@ NIRRT_FN __device__ void wg_query_fn()
     PROF(20);
     // one visited slot; true = Near member (sm = cost - dist, what rewire compares with cost(new) later: members of a dense,
     // well optimised tree sit within 1e-5 of that threshold by the dozen, so the margin is kept in full float64)
+    // Written with selects instead of nested branches (the common path is straight-line code; only the rare long paths -
+    // guard-band re-decision, obstacle tests, near-ties of the running minimum - sit behind branches).
     auto process = [&](const SlotRegs &p, double &sm) -> bool {
-        if (p.fl & GRID_Q) {
+        {
+            const bool isQ = (p.fl & GRID_Q) != 0;
             const double dx = qx - p.x, dy = qy - p.y;
             double wv = dx * dx + dy * dy;
             if (D == 3) { const double dz = qz - p.z; wv = wv + dz * dz; }
-            if (wv < m1 || (wv == m1 && p.id < i1)) { m2 = m1; m1 = wv; i1 = p.id; } else if (wv < m2) m2 = wv;
+            const bool lt1 = isQ && (wv < m1 || (wv == m1 && p.id < i1));
+            const double m2n = (isQ && wv < m2) ? wv : m2;
+            m2 = lt1 ? m1 : m2n;
+            m1 = lt1 ? wv : m1;
+            i1 = lt1 ? p.id : i1;
         }
-        bool member = false;
-        if (p.fl & GRID_N) {
-            const double dx = pnx - p.x, dy = pny - p.y, dz = D == 3 ? pnz - p.z : 0.;
-            double v = dx * dx + dy * dy;
-            if (D == 3) v = v + dz * dz;
-            if (v <= r2hi && p.id != new_idx) {
-                // d_j: the reference's own distance (glibc hypot in 2D) decides inside the guard band and is what choose_parent
-                // adds - but it is only evaluated where it can matter: sqrt(v) is within 2 ulp of it, which settles every
-                // member that is not in the band and cannot reach this lane's best cost + dist so far
-                const double ds = sqrt_fast(v);
-                bool exact = D == 3;                    // 3D: dist_scan IS sqrt of this very sum
-                double dj = ds;
-                bool hit = v <= r2lo;
-                if (!hit) {
-                    if (!exact) { dj = dist_scan_cold<D>(dx, dy, dz); exact = true; }
-                    hit = dj <= r;
-                }
-                if (hit) {
-                    bool col = false;
-                    if (n_ob > 0) {
-                        double l0[3], l1[3];
-                        l0[0] = fmin(pnx, p.x); l1[0] = fmax(pnx, p.x); l0[1] = fmin(pny, p.y); l1[1] = fmax(pny, p.y);
-                        if (D == 3) { l0[D - 1] = fmin(pnz, p.z); l1[D - 1] = fmax(pnz, p.z); }
-                        for (int j = 0; j < n_ob && !col; j++) {
-                            const int o = s.ob_list[j];
-                            if (seg_aabb_pass<D, NT>(s, o, l0, l1)) col = seg_obstacle_cold<D>(o, pnx, pny, pnz, p.x, p.y, D == 3 ? p.z : 0.);
-                        }
-                    }
-                    if (!col) {
-                        member = true;
-                        double c = p.c + dj;
-                        if (!exact && c <= cand * (1.0 + 0x1p-40)) c = p.c + dist_scan_cold<D>(dx, dy, dz);   // cand is always an exact value
-                        if (c < cand || (c == cand && p.id < cj)) { cand = c; cj = p.id; }
-                        sm = p.c - ds;               // margin for rewire's search (tolerance there >> 2 ulp)
-                    }
+        const double dx = pnx - p.x, dy = pny - p.y, dz = D == 3 ? pnz - p.z : 0.;
+        double v = dx * dx + dy * dy;
+        if (D == 3) v = v + dz * dz;
+        const bool in = (p.fl & GRID_N) != 0 && v <= r2hi && p.id != new_idx;
+        // d_j: the reference's own distance (glibc hypot in 2D) decides inside the guard band and is what choose_parent
+        // adds - but it is only evaluated where it can matter: sqrt(v) is within 2 ulp of it, which settles every
+        // member that is not in the band and cannot reach this lane's best cost + dist so far
+        const double ds = sqrt_fast(v);
+        bool exact = D == 3;                    // 3D: dist_scan IS sqrt of this very sum
+        double dj = ds;
+        bool hit = in && v <= r2lo;
+        if (in && !hit) {                       // inside the guard band
+            if (!exact) { dj = dist_scan_cold<D>(dx, dy, dz); exact = true; }
+            hit = dj <= r;
+        }
+        bool col = false;
+        if (n_ob > 0) {                         // uniform
+            if (hit) {
+                double l0[3], l1[3];
+                l0[0] = fmin(pnx, p.x); l1[0] = fmax(pnx, p.x); l0[1] = fmin(pny, p.y); l1[1] = fmax(pny, p.y);
+                if (D == 3) { l0[D - 1] = fmin(pnz, p.z); l1[D - 1] = fmax(pnz, p.z); }
+                for (int j = 0; j < n_ob && !col; j++) {
+                    const int o = s.ob_list[j];
+                    if (seg_aabb_pass<D, NT>(s, o, l0, l1)) col = seg_obstacle_cold<D>(o, pnx, pny, pnz, p.x, p.y, D == 3 ? p.z : 0.);
                 }
             }
+        }
+        const bool member = hit && !col;
+        sm = p.c - ds;               // margin for rewire's search (tolerance there >> 2 ulp)
+        // choose_parent's argmin of cost_j + d_j with the reference's own d_j: the lane keeps its best member by the value
+        // with sqrt(v) (within 2 ulp of d_j) and settles it exactly only when another member comes within 2^-40 of it; a
+        // lane's best is evaluated exactly ONCE, after the visit.  (Evaluating at every new per-lane minimum put a call - and
+        // with it a drain of the loads in flight - into nearly every trip.)
+        const double c = p.c + dj;
+        const bool better = member && c < ba * (1.0 - 0x1p-40);             // clearly better than the lane's best
+        const bool close = member && !better && c <= ba * (1.0 + 0x1p-40);   // too close to call: the reference's values decide
+        ba = better ? c : ba;
+        cj = better ? p.id : cj;
+        b_exact = better ? exact : b_exact;
+        if (close) {
+            if (!b_exact) { ba = near_exact_cold<D>(cj, pnx, pny, pnz); b_exact = true; }
+            const double ce = exact ? c : p.c + dist_scan_cold<D>(dx, dy, dz);
+            if (ce < ba || (ce == ba && p.id < cj)) { ba = ce; cj = p.id; }
         }
         return member;
     };
@@ -1452,8 +1481,10 @@ NIRRT_FN __device__ void wg_query_fn()
         pass++;
     }
     PROF(14);
+    double cand = ba;
     if (wantN) {
         if (lane == 0 && n_mem) atomicAdd(&s.mem_cnt, n_mem);
+        if (D == 2 && cj != 0x7fffffff && !b_exact) cand = near_exact_cold<D>(cj, pnx, pny, pnz);   // every lane's best with the reference's distance
         block_argmin<NT>(s, cand, cj);   // lexicographic (value, index): np.argmin's first minimum of the ascending list (barriers inside)
     }
     if (tid == 0) {
@@ -1589,8 +1620,11 @@ __device__ __forceinline__ unsigned char *cand_state(LdsData &s) { return reinte
 // list (first n_list stash ids) is marked for re-testing if its source has the LOWER index (the reference re-parents that
 // source before the member's turn; a source with a higher index comes after it and must not change the member's test).
 template <int D, int NT>
-__device__ __forceinline__ void wg_recost_queue(Lds<NT> &s, TreeHot &t, int n_src, int walk_from, int through, int n_list)
+NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int through_in, int n_list_in)
 {
+    Lds<NT> &s = g_lds;
+    TreeHot &t = g_lds.hot;
+    const int n_src = uni(n_src_in), walk_from = uni(walk_from_in), through = uni(through_in), n_list = uni(n_list_in);
     const int tid = threadIdx.x;
     const int ns = uni(t.g_ns);
     int head = 0, tail = n_src, level = 0;
@@ -1662,6 +1696,12 @@ __device__ __forceinline__ void wg_recost_queue(Lds<NT> &s, TreeHot &t, int n_sr
     __syncthreads();
 }
 
+template <int D, int NT>
+__device__ __forceinline__ void wg_recost_queue(Lds<NT> &s, TreeHot &t, int n_src, int walk_from, int through, int n_list)
+{
+    wg_recost_queue_fn<D, NT>(n_src, walk_from, through, n_list);
+}
+
 // one re-parented vertex v: its own cost and everything below it
 template <int D, int NT>
 __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v, int through, int n_list = 0)
@@ -1727,14 +1767,24 @@ __device__ __forceinline__ void steer(const TreeHot &t, const double *from, cons
     }
 }
 
-// segment test spread over the workgroup: lane o tests obstacle o, OR-reduced
+// segment test spread over the workgroup: lane o tests obstacle o, OR-reduced (one out-of-line copy: the loop body calls it
+// from three places)
 template <int D, int NT>
-__device__ __forceinline__ bool wg_collision(const Lds<NT> &s, const double *a, const double *b, double clr)
+NIRRT_FN __device__ bool wg_collision_fn(double ax, double ay, double az, double bx, double by, double bz)
 {
+    const Lds<NT> &s = g_lds;
+    const double a[3] = {ax, ay, az}, b[3] = {bx, by, bz};
+    const double clr = s.k_clr;
     int M = s.n_round + s.n_box;
     bool hit = false;
     for (int o = threadIdx.x; o < M; o += NT) hit = hit || seg_obstacle<D, NT>(s, o, a, b, clr);
     return block_any(hit);
+}
+template <int D, int NT>
+__device__ __forceinline__ bool wg_collision(const Lds<NT> &s, const double *a, const double *b, double clr)
+{
+    // (clr is the tree's clearance, which is what s.k_clr holds)
+    return wg_collision_fn<D, NT>(a[0], a[1], D == 3 ? a[D - 1] : 0., b[0], b[1], D == 3 ? b[D - 1] : 0.);
 }
 
 // find_near_neighbors as a primitive (nirrt_near): every member index goes to t.nr_idx[0, k) in visiting order (the host
@@ -1895,21 +1945,28 @@ __device__ __forceinline__ void wg_goal_candidate(Lds<NT> &s, TreeHot &t, int id
 }
 
 // ------------------------------------------------------------------------------------------------
-// one loop body (rrt_star_2d.py:37-55 / irrt_star_2d.py:54-73)
+// one loop body (rrt_star_2d.py:37-55 / irrt_star_2d.py:54-73) in four out-of-line phases that hand their state on through
+// LDS (s.it): each phase gets a register allocation of its own, so nothing one phase keeps alive spills into the loops of
+// another.   it_extend: nearest / steer / edge test / insertion -> wg_query_fn -> it_connect: choose_parent, cost(new),
+// rewire -> it_book: goal bookkeeping.
 //   host_steer: node_in = node_new computed by the caller and nearest_in its nearest index
 //   else      : node_in = node_rand
 // ------------------------------------------------------------------------------------------------
 template <int D, int NT>
-__device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const double *node_in, bool host_steer,
-                                             int nearest_in, unsigned flags, nirrt_step_result *res,
-                                             int pref_ni = -1, const double *q_next = nullptr)
+NIRRT_FN __device__ void it_extend()
 {
     // pref_ni >= 0: nearest_neighbor(node_in) already known from the previous iteration's fused query.
     // q_next != nullptr: the next iteration's node_rand; if this iteration runs a Near query its nearest index is
     // left in s.bc_i[6] (else -1) for the caller to pass back as pref_ni.
+    Lds<NT> &s = g_lds;
+    TreeHot &t = g_lds.hot;
     const int tid = threadIdx.x;
     const double clr = t.clearance;
     int n = uni(t.n);
+    const bool host_steer = uni(s.it.host_steer) != 0;
+    const int nearest_in = uni(s.it.ni), pref_ni = uni(s.it.pref_ni);
+    nirrt_step_result *res = s.it.res;
+    const double node_in[3] = {uni(s.it.node_in[0]), uni(s.it.node_in[1]), uni(s.it.node_in[2])};
     long long alg = host_steer ? 0 : n;
     PROF_DECL
     // keep the cell-ordered part of the grid index within GRID_REBUILD_EVERY vertices of the tree
@@ -1936,7 +1993,6 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
     nearest[0] = vnear.x; nearest[1] = vnear.y;
     if (D == 3) nearest[D - 1] = vnear.z;
     if (!host_steer) steer<D>(t, nearest, node_in, node_new);
-    int next_ni = -1;
     if (res && tid == 0) {
         res->collided = 0; res->inserted = 0; res->nearest_idx = ni; res->new_idx = -1; res->n_near = 0;
         res->reparented = 0; res->n_rewired = 0; res->in_goal = 0; res->status = 0; res->reserved = 0;
@@ -1945,6 +2001,8 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
     bool collided = wg_collision<D, NT>(s, nearest, node_new, clr);
     PROF(1);
     int new_idx = -1;
+    bool dup_ = false, inserted_ = false;
+    double edge_new_ = 0.;
     if (!collided) {
         double diff[D];
 #pragma unroll
@@ -1989,25 +2047,45 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
             inserted = true;
             __syncthreads();
         }
-        if (new_idx >= 0) {
-            // the fused query: Near members of node_new (stash + choose_parent's argmin) and the next sample's nearest vertex
-            NearResult nr;
-            const int cap_lds = uni(s.stash_cap);
-            // (measured: reaching the query through a noinline call instead costs 25 % - the values alive around it get spilled)
-            // Rewire can only re-parent a member j with cost(j) - d_j > cost(new) (rrt_star_2d.py:95), and cost(new) - a sum of
-            // edge lengths along a polyline root -> new, each within an ulp - is at least the straight distance root -> new
-            // up to 1e-13 relative.  Members whose margin stays below that floor are counted but not kept: in a converged
-            // tree (costs close to straight-line distances: exactly the problems with thousands of Near members) that is
-            // nearly all of them, and the stash stays inside LDS.
-            double d_root[D];
+        dup_ = dup; inserted_ = inserted; edge_new_ = edge_new;
+    }
+    PROF(6);
+    // hand over (the values are the same in every thread)
+    if (tid == 0) {
+        s.it.collided = collided ? 1 : 0; s.it.new_idx = new_idx; s.it.ni = ni; s.it.n = n; s.it.alg = alg;
+        if (!collided) {
 #pragma unroll
-            for (int kk = 0; kk < D; kk++) d_root[kk] = node_new[kk] - t.start[kk];
-            const double lb_new = __builtin_sqrt(dist2<D>(d_root));
-            const double floor_m = lb_new - (1e-9 + 1e-11 * lb_new);
-            wg_query<D, NT>(s, t, n, node_new, inserted ? r_grown : r_same, new_idx, q_next, &next_ni, &nr, cap_lds, floor_m);
+            for (int k = 0; k < D; k++) s.it.node_new[k] = node_new[k];
+            s.it.dup = dup_ ? 1 : 0; s.it.inserted = inserted_ ? 1 : 0; s.it.edge_new = edge_new_; s.it.cost_ni = vnear.cost;
+            s.it.r_query = inserted_ ? r_grown : r_same;
+            s.it.dup_parent = tnear.a[0]; s.it.dup_ns = tnear.ns; s.it.dup_ps = tnear.ps; s.it.dup_fc = tnear.fc;
+        }
+    }
+    __syncthreads();
+}
+
+template <int D, int NT>
+NIRRT_FN __device__ void it_connect()
+{
+    Lds<NT> &s = g_lds;
+    TreeHot &t = g_lds.hot;
+    const int tid = threadIdx.x;
+    const int new_idx = uni(s.it.new_idx), ni = uni(s.it.ni);
+    const bool dup = uni(s.it.dup) != 0;
+    const double edge_new = uni(s.it.edge_new);
+    double node_new[D];
+#pragma unroll
+    for (int kk = 0; kk < D; kk++) node_new[kk] = uni(s.it.node_new[kk]);
+    struct { double cost; } vnear = {uni(s.it.cost_ni)};
+    struct { int a[1]; int ns, ps, fc; } tnear = {{uni(s.it.dup_parent)}, uni(s.it.dup_ns), uni(s.it.dup_ps), uni(s.it.dup_fc)};
+    struct { int k, n_stash, cj; double cand; } nr = {uni(s.mem_cnt), uni(s.hit_cnt), uni(s.qa.cj), uni(s.qa.cand)};
+    const int cap_lds = uni(s.stash_cap);
+    PROF_DECL
+    int k_out = 0, reparented_out = 0, n_rewired_out = 0;
+    {
+        {
             const int k = nr.k;            // Near members
             const int ks = nr.n_stash;     // ... of which on the stash
-            alg += n;
             PROF(2);
             int reparented = 0, n_rewired = 0;
             // curr_node_new_cost (rrt_star_2d.py:45 "same point" / :51)
@@ -2339,7 +2417,31 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                     rewire_one(first, d);
                 }
             }
-            PROF(5);
+            k_out = k; reparented_out = reparented; n_rewired_out = n_rewired;
+        }
+    }
+    PROF(5);
+    if (tid == 0) { s.it.k = k_out; s.it.reparented = reparented_out; s.it.n_rewired = n_rewired_out; }
+    __syncthreads();
+}
+
+template <int D, int NT>
+NIRRT_FN __device__ void it_book()
+{
+    Lds<NT> &s = g_lds;
+    TreeHot &t = g_lds.hot;
+    const int tid = threadIdx.x;
+    const int new_idx = uni(s.it.new_idx);
+    const bool inserted = uni(s.it.inserted) != 0;
+    const unsigned flags = (unsigned)uni((int)s.it.flags);
+    const double clr = t.clearance;
+    nirrt_step_result *res = s.it.res;
+    double node_new[D];
+#pragma unroll
+    for (int kk = 0; kk < D; kk++) node_new[kk] = uni(s.it.node_new[kk]);
+    PROF_DECL
+    {
+        {
             if (inserted) wg_goal_candidate<D, NT>(s, t, new_idx, node_new);
             int in_goal = 0;
             if (flags & NIRRT_F_IRRT) {
@@ -2355,16 +2457,58 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
                 }
             }
             if (res && tid == 0) {
-                res->inserted = inserted ? 1 : 0; res->new_idx = new_idx; res->n_near = k;
-                res->reparented = reparented; res->n_rewired = n_rewired; res->in_goal = in_goal;
+                res->inserted = inserted ? 1 : 0; res->new_idx = new_idx; res->n_near = s.it.k;
+                res->reparented = s.it.reparented; res->n_rewired = s.it.n_rewired; res->in_goal = in_goal;
                 res->node_new[0] = node_new[0]; res->node_new[1] = node_new[1];
                 res->node_new[2] = D == 3 ? node_new[D - 1] : 0.;
             }
         }
+    }
+    PROF(6);
+    __syncthreads();
+}
+
+template <int D, int NT>
+__device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const double *node_in, bool host_steer,
+                                             int nearest_in, unsigned flags, nirrt_step_result *res,
+                                             int pref_ni = -1, const double *q_next = nullptr)
+{
+    // pref_ni >= 0: nearest_neighbor(node_in) already known from the previous iteration's fused query.
+    // q_next != nullptr: the next iteration's node_rand; if this iteration runs a Near query its nearest index is
+    // left in s.bc_i[6] (else -1) for the caller to pass back as pref_ni.
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) s.it.node_in[k] = k < D ? node_in[k] : 0.;
+        s.it.host_steer = host_steer ? 1 : 0; s.it.ni = nearest_in; s.it.pref_ni = pref_ni; s.it.flags = flags; s.it.res = res;
+    }
+    __syncthreads();
+    it_extend<D, NT>();
+    int next_ni = -1;
+    long long alg = s.it.alg;
+    const int new_idx = uni(s.it.new_idx);
+    if (!uni(s.it.collided)) {
+        if (new_idx >= 0) {
+            // the fused query: Near members of node_new (stash + choose_parent's argmin) and the next sample's nearest vertex.
+            // Rewire can only re-parent a member j with cost(j) - d_j > cost(new) (rrt_star_2d.py:95), and cost(new) - a sum of
+            // edge lengths along a polyline root -> new, each within an ulp - is at least the straight distance root -> new
+            // up to 1e-13 relative.  Members whose margin stays below that floor are counted but not kept: in a converged
+            // tree (costs close to straight-line distances: exactly the problems with thousands of Near members) that is
+            // nearly all of them, and the stash stays inside LDS.
+            double node_new[D], d_root[D];
+#pragma unroll
+            for (int kk = 0; kk < D; kk++) { node_new[kk] = uni(s.it.node_new[kk]); d_root[kk] = node_new[kk] - t.start[kk]; }
+            const double lb_new = __builtin_sqrt(dist2<D>(d_root));
+            const double floor_m = lb_new - (1e-9 + 1e-11 * lb_new);
+            const int n = uni(s.it.n);
+            wg_query<D, NT>(s, t, n, node_new, uni(s.it.r_query), new_idx, q_next, &next_ni, nullptr, uni(s.stash_cap), floor_m);
+            alg += n;
+            it_connect<D, NT>();
+            it_book<D, NT>();
+        }
     } else if (res && tid == 0) {
         res->collided = 1;
     }
-    PROF(6);
     if (tid == 0) { s.stat[ST_ITERS] += 1; s.stat[ST_ALG] += alg; s.bc_i[6] = next_ni; }
     __syncthreads();
 }

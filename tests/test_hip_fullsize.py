@@ -152,3 +152,42 @@ def test_rrt3d_50k_bit_exact_against_oracle(oracle):
     assert np.array_equal(p, o.parents) and np.array_equal(v, o.vertices)
     t.close()
     o.close()
+
+
+@pytest.mark.parametrize("world,pid,iters", [("b30", 3, ITERS), ("b30r16", 1, 20000)])
+def test_bench_configuration_50k_against_oracle(oracle, monkeypatch, world, pid, iters):
+    """The benchmarked configuration itself at full size: 2D IRRT*, 30 circles, 50 000 iterations,
+    in-kernel sampling from the problem's own seeded generators, the one-wave-per-tree kernels (`slim`) - one problem of
+    bench.py's batch (and one of the r in [16, 24] world) against orc_run_sampling fed with the same words: vertex count,
+    parents, solution list, generator words consumed identical; vertices <= 1e-9; best path cost <= 1e-5
+    (irrt_star_2d.py:42-97).  The oracle needs 2 - 4 minutes for the 50 000-iteration problem (its cost walks are the
+    reference's, un-cached), so the r in [16, 24] problem stops at 20 000."""
+    from types import SimpleNamespace
+    import bench
+    from nirrt_star_amd import _hip, sampling
+    from oracle import oracle as orc
+    monkeypatch.setenv("NIRRT_FORCE_VARIANT", "slim")
+    a = SimpleNamespace(algo="irrt", dim=2, world=world, iters=iters, trees=1)
+    pr = bench.make_problem(a, pid)
+    n_np, n_py = bench.word_budgets(a)
+    npw, pyw = bench.problem_words(a, pid, n_np, n_py)
+    frame = sampling.informed_frame(pr["x_start"], pr["x_goal"])
+    t = _hip.HipTree(2, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"])
+    t.set_informed(*frame)
+    res = _hip.run_sampling([t], iters, [npw], [pyw], flags=_hip.F_IRRT, want_trace=True)
+    assert res["iters_done"][0] == iters and res["status"][0] == 0
+    o = orc.OracleTree(2, iters, pr["x_start"], pr["x_goal"], 10.0, float(pr["search_radius"]), float(pr["clearance"]), pr["env_dict"])
+    ro = o.run_sampling(iters, npw, pyw, irrt=True, frame=frame, want_trace=True)
+    assert ro["iters_done"] == iters
+    assert int(res["np_used"][0]) == ro["np_used"] and int(res["py_used"][0]) == ro["py_used"]
+    v, p = t.download()
+    assert len(v) == o.n > 0.8 * iters
+    assert np.array_equal(p, o.parents)
+    assert np.max(np.abs(v - o.vertices)) <= 1e-9
+    assert np.array_equal(t.solutions, o.solutions) and len(t.solutions) > 0
+    tr, tro = res["cost_trace"][0], ro["cost_trace"]
+    assert np.array_equal(np.isfinite(tr), np.isfinite(tro))
+    fin = np.isfinite(tr)
+    assert np.max(np.abs(tr[fin] - tro[fin])) <= 1e-5
+    t.close()
+    o.close()
