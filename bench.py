@@ -61,7 +61,7 @@ def parse(argv=None):
                     help="nirrt / nirrt_c: NIRRT*-PNG[(C)] with PointNet++ guidance (BASELINE configs 3-4) through the batched driver")
     ap.add_argument("--world", default="b30", choices=sorted(WORLDS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=20000, help="iterations each CPU-baseline process runs")
+    ap.add_argument("--cpu-iters", type=int, default=12000, help="iterations each CPU-baseline process runs (per repetition)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline processes (0 = min(host cores, 32))")
     ap.add_argument("--no-ttfs", action="store_true")
     ap.add_argument("--pilot", type=int, default=0,
@@ -71,9 +71,18 @@ def parse(argv=None):
     ap.add_argument("--narrow-frac", type=float, default=0.03, help="next share of the batch run on 128 lanes")
     ap.add_argument("--first-frac", type=float, default=0.04, help="share of the batch (largest Near sets in the pilot) dispatched first; the rest keeps its order")
     ap.add_argument("--free-first", type=int, default=1, help="1: problems with a free start-goal segment are dispatched first in the first launch")
-    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "r02_traffic.json"),
+    ap.add_argument("--free-lanes", type=int, default=0, choices=[0, 64, 128, 256],
+                    help="workgroup size for the problems with a free start-goal segment (their Near sets grow to thousands of members: the "
+                         "visit is arithmetic-bound and scales with the lanes); 0 = like the others")
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "r03_traffic.json"),
                     help="PMC traffic table written by scripts/collect_traffic.py (an entry is used only if its key names this exact configuration)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group / timing protocol only, no GPU work (CPU test of --gpus N)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank plans --trees problems of its own; strong: ONE fixed set of --problems problems (BASELINE config 5: "
+                         "the 1000-problem evaluation set) is sharded round-robin over the ranks (problem i -> rank i mod N)")
+    ap.add_argument("--problems", type=int, default=1000, help="size of the fixed problem set of --scaling strong")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other BASELINE configurations (N = 1 only)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of the CPU-baseline sample (the median is reported)")
     return ap.parse_args(argv)
 
 
@@ -81,13 +90,18 @@ def config_key(args):
     return "%s_%dd_%s_%dx%d" % (args.algo, args.dim, args.world if args.dim == 2 else "ref3d", args.trees, args.iters)
 
 
+def rank_problem_ids(args, rank, world):
+    """problem ids this rank plans: weak = its own block of --trees problems; strong = its round-robin share of the fixed set"""
+    if getattr(args, "scaling", "weak") == "strong":
+        return list(range(rank, args.problems, world))
+    return [rank * args.trees + b for b in range(args.trees)]
+
+
 def make_problems(args, rank):
     """B problems for this rank: worlds 0..249 x 4 start/goal pairs = the 1000-problem evaluation set of
     SURVEY.md §8d (wrapping around for larger batches); planner seed = 1000 + problem id."""
-    from nirrt_star_amd import worlds
     probs, cache = [], {}
-    for b in range(args.trees):
-        pid = rank * args.trees + b
+    for pid in rank_problem_ids(args, rank, int(os.environ.get("WORLD_SIZE", "1"))):
         probs.append(make_problem(args, pid, cache))
     return probs
 
@@ -207,7 +221,7 @@ def main():
         return bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work)
 
     probs = make_problems(args, rank)
-    D, B, iters = args.dim, args.trees, args.iters
+    D, B, iters = args.dim, len(probs), args.iters   # (strong scaling: this rank's share of the fixed set)
     flags = _hip.F_IRRT if args.algo == "irrt" else 0
     trees = []
     for pr in probs:
@@ -222,10 +236,15 @@ def main():
     # Optional (--pilot N, off by default: it did not beat the simple ordering): run N iterations first, then the rest with the
     # trees of the largest measured Near sets dispatched first and on 256- / 128-lane workgroups (nirrt_run_args.lanes_hint).
     first_order = list(range(B))
-    if args.algo == "irrt" and B > 1 and args.free_first:
+    first_hint = None
+    if args.algo == "irrt" and B > 1 and (args.free_first or args.free_lanes):
         free_line = [not t.is_collision(pr["x_start"], pr["x_goal"]) for t, pr in zip(trees, probs)]
-        first_order = sorted(range(B), key=lambda b: (not free_line[b], b))
+        if args.free_first:
+            first_order = sorted(range(B), key=lambda b: (not free_line[b], b))
+        if args.free_lanes:
+            first_hint = np.array([args.free_lanes if free_line[b] else 0 for b in first_order], dtype=np.int32)
     # inputs: each problem's generator outputs (np.random.seed(s); random.seed(s)), resident in HBM
+    t_inputs = time.perf_counter()
     n_np, n_py = word_budgets(args)
     py_stride = max(n_py, 1)
     d_np = torch.empty((B, n_np), dtype=torch.int32, device=dev)
@@ -246,6 +265,7 @@ def main():
     py_tab = [(d_py.data_ptr() + 4 * py_stride * b, n_py) for b in range(B)] if n_py else None
     torch.cuda.synchronize()
     del h_np, h_py
+    input_generation_s = time.perf_counter() - t_inputs   # host MT19937 outputs of every problem + upload (outside the timed region)
 
     seg_len = [args.pilot, iters - args.pilot] if 0 < args.pilot < iters and B > 1 else [iters]
     n_seg = len(seg_len)
@@ -256,7 +276,7 @@ def main():
         used_np = np.zeros(B, dtype=np.int64)
         used_py = np.zeros(B, dtype=np.int64)
         order = list(first_order)
-        hint = None
+        hint = first_hint
         tot = {"kernel_ms": 0.0, "stats": np.zeros((B, _hip.N_STATS), dtype=np.int64), "alg_elems": np.zeros(B, dtype=np.int64),
                "iters_done": np.zeros(B, dtype=np.int64), "seconds": np.zeros(B), "wide": 0, "narrow": 0}
         for si, n_it in enumerate(seg_len):
@@ -319,13 +339,16 @@ def main():
         out = {
             "metric": "RRT* iters/sec (50k-node tree), random_%dd" % D,
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "input_generation_s": input_generation_s,
             "config": {"workload": ("%s_star random_2d (%s: %s; clearance 3, step_len 10), %d problems/GPU x %d iters, "
                                     "device-resident batched loop with in-kernel sampling" % (args.algo, args.world, WORLDS[args.world], B, iters))
                        if D == 2 else ("%s_star random_3d (50^3, 6-9 boxes + 6-9 balls; clearance 2, step_len 10), %d problems/GPU x %d iters, "
                                        "device-resident batched loop with in-kernel sampling" % (args.algo, B, iters)),
                        "key": config_key(args), "trees_per_gpu": B, "iters": iters, "dim": D, "step_len": 10,
+                       "problem_set": ("fixed set of %d problems, problem i on rank i mod %d" % (args.problems, world)) if args.scaling == "strong"
+                                      else "%d problems per rank" % B,
                        "clearance": probs[0]["clearance"], "mean_final_vertices": float(np.mean(n_final)),
                        "mean_solutions_per_tree": float(np.mean(n_sol)), "trees_stopped_early": short,
                        "launches_per_step": n_seg, "trees_on_256_lanes": r["wide"], "trees_on_128_lanes": r["narrow"],
@@ -343,10 +366,23 @@ def main():
                          "reference_scan_equiv_GBps": float(np.mean(alg_elems)) * D * 8.0 / k_s / 1e9},
             "reference_python_survey_container_its": REF_PY[args.algo],
         }
+        if short:
+            out["warning"] = ("%d of %d trees stopped before iteration %d (generator words ran out): `value` counts only the iterations "
+                              "that ran" % (short, B, iters))
         if not args.no_ttfs:
             out["time_to_first_solution"] = time_to_first_solution(args, trees, np_tab, py_tab, flags)
+            out["single_tree"] = single_tree_latency(args, trees, np_tab, py_tab, flags)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
+        if world == 1 and not args.no_secondary:
+            # the other BASELINE configurations as short runs in processes of their own: this one's trees and inputs go first
+            for t_ in trees:
+                t_.close()
+            trees = []
+            del d_np, d_py
+            torch.cuda.empty_cache()
+            _hip.pool_trim()
+            out["secondary"] = secondary_runs(args)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -431,6 +467,56 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
         dist.destroy_process_group()
 
 
+SECONDARY = [   # (label, bench arguments): each runs `--steps 1 --warmup 0` in a process of its own
+    ("rrt_2d", ["--algo", "rrt"]),
+    ("rrt_3d", ["--algo", "rrt", "--dim", "3"]),
+    ("irrt_3d", ["--algo", "irrt", "--dim", "3", "--trees", "4096"]),
+    ("irrt_2d_b30r16", ["--algo", "irrt", "--world", "b30r16"]),
+    ("nirrt_c_2d (config 3)", ["--algo", "nirrt_c", "--trees", "2048"]),
+    ("nirrt_3d (config 4)", ["--algo", "nirrt", "--dim", "3", "--trees", "512"]),
+]
+
+
+def secondary_runs(args):
+    """Short driver-witnessed lines of the other BASELINE configurations (RRT* 2D / 3D, IRRT* 3D, the r in [16, 24] world, configs
+    3 and 4): one step each, no warm-up, same iteration count; the fields a reader needs to judge them."""
+    out = {}
+    for label, extra in SECONDARY:
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--iters", str(args.iters),
+               "--no-cpu-baseline", "--no-ttfs", "--no-secondary"] + extra
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not line:
+                out[label] = {"error": "rc %d: %s" % (p.returncode, p.stderr.strip().splitlines()[-1] if p.stderr.strip() else "no output")}
+                continue
+            d = json.loads(line[-1])
+            cfg, rf = d["config"], d["roofline"]
+            out[label] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "kernel_ms": rf.get("kernel_ms"),
+                          "roofline_frac": rf.get("frac"), "traffic": rf.get("traffic"), "key": cfg.get("key"),
+                          "trees_per_gpu": cfg.get("trees_per_gpu"), "trees_stopped_early": cfg.get("trees_stopped_early", cfg.get("failed")),
+                          "per_tree_seconds": cfg.get("per_tree_seconds"), "host_seconds": cfg.get("host_seconds_last_step"),
+                          "warning": d.get("warning"), "wall_s": time.perf_counter() - t0}
+        except subprocess.TimeoutExpired:
+            out[label] = {"error": "timed out after 900 s"}
+    return out
+
+
+def single_tree_latency(args, trees, np_tab, py_tab, flags):
+    """ONE problem planned alone for the full iteration count (what demo_planning_2d.py:85-90 does): the whole GPU serves one
+    tree, 256-thread kernels; HIP-event time of the launch, median over the first 3 problems of the batch."""
+    from nirrt_star_amd import _hip
+    ms, n_fin = [], []
+    for b in range(min(3, len(trees))):
+        trees[b].reset()
+        r = _hip.run_sampling([trees[b]], args.iters, [np_tab[b]], [py_tab[b]] if py_tab else None, flags=flags, on_device=True)
+        ms.append(r["kernel_ms"])
+        n_fin.append(int(trees[b].n))
+    return {"problems": len(ms), "iterations": args.iters, "median_seconds": float(np.median(ms)) * 1e-3,
+            "iterations_per_second": args.iters / (float(np.median(ms)) * 1e-3), "final_vertices": n_fin}
+
+
 def time_to_first_solution(args, trees, np_tab, py_tab, flags):
     """Measured, not interpolated: NIRRT_F_STOP_FIRST launches on the first problems of the batch.  `single` = one
     problem per launch (the whole GPU serves one tree, 256-thread kernels): HIP-event time of the launch.  `batch` =
@@ -482,27 +568,37 @@ def measured_traffic(args):
 def cpu_baseline(args):
     """The oracle (C port of the reference loop, incl. sampling and the reference's un-cached cost walks) on this box's
     host cores: C independent processes (oracle/cpu_bench.py), process i plans problem i of the batch for --cpu-iters
-    iterations from its own seeded generators.  value = iterations of all processes / wall time of the slowest."""
+    iterations from its own seeded generators.  One repetition's value = iterations of all processes / wall time of the
+    slowest; --cpu-reps repetitions, the MEDIAN is reported."""
     procs = args.cpu_procs or min(os.cpu_count() or 1, 32)
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--algo", args.algo, "--dim", str(args.dim),
            "--world", args.world, "--iters", str(min(args.cpu_iters, args.iters)), "--cap", str(args.iters)]
-    t0 = time.perf_counter()
-    ps = [subprocess.Popen(cmd + ["--pid", str(i)], stdout=subprocess.PIPE, text=True) for i in range(procs)]
-    res = []
-    for p in ps:
-        outp = p.communicate()[0]
-        if p.returncode == 0:
-            res.append(json.loads(outp.strip().splitlines()[-1]))
-    wall = time.perf_counter() - t0
-    if not res:
+    reps = []
+    t_all = time.perf_counter()
+    for _ in range(max(1, args.cpu_reps)):
+        ps = [subprocess.Popen(cmd + ["--pid", str(i)], stdout=subprocess.PIPE, text=True) for i in range(procs)]
+        res = []
+        for p in ps:
+            outp = p.communicate()[0]
+            if p.returncode == 0:
+                res.append(json.loads(outp.strip().splitlines()[-1]))
+        if res:
+            loop_s = max(r["seconds"] for r in res)
+            rates = sorted(r["iters"] / r["seconds"] for r in res)
+            reps.append({"value": sum(r["iters"] for r in res) / loop_s, "cores": len(res), "loop_s": loop_s, "iters": res[0]["iters"],
+                         "single_core_median": rates[len(rates) // 2], "single_core_min": rates[0], "single_core_max": rates[-1]})
+    wall = time.perf_counter() - t_all
+    if not reps:
         return None
-    loop_s = max(r["seconds"] for r in res)
-    rates = sorted(r["iters"] / r["seconds"] for r in res)
-    return {"value": sum(r["iters"] for r in res) / loop_s, "unit": "iterations/s", "cores": len(res), "kind": "port",
-            "single_core_median": rates[len(rates) // 2], "single_core_min": rates[0], "single_core_max": rates[-1],
-            "sample": "%d processes x first %d of %d iterations of problems 0..%d of the batch (oracle loop only, %.1f s for the "
-                      "slowest, %.1f s incl. start-up); the per-iteration cost grows with the tree, so a truncated sample flatters the CPU"
-                      % (len(res), res[0]["iters"], args.iters, len(res) - 1, loop_s, wall)}
+    reps.sort(key=lambda r: r["value"])
+    m = reps[len(reps) // 2]
+    return {"value": m["value"], "unit": "iterations/s", "cores": m["cores"], "kind": "port", "repetitions": len(reps),
+            "values_of_repetitions": [r["value"] for r in reps],
+            "single_core_median": m["single_core_median"], "single_core_min": m["single_core_min"], "single_core_max": m["single_core_max"],
+            "sample": "median of %d repetitions of: %d processes x first %d of %d iterations of problems 0..%d of the batch (oracle loop only, "
+                      "%.1f s for the slowest process of the median repetition, %.1f s for everything incl. start-up); the per-iteration cost "
+                      "grows with the tree, so a truncated sample flatters the CPU"
+                      % (len(reps), m["cores"], m["iters"], args.iters, m["cores"] - 1, m["loop_s"], wall)}
 
 
 if __name__ == "__main__":

@@ -103,6 +103,10 @@ int nirrt_device_count(int *count);
 int nirrt_create(const nirrt_config *cfg, nirrt_tree **out);
 int nirrt_destroy(nirrt_tree *t);
 int nirrt_reset(nirrt_tree *t);
+/* Trees of at least 1 MB are carved out of multi-GB device chunks that stay with the process (NIRRT_POOL_CHUNK_MB, default
+ * 4096, 0 = one allocation per tree; no counterpart in the reference, whose arrays are numpy's): hand the chunks that hold no
+ * live tree back to the driver - a process that is done with one batch and starts helpers that need the memory calls this */
+int nirrt_pool_trim(void);
 /* the same for every tree of a batch (same device and dim) in ONE launch, one workgroup per tree: the planner objects of an
  * evaluation set are single-use in the reference (demo_planning_2d.py:90); a benchmark step re-plans the same problems */
 int nirrt_reset_batch(nirrt_tree *const *trees, int32_t n_trees);
@@ -197,8 +201,9 @@ typedef struct nirrt_run_args {
                             nearest_neighbor + n per find_near_neighbors - i.e. algorithmic bytes = alg_elems * dim * 8
                             (B_iter = 2*n*D*8) */
     int64_t *stats;      /* optional (n_trees, NIRRT_N_STATS): what this launch did per tree -
-                            [0] slots visited by the fused nearest / Near passes, [1] bytes those visits read,
-                            [2] Near members, [3] members spilled out of LDS, [4] 48-byte chain records walked,
+                            [0] slots visited by the fused nearest / Near passes, [1] bytes those visits read (32 B per slot
+                            record, + 4 in 3D), [2] Near members, [3] members spilled out of LDS, [4] tree records (64 B, four
+                            hops each) read by cost walks,
                             [5] rewire candidates examined, [6] vertices rewired, [7] vertices re-costed,
                             [8] solution / goal-candidate list entries re-evaluated, [9] vertices inserted,
                             [10] vertices passed through index rebuilds, [11] widened nearest visits,

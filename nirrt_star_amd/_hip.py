@@ -24,7 +24,7 @@ EXPORTS = [
     "nirrt_last_error", "nirrt_device_count", "nirrt_create", "nirrt_destroy", "nirrt_reset", "nirrt_upload",
     "nirrt_download", "nirrt_num_vertices", "nirrt_nearest", "nirrt_collision_batch", "nirrt_points_in_obs",
     "nirrt_near", "nirrt_cost", "nirrt_search_goal_parent", "nirrt_best_solution", "nirrt_solutions",
-    "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed", "nirrt_debug_prof", "nirrt_set_cloud", "nirrt_reset_batch",
+    "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed", "nirrt_debug_prof", "nirrt_set_cloud", "nirrt_reset_batch", "nirrt_pool_trim",
 ]
 
 
@@ -69,14 +69,14 @@ STAT_NAMES = ["visited", "visit_bytes", "members", "spilled", "hop_records", "re
 
 def useful_bytes(stats, dim):
     """Bytes the IMPLEMENTED algorithm has to move for what a launch did (per tree or summed), from the kernel's own
-    counters (include/nirrt_hip.h, nirrt_run_args.stats): visited slots (28 / 36 B per cell-ordered slot, 32 B per tail
-    record - already in bytes), 48 B per chain record walked, one 32-byte record per rewire candidate and 32 + 8 B written
-    per re-costed vertex, 12 B + one 32-byte record per re-evaluated list entry, ~160 B written per inserted vertex
-    (coordinates, record, aux, 4-hop record, links), 32 B read + (8 * dim + 16) B written per vertex of an index rebuild."""
+    counters (include/nirrt_hip.h, nirrt_run_args.stats): visited slot records (32 B, + 4 B of index in 3D - already in
+    bytes), 64 B per tree record walked (four hops each), one 32-byte vertex record + one 64-byte tree record per rewire
+    candidate examined, 16 B written per re-costed vertex (its record's and its slot's cost), 12 B + one 32-byte record per
+    re-evaluated list entry, 136 B (+ 4 in 3D) written per inserted vertex (vertex record 32, tree record 64, slot record 32,
+    two link words), 32 B read + 32 + 4 (+ 4 in 3D) + 8 B written per vertex of an index rebuild."""
     st = np.asarray(stats, dtype=np.float64).reshape(-1, N_STATS).sum(axis=0)
-    return float(st[1] + 48 * st[4] + 32 * st[5] + 40 * st[7] + 44 * st[8] + (112 + 16 * dim) * st[9]
-                 + (32 + 8 * dim + 16 + 8) * st[10])
-
+    d3 = 4 if dim == 3 else 0
+    return float(st[1] + 64 * st[4] + 96 * st[5] + 16 * st[7] + 44 * st[8] + (136 + d3) * st[9] + (32 + 32 + 4 + d3 + 8) * st[10])
 
 
 _lib = None
@@ -99,6 +99,7 @@ def load():
     L.nirrt_destroy.argtypes = [vp]
     L.nirrt_reset.argtypes = [vp]
     L.nirrt_reset_batch.argtypes = [C.POINTER(vp), C.c_int32]
+    L.nirrt_pool_trim.argtypes = []
     L.nirrt_upload.argtypes = [vp, C.c_int64, dp, ip]
     L.nirrt_download.argtypes = [vp, dp, ip, ip]
     L.nirrt_num_vertices.argtypes = [vp, ip]
@@ -320,6 +321,11 @@ class HipTree:
         q = _f64(node_new)
         _check(self.L.nirrt_extend(self.h, int(nearest_idx), _dp(q), int(flags), C.byref(self._res)))
         return self._res
+
+
+def pool_trim():
+    """device chunks that hold no live tree go back to the driver (see nirrt_pool_trim)"""
+    _check(load().nirrt_pool_trim())
 
 
 def reset_batch(trees):

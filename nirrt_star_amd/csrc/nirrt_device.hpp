@@ -26,6 +26,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/nirrt_hip.h"
 
@@ -204,6 +205,7 @@ struct TreeHotT {
     typename P<Topo>::type topo;     // topo[cap]: parent chain (4 hops), child-list links, flags
     typename P<VRec>::type vrec;     // vrec[cap]: coordinates + exact cost by vertex index (random access, download)
     typename P<int>::type bfs_q;     // scratch queue for subtree traversals
+    typename P<int>::type bfs_fc;    // ... first child of each queue entry (-2: not known, read the record)
     typename P<double>::type chain_g;   // edge lengths of the chain new -> root beyond the first CHAIN_MAX (which live in LDS)
     int cap;
     int n;          // num_vertices
@@ -264,6 +266,16 @@ struct TreeHotT {
     double g_rho;            // running estimate of the nearest-vertex distance of the samples (first box of a nearest query)
     double g_inv_h[3];       // cells per unit length, per axis
     double g_margin[3];      // slack added to every query box
+    // second, coarse level over the vertices appended since the last (full) rebuild: slots [g_ns, g_ns2) hold vertices
+    // [g_ns, g_ns2) ordered by cell of a G2^D grid (re-sorted every g_every2 insertions - a few hundred vertices), so a query
+    // reads a few coarse cells of them instead of all; only slots [g_ns2, n) are visited unconditionally
+    typename P<int>::type g_start2;   // g_start2[c] .. g_start2[c+1]: slots (absolute) of coarse cell c; g_ncell2 + 1 entries
+    int g_ns2;
+    int g_G2;
+    int g_ncell2;
+    int g_every2;
+    double g_inv_h2[3];
+    double g_margin2[3];
 };
 using TreeHotH = TreeHotT<gp_plain>;    // as stored in HBM and as the host fills it in
 using TreeHot = TreeHotT<gp_global>;    // the device code's view (same layout)
@@ -1024,21 +1036,23 @@ __device__ __forceinline__ int wg_nearest_finish(Lds<NT> &s, double m1, int i1, 
 // fall into border cells, which extend to infinity.  The order inside a cell is whatever the atomics produce; no result
 // depends on it (minima are reduced as (value, index) pairs, rewire selects by index).
 // ------------------------------------------------------------------------------------------------
+template <int L = 0>   // L = 0: the G^D grid of the cell-ordered part; L = 1: the coarse grid of the second level
 __device__ __forceinline__ int grid_cell_axis(const TreeHot &t, int k, double x)
 {
-    const double a = (x - t.lo[k]) * t.g_inv_h[k];
-    const int G = t.g_G;
+    const double a = (x - t.lo[k]) * (L == 0 ? t.g_inv_h[k] : t.g_inv_h2[k]);
+    const int G = L == 0 ? t.g_G : t.g_G2;
     return a <= 0.0 ? 0 : (a >= (double)G ? G - 1 : (int)a);
 }
 
-template <int D>
+template <int D, int L = 0>
 __device__ __forceinline__ void grid_box(const TreeHot &t, const double *p, double rad, int (&c0)[3], int (&c1)[3])
 {
     c0[2] = 0; c1[2] = 0;
 #pragma unroll
     for (int k = 0; k < D; k++) {
-        c0[k] = grid_cell_axis(t, k, p[k] - rad - t.g_margin[k]);
-        c1[k] = grid_cell_axis(t, k, p[k] + rad + t.g_margin[k]);
+        const double m = L == 0 ? t.g_margin[k] : t.g_margin2[k];
+        c0[k] = grid_cell_axis<L>(t, k, p[k] - rad - m);
+        c1[k] = grid_cell_axis<L>(t, k, p[k] + rad + m);
     }
 }
 
@@ -1140,7 +1154,80 @@ NIRRT_FN __device__ void wg_grid_rebuild(int n)
             }
         }
     }
-    if (tid == 0) { t.g_ns = n; s.stat[ST_REBUILT] += n; }
+    if (tid == 0) { t.g_ns = n; t.g_ns2 = n; s.stat[ST_REBUILT] += n; }
+    __syncthreads();
+}
+
+// counting sort of the vertices appended since the last full rebuild, [g_ns, n), by coarse cell into slots [g_ns, n)
+template <int D, int NT>
+NIRRT_FN __device__ void wg_grid_rebuild2(int n)
+{
+    Lds<NT> &s = g_lds;
+    TreeHot &t = g_lds.hot;
+    const int tid = threadIdx.x, nc = t.g_ncell2, G = t.g_G2, v0 = t.g_ns, m = n - v0;
+    for (int c = tid; c < nc; c += NT) t.g_cnt[c] = 0;
+    __syncthreads();
+    auto cell_of = [&](const VRec &v) -> int {
+        int c = grid_cell_axis<1>(t, 0, v.x) + G * grid_cell_axis<1>(t, 1, v.y);
+        if (D == 3) c += G * G * grid_cell_axis<1>(t, 2, v.z);
+        return c;
+    };
+    for (int j0 = tid; j0 < m; j0 += NT * REBUILD_U) {
+        VRec v[REBUILD_U];
+        int cell[REBUILD_U], rk[REBUILD_U];
+#pragma unroll
+        for (int u = 0; u < REBUILD_U; u++)
+            if (j0 + u * NT < m) v[u] = ldg(&t.vrec[v0 + j0 + u * NT]);
+#pragma unroll
+        for (int u = 0; u < REBUILD_U; u++) cell[u] = j0 + u * NT < m ? cell_of(v[u]) : -1;
+#pragma unroll
+        for (int u = 0; u < REBUILD_U; u++)
+            rk[u] = cell[u] >= 0 ? __hip_atomic_fetch_add(&t.g_cnt[cell[u]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+#pragma unroll
+        for (int u = 0; u < REBUILD_U; u++)
+            if (cell[u] >= 0) t.g_rank[v0 + j0 + u * NT] = rk[u];
+    }
+    __syncthreads();
+    const int per = (nc + NT - 1) / NT, b = tid * per;
+    int sum = 0;
+    for (int j = 0; j < per; j++)
+        if (b + j < nc) sum += t.g_cnt[b + j];
+    int run;
+    block_excl_scan<NT>(s, sum, run);
+    run += v0;
+    for (int j = 0; j < per; j++) {
+        if (b + j < nc) {
+            int c = t.g_cnt[b + j];
+            t.g_start2[b + j] = run;
+            run += c;
+        }
+    }
+    if (tid == 0) t.g_start2[nc] = n;
+    __syncthreads();
+    for (int j0 = tid; j0 < m; j0 += NT * REBUILD_U) {
+        VRec v[REBUILD_U];
+        int rk[REBUILD_U], st[REBUILD_U];
+#pragma unroll
+        for (int u = 0; u < REBUILD_U; u++) {
+            const int j = j0 + u * NT;
+            rk[u] = 0;
+            if (j < m) { v[u] = ldg(&t.vrec[v0 + j]); rk[u] = t.g_rank[v0 + j]; }
+        }
+#pragma unroll
+        for (int u = 0; u < REBUILD_U; u++) st[u] = j0 + u * NT < m ? t.g_start2[cell_of(v[u])] : 0;
+#pragma unroll
+        for (int u = 0; u < REBUILD_U; u++) {
+            const int j = j0 + u * NT;
+            if (j < m) {
+                const int i = v0 + j, sl = st[u] + rk[u];
+                const double xyz[3] = {v[u].x, v[u].y, v[u].z};
+                stg(&t.g_rec[sl], slot_make<D>(xyz, v[u].cost, i));
+                if (D == 3) t.g_idx[sl] = i;
+                t.pos[i] = sl;
+            }
+        }
+    }
+    if (tid == 0) { t.g_ns2 = n; s.stat[ST_REBUILT] += m; }
     __syncthreads();
 }
 
@@ -1218,43 +1305,55 @@ NIRRT_FN __device__ void wg_query_fn()
             if (seg_aabb_pass<D, NT>(s, o, l0, l1)) s.ob_list[atomicAdd(&s.ob_n, 1)] = (unsigned char)o;
         }
     }
-    // row `row` of box (c0, c1) -> slot range.  ball != nullptr: only the cells of the row that the ball (ball, rad)
-    // can reach are kept (the corner cells of the box are dropped)
-    auto row_range = [&](const int (&c0)[3], const int (&c1)[3], int row, const double *ball, double rad, int &rb, int &rl) {
+    // row `row` of box (c0, c1) of grid level L -> slot range.  ball != nullptr: only the cells of the row that the ball
+    // (ball, rad) can reach are kept (the corner cells of the box are dropped)
+    auto row_range = [&](auto lvl, const int (&c0)[3], const int (&c1)[3], int row, const double *ball, double rad, int &rb, int &rl) {
+        constexpr int L = decltype(lvl)::value;
+        const int GL = L == 0 ? G : t.g_G2;
         const int ny_ = c1[1] - c0[1] + 1;
         const int cy = c0[1] + row % ny_, cz = c0[2] + row / ny_;
         int x0 = c0[0], x1 = c1[0];
         bool empty = false;
         if (ball) {
             // distance from the ball centre to the row's slab in y (and z); border cells extend to infinity
-            double rem = (rad + t.g_margin[0]) * (rad + t.g_margin[0]);
+            const double m0 = L == 0 ? t.g_margin[0] : t.g_margin2[0];
+            double rem = (rad + m0) * (rad + m0);
 #pragma unroll
             for (int k = 1; k < D; k++) {
                 const int ck = k == 1 ? cy : cz;
-                const double h = 1.0 / t.g_inv_h[k];
+                const double h = 1.0 / (L == 0 ? t.g_inv_h[k] : t.g_inv_h2[k]);
                 const double a = ck == 0 ? -__builtin_inf() : t.lo[k] + ck * h;
-                const double b = ck == G - 1 ? __builtin_inf() : t.lo[k] + (ck + 1) * h;
-                double dk = fmax(fmax(a - ball[k], ball[k] - b), 0.0) - t.g_margin[k];
+                const double b = ck == GL - 1 ? __builtin_inf() : t.lo[k] + (ck + 1) * h;
+                double dk = fmax(fmax(a - ball[k], ball[k] - b), 0.0) - (L == 0 ? t.g_margin[k] : t.g_margin2[k]);
                 if (dk > 0.0) rem -= dk * dk;
             }
             if (rem < 0.0) empty = true;
             else {
-                const double w = __builtin_sqrt(rem) + t.g_margin[0];
-                x0 = max(x0, grid_cell_axis(t, 0, ball[0] - w));
-                x1 = min(x1, grid_cell_axis(t, 0, ball[0] + w));
+                const double w = __builtin_sqrt(rem) + m0;
+                x0 = max(x0, grid_cell_axis<L>(t, 0, ball[0] - w));
+                x1 = min(x1, grid_cell_axis<L>(t, 0, ball[0] + w));
                 if (x1 < x0) empty = true;
             }
         }
-        const int base = (cz * G + cy) * G;
+        const int base = (cz * GL + cy) * GL;
         int b = 0, e = 0;
-        if (!empty) { b = t.g_start[base + x0]; e = t.g_start[base + x1 + 1]; }
+        if (!empty) {
+            if (L == 0) { b = t.g_start[base + x0]; e = t.g_start[base + x1 + 1]; }
+            else { b = t.g_start2[base + x0]; e = t.g_start2[base + x1 + 1]; }
+        }
         rb = b; rl = e;     // first slot / end slot: nothing is computed from the two loads here, so they stay in flight
     };
+    const std::integral_constant<int, 0> LV0;
+    const std::integral_constant<int, 1> LV1;
     int nb0[3] = {0, 0, 0}, nb1[3] = {0, 0, 0}, qb0[3] = {0, 0, 0}, qb1[3] = {0, 0, 0};
-    int rowsN = 0, rowsQ = 0;
+    int cb0[3] = {0, 0, 0}, cb1[3] = {0, 0, 0}, db0[3] = {0, 0, 0}, db1[3] = {0, 0, 0};   // the same boxes on the coarse level
+    int rowsN = 0, rowsQ = 0, rows2N = 0, rows2Q = 0;
     // whole-tree visit: no index yet, or a box of more rows than the range list holds (never the case for the Near
     // radius of an indexed tree)
     bool brute = ns == 0;
+    const int ns2 = uni(t.g_ns2);
+    bool lvl2 = !brute && ns2 > ns;       // a coarse level exists: rows of it are listed like rows of the main level
+    bool coarse_whole = false;            // ... or, when the range list has no room for them, it is visited whole
     if (!brute) {
         if (wantN) { grid_box<D>(t, pnv, r, nb0, nb1); rowsN = grid_rows(nb0, nb1); }
         if (wantQ) {
@@ -1263,17 +1362,27 @@ NIRRT_FN __device__ void wg_query_fn()
             rowsQ = grid_rows(qb0, qb1);
         }
         if (rowsN + rowsQ > GRID_RG_MAX) brute = true;
+        else if (lvl2) {
+            if (wantN) { grid_box<D, 1>(t, pnv, r, cb0, cb1); rows2N = grid_rows(cb0, cb1); }
+            if (wantQ) { grid_box<D, 1>(t, qv, 1.5 * t.g_rho, db0, db1); rows2Q = grid_rows(db0, db1); }
+            if (rowsN + rowsQ + rows2N + rows2Q > GRID_RG_MAX) { coarse_whole = true; rows2N = 0; rows2Q = 0; }
+        }
     }
+    if (brute) lvl2 = false;
+    const int rows1 = rowsN + rowsQ, rowsAll = rows1 + rows2N + rows2Q;
     const unsigned fl_all = (wantN ? GRID_N : 0u) | (wantQ ? GRID_Q : 0u);
-    // the rows' slot ranges (two g_start loads per row; rowsN + rowsQ <= GRID_RG_MAX <= NT: one row per thread) are
+    // the rows' slot ranges (two g_start loads per row; at most GRID_RG_MAX <= NT rows: one row per thread) are
     // requested now and consumed after the first pass of the loop
     int rb = 0, rl = 0;
     if (!brute) {
-        if (tid < rowsN) row_range(nb0, nb1, tid, pnv, r, rb, rl);
-        else if (tid < rowsN + rowsQ) row_range(qb0, qb1, tid - rowsN, nullptr, 0., rb, rl);
+        if (tid < rowsN) row_range(LV0, nb0, nb1, tid, pnv, r, rb, rl);
+        else if (tid < rows1) row_range(LV0, qb0, qb1, tid - rowsN, nullptr, 0., rb, rl);
+        else if (tid < rows1 + rows2N) row_range(LV1, cb0, cb1, tid - rows1, pnv, r, rb, rl);
+        else if (tid < rowsAll) row_range(LV1, db0, db1, tid - rows1 - rows2N, nullptr, 0., rb, rl);
     }
     if (tid == 0) {
-        const int beg = brute ? 0 : ns;
+        // first pass: the vertices no level covers yet (and the coarse level whole if its rows found no room in the list)
+        const int beg = brute ? 0 : (coarse_whole || !lvl2 ? ns : ns2);
         s.rg_beg[0] = beg; s.rg_len[0] = n - beg; s.rg_flag[0] = (unsigned char)fl_all; s.rg_n = 1;
     }
     double m1 = __builtin_inf(), m2 = __builtin_inf();   // nearest: smallest / second-smallest squared distance of this lane
@@ -1420,12 +1529,15 @@ NIRRT_FN __device__ void wg_query_fn()
         if (stage == 0) {
             // the rows of cells: the range list goes to LDS now (their g_start words have had the first pass to arrive)
             __syncthreads();
-            if (tid < rowsN + rowsQ) { s.rg_beg[tid] = rb; s.rg_len[tid] = rl - rb; s.rg_flag[tid] = tid < rowsN ? GRID_N : GRID_Q; }
-            if (tid == 0) s.rg_n = rowsN + rowsQ;
+            if (tid < rowsAll) {
+                s.rg_beg[tid] = rb; s.rg_len[tid] = rl - rb;
+                s.rg_flag[tid] = (tid < rowsN || (tid >= rows1 && tid < rows1 + rows2N)) ? GRID_N : GRID_Q;
+            }
+            if (tid == 0) s.rg_n = rowsAll;
             __syncthreads();
             stage = 1;
             PROF(13);
-            if (rowsN + rowsQ > 0) continue;
+            if (rowsAll > 0) continue;
         }
         if (!wantQ) break;
         // widen the box until it provably contains the nearest vertex: nothing found -> one more ring of cells (twice),
@@ -1450,6 +1562,12 @@ NIRRT_FN __device__ void wg_query_fn()
             bool covered = true;
 #pragma unroll
             for (int k = 0; k < D; k++) covered = covered && eb0[k] >= qb0[k] && eb1[k] <= qb1[k];
+            if (covered && lvl2 && !coarse_whole) {   // the same ball on the coarse level
+                int fb0[3], fb1[3];
+                grid_box<D, 1>(t, qv, rad, fb0, fb1);
+#pragma unroll
+                for (int k = 0; k < D; k++) covered = covered && fb0[k] >= db0[k] && fb1[k] <= db1[k];
+            }
             if (covered) {
                 result_ni = gi >= 0 ? gi : wg_nearest_exact<D, NT>(n, qx, qy, qz);
                 if (tid == 0) {   // statistics only: no decision depends on it
@@ -1470,11 +1588,12 @@ NIRRT_FN __device__ void wg_query_fn()
         } else {
             revisits++;
             int eb = 0, el = 0;
-            if (tid < rowsE) row_range(eb0, eb1, tid, nullptr, 0., eb, el);
+            if (tid < rowsE) row_range(LV0, eb0, eb1, tid, nullptr, 0., eb, el);
             if (tid < rowsE) { s.rg_beg[tid] = eb; s.rg_len[tid] = el - eb; s.rg_flag[tid] = GRID_Q; }
             if (tid == 0) { s.rg_beg[rowsE] = ns; s.rg_len[rowsE] = n - ns; s.rg_flag[rowsE] = GRID_Q; s.rg_n = rowsE + 1; }
 #pragma unroll
             for (int k = 0; k < 3; k++) { qb0[k] = eb0[k]; qb1[k] = eb1[k]; }
+            coarse_whole = true;   // (everything behind the cell-ordered part has been visited whole from here on)
         }
         __syncthreads();
         stage = 2;
@@ -1619,38 +1738,52 @@ __device__ __forceinline__ unsigned char *cand_state(LdsData &s) { return reinte
 // The cost lands in the vertex's record and in its slot record.  n_list > 0: a re-costed vertex that is on rewire's candidate
 // list (first n_list stash ids) is marked for re-testing if its source has the LOWER index (the reference re-parents that
 // source before the member's turn; a source with a higher index comes after it and must not change the member's test).
+#define BFS_FRONT 32   // frontier entries kept in LDS per level (6 * BFS_FRONT ints: two buffers of vertex / first child / source)
 template <int D, int NT>
-NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int through_in, int n_list_in)
+NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int through_in, int n_list_in, int front_off_in)
 {
+    // front_off >= 0: byte offset (from the Near stash's margin area) of 6 * BFS_FRONT ints the traversal may use for its
+    // frontier: a level of up to BFS_FRONT vertices then costs ONE memory round trip (the records of its children) instead
+    // of re-reading the queue and the parents' records first - what counts for the long chains of degenerate trees
     Lds<NT> &s = g_lds;
     TreeHot &t = g_lds.hot;
     const int n_src = uni(n_src_in), walk_from = uni(walk_from_in), through = uni(through_in), n_list = uni(n_list_in);
+    const int front_off = uni(front_off_in);
+    int *fr = front_off >= 0 ? reinterpret_cast<int *>(cand_state(s) + front_off) : nullptr;
     const int tid = threadIdx.x;
-    const int ns = uni(t.g_ns);
-    int head = 0, tail = n_src, level = 0;
+    const int ns = uni(t.g_ns2);   // vertices below it have their slot in pos[]
+    int head = 0, tail = n_src, level = 0, cur = 0;
+    bool in_lds = false;   // the sources come from the global queue (their child lists have just been edited: read afresh)
     while (head < tail) {   // one BFS level per trip; uniform
         for (int i = head + tid; i < tail; i += NT) {
-            const int u = t.bfs_q[i];
-            const int su = t.g_rank[i];
-            int c = t.topo[u].fc;
+            int u, su, c;
+            if (in_lds) { const int *f = fr + cur * 3 * BFS_FRONT; u = f[i - head]; c = f[BFS_FRONT + i - head]; su = f[2 * BFS_FRONT + i - head]; }
+            else { u = t.bfs_q[i]; su = t.g_rank[i]; c = t.bfs_fc[i]; }
+            if (c == -2) c = t.topo[u].fc;
             // the records of the three levels below a re-parented vertex mention its edge too
             Hop4 hu;
             if (level < 3 && c >= 0) hu = ld_hop(&t.topo[u]);
             while (c >= 0) {
-                int pos = atomicAdd(&s.bc_i[4], 1);
+                GAS Topo &hc = t.topo[c];
+                const int c_ns = hc.ns, c_fc = hc.fc;   // one record: the sibling link now, the child link for the next level
+                const int pos = atomicAdd(&s.bc_i[4], 1);
                 t.bfs_q[pos] = c;
                 t.g_rank[pos] = su;
-                GAS Topo &hc = t.topo[c];
+                t.bfs_fc[pos] = c_fc;
+                const int lp = pos - tail;
+                if (fr && lp < BFS_FRONT) { int *f = fr + (cur ^ 1) * 3 * BFS_FRONT; f[lp] = c; f[BFS_FRONT + lp] = c_fc; f[2 * BFS_FRONT + lp] = su; }
                 if (level < 3) {   // entry 0 of the child's record (its own edge) is unchanged
                     hc.e[1] = hu.e[0]; hc.e[2] = hu.e[1]; hc.e[3] = hu.e[2];
                     hc.a[1] = hu.a[0]; hc.a[2] = hu.a[1]; hc.a[3] = hu.a[2];
                 }
-                c = hc.ns;
+                c = c_ns;
             }
         }
         __syncthreads();
         head = tail;
         tail = s.bc_i[4];
+        in_lds = fr != nullptr && tail - head <= BFS_FRONT;
+        cur ^= 1;
         level++;
         __syncthreads();
     }
@@ -1697,9 +1830,9 @@ NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int 
 }
 
 template <int D, int NT>
-__device__ __forceinline__ void wg_recost_queue(Lds<NT> &s, TreeHot &t, int n_src, int walk_from, int through, int n_list)
+__device__ __forceinline__ void wg_recost_queue(Lds<NT> &s, TreeHot &t, int n_src, int walk_from, int through, int n_list, int front_off = -1)
 {
-    wg_recost_queue_fn<D, NT>(n_src, walk_from, through, n_list);
+    wg_recost_queue_fn<D, NT>(n_src, walk_from, through, n_list, front_off);
 }
 
 // one re-parented vertex v: its own cost and everything below it
@@ -1707,7 +1840,7 @@ template <int D, int NT>
 __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v, int through, int n_list = 0)
 {
     __syncthreads();
-    if (threadIdx.x == 0) { t.bfs_q[0] = v; t.g_rank[0] = v; s.bc_i[4] = 1; }
+    if (threadIdx.x == 0) { t.bfs_q[0] = v; t.g_rank[0] = v; t.bfs_fc[0] = -2; s.bc_i[4] = 1; }
     __syncthreads();
     wg_recost_queue<D, NT>(s, t, 1, 0, through, n_list);
 }
@@ -1971,6 +2104,7 @@ NIRRT_FN __device__ void it_extend()
     PROF_DECL
     // keep the cell-ordered part of the grid index within GRID_REBUILD_EVERY vertices of the tree
     if (n >= t.g_min && n - t.g_ns >= t.g_every) wg_grid_rebuild<D, NT>(n);   // uniform
+    else if (t.g_ns > 0 && n - t.g_ns2 >= t.g_every2) wg_grid_rebuild2<D, NT>(n);   // the coarse level over what was appended since
     PROF(12);
     int ni;
     double node_new[D], nearest[D];
@@ -2193,7 +2327,7 @@ NIRRT_FN __device__ void it_connect()
                         const bool leaf = t.topo[vj].fc < 0;
                         const int old_p = t.topo[vj].a[0], nx = t.topo[vj].ns, pv = t.topo[vj].ps;
                         const int li = t.topo[vj].flags;
-                        const int slot = vj < t.g_ns ? t.pos[vj] : vj;
+                        const int slot = vj < t.g_ns2 ? t.pos[vj] : vj;
                         const int fc_new = s.new_fc;   // head of new's child list: kept in LDS during the pass
                         const double el = hypot_py<D>(d);
                         if (pv >= 0) t.topo[pv].ns = nx; else t.topo[old_p].fc = nx;
@@ -2249,9 +2383,11 @@ NIRRT_FN __device__ void it_connect()
                 const bool batch_ok = listed_all && cap_lds >= 128;   // (room for the relink chunk behind the state bytes; small test builds take the sequential path)
                 if (batch_ok) {
                     int *ch_v = reinterpret_cast<int *>(state + ((cap_lds + 7) & ~7)), *ch_pv = ch_v + 64, *ch_nx = ch_v + 128;
+                    // behind the chunk arrays: the frontier buffers of the subtree traversal, if the margin area has the room
+                    const int front_off = (((cap_lds + 7) & ~7) + 768 + 24 * BFS_FRONT <= 8 * cap_lds) ? ((cap_lds + 7) & ~7) + 768 : -1;
                     const int lane = tid & 63;
                     const bool single = n_list <= 64;   // every candidate has its own lane of wave 0: records stay in registers across the phases
-                    const int ns_ = uni(t.g_ns);
+                    const int ns_ = uni(t.g_ns2);   // vertices below it have their slot in pos[]
                     const double bound = new_cost - (1e-9 + 1e-11 * new_cost);   // an ancestor that passes costs more than cost(new)
                     const int clen = s.chain_len;
                     VRec vr;
@@ -2274,11 +2410,15 @@ NIRRT_FN __device__ void it_connect()
                                     st = vr.cost > new_cost + dist_scan_cold<D>(dx, dy, dz) ? CAND_PASS : 0u;
                                     state[a] = (unsigned char)st;
                                 }
-                                if (st & CAND_PASS) atomicAdd(&s.bc_i[5], 1);
+                                if (st & CAND_PASS) {   // the passing members of this round, compact (phase B looks ancestors up in it)
+                                    const int pi = atomicAdd(&s.bc_i[5], 1);
+                                    if (pi < 192) ch_v[pi] = ids[a];
+                                }
                             }
                         }
                         __syncthreads();
-                        if (uni(s.bc_i[5]) == 0) break;
+                        const int n_pass = uni(s.bc_i[5]);
+                        if (n_pass == 0) break;
                         // phase B: a passing member with a passing ancestor of lower index waits for that one
                         for (int base = 0; base < n_list; base += NT) {
                             const int a = base + tid;
@@ -2297,8 +2437,13 @@ NIRRT_FN __device__ void it_connect()
                                             cst -= h.e[j];   // ~ cost(anc)
                                             if (anc <= 0 || cst < bound) stop = true;
                                             else if (anc < id) {
-                                                for (int b = 0; b < n_list; b++)
-                                                    if (ids[b] == anc && (state[b] & CAND_PASS)) { blocked = true; stop = true; }
+                                                if (n_pass <= 192) {
+                                                    for (int b = 0; b < n_pass; b++)
+                                                        if (ch_v[b] == anc) { blocked = true; stop = true; }
+                                                } else {
+                                                    for (int b = 0; b < n_list; b++)
+                                                        if (ids[b] == anc && (state[b] & CAND_PASS)) { blocked = true; stop = true; }
+                                                }
                                             }
                                         }
                                     }
@@ -2313,6 +2458,7 @@ NIRRT_FN __device__ void it_connect()
                         for (int base = 0; base < n_list; base += 64) {
                             const int a = base + tid;
                             const bool mine = tid < 64 && a < n_list && state[a] == CAND_PASS;
+                            if (!block_any(mine)) continue;   // (uniform) nothing to re-parent among these 64
                             int v = -1, pv = -1, nx = -1, old_p = -1, fc = -1, flg = 0;
                             if (mine) {
                                 v = ids[a];
@@ -2375,6 +2521,7 @@ NIRRT_FN __device__ void it_connect()
                                             const int qp = atomicAdd(&s.bc_i[4], 1);
                                             t.bfs_q[qp] = v;
                                             t.g_rank[qp] = v;
+                                            t.bfs_fc[qp] = -2;   // (a chunk member that was v's first child has just edited the list)
                                         }
                                     }
                                     if (lane == 0) { s.bc_i[7] += __popcll(m); s.stat[ST_REWIRED] += __popcll(m); }
@@ -2385,7 +2532,7 @@ NIRRT_FN __device__ void it_connect()
                         PROF(9);
                         n_rewired += uni(s.bc_i[7]);
                         const int n_src = uni(s.bc_i[4]);
-                        if (n_src > 0) wg_recost_queue<D, NT>(s, t, n_src, n_src, new_idx, n_list);   // uniform
+                        if (n_src > 0) wg_recost_queue<D, NT>(s, t, n_src, n_src, new_idx, n_list, front_off);   // uniform
                         for (int a = tid; a < n_list; a += NT)
                             if (state[a] & CAND_BLOCKED) state[a] = (unsigned char)CAND_DIRTY;
                         PROF(10);

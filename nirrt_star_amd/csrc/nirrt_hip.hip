@@ -290,14 +290,20 @@ static int push_desc(nirrt_tree *t)
 namespace {
 struct ArenaPool {
     std::mutex mu;
-    struct Chunk { char *base; size_t size, used; };
-    std::map<int, std::vector<Chunk>> chunks;                       // per device
+    struct Chunk { int device; char *base; size_t size, used; long live; };
+    std::vector<Chunk> chunks;
     std::map<std::pair<int, size_t>, std::vector<void *>> free_list;   // (device, bytes) -> arenas handed back
     static size_t chunk_bytes()
     {
         const char *e = std::getenv("NIRRT_POOL_CHUNK_MB");
         const long long mb = (e && *e) ? std::atoll(e) : 4096;
         return mb <= 0 ? 0 : (size_t)mb << 20;
+    }
+    Chunk *owner(const void *p)
+    {
+        for (Chunk &c : chunks)
+            if ((const char *)p >= c.base && (const char *)p < c.base + c.size) return &c;
+        return nullptr;
     }
     // returns nullptr when pooling is off or the request is small / larger than a chunk (the caller then uses hipMalloc)
     void *take(int device, size_t bytes)
@@ -306,27 +312,58 @@ struct ArenaPool {
         if (cb == 0 || bytes < ((size_t)1 << 20) || bytes > cb) return nullptr;
         std::lock_guard<std::mutex> g(mu);
         auto &fl = free_list[{device, bytes}];
-        if (!fl.empty()) { void *p = fl.back(); fl.pop_back(); return p; }
+        if (!fl.empty()) {
+            void *p = fl.back();
+            fl.pop_back();
+            owner(p)->live++;
+            return p;
+        }
         const size_t A = (size_t)2 << 20;   // arenas start on 2 MB boundaries
         const size_t need = (bytes + A - 1) / A * A;
-        auto &cs = chunks[device];
-        if (cs.empty() || cs.back().used + need > cs.back().size) {
+        Chunk *c = nullptr;
+        for (Chunk &k : chunks)
+            if (k.device == device && k.used + need <= k.size) c = &k;
+        if (!c) {
             void *b = nullptr;
             if (hipMalloc(&b, cb) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-            cs.push_back(Chunk{(char *)b, cb, 0});
+            chunks.push_back(Chunk{device, (char *)b, cb, 0, 0});
+            c = &chunks.back();
         }
-        Chunk &c = cs.back();
-        void *p = c.base + c.used;
-        c.used += need;
+        void *p = c->base + c->used;
+        c->used += need;
+        c->live++;
         return p;
     }
     void give(int device, size_t bytes, void *p)
     {
         std::lock_guard<std::mutex> g(mu);
+        owner(p)->live--;
         free_list[{device, bytes}].push_back(p);
+    }
+    // chunks none of whose arenas is in use go back to the driver
+    void trim()
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < chunks.size();) {
+            Chunk c = chunks[i];
+            if (c.live > 0) { i++; continue; }
+            for (auto &kv : free_list) {
+                auto &v = kv.second;
+                v.erase(std::remove_if(v.begin(), v.end(), [&](void *p) { return (char *)p >= c.base && (char *)p < c.base + c.size; }), v.end());
+            }
+            (void)hipSetDevice(c.device);
+            (void)hipFree(c.base);
+            chunks.erase(chunks.begin() + (long)i);
+        }
     }
 };
 ArenaPool g_pool;
+}
+
+extern "C" int nirrt_pool_trim(void)
+{
+    g_pool.trim();
+    return NIRRT_OK;
 }
 
 extern "C" int nirrt_destroy(nirrt_tree *t)
@@ -434,6 +471,10 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     h.g_G = D == 2 ? 256 : 16;
     if (const char *e = std::getenv("NIRRT_GRID_G")) h.g_G = std::min(D == 2 ? 256 : 40, std::max(1, std::atoi(e)));
     h.g_ncell = D == 2 ? h.g_G * h.g_G : h.g_G * h.g_G * h.g_G;
+    // second level over the vertices appended since the last full rebuild: 32^2 / 8^3 coarse cells, re-sorted every 64 insertions
+    h.g_G2 = D == 2 ? 32 : 8;
+    if (const char *e = std::getenv("NIRRT_GRID_G2")) h.g_G2 = std::min(D == 2 ? 64 : 16, std::max(1, std::atoi(e)));
+    h.g_ncell2 = D == 2 ? h.g_G2 * h.g_G2 : h.g_G2 * h.g_G2 * h.g_G2;
     // One allocation per tree (~12 MB at 50k vertices in 2D), carved into its arrays: a workgroup's scattered accesses then
     // fall into half a dozen 2 MB pages instead of ~35 separately placed buffers of 50 - 2400 KB (address translation, not
     // HBM, is what a latency-bound chase across 8192 such trees pays for).  Arrays the loop body touches every iteration
@@ -450,11 +491,12 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         want(&h.topo, np);
         want(&h.g_rec, np); want(&h.g_idx, np); want(&h.pos, np);
         want(&h.g_start, (size_t)h.g_ncell + 1);
+        want(&h.g_start2, (size_t)h.g_ncell2 + 1);
         want(&h.sol, np); want(&h.sol_line, np);
         want(&h.gc_idx, np); want(&h.gc_dist, np); want(&h.gc_col, np);
         want(&h.nr_idx, np); want(&h.nr_m, np);
-        want(&h.bfs_q, np); want(&h.chain_g, np);
-        want(&h.g_cnt, (size_t)h.g_ncell); want(&h.g_rank, np);
+        want(&h.bfs_q, np); want(&h.bfs_fc, np); want(&h.chain_g, np);
+        want(&h.g_cnt, (size_t)std::max(h.g_ncell, h.g_ncell2)); want(&h.g_rank, np);   // (both levels' rebuilds count in it)
         const size_t A = 256;
         size_t total = 0;
         for (const Piece &pc : pieces) total += (pc.bytes + A - 1) / A * A;
@@ -471,16 +513,21 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     h.dim = D;
     h.cap_sol = t->cap;
     h.g_ns = 0;
+    h.g_ns2 = 0;
     h.g_rho = 0.;
     h.g_min = GRID_MIN_VERTICES;
     h.g_every = GRID_REBUILD_EVERY;
     if (const char *e = std::getenv("NIRRT_GRID_MIN")) h.g_min = std::max(2, std::atoi(e));         // test / tuning knobs
     if (const char *e = std::getenv("NIRRT_GRID_REBUILD")) h.g_every = std::max(1, std::atoi(e));
+    h.g_every2 = std::max(1, h.g_every / 16);
+    if (const char *e = std::getenv("NIRRT_GRID_REBUILD2")) h.g_every2 = std::max(1, std::atoi(e));   // >= g_every: no second level
     for (int k = 0; k < 3; k++) {
         double ext = k < D ? cfg->range_hi[k] - cfg->range_lo[k] : 1.0;
         if (!(ext > 0.)) ext = 1.0;
         h.g_inv_h[k] = (double)h.g_G / ext;
         h.g_margin[k] = ext / (double)h.g_G / 256.0;
+        h.g_inv_h2[k] = (double)h.g_G2 / ext;
+        h.g_margin2[k] = ext / (double)h.g_G2 / 256.0;
     }
     HIPCHK_T(hipMemcpy(t->self_dev, &t->dev, sizeof(TreeDev *), hipMemcpyHostToDevice));
     HIPCHK_T(hipHostMalloc((void **)&t->scratch, sizeof(Scratch), hipHostMallocMapped));

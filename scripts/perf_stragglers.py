@@ -47,9 +47,8 @@ if mode == "find":
     slow, secs = report(res, pids, trees)
     json.dump({"slow": slow, "secs": [float(s) for s in secs]}, open(OUT, "w"))
 else:
-    slow = json.load(open(OUT))["slow"]
-    if len(sys.argv) > 2:
-        slow = slow[:int(sys.argv[2])]
+    # pids: from the command line ("1626,5727,...") or the file a `find` run of the same gpurun call left
+    slow = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 and "," in sys.argv[2] else json.load(open(OUT))["slow"]
     trees, npw, pyw = setup(slow)
     res = _hip.run_sampling(trees, iters, npw, pyw, flags=_hip.F_IRRT)
     report(res, slow, trees, top=8)

@@ -1,0 +1,48 @@
+"""The sharded evaluation harness END TO END on one rank: `python -m nirrt_star_amd.eval_sharded
+--max_problems 16` - argument handling, problem loading, the batched device loop, the RCCL-side gather on `cuda`, the
+summary JSON and the reference-format result pickle (eval_planning_2d.py:99-136) - and the same problems through
+plan_batch directly must give the same records."""
+import json
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_eval_sharded_main_end_to_end(tmp_path):
+    out = tmp_path / "res.json"
+    pk = tmp_path / "res.pickle"
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "nirrt_star_amd.eval_sharded", "--problem", "random_2d", "-p", "irrt_star", "--max_problems", "16",
+           "--iter_max", "3000", "--batch", "8", "--out", str(out), "--pickle_out", str(pk)]
+    p = subprocess.run(cmd, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    summary = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert summary["problems"] == 16 and summary["world_size"] == 1 and summary["solved"] > 0
+    d = json.load(open(out))
+    recs = np.array(d["records"])
+    assert recs.shape[0] == 16 and sorted(recs[:, 0].astype(int).tolist()) == list(range(16))
+    # the reference's pickle: list of env configs, each with its per-iteration 'result' list (eval_planning_2d.py:125-136)
+    with open(pk, "rb") as f:
+        cfgs = pickle.load(f)
+    assert len(cfgs) == 16 and all("result" in c and "env_dict" in c for c in cfgs)
+    assert all(len(c["result"]) > 0 for c in cfgs)
+    # the same 16 problems through the batch function in this process: identical records (seeded, deterministic)
+    from types import SimpleNamespace as NS
+    from nirrt_star_amd import eval_sharded as es, problems as P
+    a = NS(problem="random_2d", planner="irrt_star", neural_net="none", iter_max=3000, iter_after_initial=3000, step_len=10, clearance=3,
+           pc_n_points=2048, pc_over_sample_scale=5, pc_sample_rate=0.5, pc_update_cost_ratio=0.9, connect_max_trial_attempts=5,
+           root_dir=".", segment=2000)
+    cfgs2 = P.get_random_2d_env_configs()[:16]
+    probs = [P.get_random_2d_problem_input(c) for c in cfgs2]
+    r, _ = es.plan_batch(probs, list(range(16)), a, 0, None)
+    r = np.array(r).reshape(-1, es.RECORD_LEN)
+    order = np.argsort(recs[:, 0])
+    assert np.array_equal(np.nan_to_num(recs[order], posinf=1e300), np.nan_to_num(r, posinf=1e300))
