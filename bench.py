@@ -472,8 +472,11 @@ SECONDARY = [   # (label, bench arguments): each runs `--steps 1 --warmup 0` in 
     ("rrt_3d", ["--algo", "rrt", "--dim", "3"]),
     ("irrt_3d", ["--algo", "irrt", "--dim", "3", "--trees", "4096"]),
     ("irrt_2d_b30r16", ["--algo", "irrt", "--world", "b30r16"]),
-    ("nirrt_c_2d (config 3)", ["--algo", "nirrt_c", "--trees", "2048"]),
-    ("nirrt_3d (config 4)", ["--algo", "nirrt", "--dim", "3", "--trees", "512"]),
+    ("nirrt_2d", ["--algo", "nirrt", "--trees", "4096"]),
+    # config 3 as composed (-c bfs): the neural-connect rounds run a breadth-first search per cloud on the HOST (bfs_connect.py,
+    # like the reference) - a small batch keeps the line within minutes; it is not a throughput configuration
+    ("nirrt_c_2d (config 3)", ["--algo", "nirrt_c", "--trees", "64"]),
+    ("nirrt_3d (config 4)", ["--algo", "nirrt", "--dim", "3", "--trees", "1024"]),
 ]
 
 

@@ -222,6 +222,14 @@ typedef struct nirrt_run_args {
 } nirrt_run_args;
 int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *args);
 
+/* update_point_cloud's last step (nirrt_star_png_2d.py:166-174) for a batch of stopped trees in ONE launch: tree i keeps the
+ * points of its cloud whose prediction is non-zero, in order, and the policy scalars of nirrt_set_cloud.  clouds: DEVICE
+ * f64, cloud i at clouds + i * cloud_stride doubles, (n_points[i], 3) row-major (<= 4096 points); pred: DEVICE bytes, row i at
+ * pred + i * pred_stride; n_points, c_update: HOST; n_path_out: optional HOST out (points kept per tree). */
+int nirrt_set_cloud_batch(nirrt_tree *const *trees, int32_t n_trees, const double *clouds, int64_t cloud_stride,
+                          const int32_t *n_points, const uint8_t *pred, int64_t pred_stride, double sample_rate,
+                          double update_cost_ratio, const double *c_update, int32_t *n_path_out);
+
 /* debug aid: per-phase device tick counters of the loop body (zeros unless the library was built
  * with -DNIRRT_PROFILE); out24 = int64[24] */
 int nirrt_debug_prof(nirrt_tree *t, int64_t *out24);

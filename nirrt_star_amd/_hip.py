@@ -24,7 +24,7 @@ EXPORTS = [
     "nirrt_last_error", "nirrt_device_count", "nirrt_create", "nirrt_destroy", "nirrt_reset", "nirrt_upload",
     "nirrt_download", "nirrt_num_vertices", "nirrt_nearest", "nirrt_collision_batch", "nirrt_points_in_obs",
     "nirrt_near", "nirrt_cost", "nirrt_search_goal_parent", "nirrt_best_solution", "nirrt_solutions",
-    "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed", "nirrt_debug_prof", "nirrt_set_cloud", "nirrt_reset_batch", "nirrt_pool_trim",
+    "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed", "nirrt_debug_prof", "nirrt_set_cloud", "nirrt_reset_batch", "nirrt_pool_trim", "nirrt_set_cloud_batch",
 ]
 
 
@@ -100,6 +100,8 @@ def load():
     L.nirrt_reset.argtypes = [vp]
     L.nirrt_reset_batch.argtypes = [C.POINTER(vp), C.c_int32]
     L.nirrt_pool_trim.argtypes = []
+    L.nirrt_set_cloud_batch.argtypes = [C.POINTER(vp), C.c_int32, vp, C.c_int64, C.POINTER(C.c_int32), vp, C.c_int64, C.c_double,
+                                        C.c_double, dp, C.POINTER(C.c_int32)]
     L.nirrt_upload.argtypes = [vp, C.c_int64, dp, ip]
     L.nirrt_download.argtypes = [vp, dp, ip, ip]
     L.nirrt_num_vertices.argtypes = [vp, ip]
@@ -321,6 +323,19 @@ class HipTree:
         q = _f64(node_new)
         _check(self.L.nirrt_extend(self.h, int(nearest_idx), _dp(q), int(flags), C.byref(self._res)))
         return self._res
+
+
+def set_cloud_batch(trees, clouds_ptr, cloud_stride, n_points, pred_ptr, pred_stride, sample_rate, update_cost_ratio, c_update):
+    """path points of a batch of clouds into their trees in one launch (device pointers); returns the points kept per tree"""
+    nt = len(trees)
+    handles = (C.c_void_p * nt)(*[t.h for t in trees])
+    npts = np.ascontiguousarray(n_points, dtype=np.int32)
+    cu = np.ascontiguousarray(c_update, dtype=np.float64)
+    out = np.zeros(nt, dtype=np.int32)
+    _check(load().nirrt_set_cloud_batch(handles, nt, C.c_void_p(int(clouds_ptr)), int(cloud_stride), npts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        C.c_void_p(int(pred_ptr)), int(pred_stride), float(sample_rate), float(update_cost_ratio),
+                                        _dp(cu), out.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out
 
 
 def pool_trim():

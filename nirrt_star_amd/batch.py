@@ -191,25 +191,18 @@ class Guidance:
         self.connect = connect
         self.max_trials = connect_max_trial_attempts
         self.device_id = device_id
+        self.device_clouds = os.environ.get("NIRRT_HOST_CLOUDS", "0") != "1"   # clouds generated on the device (0: the host path of round 2)
         self.calls = 0                      # PointNet++ forwards (batched ones count once)
         self.clouds_classified = 0
         self.seconds = {"candidates": 0.0, "downsample": 0.0, "classify": 0.0, "set_cloud": 0.0}   # host wall time per refresh stage
 
-    def refresh(self, due, problems, trees, streams, c_best, frames):
-        """new clouds for the trees `due` (indices into the batch): c_best[i] = inf draws the whole-world cloud
-        (nirrt_star_png_2d.py:132-145), otherwise the ellipse / ellipsoid-restricted one (:146-160)"""
-        import time
+    # ---- cloud generation -------------------------------------------------------------------------------------------
+    def _host_clouds(self, idx, problems, streams, c_best, frames):
+        """candidates from the problem's own numpy generator on the host + one batched down-sampling launch (the 3D ellipsoid
+        candidates go through sin / cos and stay with the host's libm; also the path when no resident look-ahead is wanted)"""
         from . import pointops
-        if self.rate == 0:
-            # update_point_cloud returns at once when pc_sample_rate == 0 (nirrt_star_png_2d.py:121-124): no candidates are
-            # drawn (the problem's generators stay where they are), no forward; the trees only get the policy scalars
-            empty = np.zeros((0, self.dim))
-            for i in due:
-                trees[i].set_cloud(empty, 0.0, self.ratio, c_best[i])
-            return {i: (empty, np.zeros(0, dtype=np.int64)) for i in due}
-        t0 = time.perf_counter()
         cands = []
-        for i in due:
+        for i in idx:
             pr, rng = problems[i], streams[i].rs
             xs, xg = np.asarray(pr["x_start"], dtype=np.float64), np.asarray(pr["x_goal"], dtype=np.float64)
             cmax = c_best[i]
@@ -231,19 +224,106 @@ class Guidance:
             if need_full and len(c) < self.n_points:
                 raise ValueError("farthest_point_down_sample: %d candidates for %d samples (problem %d)" % (len(c), self.n_points, i))
             cands.append(np.ascontiguousarray(c, dtype=np.float64))
-        t1 = time.perf_counter()
         masks = pointops.farthest_point_down_sample_f64_batch(cands, self.n_points, self.device_id)
-        clouds = [c[m][:, : self.dim] for c, m in zip(cands, masks)]
+        return [c[m] for c, m in zip(cands, masks)]          # (n_b, 3) each
+
+    def _device_jobs(self, idx, problems, streams, c_best, frames, dev):
+        """nirrt_cloud_job of every problem in idx (2D: whole image / ellipse; 3D: whole box), reading the generator outputs from
+        the problem's resident look-ahead at its current position"""
+        import torch
+        from . import pointops
+        n_raw = self.n_points * self.scale
+        n_words = 2 * (2 if self.dim == 2 else 3) * n_raw
+        jobs = []
+        for i in idx:
+            pr = problems[i]
+            j = pointops.CloudJob()
+            addr, _ = streams[i].window_np(n_words, dev)
+            j.words = addr
+            if self.dim == 2:
+                if "_free_tab_dev" not in pr:
+                    pr["_free_tab_dev"] = torch.from_numpy(pcu.free_block_table(pr["binary_mask"])).to(dev)
+                h, w = pr["binary_mask"].shape
+                j.free_tab, j.w, j.h = pr["_free_tab_dev"].data_ptr(), int(w), int(h)
+                if c_best[i] < np.inf:
+                    xs, xg = np.asarray(pr["x_start"], dtype=np.float64), np.asarray(pr["x_goal"], dtype=np.float64)
+                    j.mode = 1
+                    for k, v in enumerate(pcu.ellipse_transform_2d(xs, xg, c_best[i] / frames[i][0])):
+                        j.a[k] = v
+                else:
+                    j.mode = 0
+                    j.a[0], j.a[1] = float(w), float(h)
+            else:
+                env = pr["env"]
+                if "_obs_dev" not in pr:
+                    pr["_obs_dev"] = (torch.from_numpy(np.ascontiguousarray(np.asarray(env.obs_ball, dtype=np.float64).reshape(-1, 4))).to(dev),
+                                      torch.from_numpy(np.ascontiguousarray(np.asarray(env.obs_box, dtype=np.float64).reshape(-1, 6))).to(dev))
+                balls, boxes = pr["_obs_dev"]
+                j.mode, j.balls, j.boxes, j.n_ball, j.n_box = 2, balls.data_ptr(), boxes.data_ptr(), int(balls.shape[0]), int(boxes.shape[0])
+                lo = np.array([env.x_range[0] + 0, env.y_range[0] + 0, env.z_range[0] + 0], dtype=np.float64)
+                hi = np.array([env.x_range[1] - 0, env.y_range[1] - 0, env.z_range[1] - 0], dtype=np.float64)
+                diff = hi - lo
+                for k in range(3):
+                    j.a[k], j.a[3 + k] = float(lo[k]), float(diff[k])
+                j.clearance = 0.0
+            jobs.append(j)
+        return jobs, n_raw, n_words
+
+    def refresh(self, due, problems, trees, streams, c_best, frames):
+        """new clouds for the trees `due` (indices into the batch): c_best[i] = inf draws the whole-world cloud
+        (nirrt_star_png_2d.py:132-145), otherwise the ellipse / ellipsoid-restricted one (:146-160).  Clouds are generated, down-
+        sampled and handed to the trees ON the device (candidates from each problem's resident generator look-ahead); the host
+        sees them once, for the network's input block and the caller's records."""
+        import time
+        import torch
+        from . import pointops
+        if self.rate == 0:
+            # update_point_cloud returns at once when pc_sample_rate == 0 (nirrt_star_png_2d.py:121-124): no candidates are
+            # drawn (the problem's generators stay where they are), no forward; the trees only get the policy scalars
+            empty = np.zeros((0, self.dim))
+            for i in due:
+                trees[i].set_cloud(empty, 0.0, self.ratio, c_best[i])
+            return {i: (empty, np.zeros(0, dtype=np.int64)) for i in due}
+        t0 = time.perf_counter()
+        dev = torch.device("cuda", self.device_id)
+        nd = len(due)
+        on_dev = [j for j, i in enumerate(due) if self.device_clouds and not (self.dim == 3 and c_best[i] < np.inf)]
+        on_host = [j for j in range(nd) if j not in set(on_dev)]
+        clouds_dev = torch.zeros((nd, self.n_points, 3), dtype=torch.float64, device=dev)
+        n_out = np.zeros(nd, dtype=np.int32)
+        clouds = [None] * nd
+        if on_dev:
+            idx = [due[j] for j in on_dev]
+            jobs, n_raw, n_words = self._device_jobs(idx, problems, streams, c_best, frames, dev)
+            sub = clouds_dev if len(on_dev) == nd else torch.zeros((len(on_dev), self.n_points, 3), dtype=torch.float64, device=dev)
+            n_cand, n_o = pointops.guidance_clouds(jobs, n_raw, self.n_points, sub, self.device_id)
+            for k, j in enumerate(on_dev):
+                i = due[j]
+                if self.dim == 2 and not (c_best[i] < np.inf) and n_cand[k] < self.n_points:
+                    raise ValueError("farthest_point_down_sample: %d candidates for %d samples (problem %d)" % (n_cand[k], self.n_points, i))
+                streams[i].advance_np(n_words)      # what rng.random_sample / rng.uniform would have consumed
+                n_out[j] = n_o[k]
+            if sub is not clouds_dev:
+                clouds_dev[torch.as_tensor(on_dev, device=dev)] = sub
+            host = sub.cpu().numpy()
+            for k, j in enumerate(on_dev):
+                clouds[j] = host[k, : n_out[j], : self.dim].copy()
+        t1 = time.perf_counter()
+        if on_host:
+            pts = self._host_clouds([due[j] for j in on_host], problems, streams, c_best, frames)
+            for k, j in enumerate(on_host):
+                clouds[j] = pts[k][:, : self.dim]
+                n_out[j] = len(pts[k])
+                clouds_dev[j, : len(pts[k])] = torch.from_numpy(np.ascontiguousarray(pts[k]))
         t2 = time.perf_counter()
         xs_l = [np.asarray(problems[i]["x_start"], dtype=np.float64) for i in due]
         xg_l = [np.asarray(problems[i]["x_goal"], dtype=np.float64) for i in due]
 
         def fps_starts_for(group):   # group: positions inside `due`
-            import torch
             sizes = (len(clouds[group[0]]), 1024, 256, 64)
             return [torch.cat([streams[due[j]].fps_start(n) for j in group]) for n in sizes]
 
-        preds = [None] * len(due)
+        preds = [None] * nd
         if self.connect:
             res = self.wrapper.generate_connected_path_points_batch([c.astype(np.float32) for c in clouds], xs_l, xg_l, self.radius,
                                                                     self.max_trials, fps_starts_for)
@@ -260,13 +340,16 @@ class Guidance:
                 for jj, j in enumerate(grp):
                     preds[j] = pred[jj]
                 self.calls += 1
-        self.clouds_classified += len(due)
+        self.clouds_classified += nd
         t3 = time.perf_counter()
-        out = {}
-        for j, i in enumerate(due):
-            path_pts = clouds[j][np.asarray(preds[j]).nonzero()[0]]
-            trees[i].set_cloud(path_pts, self.rate, self.ratio, c_best[i])
-            out[i] = (clouds[j], np.asarray(preds[j]))
+        # path points into the trees: one launch for the whole batch (prediction bytes cross once)
+        pb = np.zeros((nd, self.n_points), dtype=np.uint8)
+        for j in range(nd):
+            pb[j, : n_out[j]] = np.asarray(preds[j]) != 0
+        pred_dev = torch.from_numpy(pb).to(dev)
+        _hip.set_cloud_batch([trees[i] for i in due], clouds_dev.data_ptr(), self.n_points * 3, n_out, pred_dev.data_ptr(), self.n_points,
+                             self.rate, self.ratio, [c_best[i] for i in due])
+        out = {i: (clouds[j], np.asarray(preds[j])) for j, i in enumerate(due)}
         t4 = time.perf_counter()
         for k, v in zip(("candidates", "downsample", "classify", "set_cloud"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
             self.seconds[k] += v

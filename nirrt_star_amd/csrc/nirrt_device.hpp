@@ -1369,6 +1369,13 @@ NIRRT_FN __device__ void wg_query_fn()
         }
     }
     if (brute) lvl2 = false;
+    // (everything about the boxes is the same in every lane: scalar registers)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        nb0[k] = uni(nb0[k]); nb1[k] = uni(nb1[k]); qb0[k] = uni(qb0[k]); qb1[k] = uni(qb1[k]);
+        cb0[k] = uni(cb0[k]); cb1[k] = uni(cb1[k]); db0[k] = uni(db0[k]); db1[k] = uni(db1[k]);
+    }
+    rowsN = uni(rowsN); rowsQ = uni(rowsQ); rows2N = uni(rows2N); rows2Q = uni(rows2Q);
     const int rows1 = rowsN + rowsQ, rowsAll = rows1 + rows2N + rows2Q;
     const unsigned fl_all = (wantN ? GRID_N : 0u) | (wantQ ? GRID_Q : 0u);
     // the rows' slot ranges (two g_start loads per row; at most GRID_RG_MAX <= NT rows: one row per thread) are
@@ -2300,10 +2307,16 @@ NIRRT_FN __device__ void it_connect()
                     }
                     __syncthreads();
                 }
-                for (int a = cap_lds + tid; a < ks; a += NT) {   // spilled part (large Near sets only)
-                    if (t.nr_m[a - cap_lds] >= thr) {
-                        const int p = atomicAdd(&s.n_cand, 1);
-                        if (p < list_cap) ids[p] = t.nr_idx[a - cap_lds]; else s.cand_listed = 0;
+                for (int a0 = cap_lds + tid; a0 < ks; a0 += 4 * NT) {   // spilled part (large Near sets only): 4 entries per lane in flight
+                    double mg[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) mg[u] = a0 + u * NT < ks ? t.nr_m[a0 + u * NT - cap_lds] : -__builtin_inf();
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (mg[u] >= thr) {
+                            const int p = atomicAdd(&s.n_cand, 1);
+                            if (p < list_cap) ids[p] = t.nr_idx[a0 + u * NT - cap_lds]; else s.cand_listed = 0;
+                        }
                     }
                 }
                 __syncthreads();
@@ -2651,7 +2664,12 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
             wg_query<D, NT>(s, t, n, node_new, uni(s.it.r_query), new_idx, q_next, &next_ni, nullptr, uni(s.stash_cap), floor_m);
             alg += n;
             it_connect<D, NT>();
-            it_book<D, NT>();
+            // goal bookkeeping only concerns vertices within step_len of the goal (wg_goal_candidate / InGoalRegion test the same
+            // distance again, with the reference's formulas); the step kernel's result record is filled in there too
+            double d_goal[D];
+#pragma unroll
+            for (int kk = 0; kk < D; kk++) d_goal[kk] = t.goal[kk] - node_new[kk];
+            if (res != nullptr || dist2<D>(d_goal) <= t.step_len * t.step_len * BAND_HI) it_book<D, NT>();
         }
     } else if (res && tid == 0) {
         res->collided = 1;

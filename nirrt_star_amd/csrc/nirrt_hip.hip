@@ -851,6 +851,94 @@ extern "C" int nirrt_set_cloud(nirrt_tree *t, int64_t n, const double *pts, doub
     return NIRRT_OK;
 }
 
+// update_point_cloud's last step for a whole batch (nirrt_star_png_2d.py:166-174: self.path_point_cloud_pred = pc[path_pred
+// .nonzero()[0]]): tree i gets the points of its cloud whose prediction is non-zero, in order, plus the sampling-policy
+// scalars - straight into its arena and descriptor, one workgroup per tree, no per-tree copies.
+struct SetCloudJob {
+    TreeDev *tree;
+    double *pc_own;            // the tree's cloud buffer (PC_OWN_POINTS points)
+    const double *cloud;       // DEVICE (n, 3) f64
+    const unsigned char *pred; // DEVICE (n,) bytes
+    int n, dim;
+    double rate, ratio, c_update;
+};
+__global__ __launch_bounds__(256) void k_set_clouds(const SetCloudJob *jobs, int *n_path)
+{
+    __shared__ int wave_tot[4];
+    __shared__ int base_s;
+    const SetCloudJob jb = jobs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < jb.n; i0 += 256) {
+        const int i = i0 + tid;
+        const bool keep = i < jb.n && jb.pred[i] != 0;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wave_tot[wv] = __popcll(m);
+        __syncthreads();
+        int off = base_s, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { if (k < wv) off += wave_tot[k]; tot += wave_tot[k]; }
+        if (keep) {
+            const int p = off + __popcll(m & ((1ull << lane) - 1ull));
+            for (int k = 0; k < jb.dim; k++) jb.pc_own[(size_t)p * jb.dim + k] = jb.cloud[3 * (size_t)i + k];
+        }
+        __syncthreads();
+        if (tid == 0) base_s += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        TreeDev *t = jb.tree;
+        t->pc = jb.pc_own; t->pc_n = base_s; t->pad2 = 0;
+        t->pc_rate = jb.rate; t->pc_ratio = jb.ratio; t->c_update = jb.c_update;
+        n_path[blockIdx.x] = base_s;
+    }
+}
+
+extern "C" int nirrt_set_cloud_batch(nirrt_tree *const *trees, int32_t n_trees, const double *clouds, int64_t cloud_stride,
+                                     const int32_t *n_points, const uint8_t *pred, int64_t pred_stride, double sample_rate,
+                                     double update_cost_ratio, const double *c_update, int32_t *n_path_out)
+{
+    if (!trees || n_trees <= 0 || !clouds || !n_points || !pred || !c_update) return NIRRT_E_ARG;
+    nirrt_tree *t0 = trees[0];
+    HIPCHK(hipSetDevice(t0->device));
+    std::vector<SetCloudJob> jobs((size_t)n_trees);
+    for (int i = 0; i < n_trees; i++) {
+        nirrt_tree *t = trees[i];
+        if (!t || t->device != t0->device || t->dim != t0->dim || n_points[i] < 0 || n_points[i] > PC_OWN_POINTS) {
+            g_err = "nirrt_set_cloud_batch: trees must share device and dim, clouds hold at most 4096 points";
+            return NIRRT_E_ARG;
+        }
+        HIPCHK(hipStreamSynchronize(t->stream));
+        if (t->pc_dev && t->pc_dev != t->pc_own) (void)hipFree(t->pc_dev);
+        t->pc_dev = t->pc_own;
+        jobs[(size_t)i] = SetCloudJob{t->dev, t->pc_own, clouds + (size_t)i * (size_t)cloud_stride, pred + (size_t)i * (size_t)pred_stride,
+                                      n_points[i], t->dim, sample_rate, update_cost_ratio, c_update[i]};
+    }
+    SetCloudJob *d_jobs = nullptr;
+    int *d_n = nullptr;
+    HIPCHK(hipMalloc(&d_jobs, sizeof(SetCloudJob) * (size_t)n_trees));
+    HIPCHK(hipMalloc(&d_n, sizeof(int) * (size_t)n_trees));
+    std::vector<int> n_path((size_t)n_trees);
+    hipError_t e = hipMemcpyAsync(d_jobs, jobs.data(), sizeof(SetCloudJob) * (size_t)n_trees, hipMemcpyHostToDevice, t0->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_set_clouds, dim3(n_trees), dim3(256), 0, t0->stream, (const SetCloudJob *)d_jobs, d_n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(n_path.data(), d_n, sizeof(int) * (size_t)n_trees, hipMemcpyDeviceToHost, t0->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t0->stream);
+    (void)hipFree(d_jobs);
+    (void)hipFree(d_n);
+    if (e != hipSuccess) { g_err = std::string("nirrt_set_cloud_batch: ") + hipGetErrorString(e); return NIRRT_E_HIP; }
+    for (int i = 0; i < n_trees; i++) {   // host mirrors follow (later per-tree patches copy from them)
+        nirrt_tree *t = trees[i];
+        t->host.pc = t->pc_own; t->host.pc_n = n_path[(size_t)i]; t->host.pad2 = 0;
+        t->host.pc_rate = sample_rate; t->host.pc_ratio = update_cost_ratio; t->host.c_update = c_update[i];
+        if (n_path_out) n_path_out[i] = n_path[(size_t)i];
+    }
+    return NIRRT_OK;
+}
+
 // {n, status, stat[NSTAT]} of every tree of a batch in one array: one small kernel + one copy instead of a descriptor
 // read per tree (8192 trees per launch in the bench)
 #define COLLECT_W (NSTAT + 2)

@@ -280,6 +280,7 @@ __global__ __launch_bounds__(FPS_NT) void k_fps_f64(const double *__restrict__ b
     __shared__ int ri[FPS_NT / 64];
     const long long o = off[blockIdx.x];
     const int N = cnt[blockIdx.x], S = ns[blockIdx.x];
+    if (N <= S) return;   // nothing to drop (the callers keep such clouds whole)
     const double *x = buf + o, *y = buf + total + o, *z = buf + 2 * total + o;
     unsigned char *sel = sel_all + o;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -387,23 +388,210 @@ extern "C" int nirrt_fps_f64(const double *pts, int N, int num_samples, unsigned
 }
 
 // ------------------------------------------------------------------------------------------------
+// Guidance clouds generated ON the device (datasets/point_cloud_mask_utils.py:35-73, 104-174; datasets_3d/..._3d.py:83-113):
+// the over-sampled candidates are drawn from the problem's numpy generator outputs (resident in HBM), filtered, down-sampled
+// (k_fps_f64) and compacted without a host round trip.  Arithmetic restated op by op: legacy RandomState doubles
+// (a = w0 >> 5, b = w1 >> 6, (a * 2^26 + b) / 2^53), uniform(lo, hi) = lo + (hi - lo) * u, the ellipse transform as numpy's
+// dgemm evaluates it for K = 3 (fma chain in k order: fma(a1, s1, a0 * s0), the z term adds an exact zero), np.linalg.norm
+// (axis) = sqrt(x*x + y*y), astype(int) = truncation.  The 3D ellipsoid candidates go through sin / cos and stay on the host.
+// ------------------------------------------------------------------------------------------------
+struct nirrt_cloud_job {
+    const unsigned *words;          // DEVICE: generator outputs from the problem's current position (>= 2 * n_doubles of them)
+    const unsigned char *free_tab;  // DEVICE, 2D: (h + 1) x (w + 1) table "the 2 x 2 pixel block around this integer position is free"
+    const double *balls;            // DEVICE, 3D: (n_ball, 4) cx, cy, cz, r
+    const double *boxes;            // DEVICE, 3D: (n_box, 6) x, y, z, w, h, d
+    int mode;                       // 0: whole image (2D), 1: ellipse (2D), 2: whole box (3D)
+    int w, h, n_ball, n_box, pad;
+    double a[8];                    // mode 0: w, h; mode 1: CL00, CL01, CL10, CL11, cx, cy; mode 2: lo[3], hi - lo [3]
+    double clearance;               // 3D obstacle inflation
+};
+
+__device__ __forceinline__ double mt_double(const unsigned *w, long long j)
+{
+    const unsigned a = w[2 * j] >> 5, b = w[2 * j + 1] >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+#define CAND_NT 256
+// one workgroup per cloud: candidate i of cloud b -> (x, y, z) + keep flag; survivors compacted in order into the SoA
+// buffer region [b * n_raw, (b + 1) * n_raw) (x of all clouds, then y, then z), cnt[b] = their number
+__global__ __launch_bounds__(CAND_NT) void k_cloud_candidates(const nirrt_cloud_job *jobs, int n_raw, double *buf, long long total, int *cnt)
+{
+    __shared__ int wave_tot[CAND_NT / 64];
+    __shared__ int base_s;
+    const nirrt_cloud_job jb = jobs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *ox = buf + (long long)blockIdx.x * n_raw, *oy = ox + total, *oz = oy + total;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n_raw; i0 += CAND_NT) {
+        const int i = i0 + tid;
+        double x = 0., y = 0., z = 0.;
+        bool keep = false;
+        if (i < n_raw) {
+            if (jb.mode == 2) {
+                x = jb.a[0] + jb.a[3] * mt_double(jb.words, 3ll * i);
+                y = jb.a[1] + jb.a[4] * mt_double(jb.words, 3ll * i + 1);
+                z = jb.a[2] + jb.a[5] * mt_double(jb.words, 3ll * i + 2);
+                bool inside = false;
+                for (int o = 0; o < jb.n_ball; o++) {
+                    const double *c = jb.balls + 4 * o;
+                    const double rc = c[3] + jb.clearance;
+                    const double dx = x - c[0], dy = y - c[1], dz = z - c[2];
+                    inside = inside || (dx * dx + dy * dy + dz * dz < rc * rc);
+                }
+                for (int o = 0; o < jb.n_box; o++) {
+                    const double *bx = jb.boxes + 6 * o;
+                    const double cl = jb.clearance;
+                    inside = inside || (bx[0] - cl <= x && x <= bx[0] + bx[3] + cl && bx[1] - cl <= y && y <= bx[1] + bx[4] + cl &&
+                                        bx[2] - cl <= z && z <= bx[2] + bx[5] + cl);
+                }
+                keep = !inside;
+            } else {
+                const double u0 = mt_double(jb.words, 2ll * i), u1 = mt_double(jb.words, 2ll * i + 1);
+                bool ok = true;
+                if (jb.mode == 0) {
+                    x = u0 * jb.a[0]; y = u1 * jb.a[1];
+                } else {
+                    const double s0 = -1.0 + 2.0 * u0, s1 = -1.0 + 2.0 * u1;
+                    ok = __builtin_sqrt(s0 * s0 + s1 * s1) <= 1.0;
+                    x = __builtin_fma(jb.a[1], s1, jb.a[0] * s0) + jb.a[4];
+                    y = __builtin_fma(jb.a[3], s1, jb.a[2] * s0) + jb.a[5];
+                    ok = ok && 0.0 <= x && x <= (double)jb.w && 0.0 <= y && y <= (double)jb.h;
+                }
+                int ix = (int)x + 1, iy = (int)y + 1;
+                ix = ix < 0 ? 0 : (ix > jb.w ? jb.w : ix);
+                iy = iy < 0 ? 0 : (iy > jb.h ? jb.h : iy);
+                keep = ok && jb.free_tab[iy * (jb.w + 1) + ix] != 0;
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wave_tot[wv] = __popcll(m);
+        __syncthreads();
+        int off = base_s, tot = 0;
+#pragma unroll
+        for (int k = 0; k < CAND_NT / 64; k++) { if (k < wv) off += wave_tot[k]; tot += wave_tot[k]; }
+        if (keep) {
+            const int p = off + __popcll(m & ((1ull << lane) - 1ull));
+            ox[p] = x; oy[p] = y; oz[p] = z;
+        }
+        __syncthreads();
+        if (tid == 0) base_s += tot;
+        __syncthreads();
+    }
+    if (tid == 0) cnt[blockIdx.x] = base_s;
+}
+
+// survivors of cloud b (sel bytes over its region of the SoA buffer) -> out (b, n_points, 3) row-major, in order; n_out[b]
+__global__ __launch_bounds__(CAND_NT) void k_cloud_compact(const double *buf, long long total, int n_raw, const int *cnt, int n_points,
+                                                           const unsigned char *sel, double *out, int *n_out)
+{
+    __shared__ int wave_tot[CAND_NT / 64];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int N = cnt[blockIdx.x];
+    const double *x = buf + (long long)blockIdx.x * n_raw, *y = x + total, *z = y + total;
+    const unsigned char *sl = sel + (long long)blockIdx.x * n_raw;
+    double *o = out + (long long)blockIdx.x * n_points * 3;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < N; i0 += CAND_NT) {
+        const int i = i0 + tid;
+        const bool keep = i < N && (N <= n_points || sl[i] != 0);
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wave_tot[wv] = __popcll(m);
+        __syncthreads();
+        int off = base_s, tot = 0;
+#pragma unroll
+        for (int k = 0; k < CAND_NT / 64; k++) { if (k < wv) off += wave_tot[k]; tot += wave_tot[k]; }
+        if (keep) {
+            const int p = off + __popcll(m & ((1ull << lane) - 1ull));
+            if (p < n_points) { o[3 * p] = x[i]; o[3 * p + 1] = y[i]; o[3 * p + 2] = z[i]; }
+        }
+        __syncthreads();
+        if (tid == 0) base_s += tot;
+        __syncthreads();
+    }
+    if (tid == 0) n_out[blockIdx.x] = base_s < n_points ? base_s : n_points;
+}
+
+static FpsScratch g_cloud_scratch[16];
+
+// Candidates -> down-sampling -> compaction for n_jobs clouds, all on `device_id`.  jobs: HOST array (its pointers are DEVICE
+// addresses); clouds: DEVICE (n_jobs, n_points, 3) f64 out; n_cand / n_out: HOST out (candidates that survived the filters / points
+// of the final cloud, <= n_points).  n_raw <= 16384.
+extern "C" int nirrt_guidance_clouds(const nirrt_cloud_job *jobs, int n_jobs, int n_raw, int n_points, double *clouds, int *n_cand,
+                                     int *n_out, int device_id)
+{
+    if (!jobs || !clouds || !n_cand || !n_out || n_jobs <= 0 || n_raw <= 0 || n_points <= 0 || n_raw > FPS_NT * FPS64_MAX_PER_THREAD) return -1;
+    if (hipSetDevice(device_id) != hipSuccess) return -4;
+    const long long total = (long long)n_jobs * n_raw;
+    const size_t a256 = 255;
+    const size_t b_pts = (sizeof(double) * 3 * (size_t)total + a256) & ~a256, b_sel = ((size_t)total + a256) & ~a256;
+    const size_t b_off = (sizeof(long long) * (size_t)n_jobs + a256) & ~a256, b_int = (sizeof(int) * (size_t)n_jobs + a256) & ~a256;
+    const size_t b_job = (sizeof(nirrt_cloud_job) * (size_t)n_jobs + a256) & ~a256;
+    const size_t need = b_pts + b_sel + b_off + 3 * b_int + b_job;
+    std::lock_guard<std::mutex> hold(g_fps_mu);
+    FpsScratch &sc = g_cloud_scratch[device_id & 15];
+    if (sc.cap < need) {
+        if (sc.p) (void)hipFree(sc.p);
+        sc.p = nullptr; sc.cap = 0;
+        const size_t want = need + need / 2;
+        if (hipMalloc(&sc.p, want) != hipSuccess) return -2;
+        sc.cap = want;
+    }
+    char *base = (char *)sc.p;
+    double *d = (double *)base;
+    unsigned char *ds = (unsigned char *)(base + b_pts);
+    long long *d_off = (long long *)(base + b_pts + b_sel);
+    int *d_cnt = (int *)(base + b_pts + b_sel + b_off), *d_ns = d_cnt + b_int / sizeof(int), *d_nout = d_ns + b_int / sizeof(int);
+    nirrt_cloud_job *d_jobs = (nirrt_cloud_job *)(base + b_pts + b_sel + b_off + 3 * b_int);
+    long long *h_off = (long long *)malloc(sizeof(long long) * (size_t)n_jobs);
+    int *h_ns = (int *)malloc(sizeof(int) * (size_t)n_jobs);
+    for (int b = 0; b < n_jobs; b++) { h_off[b] = (long long)b * n_raw; h_ns[b] = n_points; }
+    int rc = 0;
+    if (hipMemcpy(d_jobs, jobs, sizeof(nirrt_cloud_job) * (size_t)n_jobs, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_off, h_off, sizeof(long long) * (size_t)n_jobs, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ns, h_ns, sizeof(int) * (size_t)n_jobs, hipMemcpyHostToDevice) != hipSuccess)
+        rc = -2;
+    free(h_off);
+    free(h_ns);
+    if (!rc) {
+        hipLaunchKernelGGL(k_cloud_candidates, dim3(n_jobs), dim3(CAND_NT), 0, 0, (const nirrt_cloud_job *)d_jobs, n_raw, d, total, d_cnt);
+        // k_fps_f64 leaves clouds with cnt <= num_samples alone (k_cloud_compact keeps all of their points)
+        hipLaunchKernelGGL(k_fps_f64, dim3(n_jobs), dim3(FPS_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
+                           (const int *)d_cnt, (const int *)d_ns, ds);
+        hipLaunchKernelGGL(k_cloud_compact, dim3(n_jobs), dim3(CAND_NT), 0, 0, (const double *)d, total, n_raw, (const int *)d_cnt, n_points,
+                           (const unsigned char *)ds, clouds, d_nout);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(n_cand, d_cnt, sizeof(int) * (size_t)n_jobs, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(n_out, d_nout, sizeof(int) * (size_t)n_jobs, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = -2;
+    }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused set-abstraction branch (PointNetSetAbstractionMsg.forward, pointnet2_utils.py:236-262, one radius): gather the K
 // grouped points of a centroid, run the three 1x1-conv + BatchNorm (folded: W, b) + ReLU layers and take the maximum over
 // the K members - without ever writing the grouped tensor (B, S, K, C_in) or an intermediate activation to HBM.
 //
-// One wave owns one group at a time; its rows are processed as 16-row tiles through v_mfma_f32_16x16x4_f32 (fp32 in,
-// fp32 accumulate - the reference computes in fp32):
-//     A (16 x 4)  lane l holds A[l % 16][l / 16]          activations, read from the wave's LDS tile
-//     B (4 x 16)  lane l holds B[l / 16][l % 16]          W^T, read from the workgroup's LDS copy of the weights
+// One wave owns 32 rows at a time (one group of K = 32 members or two groups of 16) as TWO 16-row tiles that go through
+// v_mfma_f32_16x16x4_f32 side by side (fp32 in, fp32 accumulate - the reference computes in fp32):
+//     A (16 x 4)  lane l holds A[l % 16][k(l / 16, step)]     activations
+//     B (4 x 16)  lane l holds B[k(l / 16, step)][l % 16]     weights
 //     D (16 x 16) lane l, register v holds D[4 * (l / 16) + v][l % 16]
-// Layer l: for every 16-column tile, acc = bias; acc += A[:, k0:k0+4] . W^T[k0:k0+4, tile] over k0; ReLU; the tile goes to the
-// other LDS activation buffer (layers 1, 2) or is reduced over its 16 rows in registers (layer 3: max over the 4 registers
-// of a lane, then over the 4 lane groups with two DPP-free shuffles) and written out.  Input rows are
-// [features of the member, xyz(member) - xyz(centroid)] (:247-250), zero-padded to a multiple of 4 channels.
+// The reduction index is assigned kq-major, k(kq, step) = kq * (K / 4) + step (any assignment is a valid order of the same
+// dot product as long as A and B agree), so that the operands of FOUR consecutive steps are 16 contiguous bytes: a layer
+// loads its A operands ONCE (K / 16 ds_read_b128 per tile, kept in registers - the activation tile is dead afterwards and
+// the layer's output overwrites it) and every weight fragment with one ds_read_b128 that feeds 4 steps x 2 tiles = 8 MFMAs
+// on two independent accumulators.  (Round 2: one ds_read_b32 per operand per MFMA on a single dependent chain.)
+// Weights sit in LDS as [column][k] rows of stride K + 4 floats (16-byte aligned rows that start 4 banks apart).
+// Input rows are [features of the member, xyz(member) - xyz(centroid)] (:247-250), zero-padded to a multiple of 16 channels.
 // ------------------------------------------------------------------------------------------------
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
-#define SA_WAVES 4
+#define SA_WAVES 4          // waves per workgroup when the branch's LDS footprint allows (the host picks 4, 3 or 2)
+#define SA_KMAX 128         // widest layer input (C_in padded, C1, C2)
 
 struct SaMlpArgs {
     const float *feats;     // (B, N, C)
@@ -411,124 +599,158 @@ struct SaMlpArgs {
     const float *new_xyz;   // (B, S, 3)
     const long long *gidx;  // (B, S, K)
     float *out;             // (B, S, out_stride) - this branch writes columns [out_off, out_off + C3)
-    const float *w1t, *b1, *w2t, *b2, *w3t, *b3;   // W^T row-major (C_in_pad x C1), (C1 x C2), (C2 x C3); biases
-    int B, N, S, K, C, Cin_pad, C1, C2, C3, out_stride, out_off;
+    const float *w1t, *w2t, *w3t;   // W^T row-major (cin_src x C1), (C1 x C2), (C2 x C3): as packed by the host
+    const float *b1, *b2, *b3;
+    int B, N, S, K, C, cin_src, Cin, C1, C2, C3, out_stride, out_off;   // Cin = C + 3 padded to a multiple of 16
 };
+
+// one layer on the wave's two tiles: act (32 rows x stride sa floats, K_ inputs) -> C_ outputs; LAST: maximum over each group's
+// rows instead of a new activation tile
+template <bool LAST>
+__device__ __forceinline__ void sa_layer(float *act, int sa, const float *W, const float *bias, int K_, int C_, int lane, int gsz,
+                                         float (&best)[2][8])
+{
+    const int row = lane & 15, kq = lane >> 4, kc = K_ >> 2;   // this lane's k range: [kq * kc, (kq + 1) * kc)
+    const int sw = K_ + 4;
+    float4_t a0[SA_KMAX / 16], a1[SA_KMAX / 16];
+#pragma unroll
+    for (int j = 0; j < SA_KMAX / 16; j++) {
+        if (4 * j < kc) {
+            a0[j] = *reinterpret_cast<const float4_t *>(act + row * sa + kq * kc + 4 * j);
+            a1[j] = *reinterpret_cast<const float4_t *>(act + (16 + row) * sa + kq * kc + 4 * j);
+        }
+    }
+    // (same wave reads and later writes `act`: the reads above have returned before the first write below is issued only if we
+    // wait for them - the compiler's lgkmcnt tracking does that, the values are consumed by the MFMAs first)
+    for (int ct = 0, ci = 0; ct < C_; ct += 16, ci++) {
+        float4_t acc0, acc1;
+        const float bv = bias[ct + row];
+        acc0[0] = bv; acc0[1] = bv; acc0[2] = bv; acc0[3] = bv;
+        acc1 = acc0;
+        const float *wrow = W + (ct + row) * sw + kq * kc;
+#pragma unroll
+        for (int j = 0; j < SA_KMAX / 16; j++) {
+            if (4 * j < kc) {
+                const float4_t wf = *reinterpret_cast<const float4_t *>(wrow + 4 * j);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j][u], wf[u], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j][u], wf[u], acc1, 0, 0, 0);
+                }
+            }
+        }
+        if (!LAST) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                act[(4 * kq + v) * sa + ct + row] = acc0[v] > 0.f ? acc0[v] : 0.f;
+                act[(16 + 4 * kq + v) * sa + ct + row] = acc1[v] > 0.f ? acc1[v] : 0.f;
+            }
+        } else {
+            // maximum over the rows of each tile, per output column (ReLU first); gsz == 32: one group spans both tiles
+            float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; v++) { m0 = fmaxf(m0, acc0[v]); m1 = fmaxf(m1, acc1[v]); }
+            m0 = fmaxf(m0, __shfl_xor(m0, 16)); m0 = fmaxf(m0, __shfl_xor(m0, 32));
+            m1 = fmaxf(m1, __shfl_xor(m1, 16)); m1 = fmaxf(m1, __shfl_xor(m1, 32));
+            if (gsz == 32) { best[0][ci] = fmaxf(m0, m1); } else { best[0][ci] = m0; best[1][ci] = m1; }
+        }
+    }
+}
 
 __global__ __launch_bounds__(64 * SA_WAVES) void k_sa_mlp(SaMlpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float sa_lds[];
+    const int nw = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int Cin = a.Cin_pad, C1 = a.C1, C2 = a.C2, C3 = a.C3;
-    float *W1 = sa_lds;                       // Cin x C1
-    float *W2 = W1 + Cin * C1;                // C1 x C2
-    float *W3 = W2 + C1 * C2;                 // C2 x C3
-    float *Bs = W3 + C2 * C3;                 // C1 + C2 + C3 biases
-    const int sA = (Cin > C2 ? Cin : C2) + 1, sB = C1 + 1;      // row strides (odd: rows fall into different banks)
-    float *bufA = Bs + C1 + C2 + C3 + (size_t)w * 16 * (sA + sB);   // this wave's tiles: input / layer-2 output ...
-    float *bufB = bufA + 16 * sA;                                   // ... and layer-1 output
-    for (int i = tid; i < Cin * C1; i += 64 * SA_WAVES) W1[i] = a.w1t[i];
-    for (int i = tid; i < C1 * C2; i += 64 * SA_WAVES) W2[i] = a.w2t[i];
-    for (int i = tid; i < C2 * C3; i += 64 * SA_WAVES) W3[i] = a.w3t[i];
-    for (int i = tid; i < C1; i += 64 * SA_WAVES) Bs[i] = a.b1[i];
-    for (int i = tid; i < C2; i += 64 * SA_WAVES) Bs[C1 + i] = a.b2[i];
-    for (int i = tid; i < C3; i += 64 * SA_WAVES) Bs[C1 + C2 + i] = a.b3[i];
+    const int Cin = a.Cin, C1 = a.C1, C2 = a.C2, C3 = a.C3;
+    // weights as [column][k], rows of stride K + 4
+    float *W1 = sa_lds;
+    float *W2 = W1 + C1 * (Cin + 4);
+    float *W3 = W2 + C2 * (C1 + 4);
+    float *Bs = W3 + C3 * (C2 + 4);           // C1 + C2 + C3 biases
+    int kmax = Cin > C1 ? Cin : C1;
+    kmax = kmax > C2 ? kmax : C2;
+    const int sa = kmax + 4;                  // activation row stride (16-byte aligned rows, 4 banks apart)
+    float *act = Bs + C1 + C2 + C3 + (size_t)w * 32 * sa;
+    for (int i = tid; i < C1 * Cin; i += blockDim.x) { const int c = i / Cin, k = i - c * Cin; W1[c * (Cin + 4) + k] = k < a.cin_src ? a.w1t[k * C1 + c] : 0.f; }
+    for (int i = tid; i < C2 * C1; i += blockDim.x) { const int c = i / C1, k = i - c * C1; W2[c * (C1 + 4) + k] = a.w2t[k * C2 + c]; }
+    for (int i = tid; i < C3 * C2; i += blockDim.x) { const int c = i / C2, k = i - c * C2; W3[c * (C2 + 4) + k] = a.w3t[k * C3 + c]; }
+    for (int i = tid; i < C1; i += blockDim.x) Bs[i] = a.b1[i];
+    for (int i = tid; i < C2; i += blockDim.x) Bs[C1 + i] = a.b2[i];
+    for (int i = tid; i < C3; i += blockDim.x) Bs[C1 + C2 + i] = a.b3[i];
     __syncthreads();
-    const int row = lane & 15, kq = lane >> 4;            // A / B operand coordinates of this lane
+    const int gsz = a.K;                                   // 16 or 32 members per group
+    const int gpp = 32 / gsz;                              // groups per 32-row pass
     const long long groups = (long long)a.B * a.S;
+    const long long passes = (groups + gpp - 1) / gpp;
     const int CC = a.C + 3;
-    for (long long g = (long long)blockIdx.x * SA_WAVES + w; g < groups; g += (long long)gridDim.x * SA_WAVES) {
-        const int b = (int)(g / a.S);
-        const float *cen = a.new_xyz + g * 3;
-        const float cx = cen[0], cy = cen[1], cz = cen[2];
-        float best[8];                                     // running maxima of this lane's output columns (C3 <= 128)
-#pragma unroll
-        for (int i = 0; i < 8; i++) best[i] = -3.4e38f;
-        for (int r0 = 0; r0 < a.K; r0 += 16) {             // 16-row tiles of the group
-            // gather: element e of the tile = (row e / Cin, channel e % Cin); consecutive lanes read consecutive channels
-            for (int e = lane; e < 16 * Cin; e += 64) {
-                const int r = e / Cin, c = e - r * Cin;
-                float v = 0.f;
-                if (r0 + r < a.K && c < CC) {
-                    const long long idx = a.gidx[g * a.K + r0 + r];
-                    if (c < a.C) v = a.feats[((long long)b * a.N + idx) * a.C + c];
-                    else {
-                        const float p = a.xyz[((long long)b * a.N + idx) * 3 + (c - a.C)];
-                        v = p - (c - a.C == 0 ? cx : (c - a.C == 1 ? cy : cz));
-                    }
+    for (long long ps = (long long)blockIdx.x * nw + w; ps < passes; ps += (long long)gridDim.x * nw) {
+        const long long g0 = ps * gpp;
+        // gather: element e of the 32 x Cin tile = (row e / Cin, channel e % Cin); consecutive lanes read consecutive channels
+        for (int e = lane; e < 32 * Cin; e += 64) {
+            const int r = e / Cin, c = e - r * Cin;
+            const long long g = g0 + r / gsz;
+            float v = 0.f;
+            if (g < groups && c < CC) {
+                const int b = (int)(g / a.S);
+                const long long idx = a.gidx[g * a.K + (r % gsz)];
+                if (c < a.C) v = a.feats[((long long)b * a.N + idx) * a.C + c];
+                else {
+                    const float p = a.xyz[((long long)b * a.N + idx) * 3 + (c - a.C)];
+                    v = p - a.new_xyz[g * 3 + (c - a.C)];
                 }
-                bufA[r * sA + c] = v;
             }
-            // rows beyond K (K < 16 never happens in this network; K is 16 or 32) would be padding: keep them out of the max
-            // layer 1: bufA (16 x Cin) -> bufB (16 x C1)
-            for (int ct = 0; ct < C1; ct += 16) {
-                float4_t acc;
-                const float bias = Bs[ct + row];
-                acc[0] = bias; acc[1] = bias; acc[2] = bias; acc[3] = bias;
-                for (int k0 = 0; k0 < Cin; k0 += 4)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bufA[row * sA + k0 + kq], W1[(k0 + kq) * C1 + ct + row], acc, 0, 0, 0);
-#pragma unroll
-                for (int v = 0; v < 4; v++) bufB[(4 * kq + v) * sB + ct + row] = acc[v] > 0.f ? acc[v] : 0.f;
-            }
-            // layer 2: bufB (16 x C1) -> bufA (16 x C2)
-            for (int ct = 0; ct < C2; ct += 16) {
-                float4_t acc;
-                const float bias = Bs[C1 + ct + row];
-                acc[0] = bias; acc[1] = bias; acc[2] = bias; acc[3] = bias;
-                for (int k0 = 0; k0 < C1; k0 += 4)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bufB[row * sB + k0 + kq], W2[(k0 + kq) * C2 + ct + row], acc, 0, 0, 0);
-#pragma unroll
-                for (int v = 0; v < 4; v++) bufA[(4 * kq + v) * sA + ct + row] = acc[v] > 0.f ? acc[v] : 0.f;
-            }
-            // layer 3: bufA (16 x C2) -> maximum over the rows, per output column
-            for (int ct = 0, ci = 0; ct < C3; ct += 16, ci++) {
-                float4_t acc;
-                const float bias = Bs[C1 + C2 + ct + row];
-                acc[0] = bias; acc[1] = bias; acc[2] = bias; acc[3] = bias;
-                for (int k0 = 0; k0 < C2; k0 += 4)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bufA[row * sA + k0 + kq], W3[(k0 + kq) * C3 + ct + row], acc, 0, 0, 0);
-                float m = -3.4e38f;
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const float x = acc[v] > 0.f ? acc[v] : 0.f;
-                    if (r0 + 4 * kq + v < a.K) m = x > m ? x : m;
-                }
-                m = fmaxf(m, __shfl_xor(m, 16));
-                m = fmaxf(m, __shfl_xor(m, 32));
-                best[ci] = fmaxf(best[ci], m);             // every lane now holds the column maximum of its `row` column
-            }
+            act[r * sa + c] = v;
         }
+        float best[2][8];
+        sa_layer<false>(act, sa, W1, Bs, Cin, C1, lane, gsz, best);
+        sa_layer<false>(act, sa, W2, Bs + C1, C1, C2, lane, gsz, best);
+        sa_layer<true>(act, sa, W3, Bs + C1 + C2, C2, C3, lane, gsz, best);
         if (lane < 16) {
-            float *o = a.out + g * a.out_stride + a.out_off;
-            for (int ct = 0, ci = 0; ct < C3; ct += 16, ci++) o[ct + lane] = best[ci];
+            for (int q = 0; q < gpp; q++) {
+                if (g0 + q < groups) {
+                    float *o = a.out + (g0 + q) * a.out_stride + a.out_off;
+                    for (int ct = 0, ci = 0; ct < C3; ct += 16, ci++) o[ct + lane] = best[q][ci];
+                }
+            }
         }
     }
 }
 
 // One branch of a set-abstraction level.  DEVICE pointers; w*t are the folded weights TRANSPOSED (C_in x C_out, row-major), the
-// first with its C + 3 input rows padded with zero rows to cin_pad (a multiple of 4); C1, C2, C3 multiples of 16, C3 <= 128.
-// Needs 4 * (cin_pad * C1 + C1 * C2 + C2 * C3 + C1 + C2 + C3 + 4 * 16 * (max(cin_pad, C2) + C1 + 2)) bytes of LDS (<= 160 KB):
-// returns -3 when the level does not fit (the caller then uses library GEMMs).
+// first with cin_pad >= C + 3 rows (zero rows behind the real ones); C1, C2, C3 multiples of 16 and <= 128, K = 16 or 32.
+// LDS: 4 * (C1 * (Cin + 4) + C2 * (C1 + 4) + C3 * (C2 + 4) + C1 + C2 + C3 + waves * 32 * (max(Cin, C1, C2) + 4)) bytes with
+// Cin = C + 3 rounded up to 16; the launcher takes 4, 3 or 2 waves per workgroup, whatever fits 160 KB, and returns -3 when not
+// even 2 do (the caller then uses library GEMMs).
 extern "C" int nirrt_pn2_sa_mlp(const float *feats, const float *xyz, const float *new_xyz, const int64_t *gidx, int B, int N, int S,
                                 int K, int C, int cin_pad, const float *w1t, const float *b1, int C1, const float *w2t, const float *b2,
                                 int C2, const float *w3t, const float *b3, int C3, float *out, int out_stride, int out_off, void *stream)
 {
-    if (C1 % 16 || C2 % 16 || C3 % 16 || C3 > 128 || cin_pad % 4 || cin_pad < C + 3 || K <= 0 || B <= 0 || S <= 0) return -1;
-    const int sA = (cin_pad > C2 ? cin_pad : C2) + 1, sB = C1 + 1;
-    const size_t lds = sizeof(float) * ((size_t)cin_pad * C1 + (size_t)C1 * C2 + (size_t)C2 * C3 + C1 + C2 + C3 +
-                                        (size_t)SA_WAVES * 16 * (sA + sB));
-    if (lds > 160 * 1024) return -3;
+    if (C1 % 16 || C2 % 16 || C3 % 16 || C3 > 128 || C1 > SA_KMAX || C2 > SA_KMAX || cin_pad < C + 3 || (K != 16 && K != 32) || B <= 0 || S <= 0) return -1;
+    const int Cin = (C + 3 + 15) / 16 * 16;
+    if (Cin > SA_KMAX) return -3;
+    int kmax = Cin > C1 ? Cin : C1;
+    kmax = kmax > C2 ? kmax : C2;
+    const size_t fixed = (size_t)C1 * (Cin + 4) + (size_t)C2 * (C1 + 4) + (size_t)C3 * (C2 + 4) + C1 + C2 + C3;
+    int nw = SA_WAVES;
+    size_t lds = 0;
+    for (; nw >= 2; nw--) {
+        lds = sizeof(float) * (fixed + (size_t)nw * 32 * (kmax + 4));
+        if (lds <= 160 * 1024) break;
+    }
+    if (nw < 2) return -3;
     // the attribute belongs to the CURRENT device's copy of the kernel (a process may drive several GPUs): set on every call,
     // it is a host-side table write
     if (hipFuncSetAttribute((const void *)k_sa_mlp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
     SaMlpArgs a;
     a.feats = feats; a.xyz = xyz; a.new_xyz = new_xyz; a.gidx = (const long long *)gidx; a.out = out;
     a.w1t = w1t; a.b1 = b1; a.w2t = w2t; a.b2 = b2; a.w3t = w3t; a.b3 = b3;
-    a.B = B; a.N = N; a.S = S; a.K = K; a.C = C; a.Cin_pad = cin_pad; a.C1 = C1; a.C2 = C2; a.C3 = C3;
+    a.B = B; a.N = N; a.S = S; a.K = K; a.C = C; a.cin_src = cin_pad; a.Cin = Cin; a.C1 = C1; a.C2 = C2; a.C3 = C3;
     a.out_stride = out_stride; a.out_off = out_off;
     const long long groups = (long long)B * S;
-    long long grid = (groups + SA_WAVES - 1) / SA_WAVES;
-    if (grid > 2048) grid = 2048;      // grid-stride over the groups: the weights are staged once per workgroup
-    hipLaunchKernelGGL(k_sa_mlp, dim3((unsigned)grid), dim3(64 * SA_WAVES), lds, (hipStream_t)stream, a);
+    const long long passes = (groups + (32 / K) - 1) / (32 / K);
+    long long grid = (passes + nw - 1) / nw;
+    if (grid > 2048) grid = 2048;      // grid-stride over the passes: the weights are staged once per workgroup
+    hipLaunchKernelGGL(k_sa_mlp, dim3((unsigned)grid), dim3(64 * nw), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -59,6 +59,33 @@ def _free_pixels_2d(point_cloud, binary_mask):
     return np.flatnonzero(block_free.ravel()[iy * (w + 1) + ix])
 
 
+def free_block_table(binary_mask):
+    """(h + 1, w + 1) uint8: entry [iy, ix] = 1 iff the clipped pixel pairs (iy - 1, iy) x (ix - 1, ix) are all free - the table
+    _free_pixels_2d looks points up in (row-major; what the device-side candidate filter reads)"""
+    h, w = binary_mask.shape
+    P = np.empty((h + 2, w + 2), dtype=bool)
+    P[1:-1, 1:-1] = binary_mask != 0
+    P[0, 1:-1] = P[1, 1:-1]
+    P[-1, 1:-1] = P[-2, 1:-1]
+    P[:, 0] = P[:, 1]
+    P[:, -1] = P[:, -2]
+    return np.ascontiguousarray((P[:-1, :-1] & P[:-1, 1:] & P[1:, :-1] & P[1:, 1:]).astype(np.uint8))
+
+
+def ellipse_transform_2d(start_point, goal_point, max_min_ratio):
+    """the constants of ellipsoid_candidates' transform: (C.L rows 0-1 / columns 0-1, x_center) exactly as the reference forms them
+    (point_cloud_mask_utils.py:118-135)"""
+    dx, dy = goal_point - start_point
+    c_min = math.hypot(dx, dy)
+    C = _rotation_to_world_2d(start_point, goal_point, c_min)
+    x_center = np.concatenate([(start_point + goal_point) / 2., np.array([0.])], axis=0)
+    c_max = c_min * max_min_ratio
+    eps = 1e-6 if c_max ** 2 - c_min ** 2 < 0 else 0
+    r = [c_max / 2.0, math.sqrt(c_max ** 2 - c_min ** 2 + eps) / 2.0, math.sqrt(c_max ** 2 - c_min ** 2 + eps) / 2.0]
+    CL = np.dot(C, np.diag(r))
+    return [float(CL[0, 0]), float(CL[0, 1]), float(CL[1, 0]), float(CL[1, 1]), float(x_center[0]), float(x_center[1])]
+
+
 def rectangle_candidates(binary_mask, n_points, over_sample_scale=5, rng=None):
     """the over-sampled free-space candidates the reference hands to open3d (point_cloud_mask_utils.py:35-68):
     (m, 3) with z = 0.  `rng`: a numpy RandomState (default: the process-global legacy generator, like the reference)."""

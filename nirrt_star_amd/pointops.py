@@ -36,6 +36,8 @@ def _lib():
         L.nirrt_pn2_three_nn.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         L.nirrt_fps_f64.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
         L.nirrt_fps_f64_batch.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
+        L.nirrt_guidance_clouds.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int]
+        L.nirrt_guidance_clouds.restype = C.c_int
         L.nirrt_pn2_sa_mlp.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp,
                                        C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]
         for f in (L.nirrt_pn2_fps, L.nirrt_pn2_ball_query, L.nirrt_pn2_three_nn, L.nirrt_fps_f64, L.nirrt_fps_f64_batch,
@@ -162,3 +164,25 @@ def farthest_point_down_sample_f64_batch(clouds, num_samples, device_id=0):
         masks[b] = sel[off:off + c].astype(bool)
         off += int(c)
     return masks
+
+
+class CloudJob(C.Structure):
+    """nirrt_cloud_job of include/nirrt_pointops.h"""
+    _fields_ = [("words", C.c_void_p), ("free_tab", C.c_void_p), ("balls", C.c_void_p), ("boxes", C.c_void_p),
+                ("mode", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("n_ball", C.c_int32), ("n_box", C.c_int32), ("pad", C.c_int32),
+                ("a", C.c_double * 8), ("clearance", C.c_double)]
+
+
+def guidance_clouds(jobs, n_raw, n_points, clouds, device_id=0):
+    """candidates -> down-sampling -> compaction of len(jobs) guidance clouds on the device (nirrt_guidance_clouds): `jobs` a
+    list of CloudJob, `clouds` a cuda float64 tensor (len(jobs), n_points, 3) that receives them -> (n_cand, n_out) int32 arrays"""
+    import numpy as np
+    n = len(jobs)
+    arr = (CloudJob * n)(*jobs)
+    n_cand = np.zeros(n, dtype=np.int32)
+    n_out = np.zeros(n, dtype=np.int32)
+    assert clouds.is_cuda and clouds.dtype == torch.float64 and clouds.is_contiguous() and tuple(clouds.shape) == (n, n_points, 3)
+    torch.cuda.current_stream(clouds.device).synchronize()
+    _check(_lib().nirrt_guidance_clouds(C.cast(arr, C.c_void_p), n, int(n_raw), int(n_points), clouds.data_ptr(), n_cand.ctypes.data,
+                                        n_out.ctypes.data, int(device_id)), "guidance_clouds")
+    return n_cand, n_out

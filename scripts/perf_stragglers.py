@@ -10,7 +10,9 @@ from nirrt_star_amd import _hip, sampling
 
 mode = sys.argv[1]
 iters = 50000
-a = SimpleNamespace(algo="irrt", dim=2, world="b30", iters=iters, trees=0)
+DIM = int(os.environ.get("STRAG_DIM", "2"))
+ALGO = os.environ.get("STRAG_ALGO", "irrt")
+a = SimpleNamespace(algo=ALGO, dim=DIM, world="b30", iters=iters, trees=0)
 n_np, n_py = bench.word_budgets(a)
 OUT = "gpurun_out/stragglers.json"
 
@@ -19,7 +21,7 @@ def setup(pids):
     cache, trees, npw, pyw = {}, [], [], []
     for pid in pids:
         pr = bench.make_problem(a, pid, cache)
-        t = _hip.HipTree(2, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], 3, pr["env"])
+        t = _hip.HipTree(DIM, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"])
         t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
         w1, w2 = bench.problem_words(a, pid, n_np, n_py)
         trees.append(t); npw.append(w1); pyw.append(w2)
@@ -43,14 +45,14 @@ if mode == "find":
     pids = list(range(B))
     trees, npw, pyw = setup(pids)
     free_line = [not t.is_collision(t_pr[0], t_pr[1]) for t, t_pr in zip(trees, [(bench.make_problem(a, p)["x_start"], bench.make_problem(a, p)["x_goal"]) for p in pids])] if False else None
-    res = _hip.run_sampling(trees, iters, npw, pyw, flags=_hip.F_IRRT)
+    res = _hip.run_sampling(trees, iters, npw, pyw if DIM == 2 and ALGO == "irrt" else None, flags=_hip.F_IRRT if ALGO == "irrt" else 0)
     slow, secs = report(res, pids, trees)
     json.dump({"slow": slow, "secs": [float(s) for s in secs]}, open(OUT, "w"))
 else:
     # pids: from the command line ("1626,5727,...") or the file a `find` run of the same gpurun call left
     slow = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 and "," in sys.argv[2] else json.load(open(OUT))["slow"]
     trees, npw, pyw = setup(slow)
-    res = _hip.run_sampling(trees, iters, npw, pyw, flags=_hip.F_IRRT)
+    res = _hip.run_sampling(trees, iters, npw, pyw if DIM == 2 and ALGO == "irrt" else None, flags=_hip.F_IRRT if ALGO == "irrt" else 0)
     report(res, slow, trees, top=8)
     pr_ = np.array([t.debug_prof() for t in trees]).astype(float)
     names = ["nearest", "steer+edge", "query", "choose", "cost(new)", "rewire", "goal/ingoal", "report", "(R.collect)", "(R.rounds)", "(R.recost)", "", "rebuild", "(Q.visit)", "(Q.nearest)", "(Q.finish)", "L.draw", "L.iteration", "L.report", "L.other", "(Q.setup)", "(R.test)", "(R.relink)", ""]

@@ -11,7 +11,7 @@ while read -r counters; do
   [ -z "$counters" ] && continue
   i=$((i+1))
   rocprofv3 --pmc $counters --kernel-trace --kernel-include-regex "k_run_" --output-format csv -d $out/pass$i -o p -- \
-     python $R/bench.py --no-cpu-baseline --no-ttfs --steps 1 --warmup 0 "$@" > $out/pass$i.json 2> $out/pass$i.err
+     python $R/bench.py --no-cpu-baseline --no-ttfs --no-secondary --steps 1 --warmup 0 "$@" > $out/pass$i.json 2> $out/pass$i.err
   find $out/pass$i -name "*kernel_trace.csv" -delete
 done <<'LIST'
 TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum
