@@ -37,6 +37,19 @@ int nirrt_pn2_sa_mlp(const float *feats, const float *xyz, const float *new_xyz,
                      int cin_pad, const float *w1t, const float *b1, int C1, const float *w2t, const float *b2, int C2,
                      const float *w3t, const float *b3, int C3, float *out, int out_stride, int out_off, void *stream);
 
+/* Input rows of the set-abstraction levels whose MLP runs as library GEMMs: sample_and_group's concatenation
+ * (pointnet2_utils.py:247-250) in one pass.  DEVICE pointers as for nirrt_pn2_sa_mlp; C a multiple of 4;
+ * out f32 (B * S * K, C + 4) = [feats[b, gidx], xyz[b, gidx] - new_xyz[b, s], 0] (the zero column keeps rows 16-byte aligned). */
+int nirrt_pn2_group_rows(const float *feats, const float *xyz, const float *new_xyz, const int64_t *gidx, int B, int N, int S, int K,
+                         int C, float *out, void *stream);
+
+/* Input rows of a feature-propagation level (PointNetFeaturePropagation.forward, pointnet2_utils.py:295-309): inverse-distance
+ * weights of the three neighbours from nirrt_pn2_three_nn (dist, idx), interpolation of the coarse features and concatenation
+ * behind the fine level's own: out f32 (B * N, C1 + C2) = [feats1[b, n], sum_j w_j feats2[b, idx_j]], w_j = (1 / (d_j + 1e-8)) /
+ * sum.  feats1 DEVICE f32 (B, N, C1) or NULL with C1 = 0, feats2 DEVICE f32 (B, S, C2); C1, C2 multiples of 4. */
+int nirrt_pn2_fp_rows(const float *feats1, const float *feats2, const float *dist, const int64_t *idx, int B, int N, int S, int C1,
+                      int C2, float *out, void *stream);
+
 /* open3d PointCloud.farthest_point_down_sample as called by datasets/point_cloud_mask_utils.py:69-72,170-173 and
  * datasets_3d/point_cloud_mask_utils_3d.py:49-53,196-199 (un-vendored dependency, behaviour restated: start at point 0,
  * greedy max-min squared distance in float64, first maximum on ties).  HOST pointers: pts (N, 3) f64 row-major,

@@ -43,64 +43,100 @@ class ProblemStreams:
     start indices of its PointNet++ forwards), all seeded like the reference seeds its process-global ones.
 
     The kernels consume raw 32-bit MT19937 outputs, a launch needs a window of them ahead of the current position, and a
-    batch is resumed many times (cloud refreshes): the look-ahead is therefore generated ONCE and kept - on the host for
-    the numpy stream, whose position also moves when the cloud candidates are drawn from `rs` (the window is then found
-    again inside the look-ahead by its next outputs), and as a resident copy in HBM that launches read in place
-    (`window_np/py(n, device)` -> (address, count)).  `rs` / `py` themselves always sit at the problem's true position."""
+    batch is resumed many times (cloud refreshes): the look-ahead is therefore generated ONCE and kept - on the host and as a
+    resident copy in HBM that launches (and the device-side cloud generation) read in place (`window_np/py(n, device)` ->
+    (address, count)).  What the device consumed is booked with advance_np/py(): the position inside the look-ahead moves at
+    once, the host generator itself follows lazily - by an O(1) state jump - when somebody looks at it (`rs` / `py`: host-side
+    cloud candidates, the end of a run) or the look-ahead has to be regenerated.  `rs` / `py` always return the generator at
+    the problem's true position; if a caller draws from them, the window is found again inside the look-ahead by its next
+    outputs."""
 
     def __init__(self, seed):
         self.seed = int(seed)
-        self.rs = np.random.RandomState(self.seed)
-        self.py = random.Random(self.seed)
+        self._rs = np.random.RandomState(self.seed)
+        self._pyg = random.Random(self.seed)
         self._torch = None
         self._scratch = np.random.RandomState(0)
-        self._np = {"host": None, "dev": None, "off": 0, "at": None}
-        self._py = {"host": None, "dev": None, "off": 0, "at": None}
+        self._npc = {"host": None, "dev": None, "off": 0, "pending": 0, "touched": False}
+        self._pyc = {"host": None, "dev": None, "off": 0, "pending": 0, "touched": False}
+
+    # ---- the generators themselves ----
+    @property
+    def rs(self):
+        self._settle(self._npc, True)
+        self._npc["touched"] = True      # the caller may draw from it
+        return self._rs
+
+    @property
+    def py(self):
+        self._settle(self._pyc, False)
+        self._pyc["touched"] = True
+        return self._pyg
+
+    def _set_from_outputs(self, is_np, last624):
+        """any 624 consecutive outputs determine an MT19937 generator: state rebuilt from them, position 624 = "block used up\""""
+        key = _untemper(last624)
+        if is_np:
+            st = self._rs.get_state(legacy=True)
+            self._rs.set_state((st[0], key, 624, st[3], st[4]))
+        else:
+            st = self._pyg.getstate()
+            self._pyg.setstate((st[0], tuple(int(v) for v in key) + (624,), st[2]))
+
+    def _settle(self, c, is_np):
+        """move the host generator past the outputs the device consumed since it was last looked at"""
+        n = c["pending"]
+        if not n:
+            return
+        c["pending"] = 0
+        end = c["off"]            # already counts the pending outputs
+        if c["host"] is not None and 624 <= end <= len(c["host"]):
+            self._set_from_outputs(is_np, c["host"][end - 624:end])
+        elif is_np:
+            self._rs.randint(0, 1 << 32, size=int(n), dtype=np.uint32)
+        else:
+            self._pyg.getrandbits(32 * int(n))
 
     # ---- raw outputs ahead of the current position (nothing is consumed) ----
-    def _np_sig(self):
-        st = self.rs.get_state(legacy=True)
-        return (int(st[2]), int(st[1][0]), int(st[1][623]))
-
-    def _py_sig(self):
-        st = self.py.getstate()[1]
-        return (st[624], st[0], st[623])
-
-    def _gen_np(self, n):
-        st = self.rs.get_state()
-        w = self.rs.randint(0, 1 << 32, size=int(n), dtype=np.uint32)
-        self.rs.set_state(st)
-        return w
-
-    def _gen_py(self, n):
+    def _gen(self, is_np, n):
+        if is_np:
+            st = self._rs.get_state()
+            w = self._rs.randint(0, 1 << 32, size=int(n), dtype=np.uint32)
+            self._rs.set_state(st)
+            return w
         # CPython's generator is the same MT19937 (getrandbits(32 k) = k consecutive outputs, least significant word first):
         # its state is copied into a numpy RandomState, which produces the outputs 3-4x faster than a 25-Mbit Python int
-        st = self.py.getstate()[1]
+        st = self._pyg.getstate()[1]
         self._scratch.set_state(("MT19937", np.array(st[:624], dtype=np.uint32), int(st[624])))
         return self._scratch.randint(0, 1 << 32, size=int(n), dtype=np.uint32)
 
-    def _window(self, c, sig, gen, n, device, relocate):
+    def _window(self, c, is_np, n, device):
         n = int(n)
-        if c["host"] is not None and c["at"] != sig:
-            # the generator moved without us (cloud candidates come from `rs`): its next outputs are further down the look-ahead
-            found = -1
-            if relocate:
-                probe = gen(8)
+        if c["touched"]:
+            # somebody held the generator itself (cloud candidates drawn on the host): find its next outputs in the look-ahead
+            c["touched"] = False
+            if c["host"] is not None:
+                found = -1
+                probe = self._gen(is_np, 8)
                 h, o = c["host"], c["off"]
-                for k in np.flatnonzero(h[o:len(h) - 7] == probe[0]):
-                    if np.array_equal(h[o + k:o + k + 8], probe):
-                        found = o + int(k)
-                        break
-            if found < 0:
-                c["host"] = c["dev"] = None
-            else:
-                c["off"], c["at"] = found, sig
+                if np.array_equal(h[o:o + 8], probe):
+                    found = o
+                else:
+                    for k in np.flatnonzero(h[o:len(h) - 7] == probe[0]):
+                        if np.array_equal(h[o + k:o + k + 8], probe):
+                            found = o + int(k)
+                            break
+                if found < 0:
+                    c["host"] = c["dev"] = None
+                else:
+                    c["off"] = found
         if c["host"] is None or len(c["host"]) - c["off"] < n:
             # from the current position; replaces what was left.  Rare: windows shrink as a run proceeds, and the numpy
             # look-ahead carries headroom for the candidates of the cloud refreshes in between
-            c["host"] = gen(n + (min(n // 2, 1 << 20) + 131072 if relocate else 0))
+            self._settle(c, is_np)
+            c["host"] = self._gen(is_np, n + (min(n // 2, 1 << 20) + 131072 if is_np else 0))
             c["dev"] = None
-            c["off"], c["at"] = 0, sig
+            c["off"] = 0
         if device is None:
             return c["host"][c["off"]:c["off"] + n]
         if c["dev"] is None:
@@ -110,11 +146,11 @@ class ProblemStreams:
 
     def window_np(self, n, device=None):
         """the next n outputs of the numpy stream: host array, or (device address, n) of the resident copy"""
-        return self._window(self._np, self._np_sig(), self._gen_np, n, device, True)
+        return self._window(self._npc, True, n, device)
 
     def window_py(self, n, device=None):
         """the next n 32-bit outputs of the python stream"""
-        return self._window(self._py, self._py_sig(), self._gen_py, n, device, False)
+        return self._window(self._pyc, False, n, device)
 
     def prime(self, n_np, n_py, device):
         """produce and upload the look-ahead before a run starts (bench: inputs resident before the timed region)"""
@@ -123,49 +159,45 @@ class ProblemStreams:
             self.window_py(n_py, device)
 
     def peek_np(self, n):
-        return self._gen_np(n)
+        self._settle(self._npc, True)
+        return self._gen(True, n)
 
     def peek_py(self, n):
-        return self._gen_py(n)
+        self._settle(self._pyc, False)
+        return self._gen(False, n)
 
-    # ---- consuming: the generator jumps to "n outputs later" ----
-    # Any 624 consecutive outputs determine an MT19937 generator: when the look-ahead covers the 624 outputs before the new
-    # position, the state is rebuilt from them (position 624 = "block used up") instead of producing n outputs to throw away.
-    def _jump_key(self, c, n):
-        if c["host"] is None or c["at"] is None:
-            return None
-        end = c["off"] + int(n)
-        if end < 624 or end > len(c["host"]):
-            return None
-        return _untemper(c["host"][end - 624:end])
+    # ---- consuming: "n outputs later" ----
+    def _advance(self, c, is_np, n):
+        n = int(n)
+        if not n:
+            return
+        if c["touched"]:               # position inside the look-ahead unknown until the next window: move the generator itself
+            self._settle(c, is_np)
+            if is_np:
+                self._rs.randint(0, 1 << 32, size=n, dtype=np.uint32)
+            else:
+                self._pyg.getrandbits(32 * n)
+            return
+        c["pending"] += n
+        if c["host"] is not None:
+            c["off"] += n
+            if c["off"] > len(c["host"]):      # ran past the look-ahead (cannot happen for windows handed out): settle by drawing
+                over = c["off"] - len(c["host"])
+                c["off"] = len(c["host"])
+                c["pending"] -= over
+                self._settle(c, is_np)
+                if is_np:
+                    self._rs.randint(0, 1 << 32, size=over, dtype=np.uint32)
+                else:
+                    self._pyg.getrandbits(32 * over)
+                c["host"] = c["dev"] = None
+                c["off"] = 0
 
     def advance_np(self, n):
-        if not n:
-            return
-        c = self._np
-        key = self._jump_key(c, n) if c["at"] == self._np_sig() else None
-        if key is not None:
-            st = self.rs.get_state(legacy=True)
-            self.rs.set_state((st[0], key, 624, st[3], st[4]))
-        else:
-            self.rs.randint(0, 1 << 32, size=int(n), dtype=np.uint32)
-        if c["host"] is not None:
-            c["off"] += int(n)
-            c["at"] = self._np_sig()
+        self._advance(self._npc, True, n)
 
     def advance_py(self, n):
-        if not n:
-            return
-        c = self._py
-        key = self._jump_key(c, n) if c["at"] == self._py_sig() else None
-        if key is not None:
-            st = self.py.getstate()
-            self.py.setstate((st[0], tuple(int(v) for v in key) + (624,), st[2]))
-        else:
-            self.py.getrandbits(32 * int(n))
-        if c["host"] is not None:
-            c["off"] += int(n)
-            c["at"] = self._py_sig()
+        self._advance(self._pyc, False, n)
 
     def fps_start(self, n_points):
         """the reference's `torch.randint(0, N, (B,))` of one forward over ONE cloud (pointnet2_utils.py:77), from this
@@ -248,7 +280,9 @@ class Guidance:
                 if c_best[i] < np.inf:
                     xs, xg = np.asarray(pr["x_start"], dtype=np.float64), np.asarray(pr["x_goal"], dtype=np.float64)
                     j.mode = 1
-                    for k, v in enumerate(pcu.ellipse_transform_2d(xs, xg, c_best[i] / frames[i][0])):
+                    if "_ellipse_frame" not in pr:
+                        pr["_ellipse_frame"] = pcu.ellipse_frame_2d(xs, xg)      # (the SVD behind C is the same for every refresh)
+                    for k, v in enumerate(pcu.ellipse_transform_2d(xs, xg, c_best[i] / frames[i][0], pr["_ellipse_frame"])):
                         j.a[k] = v
                 else:
                     j.mode = 0
@@ -460,6 +494,7 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
     # split pays from ~2048 trees (4096: 3.0 vs 2.8 M it/s; 1024: 1.7 vs 2.2).
     if overlap_min is None:
         overlap_min = int(os.environ.get("NIRRT_BATCH_OVERLAP_MIN", "1024"))   # trees per half; tests set 1
+    window = int(os.environ.get("NIRRT_BATCH_WINDOW", window))   # iterations per persistent launch (a stopped tree waits for its launch to end)
     n_groups = 2 if (png and B >= 2 * overlap_min) else 1
     groups = [list(range(g, B, n_groups)) for g in range(n_groups)]
     futures = [None] * n_groups

@@ -915,10 +915,22 @@ extern "C" int nirrt_set_cloud_batch(nirrt_tree *const *trees, int32_t n_trees, 
         jobs[(size_t)i] = SetCloudJob{t->dev, t->pc_own, clouds + (size_t)i * (size_t)cloud_stride, pred + (size_t)i * (size_t)pred_stride,
                                       n_points[i], t->dim, sample_rate, update_cost_ratio, c_update[i]};
     }
-    SetCloudJob *d_jobs = nullptr;
-    int *d_n = nullptr;
-    HIPCHK(hipMalloc(&d_jobs, sizeof(SetCloudJob) * (size_t)n_trees));
-    HIPCHK(hipMalloc(&d_n, sizeof(int) * (size_t)n_trees));
+    // grow-only scratch kept per device: this runs while the other half of a batch is inside a persistent launch, and hipFree
+    // would wait for that launch
+    static std::mutex mu;
+    static void *scratch[16] = {nullptr};
+    static size_t scratch_cap[16] = {0};
+    std::lock_guard<std::mutex> hold(mu);
+    const size_t need = (sizeof(SetCloudJob) + sizeof(int)) * (size_t)n_trees + 256;
+    const int dv = t0->device & 15;
+    if (scratch_cap[dv] < need) {
+        if (scratch[dv]) (void)hipFree(scratch[dv]);
+        scratch[dv] = nullptr; scratch_cap[dv] = 0;
+        HIPCHK(hipMalloc(&scratch[dv], 2 * need));
+        scratch_cap[dv] = 2 * need;
+    }
+    SetCloudJob *d_jobs = (SetCloudJob *)scratch[dv];
+    int *d_n = (int *)((char *)scratch[dv] + ((sizeof(SetCloudJob) * (size_t)n_trees + 255) & ~(size_t)255));
     std::vector<int> n_path((size_t)n_trees);
     hipError_t e = hipMemcpyAsync(d_jobs, jobs.data(), sizeof(SetCloudJob) * (size_t)n_trees, hipMemcpyHostToDevice, t0->stream);
     if (e == hipSuccess) {
@@ -927,8 +939,6 @@ extern "C" int nirrt_set_cloud_batch(nirrt_tree *const *trees, int32_t n_trees, 
     }
     if (e == hipSuccess) e = hipMemcpyAsync(n_path.data(), d_n, sizeof(int) * (size_t)n_trees, hipMemcpyDeviceToHost, t0->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t0->stream);
-    (void)hipFree(d_jobs);
-    (void)hipFree(d_n);
     if (e != hipSuccess) { g_err = std::string("nirrt_set_cloud_batch: ") + hipGetErrorString(e); return NIRRT_E_HIP; }
     for (int i = 0; i < n_trees; i++) {   // host mirrors follow (later per-tree patches copy from them)
         nirrt_tree *t = trees[i];

@@ -268,42 +268,56 @@ extern "C" int nirrt_pn2_three_nn(const float *xyz1, const float *xyz2, int B, i
 // point 0, greedy max-min squared distance, first maximum on ties; the caller keeps the selected points
 // in their original order.  One workgroup, running min-distances in registers, cloud read from L2.
 // ------------------------------------------------------------------------------------------------
-#define FPS64_MAX_PER_THREAD 16   // N <= 16384
+#define FPS64_NT 512              // 8 waves at <= 96 VGPRs: a workgroup fits NEXT to the 8 - 16 one-wave trees a CU holds while the
+#define FPS64_MAX_PER_THREAD 32   // other half of a guided batch is inside its persistent launch (N <= 16384).  (Round 2: 1024 threads
+                                  // at 128 VGPRs = a whole CU's register file - every refresh waited for the running launch to drain.)
 
 // one workgroup per cloud: cloud b = points [off[b], off[b] + cnt[b]) of the concatenated SoA buffer
-// (x of all clouds, then y, then z; `total` points in all), ns[b] survivors, sel concatenated likewise
-__global__ __launch_bounds__(FPS_NT) void k_fps_f64(const double *__restrict__ buf, long long total, const long long *__restrict__ off,
-                                                   const int *__restrict__ cnt, const int *__restrict__ ns,
-                                                   unsigned char *__restrict__ sel_all)
+// (x of all clouds, then y, then z; `total` points in all), ns[b] survivors, sel concatenated likewise.
+// open3d's farthest_point_down_sample restated: start at point 0, greedy max-min SQUARED distance in float64, first maximum
+// on ties.  The running minimum distances stay in registers; has_z == 0 (planar clouds: z is all zeros) skips that column.
+template <int MAXP>   // points per thread: 20 (N <= 10240, the guidance clouds' 5 x 2048 candidates) or 32
+__global__ __launch_bounds__(FPS64_NT, 5) void k_fps_f64(const double *__restrict__ buf, long long total, const long long *__restrict__ off,
+                                                        const int *__restrict__ cnt, const int *__restrict__ ns,
+                                                        unsigned char *__restrict__ sel_all, int has_z)
 {
-    __shared__ double rv[FPS_NT / 64];
-    __shared__ int ri[FPS_NT / 64];
+    __shared__ double rv[FPS64_NT / 64];
+    __shared__ int ri[FPS64_NT / 64];
     const long long o = off[blockIdx.x];
     const int N = cnt[blockIdx.x], S = ns[blockIdx.x];
     if (N <= S) return;   // nothing to drop (the callers keep such clouds whole)
     const double *x = buf + o, *y = buf + total + o, *z = buf + 2 * total + o;
     unsigned char *sel = sel_all + o;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    double dist[FPS64_MAX_PER_THREAD];
+    double dist[MAXP];
 #pragma unroll
-    for (int j = 0; j < FPS64_MAX_PER_THREAD; j++) dist[j] = __builtin_inf();
-    for (int i = tid; i < N; i += FPS_NT) sel[i] = 0;
+    for (int j = 0; j < MAXP; j++) dist[j] = __builtin_inf();
+    for (int i = tid; i < N; i += FPS64_NT) sel[i] = 0;
     int far = 0;
     __syncthreads();
     for (int s = 0; s < S; s++) {
         if (tid == 0) sel[far] = 1;
-        const double cx = x[far], cy = y[far], cz = z[far];
+        const double cx = x[far], cy = y[far], cz = has_z ? z[far] : 0.;
         double bv = -1.;
         int bi = 0x7fffffff;
+        // (one 32-bit byte offset per point on top of the three scalar bases: separate 64-bit addresses per point and column
+        // would need more registers than the running minima themselves)
+        unsigned ob = (unsigned)tid * 8u;
+        asm volatile("" : "+v"(ob));   // (keeps the per-point addresses from being formed once, outside the loop over the steps, and spilled)
 #pragma unroll
-        for (int j = 0; j < FPS64_MAX_PER_THREAD; j++) {
-            int i = tid + j * FPS_NT;
+        for (int j = 0; j < MAXP; j++) {
+            const int i = tid + j * FPS64_NT;
             if (i < N) {
-                double dx = x[i] - cx, dy = y[i] - cy, dz = z[i] - cz;
-                double d = dx * dx + dy * dy + dz * dz;
+                const double px = *(const double *)((const char *)x + ob), py = *(const double *)((const char *)y + ob);
+                const double pz = has_z ? *(const double *)((const char *)z + ob) : 0.;
+                const double dx = px - cx, dy = py - cy, dz = pz - cz;
+                const double d = dx * dx + dy * dy + dz * dz;
                 if (d < dist[j]) dist[j] = d;
                 if (dist[j] > bv) { bv = dist[j]; bi = i; }
             }
+            ob += FPS64_NT * 8u;
+            // four points' loads in flight at a time: hoisting all of them above the arithmetic spills the running minima
+            if ((j & 3) == 3) asm volatile("" ::: "memory");
         }
 #pragma unroll
         for (int off2 = 32; off2 >= 1; off2 >>= 1) {
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(FPS_NT) void k_fps_f64(const double *__restrict__ b
         __syncthreads();
         bv = rv[0]; bi = ri[0];
 #pragma unroll
-        for (int i = 1; i < FPS_NT / 64; i++) {
+        for (int i = 1; i < FPS64_NT / 64; i++) {
             double ov = rv[i];
             int oi = ri[i];
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
@@ -339,7 +353,7 @@ extern "C" int nirrt_fps_f64_batch(const double *pts, int n_clouds, const int *c
     long long total = 0;
     long long *h_off = (long long *)malloc(sizeof(long long) * (size_t)n_clouds);
     for (int b = 0; b < n_clouds; b++) {
-        if (cnt[b] <= 0 || num_samples[b] <= 0 || num_samples[b] > cnt[b] || cnt[b] > FPS_NT * FPS64_MAX_PER_THREAD) { free(h_off); return -1; }
+        if (cnt[b] <= 0 || num_samples[b] <= 0 || num_samples[b] > cnt[b] || cnt[b] > FPS64_NT * FPS64_MAX_PER_THREAD) { free(h_off); return -1; }
         h_off[b] = total;
         total += cnt[b];
     }
@@ -371,8 +385,14 @@ extern "C" int nirrt_fps_f64_batch(const double *pts, int n_clouds, const int *c
                 hipMemcpy(d_ns, num_samples, sizeof(int) * (size_t)n_clouds, hipMemcpyHostToDevice) != hipSuccess))
         rc = -2;
     if (!rc) {
-        hipLaunchKernelGGL(k_fps_f64, dim3(n_clouds), dim3(FPS_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
-                           (const int *)d_cnt, (const int *)d_ns, ds);
+        int nmax = 0;
+        for (int b = 0; b < n_clouds; b++) nmax = cnt[b] > nmax ? cnt[b] : nmax;
+        if (nmax <= 20 * FPS64_NT)
+            hipLaunchKernelGGL(k_fps_f64<20>, dim3(n_clouds), dim3(FPS64_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
+                               (const int *)d_cnt, (const int *)d_ns, ds, 1);
+        else
+            hipLaunchKernelGGL(k_fps_f64<32>, dim3(n_clouds), dim3(FPS64_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
+                               (const int *)d_cnt, (const int *)d_ns, ds, 1);
         if (hipGetLastError() != hipSuccess || hipMemcpy(sel, ds, (size_t)total, hipMemcpyDeviceToHost) != hipSuccess) rc = -2;
     }
     free(h);
@@ -523,7 +543,7 @@ static FpsScratch g_cloud_scratch[16];
 extern "C" int nirrt_guidance_clouds(const nirrt_cloud_job *jobs, int n_jobs, int n_raw, int n_points, double *clouds, int *n_cand,
                                      int *n_out, int device_id)
 {
-    if (!jobs || !clouds || !n_cand || !n_out || n_jobs <= 0 || n_raw <= 0 || n_points <= 0 || n_raw > FPS_NT * FPS64_MAX_PER_THREAD) return -1;
+    if (!jobs || !clouds || !n_cand || !n_out || n_jobs <= 0 || n_raw <= 0 || n_points <= 0 || n_raw > FPS64_NT * FPS64_MAX_PER_THREAD) return -1;
     if (hipSetDevice(device_id) != hipSuccess) return -4;
     const long long total = (long long)n_jobs * n_raw;
     const size_t a256 = 255;
@@ -559,8 +579,12 @@ extern "C" int nirrt_guidance_clouds(const nirrt_cloud_job *jobs, int n_jobs, in
     if (!rc) {
         hipLaunchKernelGGL(k_cloud_candidates, dim3(n_jobs), dim3(CAND_NT), 0, 0, (const nirrt_cloud_job *)d_jobs, n_raw, d, total, d_cnt);
         // k_fps_f64 leaves clouds with cnt <= num_samples alone (k_cloud_compact keeps all of their points)
-        hipLaunchKernelGGL(k_fps_f64, dim3(n_jobs), dim3(FPS_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
-                           (const int *)d_cnt, (const int *)d_ns, ds);
+        if (n_raw <= 20 * FPS64_NT)
+            hipLaunchKernelGGL(k_fps_f64<20>, dim3(n_jobs), dim3(FPS64_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
+                               (const int *)d_cnt, (const int *)d_ns, ds, jobs[0].mode == 2 ? 1 : 0);
+        else
+            hipLaunchKernelGGL(k_fps_f64<32>, dim3(n_jobs), dim3(FPS64_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
+                               (const int *)d_cnt, (const int *)d_ns, ds, jobs[0].mode == 2 ? 1 : 0);
         hipLaunchKernelGGL(k_cloud_compact, dim3(n_jobs), dim3(CAND_NT), 0, 0, (const double *)d, total, n_raw, (const int *)d_cnt, n_points,
                            (const unsigned char *)ds, clouds, d_nout);
         if (hipGetLastError() != hipSuccess || hipMemcpy(n_cand, d_cnt, sizeof(int) * (size_t)n_jobs, hipMemcpyDeviceToHost) != hipSuccess ||
@@ -568,6 +592,93 @@ extern "C" int nirrt_guidance_clouds(const nirrt_cloud_job *jobs, int n_jobs, in
             rc = -2;
     }
     return rc;
+}
+
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// Input rows of the levels whose MLP runs as library GEMMs (SA3, SA4, every feature-propagation level): ONE pass that writes
+// the GEMM's A matrix, instead of torch gathers + multiply + sum + cat (five kernels and four intermediate tensors per level).
+// float4 throughout: channel counts are multiples of 4 (the host checks and otherwise keeps the torch path).
+// ------------------------------------------------------------------------------------------------
+
+// grouped rows (pointnet2_utils.py:247-250): out[(b, s, k), :] = [feats[b, gidx[b, s, k], 0:C], xyz[b, gidx] - new_xyz[b, s], 0]
+// (C + 4 columns: the zero column keeps the rows 16-byte aligned; the first layer's weight gets a zero column to match)
+__global__ __launch_bounds__(256) void k_group_rows(const float4_t *__restrict__ feats, const float *__restrict__ xyz,
+                                                    const float *__restrict__ new_xyz, const long long *__restrict__ gidx, int N, int S,
+                                                    int K, int C4, long long rows, float4_t *__restrict__ out)
+{
+    const int W4 = C4 + 1;
+    const long long total = rows * W4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long row = e / W4;
+        const int c = (int)(e - row * W4);
+        const long long g = row / K;                       // (b, s)
+        const long long src = (g / S) * N + gidx[row];
+        float4_t v;
+        if (c < C4) v = feats[src * C4 + c];
+        else {
+            v[0] = xyz[src * 3] - new_xyz[g * 3];
+            v[1] = xyz[src * 3 + 1] - new_xyz[g * 3 + 1];
+            v[2] = xyz[src * 3 + 2] - new_xyz[g * 3 + 2];
+            v[3] = 0.f;
+        }
+        out[e] = v;
+    }
+}
+
+// feature-propagation rows (pointnet2_utils.py:295-309): out[(b, n), :] = [feats1[b, n, 0:C1], sum_j w_j feats2[b, idx[b, n, j], 0:C2]]
+// with w_j = (1 / (d_j + 1e-8)) / sum_j (1 / (d_j + 1e-8)), the three terms added in order j = 0, 1, 2 (no contraction: -ffp-contract=off)
+__global__ __launch_bounds__(256) void k_fp_rows(const float4_t *__restrict__ feats1, const float4_t *__restrict__ feats2,
+                                                 const float *__restrict__ dist, const long long *__restrict__ idx, int N, int S, int C14,
+                                                 int C24, long long rows, float4_t *__restrict__ out)
+{
+    const int W4 = C14 + C24;
+    const long long total = rows * W4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long row = e / W4;
+        const int c = (int)(e - row * W4);
+        float4_t v;
+        if (c < C14) v = feats1[row * C14 + c];
+        else {
+            const float r0 = 1.0f / (dist[row * 3] + 1e-8f), r1 = 1.0f / (dist[row * 3 + 1] + 1e-8f), r2 = 1.0f / (dist[row * 3 + 2] + 1e-8f);
+            const float norm = (r0 + r1) + r2;
+            const float w0 = r0 / norm, w1 = r1 / norm, w2 = r2 / norm;
+            const long long b = row / N;
+            const int cc = c - C14;
+            const float4_t a0 = feats2[(b * S + idx[row * 3]) * C24 + cc];
+            const float4_t a1 = feats2[(b * S + idx[row * 3 + 1]) * C24 + cc];
+            const float4_t a2 = feats2[(b * S + idx[row * 3 + 2]) * C24 + cc];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = (a0[u] * w0 + a1[u] * w1) + a2[u] * w2;
+        }
+        out[e] = v;
+    }
+}
+
+extern "C" int nirrt_pn2_group_rows(const float *feats, const float *xyz, const float *new_xyz, const int64_t *gidx, int B, int N, int S,
+                                    int K, int C, float *out, void *stream)
+{
+    if (B <= 0 || S <= 0 || K <= 0 || C <= 0 || C % 4 || ((uintptr_t)feats | (uintptr_t)out) % 16) return -1;
+    const long long rows = (long long)B * S * K, total = rows * (C / 4 + 1);
+    long long grid = (total + 255) / 256;
+    if (grid > 256 * 64) grid = 256 * 64;
+    hipLaunchKernelGGL(k_group_rows, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const float4_t *)feats, xyz, new_xyz,
+                       (const long long *)gidx, N, S, K, C / 4, rows, (float4_t *)out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int nirrt_pn2_fp_rows(const float *feats1, const float *feats2, const float *dist, const int64_t *idx, int B, int N, int S,
+                                 int C1, int C2, float *out, void *stream)
+{
+    if (B <= 0 || N <= 0 || S <= 0 || C2 <= 0 || C1 < 0 || C1 % 4 || C2 % 4 || ((uintptr_t)feats1 | (uintptr_t)feats2 | (uintptr_t)out) % 16)
+        return -1;
+    const long long rows = (long long)B * N, total = rows * ((C1 + C2) / 4);
+    long long grid = (total + 255) / 256;
+    if (grid > 256 * 64) grid = 256 * 64;
+    hipLaunchKernelGGL(k_fp_rows, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const float4_t *)feats1,
+                       (const float4_t *)feats2, dist, (const long long *)idx, N, S, C1 / 4, C2 / 4, rows, (float4_t *)out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -588,8 +699,6 @@ extern "C" int nirrt_guidance_clouds(const nirrt_cloud_job *jobs, int n_jobs, in
 // Weights sit in LDS as [column][k] rows of stride K + 4 floats (16-byte aligned rows that start 4 banks apart).
 // Input rows are [features of the member, xyz(member) - xyz(centroid)] (:247-250), zero-padded to a multiple of 16 channels.
 // ------------------------------------------------------------------------------------------------
-typedef float float4_t __attribute__((ext_vector_type(4)));
-
 #define SA_WAVES 4          // waves per workgroup when the branch's LDS footprint allows (the host picks 4, 3 or 2)
 #define SA_KMAX 128         // widest layer input (C_in padded, C1, C2)
 
@@ -604,61 +713,117 @@ struct SaMlpArgs {
     int B, N, S, K, C, cin_src, Cin, C1, C2, C3, out_stride, out_off;   // Cin = C + 3 padded to a multiple of 16
 };
 
-// one layer on the wave's two tiles: act (32 rows x stride sa floats, K_ inputs) -> C_ outputs; LAST: maximum over each group's
-// rows instead of a new activation tile
-template <bool LAST>
-__device__ __forceinline__ void sa_layer(float *act, int sa, const float *W, const float *bias, int K_, int C_, int lane, int gsz,
-                                         float (&best)[2][8])
+// one layer on the wave's two tiles: act (32 rows x stride sa floats, K_ = 16 * KC4 inputs) -> C_ outputs; LAST: maximum over
+// each group's rows instead of a new activation tile.  KC4 (float4 operands per lane) is a template parameter so that the loop
+// over k is straight-line code: with a run-time bound every ds_read_b128 sat in its own basic block right in front of the eight
+// MFMAs it feeds and its latency was paid every time.  The weight fragments of column tile ct + 16 are read while tile ct
+// multiplies (two register sets, ping-pong).
+template <bool LAST, int KC4>
+__device__ __forceinline__ void sa_layer(float *act, int sa, const float *W, const float *bias, int C_, int lane, int gsz)
 {
-    const int row = lane & 15, kq = lane >> 4, kc = K_ >> 2;   // this lane's k range: [kq * kc, (kq + 1) * kc)
-    const int sw = K_ + 4;
-    float4_t a0[SA_KMAX / 16], a1[SA_KMAX / 16];
+    constexpr int K_ = 16 * KC4, kc = 4 * KC4, sw = K_ + 4;
+    const int row = lane & 15, kq = lane >> 4;                 // this lane's k range: [kq * kc, (kq + 1) * kc)
+    float4_t a0[KC4], a1[KC4];
 #pragma unroll
-    for (int j = 0; j < SA_KMAX / 16; j++) {
-        if (4 * j < kc) {
-            a0[j] = *reinterpret_cast<const float4_t *>(act + row * sa + kq * kc + 4 * j);
-            a1[j] = *reinterpret_cast<const float4_t *>(act + (16 + row) * sa + kq * kc + 4 * j);
-        }
+    for (int j = 0; j < KC4; j++) {
+        a0[j] = *reinterpret_cast<const float4_t *>(act + row * sa + kq * kc + 4 * j);
+        a1[j] = *reinterpret_cast<const float4_t *>(act + (16 + row) * sa + kq * kc + 4 * j);
     }
-    // (same wave reads and later writes `act`: the reads above have returned before the first write below is issued only if we
-    // wait for them - the compiler's lgkmcnt tracking does that, the values are consumed by the MFMAs first)
-    for (int ct = 0, ci = 0; ct < C_; ct += 16, ci++) {
-        float4_t acc0, acc1;
-        const float bv = bias[ct + row];
+    const float *wbase = W + row * sw + kq * kc;
+    // fragments + bias of a column tile; `ct` is clamped so that the read-ahead past the last tile stays inside the layer (no
+    // branch between two tiles: the compiler may then run the epilogue of one under the MFMAs of the next)
+    auto wload = [&](float4_t (&wf)[KC4], float &bv, int ct) {
+        ct = ct < C_ ? ct : C_ - 16;
+#pragma unroll
+        for (int j = 0; j < KC4; j++) wf[j] = *reinterpret_cast<const float4_t *>(wbase + ct * sw + 4 * j);
+        bv = bias[ct + row];
+    };
+    auto mm = [&](const float4_t (&wf)[KC4], float bv, float4_t &acc0, float4_t &acc1) {
         acc0[0] = bv; acc0[1] = bv; acc0[2] = bv; acc0[3] = bv;
         acc1 = acc0;
-        const float *wrow = W + (ct + row) * sw + kq * kc;
 #pragma unroll
-        for (int j = 0; j < SA_KMAX / 16; j++) {
-            if (4 * j < kc) {
-                const float4_t wf = *reinterpret_cast<const float4_t *>(wrow + 4 * j);
+        for (int j = 0; j < KC4; j++) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j][u], wf[u], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j][u], wf[u], acc1, 0, 0, 0);
-                }
+            for (int u = 0; u < 4; u++) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j][u], wf[j][u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j][u], wf[j][u], acc1, 0, 0, 0);
             }
         }
+    };
+    auto epi = [&](const float4_t &acc0, const float4_t &acc1, int ct) {
         if (!LAST) {
+            // (same wave reads and later writes `act`: a0 / a1 were loaded above and LDS operations of a wave complete in order)
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 act[(4 * kq + v) * sa + ct + row] = acc0[v] > 0.f ? acc0[v] : 0.f;
                 act[(16 + 4 * kq + v) * sa + ct + row] = acc1[v] > 0.f ? acc1[v] : 0.f;
             }
         } else {
-            // maximum over the rows of each tile, per output column (ReLU first); gsz == 32: one group spans both tiles
+            // maximum over this lane's four rows of each tile (ReLU first); the four lanes of a column leave their partial maxima
+            // in rows kq (first tile) and 16 + kq (second tile) of the - by now dead - activation tile, the caller folds them
             float m0 = 0.f, m1 = 0.f;
 #pragma unroll
             for (int v = 0; v < 4; v++) { m0 = fmaxf(m0, acc0[v]); m1 = fmaxf(m1, acc1[v]); }
-            m0 = fmaxf(m0, __shfl_xor(m0, 16)); m0 = fmaxf(m0, __shfl_xor(m0, 32));
-            m1 = fmaxf(m1, __shfl_xor(m1, 16)); m1 = fmaxf(m1, __shfl_xor(m1, 32));
-            if (gsz == 32) { best[0][ci] = fmaxf(m0, m1); } else { best[0][ci] = m0; best[1][ci] = m1; }
+            const int ms = C_ + 16;                   // 4 * ms <= 16 * sa: the caller sizes sa >= C3 / 4 + 4
+            act[kq * ms + ct + row] = m0;
+            act[16 * sa + kq * ms + ct + row] = m1;
         }
+    };
+    // Two tiles per trip; the fragments of the NEXT trip are read at the end of this one (the scheduler sinks LDS reads towards
+    // their first use - placed anywhere earlier they ended up one by one, each with its own s_waitcnt, inside the MFMA stream of
+    // the tile that needed them; it cannot sink them across the back edge).  The first tile's epilogue runs under the second
+    // tile's MFMAs.
+    float4_t wA[KC4], wB[KC4], x0, x1, y0, y1;
+    float bA, bB;
+    wload(wA, bA, 0);
+    wload(wB, bB, 16);
+    int ct = 0;
+    for (; ct + 16 < C_; ct += 32) {
+        mm(wA, bA, x0, x1);
+        mm(wB, bB, y0, y1);
+        epi(x0, x1, ct);
+        wload(wA, bA, ct + 32);
+        wload(wB, bB, ct + 48);
+        epi(y0, y1, ct + 16);
+    }
+    if (ct < C_) { mm(wA, bA, x0, x1); epi(x0, x1, ct); }
+}
+
+// run-time width -> the instantiation (K_ is a multiple of 16, at most 16 * KA)
+template <bool LAST, int KA>
+__device__ __forceinline__ void sa_layer_k(float *act, int sa, const float *W, const float *bias, int K_, int C_, int lane, int gsz)
+{
+    const int k4 = K_ >> 4;
+    if (k4 == 1) sa_layer<LAST, 1>(act, sa, W, bias, C_, lane, gsz);
+    else if (k4 == 2) sa_layer<LAST, 2>(act, sa, W, bias, C_, lane, gsz);
+    else if constexpr (KA > 2) {
+        if (k4 == 3) sa_layer<LAST, 3>(act, sa, W, bias, C_, lane, gsz);
+        else if (k4 == 4) sa_layer<LAST, 4>(act, sa, W, bias, C_, lane, gsz);
+        else if (k4 == 5) sa_layer<LAST, 5>(act, sa, W, bias, C_, lane, gsz);
+        else if (k4 == 6) sa_layer<LAST, 6>(act, sa, W, bias, C_, lane, gsz);
+        else if (k4 == 7) sa_layer<LAST, 7>(act, sa, W, bias, C_, lane, gsz);
+        else sa_layer<LAST, 8>(act, sa, W, bias, C_, lane, gsz);
     }
 }
 
-__global__ __launch_bounds__(64 * SA_WAVES) void k_sa_mlp(SaMlpArgs a)
+// The gather of a pass is software-pipelined against the MFMAs of the pass before it: the member indices of pass p + 2 and the
+// feature / xyz vectors of pass p + 1 are in flight (registers) while pass p multiplies.  VW = vector width of a feature row
+// load (4, 2 or 1 floats: the widest that divides C); a lane owns the same (row, channel) positions of the 32 x C tile in every
+// pass, so their decomposition is done once.  (Round 2 / early round 3: scalar loads behind a per-element index load, nothing
+// else to run on the SIMD while they were in flight - the gather, not the MFMAs, was 80 % of the kernel.)
+// Two shapes are instantiated: PF = 2 prefetch vectors per lane and layer inputs up to 32 wide (SA1: 4 waves per SIMD hide what
+// is left of the latencies of its short passes) and PF = 16 / up to 128 wide (SA2: the weights take most of a CU's LDS, one
+// workgroup per CU, a wave has its SIMD's register file to itself).
+
+template <int VW> struct SaVec;
+template <> struct SaVec<4> { typedef float4_t T; };
+template <> struct SaVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct SaVec<1> { typedef float T; };
+
+template <int VW, int SA_PF, int KA>
+__global__ __launch_bounds__(64 * SA_WAVES, (KA <= 2 ? 2 : 1)) void k_sa_mlp(SaMlpArgs a)
 {
+    typedef typename SaVec<VW>::T vec_t;
     extern __shared__ __attribute__((aligned(16))) float sa_lds[];
     const int nw = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -670,11 +835,14 @@ __global__ __launch_bounds__(64 * SA_WAVES) void k_sa_mlp(SaMlpArgs a)
     float *Bs = W3 + C3 * (C2 + 4);           // C1 + C2 + C3 biases
     int kmax = Cin > C1 ? Cin : C1;
     kmax = kmax > C2 ? kmax : C2;
+    kmax = kmax > C3 / 4 ? kmax : C3 / 4;     // (the last layer parks 4 rows of C3 + 16 partial maxima in each half tile)
     const int sa = kmax + 4;                  // activation row stride (16-byte aligned rows, 4 banks apart)
     float *act = Bs + C1 + C2 + C3 + (size_t)w * 32 * sa;
-    for (int i = tid; i < C1 * Cin; i += blockDim.x) { const int c = i / Cin, k = i - c * Cin; W1[c * (Cin + 4) + k] = k < a.cin_src ? a.w1t[k * C1 + c] : 0.f; }
-    for (int i = tid; i < C2 * C1; i += blockDim.x) { const int c = i / C1, k = i - c * C1; W2[c * (C1 + 4) + k] = a.w2t[k * C2 + c]; }
-    for (int i = tid; i < C3 * C2; i += blockDim.x) { const int c = i / C2, k = i - c * C2; W3[c * (C2 + 4) + k] = a.w3t[k * C3 + c]; }
+    // staging: read W^T (k-major, columns fastest) in storage order - coalesced - and scatter into the [column][k] rows; the grid
+    // is one resident set of workgroups, so this happens once per CU slot, not once per 2048th of the work
+    for (int i = tid; i < C1 * Cin; i += blockDim.x) { const int k = i / C1, c = i - k * C1; W1[c * (Cin + 4) + k] = k < a.cin_src ? a.w1t[i] : 0.f; }
+    for (int i = tid; i < C2 * C1; i += blockDim.x) { const int k = i / C2, c = i - k * C2; W2[c * (C1 + 4) + k] = a.w2t[i]; }
+    for (int i = tid; i < C3 * C2; i += blockDim.x) { const int k = i / C3, c = i - k * C3; W3[c * (C2 + 4) + k] = a.w3t[i]; }
     for (int i = tid; i < C1; i += blockDim.x) Bs[i] = a.b1[i];
     for (int i = tid; i < C2; i += blockDim.x) Bs[C1 + i] = a.b2[i];
     for (int i = tid; i < C3; i += blockDim.x) Bs[C1 + C2 + i] = a.b3[i];
@@ -683,38 +851,104 @@ __global__ __launch_bounds__(64 * SA_WAVES) void k_sa_mlp(SaMlpArgs a)
     const int gpp = 32 / gsz;                              // groups per 32-row pass
     const long long groups = (long long)a.B * a.S;
     const long long passes = (groups + gpp - 1) / gpp;
-    const int CC = a.C + 3;
-    for (long long ps = (long long)blockIdx.x * nw + w; ps < passes; ps += (long long)gridDim.x * nw) {
-        const long long g0 = ps * gpp;
-        // gather: element e of the 32 x Cin tile = (row e / Cin, channel e % Cin); consecutive lanes read consecutive channels
-        for (int e = lane; e < 32 * Cin; e += 64) {
-            const int r = e / Cin, c = e - r * Cin;
-            const long long g = g0 + r / gsz;
-            float v = 0.f;
-            if (g < groups && c < CC) {
-                const int b = (int)(g / a.S);
-                const long long idx = a.gidx[g * a.K + (r % gsz)];
-                if (c < a.C) v = a.feats[((long long)b * a.N + idx) * a.C + c];
-                else {
-                    const float p = a.xyz[((long long)b * a.N + idx) * 3 + (c - a.C)];
-                    v = p - a.new_xyz[g * 3 + (c - a.C)];
-                }
-            }
-            act[r * sa + c] = v;
+    const long long stride = (long long)gridDim.x * nw;
+    const int C = a.C, CC = a.C + 3;
+    const int nv = C / VW, nvec = 32 * nv;                 // vectors per row / per tile
+    // this lane's positions in the tile: vector j covers row pr[j], channels pc[j] .. pc[j] + VW - 1 (-1: none)
+    int pr[SA_PF], pc[SA_PF];
+#pragma unroll
+    for (int j = 0; j < SA_PF; j++) {
+        const int e = j * 64 + lane;
+        pr[j] = e < nvec ? e / nv : -1;
+        pc[j] = e < nvec ? (e - (e / nv) * nv) * VW : 0;
+    }
+    // xyz: element e < 96 = (row e / 3, axis e % 3); lanes 0..63 take e = lane, lanes 0..31 also e = 64 + lane
+    const int xr0 = lane / 3, xa0 = lane - 3 * xr0;
+    const int xr1 = (64 + lane) / 3, xa1 = (64 + lane) - 3 * xr1;
+    const bool x1 = lane < 32;
+
+    // pipeline registers
+    vec_t pf[SA_PF];
+    float px0 = 0.f, px1 = 0.f, pn0 = 0.f, pn1 = 0.f;
+    // lanes 0..31: source row of tile row `lane` = rbase + ridx.  The loaded member index is NOT touched here (ridx is consumed a
+    // whole pass later, in issue()): combining it with the batch offset at this point put an s_waitcnt vmcnt(0) - behind the
+    // vector loads just issued - in front of every MFMA phase.
+    auto load_rows = [&](long long ps, int &rbase, int &ridx) {
+        rbase = -1; ridx = 0;
+        if (lane < 32 && ps < passes) {
+            const long long g = ps * gpp + lane / gsz;
+            if (g < groups) { rbase = (int)(g / a.S) * a.N; ridx = (int)a.gidx[ps * 32 + lane]; }
         }
-        float best[2][8];
-        sa_layer<false>(act, sa, W1, Bs, Cin, C1, lane, gsz, best);
-        sa_layer<false>(act, sa, W2, Bs + C1, C1, C2, lane, gsz, best);
-        sa_layer<true>(act, sa, W3, Bs + C1 + C2, C2, C3, lane, gsz, best);
-        if (lane < 16) {
-            for (int q = 0; q < gpp; q++) {
-                if (g0 + q < groups) {
-                    float *o = a.out + (g0 + q) * a.out_stride + a.out_off;
-                    for (int ct = 0, ci = 0; ct < C3; ct += 16, ci++) o[ct + lane] = best[q][ci];
-                }
+    };
+    auto issue = [&](int rbase, int ridx, long long ps) {  // this pass's row offsets (lanes 0..31)
+        const int ro = rbase < 0 ? -1 : rbase + ridx;
+#pragma unroll
+        for (int j = 0; j < SA_PF; j++) {
+            if (j * 64 < nvec) {
+                const int r = __shfl(ro, pr[j] < 0 ? 0 : pr[j]);
+                vec_t v;
+                if constexpr (VW == 1) v = 0.f; else v = (vec_t)(0.f);
+                if (pr[j] >= 0 && r >= 0) v = *reinterpret_cast<const vec_t *>(a.feats + (long long)r * C + pc[j]);
+                pf[j] = v;
+            }
+        }
+        const int r0 = __shfl(ro, xr0), r1 = __shfl(ro, x1 ? xr1 : 0);
+        const long long g0 = ps * gpp;
+        px0 = 0.f; pn0 = 0.f; px1 = 0.f; pn1 = 0.f;
+        if (r0 >= 0) { px0 = a.xyz[(long long)r0 * 3 + xa0]; pn0 = a.new_xyz[(g0 + xr0 / gsz) * 3 + xa0]; }
+        if (x1 && r1 >= 0) { px1 = a.xyz[(long long)r1 * 3 + xa1]; pn1 = a.new_xyz[(g0 + xr1 / gsz) * 3 + xa1]; }
+    };
+
+    // the maxima of a pass leave for HBM at the top of the NEXT pass (from registers), after that pass's tile went to the LDS:
+    // every wait for prefetched vectors then only has loads and stores in front of it that had a whole MFMA phase to finish
+    float oreg[4] = {0.f, 0.f, 0.f, 0.f};
+    long long og0 = -1;
+    auto flush = [&]() {
+        if (og0 < 0) return;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (q < gpp && og0 + q < groups) {
+                float *o = a.out + (og0 + q) * a.out_stride + a.out_off;
+                if (lane < C3) o[lane] = oreg[2 * q];
+                if (lane + 64 < C3) o[lane + 64] = oreg[2 * q + 1];
+            }
+        }
+    };
+    long long ps = (long long)blockIdx.x * nw + w;
+    int rb_next, ri_next;
+    load_rows(ps, rb_next, ri_next);
+    issue(rb_next, ri_next, ps);
+    load_rows(ps + stride, rb_next, ri_next);
+    for (; ps < passes; ps += stride) {
+        // the tile of this pass: registers -> LDS (channels [0, C) features, [C, C + 3) relative xyz, zero up to Cin)
+#pragma unroll
+        for (int j = 0; j < SA_PF; j++)
+            if (j * 64 < nvec && pr[j] >= 0) *reinterpret_cast<vec_t *>(act + pr[j] * sa + pc[j]) = pf[j];
+        act[xr0 * sa + C + xa0] = px0 - pn0;
+        if (x1) act[xr1 * sa + C + xa1] = px1 - pn1;
+        for (int c = CC + (lane >> 5); c < Cin; c += 2) act[(lane & 31) * sa + c] = 0.f;
+        flush();
+        // next pass's vectors and the indices of the one after it go out before the MFMAs of this one
+        issue(rb_next, ri_next, ps + stride);
+        load_rows(ps + 2 * stride, rb_next, ri_next);
+        sa_layer_k<false, KA>(act, sa, W1, Bs, Cin, C1, lane, gsz);
+        sa_layer_k<false, KA>(act, sa, W2, Bs + C1, C1, C2, lane, gsz);
+        sa_layer_k<true, KA>(act, sa, W3, Bs + C1 + C2, C2, C3, lane, gsz);
+        og0 = ps * gpp;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int c = lane + 64 * h;
+            if (c < C3) {
+                const int ms = C3 + 16;
+                float m0 = act[c], m1 = act[16 * sa + c];
+#pragma unroll
+                for (int r = 1; r < 4; r++) { m0 = fmaxf(m0, act[r * ms + c]); m1 = fmaxf(m1, act[16 * sa + r * ms + c]); }
+                if (gpp == 1) oreg[h] = fmaxf(m0, m1);
+                else { oreg[h] = m0; oreg[2 + h] = m1; }
             }
         }
     }
+    flush();
 }
 
 // One branch of a set-abstraction level.  DEVICE pointers; w*t are the folded weights TRANSPOSED (C_in x C_out, row-major), the
@@ -731,6 +965,8 @@ extern "C" int nirrt_pn2_sa_mlp(const float *feats, const float *xyz, const floa
     if (Cin > SA_KMAX) return -3;
     int kmax = Cin > C1 ? Cin : C1;
     kmax = kmax > C2 ? kmax : C2;
+    const int kin = kmax;                     // widest layer INPUT: picks the instantiation
+    kmax = kmax > C3 / 4 ? kmax : C3 / 4;
     const size_t fixed = (size_t)C1 * (Cin + 4) + (size_t)C2 * (C1 + 4) + (size_t)C3 * (C2 + 4) + C1 + C2 + C3;
     int nw = SA_WAVES;
     size_t lds = 0;
@@ -741,7 +977,14 @@ extern "C" int nirrt_pn2_sa_mlp(const float *feats, const float *xyz, const floa
     if (nw < 2) return -3;
     // the attribute belongs to the CURRENT device's copy of the kernel (a process may drive several GPUs): set on every call,
     // it is a host-side table write
-    if (hipFuncSetAttribute((const void *)k_sa_mlp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+    const uintptr_t fa = (uintptr_t)feats;      // widest vector load the rows' width and the base address allow
+    const int vw = (C % 4 == 0 && fa % 16 == 0) ? 4 : (C % 2 == 0 && fa % 8 == 0) ? 2 : 1;
+    const int npf = (32 * (C / vw) + 63) / 64;
+    if (npf > 16 || (long long)B * N >= (1ll << 31)) return -3;
+    const bool small = npf <= 2 && kin <= 32;
+    void (*kern)(SaMlpArgs) = small ? (vw == 4 ? k_sa_mlp<4, 2, 2> : vw == 2 ? k_sa_mlp<2, 2, 2> : k_sa_mlp<1, 2, 2>)
+                                    : (vw == 4 ? k_sa_mlp<4, 16, 8> : vw == 2 ? k_sa_mlp<2, 16, 8> : k_sa_mlp<1, 16, 8>);
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
     SaMlpArgs a;
     a.feats = feats; a.xyz = xyz; a.new_xyz = new_xyz; a.gidx = (const long long *)gidx; a.out = out;
     a.w1t = w1t; a.b1 = b1; a.w2t = w2t; a.b2 = b2; a.w3t = w3t; a.b3 = b3;
@@ -749,8 +992,15 @@ extern "C" int nirrt_pn2_sa_mlp(const float *feats, const float *xyz, const floa
     a.out_stride = out_stride; a.out_off = out_off;
     const long long groups = (long long)B * S;
     const long long passes = (groups + (32 / K) - 1) / (32 / K);
+    // grid-stride over the passes with exactly one resident set of workgroups: the weights are staged once per workgroup
+    int dev = 0, ncu = 256, per_cu = 1;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, 64 * nw, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     long long grid = (passes + nw - 1) / nw;
-    if (grid > 2048) grid = 2048;      // grid-stride over the passes: the weights are staged once per workgroup
-    hipLaunchKernelGGL(k_sa_mlp, dim3((unsigned)grid), dim3(64 * nw), lds, (hipStream_t)stream, a);
+    if (grid > (long long)ncu * per_cu) grid = (long long)ncu * per_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nw), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

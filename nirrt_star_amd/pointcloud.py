@@ -72,13 +72,19 @@ def free_block_table(binary_mask):
     return np.ascontiguousarray((P[:-1, :-1] & P[:-1, 1:] & P[1:, :-1] & P[1:, 1:]).astype(np.uint8))
 
 
-def ellipse_transform_2d(start_point, goal_point, max_min_ratio):
-    """the constants of ellipsoid_candidates' transform: (C.L rows 0-1 / columns 0-1, x_center) exactly as the reference forms them
-    (point_cloud_mask_utils.py:118-135)"""
+def ellipse_frame_2d(start_point, goal_point):
+    """what ellipsoid_candidates derives from the problem alone: (c_min, C, x_center) (point_cloud_mask_utils.py:118-126)"""
     dx, dy = goal_point - start_point
     c_min = math.hypot(dx, dy)
     C = _rotation_to_world_2d(start_point, goal_point, c_min)
     x_center = np.concatenate([(start_point + goal_point) / 2., np.array([0.])], axis=0)
+    return c_min, C, x_center
+
+
+def ellipse_transform_2d(start_point, goal_point, max_min_ratio, frame=None):
+    """the constants of ellipsoid_candidates' transform: (C.L rows 0-1 / columns 0-1, x_center) exactly as the reference forms them
+    (point_cloud_mask_utils.py:118-135); `frame` = ellipse_frame_2d(...) of the problem, if the caller keeps it"""
+    c_min, C, x_center = frame if frame is not None else ellipse_frame_2d(start_point, goal_point)
     c_max = c_min * max_min_ratio
     eps = 1e-6 if c_max ** 2 - c_min ** 2 < 0 else 0
     r = [c_max / 2.0, math.sqrt(c_max ** 2 - c_min ** 2 + eps) / 2.0, math.sqrt(c_max ** 2 - c_min ** 2 + eps) / 2.0]

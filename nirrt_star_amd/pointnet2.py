@@ -39,6 +39,13 @@ FP_SPECS = [  # attribute, in_channel, mlp   (pointnet2.py:15-18)
 ]
 
 
+def _affine_relu(b, x, w):
+    """relu(x @ w.T + b) as one library GEMM; on the GPU the bias and the ReLU ride in the GEMM's epilogue (hipBLASLt)"""
+    if x.is_cuda:
+        return torch._addmm_activation(b, x, w.t())
+    return F.relu(torch.addmm(b, x, w.t()))
+
+
 def _fold(conv, bn):
     """(W, b) of conv followed by eval-mode BatchNorm as one affine map; W is (C_out, C_in)."""
     w = conv.weight.reshape(conv.weight.shape[0], -1)
@@ -69,6 +76,8 @@ class SetAbstractionMSG(nn.Module):
         # the fused MFMA kernel (csrc/pointops.hip k_sa_mlp) takes the levels whose widths fit its tiles and whose weights fit
         # the LDS (SA1, SA2); the others keep one library GEMM per layer
         self._fused = None
+        # first-layer weights with a zero column behind the xyz columns: the operand of the (C + 4)-wide rows of k_group_rows
+        self._wpad = [F.pad(layers[0][0], (0, 1)).contiguous() for layers in self._folded]
         dev = self._folded[0][0][0].device
         if dev.type == "cuda":
             c_in = self.conv_blocks[0][0].weight.shape[1]
@@ -93,14 +102,27 @@ class SetAbstractionMSG(nn.Module):
                     outs.append(None)
                     off += width
                     continue
+            folded = self._folded is not None and not self.training
+            rows = pointops.group_rows(feats, xyz, new_xyz, gidx) if (folded and xyz.is_cuda) else None
+            if rows is not None:
+                # grouped rows written by one kernel, (C + 4) wide with a zero column: the first layer's weight gets one too
+                x = rows
+                for li, (w, b) in enumerate(self._folded[bi]):
+                    x = _affine_relu(b, x, self._wpad[bi] if li == 0 else w)
+                x = x.view(B, S, K, -1).max(dim=2)[0]
+                if out_all is not None:
+                    out_all[:, :, off:off + x.shape[-1]] = x
+                    off += x.shape[-1]
+                outs.append(x)
+                continue
             flat = gidx.reshape(B, S * K)
             g_xyz = torch.gather(xyz, 1, flat[..., None].expand(B, S * K, 3)).view(B, S, K, 3) - new_xyz[:, :, None, :]
             g_feat = torch.gather(feats, 1, flat[..., None].expand(B, S * K, feats.shape[-1])).view(B, S, K, -1)
             x = torch.cat([g_feat, g_xyz], dim=-1)                             # (B, S, K, C_in) points first, then rel. xyz
-            if self._folded is not None and not self.training:
+            if folded:
                 x = x.reshape(B * S * K, -1)
                 for w, b in self._folded[bi]:
-                    x = F.relu(torch.addmm(b, x, w.t()))                       # one GEMM per layer
+                    x = _affine_relu(b, x, w)                                  # one GEMM per layer
                 x = x.view(B, S, K, -1).max(dim=2)[0]                          # (B, S, C_out)
             else:
                 x = x.permute(0, 3, 2, 1)                                      # (B, C, K, S) like the reference
@@ -141,6 +163,13 @@ class FeaturePropagation(nn.Module):
             interp = feats2.repeat(1, N, 1)
         else:
             d, idx = pointops.three_nn(xyz1, xyz2)                            # (B, N, 3) each
+            if self._folded is not None and not self.training and xyz1.is_cuda:
+                rows = pointops.fp_rows(feats1, feats2, d, idx)                # weights + interpolation + cat in one kernel
+                if rows is not None:
+                    x = rows
+                    for w, b in self._folded:
+                        x = _affine_relu(b, x, w)
+                    return x.view(B, N, -1)
             recip = 1.0 / (d + 1e-8)
             wgt = recip / recip.sum(dim=2, keepdim=True)
             nb = torch.gather(feats2, 1, idx.reshape(B, N * 3)[..., None].expand(B, N * 3, feats2.shape[-1])).view(B, N, 3, -1)
@@ -149,7 +178,7 @@ class FeaturePropagation(nn.Module):
         if self._folded is not None and not self.training:
             x = x.reshape(B * N, -1)
             for w, b in self._folded:
-                x = F.relu(torch.addmm(b, x, w.t()))
+                x = _affine_relu(b, x, w)
             return x.view(B, N, -1)
         x = x.permute(0, 2, 1)
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
@@ -196,7 +225,7 @@ class get_model(nn.Module):
         if self._head is not None and not self.training:
             B, N, _ = f0.shape
             w, b = self._head
-            x = F.relu(torch.addmm(b, f0.reshape(B * N, -1), w.t()))
+            x = _affine_relu(b, f0.reshape(B * N, -1), w)
             x = torch.addmm(self.conv2.bias, x, self.conv2.weight.reshape(self.conv2.weight.shape[0], -1).t()).view(B, N, -1)
         else:
             x = self.drop1(F.relu(self.bn1(self.conv1(f0.permute(0, 2, 1)))))

@@ -40,8 +40,10 @@ def _lib():
         L.nirrt_guidance_clouds.restype = C.c_int
         L.nirrt_pn2_sa_mlp.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp,
                                        C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]
+        L.nirrt_pn2_group_rows.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+        L.nirrt_pn2_fp_rows.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         for f in (L.nirrt_pn2_fps, L.nirrt_pn2_ball_query, L.nirrt_pn2_three_nn, L.nirrt_fps_f64, L.nirrt_fps_f64_batch,
-                  L.nirrt_pn2_sa_mlp):
+                  L.nirrt_pn2_sa_mlp, L.nirrt_pn2_group_rows, L.nirrt_pn2_fp_rows):
             f.restype = C.c_int
         L._pn2_ready = True
     return L
@@ -91,6 +93,37 @@ def three_nn(xyz1, xyz2):
     _check(_lib().nirrt_pn2_three_nn(xyz1.contiguous().data_ptr(), xyz2.contiguous().data_ptr(), B, N, S, d.data_ptr(),
                                      i.data_ptr(), _stream(xyz1)), "three_nn")
     return d, i
+
+
+def group_rows(feats, xyz, new_xyz, gidx):
+    """sample_and_group's concatenation in one pass (k_group_rows): (B * S * K, C + 4) rows [feats[b, gidx], xyz[b, gidx] -
+    new_xyz[b, s], 0]; None when C is not a multiple of 4 (caller keeps the torch gathers)"""
+    B, N, C = feats.shape
+    S, K = gidx.shape[1], gidx.shape[2]
+    if C % 4:
+        return None
+    _need_cuda("group_rows", feats)
+    out = torch.empty(B * S * K, C + 4, dtype=torch.float32, device=feats.device)
+    _check(_lib().nirrt_pn2_group_rows(feats.contiguous().data_ptr(), xyz.contiguous().data_ptr(), new_xyz.contiguous().data_ptr(),
+                                       gidx.contiguous().data_ptr(), B, N, S, K, C, out.data_ptr(), _stream(feats)), "group_rows")
+    return out
+
+
+def fp_rows(feats1, feats2, dist, idx):
+    """input rows of a feature-propagation level in one pass (k_fp_rows): (B * N, C1 + C2) = [feats1, inverse-distance
+    interpolation of feats2 over the three neighbours (dist, idx)]; None when a width is not a multiple of 4"""
+    B, N, _ = dist.shape
+    S, C2 = feats2.shape[1], feats2.shape[2]
+    C1 = 0 if feats1 is None else feats1.shape[2]
+    if C1 % 4 or C2 % 4:
+        return None
+    _need_cuda("fp_rows", feats2)
+    out = torch.empty(B * N, C1 + C2, dtype=torch.float32, device=feats2.device)
+    f1 = feats1.contiguous() if feats1 is not None else None
+    _check(_lib().nirrt_pn2_fp_rows(f1.data_ptr() if f1 is not None else None, feats2.contiguous().data_ptr(),
+                                    dist.contiguous().data_ptr(), idx.contiguous().data_ptr(), B, N, S, C1, C2, out.data_ptr(),
+                                    _stream(feats2)), "fp_rows")
+    return out
 
 
 def sa_mlp_pack(layers, c_in, device):

@@ -17,8 +17,8 @@ def test_lookahead_windows_equal_fresh_peeks_after_foreign_draws():
             s.rs.random_sample(333 + step)          # foreign draws: doubles, masked-rejection integers, a 2-D uniform block
             s.rs.randint(0, 17, size=5)
             s.rs.uniform(0, 3, size=(10, 2))
-    assert a._np["off"] > 0 and a._py["off"] > 0   # served from the look-ahead, not regenerated
-    big = len(a._np["host"]) + 10
+    assert a._npc["off"] > 0 and a._pyc["off"] > 0   # served from the look-ahead, not regenerated
+    big = len(a._npc["host"]) + 10
     assert np.array_equal(a.window_np(big), b.peek_np(big))      # beyond the look-ahead: regenerated from the true position
     assert a.rs.random_sample() == b.rs.random_sample()          # windows never consume
 

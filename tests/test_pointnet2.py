@@ -163,3 +163,46 @@ def test_gpu_fused_mfma_set_abstraction_equals_library_gemms(level):
         assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4), (level, bi, float((got - ref).abs().max()))
         off += c3
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_gpu_group_rows_equal_torch_gathers():
+    """k_group_rows writes exactly what gather + subtract + cat produce (plus the zero column)"""
+    from nirrt_star_amd import pointops
+    torch.manual_seed(3)
+    B, N, S, K, C = 3, 256, 64, 16, 256
+    feats = torch.randn(B, N, C, device="cuda")
+    xyz = torch.rand(B, N, 3, device="cuda")
+    new_xyz = xyz[:, :S].contiguous()
+    gidx = torch.randint(0, N, (B, S, K), device="cuda")
+    got = pointops.group_rows(feats, xyz, new_xyz, gidx)
+    flat = gidx.reshape(B, S * K)
+    g_xyz = torch.gather(xyz, 1, flat[..., None].expand(B, S * K, 3)).view(B, S, K, 3) - new_xyz[:, :, None, :]
+    g_feat = torch.gather(feats, 1, flat[..., None].expand(B, S * K, C)).view(B, S, K, C)
+    ref = torch.cat([g_feat, g_xyz, torch.zeros(B, S, K, 1, device="cuda")], dim=-1).reshape(B * S * K, C + 4)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    assert pointops.group_rows(feats[:, :, :6].contiguous(), xyz, new_xyz, gidx) is None      # 6 channels: not float4 rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c1,c2,s", [(96, 256, 64), (0, 128, 256), (512, 1024, 16)])
+def test_gpu_fp_rows_equal_torch_interpolation(c1, c2, s):
+    """k_fp_rows against the reference formulation (pointnet2_utils.py:295-309) evaluated with torch ops"""
+    from nirrt_star_amd import pointops
+    torch.manual_seed(c2)
+    B, N = 2, 4 * s
+    xyz1 = torch.rand(B, N, 3, device="cuda")
+    xyz2 = xyz1[:, ::4].contiguous()          # every fourth point is its own neighbour at distance 0: the 1e-8 guard matters
+    feats1 = torch.randn(B, N, c1, device="cuda") if c1 else None
+    feats2 = torch.randn(B, s, c2, device="cuda")
+    d, idx = pointops.three_nn(xyz1, xyz2)
+    got = pointops.fp_rows(feats1, feats2, d, idx)
+    recip = 1.0 / (d + 1e-8)
+    wgt = recip / recip.sum(dim=2, keepdim=True)
+    nb = torch.gather(feats2, 1, idx.reshape(B, N * 3)[..., None].expand(B, N * 3, c2)).view(B, N, 3, c2)
+    interp = (nb * wgt[..., None]).sum(dim=2)
+    ref = (interp if feats1 is None else torch.cat([feats1, interp], dim=-1)).reshape(B * N, c1 + c2)
+    assert got.shape == ref.shape
+    if c1:
+        assert torch.equal(got[:, :c1], ref[:, :c1])
+    assert torch.allclose(got[:, c1:], ref[:, c1:], rtol=1e-6, atol=1e-6), float((got - ref).abs().max())
