@@ -37,6 +37,14 @@ int nirrt_pn2_sa_mlp(const float *feats, const float *xyz, const float *new_xyz,
                      int cin_pad, const float *w1t, const float *b1, int C1, const float *w2t, const float *b2, int C2,
                      const float *w3t, const float *b3, int C3, float *out, int out_stride, int out_off, void *stream);
 
+/* The network's (6, n) float32 input block of guidance clouds that are already resident (classify_path_points,
+ * pointnet_pointnet2/pointnet2_wrapper.py:43-58: pc_normalize of the float32 cloud, start / goal masks of
+ * get_point_cloud_mask_around_points with the float64 cloud, "neither" channel), bit-equal to the numpy evaluation.  DEVICE
+ * pointers: clouds f64 (n_clouds, stride_pts, 3) (z = 0 for planar clouds), rows i32 (n_rows,) = the clouds to process (all of
+ * n points), starts / goals f64 (n_rows, 3), out f32 (n_rows, 6, n).  n <= 12288. */
+int nirrt_pn2_net_input(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n, const double *starts,
+                        const double *goals, double radius, float *out, void *stream);
+
 /* Input rows of the set-abstraction levels whose MLP runs as library GEMMs: sample_and_group's concatenation
  * (pointnet2_utils.py:247-250) in one pass.  DEVICE pointers as for nirrt_pn2_sa_mlp; C a multiple of 4;
  * out f32 (B * S * K, C + 4) = [feats[b, gidx], xyz[b, gidx] - new_xyz[b, s], 0] (the zero column keeps rows 16-byte aligned). */

@@ -224,6 +224,7 @@ class Guidance:
         self.max_trials = connect_max_trial_attempts
         self.device_id = device_id
         self.device_clouds = os.environ.get("NIRRT_HOST_CLOUDS", "0") != "1"   # clouds generated on the device (0: the host path of round 2)
+        self.device_input = os.environ.get("NIRRT_HOST_INPUT", "0") != "1"     # network input blocks assembled on the device
         self.calls = 0                      # PointNet++ forwards (batched ones count once)
         self.clouds_classified = 0
         self.seconds = {"candidates": 0.0, "downsample": 0.0, "classify": 0.0, "set_cloud": 0.0}   # host wall time per refresh stage
@@ -341,7 +342,7 @@ class Guidance:
                 clouds_dev[torch.as_tensor(on_dev, device=dev)] = sub
             host = sub.cpu().numpy()
             for k, j in enumerate(on_dev):
-                clouds[j] = host[k, : n_out[j], : self.dim].copy()
+                clouds[j] = host[k, : n_out[j], : self.dim]
         t1 = time.perf_counter()
         if on_host:
             pts = self._host_clouds([due[j] for j in on_host], problems, streams, c_best, frames)
@@ -354,16 +355,33 @@ class Guidance:
         xg_l = [np.asarray(problems[i]["x_goal"], dtype=np.float64) for i in due]
 
         def fps_starts_for(group):   # group: positions inside `due`
-            sizes = (len(clouds[group[0]]), 1024, 256, 64)
+            sizes = (int(n_out[group[0]]), 1024, 256, 64)
             return [torch.cat([streams[due[j]].fps_start(n) for j in group]) for n in sizes]
 
         preds = [None] * nd
+        pred_dev = None
         if self.connect:
             res = self.wrapper.generate_connected_path_points_batch([c.astype(np.float32) for c in clouds], xs_l, xg_l, self.radius,
                                                                     self.max_trials, fps_starts_for)
             for j, (_, runs, mask) in enumerate(res):
                 preds[j] = mask
             self.calls += max(r[1] for r in res) if res else 0
+        elif self.device_input and hasattr(self.wrapper, "classify_device") and not (nd == 1 and getattr(self.wrapper, "use_graph", False)):
+            # input blocks assembled from the resident clouds (k_net_input, bit-equal to the numpy evaluation below), predictions
+            # stay on the device for set_cloud_batch; the host gets one copy of the prediction bytes for the caller's records
+            s3, g3 = np.zeros((nd, 3)), np.zeros((nd, 3))
+            for j in range(nd):
+                s3[j, : self.dim], g3[j, : self.dim] = xs_l[j][: self.dim], xg_l[j][: self.dim]
+            pred_dev = torch.zeros((nd, self.n_points), dtype=torch.uint8, device=dev)
+            for size in sorted(set(int(v) for v in n_out)):
+                grp = [j for j in range(nd) if n_out[j] == size]
+                x = pointops.net_input(clouds_dev, grp, size, s3[grp], g3[grp], self.radius)
+                pred = self.wrapper.classify_device(x, fps_starts=fps_starts_for(grp))
+                pred_dev[torch.as_tensor(grp, device=dev), :size] = (pred != 0).to(torch.uint8)
+                self.calls += 1
+            pred_host = pred_dev.cpu().numpy().astype(np.int64)
+            for j in range(nd):
+                preds[j] = pred_host[j, : n_out[j]]
         else:
             sm = [pcu.get_point_cloud_mask_around_points(c, xs[np.newaxis, :], self.radius).astype(np.float32) for c, xs in zip(clouds, xs_l)]
             gm = [pcu.get_point_cloud_mask_around_points(c, xg[np.newaxis, :], self.radius).astype(np.float32) for c, xg in zip(clouds, xg_l)]
@@ -377,10 +395,11 @@ class Guidance:
         self.clouds_classified += nd
         t3 = time.perf_counter()
         # path points into the trees: one launch for the whole batch (prediction bytes cross once)
-        pb = np.zeros((nd, self.n_points), dtype=np.uint8)
-        for j in range(nd):
-            pb[j, : n_out[j]] = np.asarray(preds[j]) != 0
-        pred_dev = torch.from_numpy(pb).to(dev)
+        if pred_dev is None:
+            pb = np.zeros((nd, self.n_points), dtype=np.uint8)
+            for j in range(nd):
+                pb[j, : n_out[j]] = np.asarray(preds[j]) != 0
+            pred_dev = torch.from_numpy(pb).to(dev)
         _hip.set_cloud_batch([trees[i] for i in due], clouds_dev.data_ptr(), self.n_points * 3, n_out, pred_dev.data_ptr(), self.n_points,
                              self.rate, self.ratio, [c_best[i] for i in due])
         out = {i: (clouds[j], np.asarray(preds[j])) for j, i in enumerate(due)}
@@ -487,18 +506,26 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
         prof["refresh"] += time.perf_counter() - t_r
         return [i for i in act if not finished[i] and remaining[i] > 0]
 
-    # Guided runs alternate between device (the loop) and host (cloud candidates, PointNet++ refresh): a large batch is split
-    # into two halves whose launches are issued from a worker thread (the C call releases the GIL), so that one half's refresh
-    # overlaps the other half's launch.  Trees are independent and draw from their own generators: the split changes no result.
-    # A launch lasts as long as its slowest tree, so two half launches take longer than one whole: measured on 2D problems the
-    # split pays from ~2048 trees (4096: 3.0 vs 2.8 M it/s; 1024: 1.7 vs 2.2).
+    # Guided runs alternate between the loop and the cloud refresh.  Round 2 split a large batch into two halves so that one
+    # half's (host-side) refresh overlapped the other half's launch.  With candidates, down-sampling, network input and
+    # predictions all on the device there is little host work left to hide, and the halves cost more than they gave: a half
+    # batch runs at two waves per SIMD instead of four, and PointNet++'s set-abstraction kernel (151 KB of LDS per workgroup)
+    # cannot share a CU with resident trees, so its forward waited for the other half's launch anyway.  4096 trees, 2D, 50000
+    # iterations: two halves 10.4 M it/s; one group 11.1 M (window 4096), 16.6 M (2048), 19.6 M (1024), 18.2 M (768), 16.1 M (512).
+    # NIRRT_BATCH_GROUPS / NIRRT_BATCH_INFLIGHT bring the split back (groups launched from worker threads; the C call releases
+    # the GIL); trees are independent and draw from their own generators, so no grouping changes a result.
     if overlap_min is None:
-        overlap_min = int(os.environ.get("NIRRT_BATCH_OVERLAP_MIN", "1024"))   # trees per half; tests set 1
-    window = int(os.environ.get("NIRRT_BATCH_WINDOW", window))   # iterations per persistent launch (a stopped tree waits for its launch to end)
-    n_groups = 2 if (png and B >= 2 * overlap_min) else 1
+        overlap_min = int(os.environ.get("NIRRT_BATCH_OVERLAP_MIN", "1024"))   # trees per group when splitting; tests set 1
+    # iterations per persistent launch: a tree whose cloud is due idles in its slot until the launch ends, so guided runs take
+    # short launches
+    if png and window > 1024:
+        window = 1024
+    window = int(os.environ.get("NIRRT_BATCH_WINDOW", window))
+    n_groups = max(1, int(os.environ.get("NIRRT_BATCH_GROUPS", "1"))) if (png and B >= 2 * overlap_min) else 1
+    in_flight = max(1, min(max(1, n_groups - 1), int(os.environ.get("NIRRT_BATCH_INFLIGHT", "1"))))   # launches on the device at once
     groups = [list(range(g, B, n_groups)) for g in range(n_groups)]
     futures = [None] * n_groups
-    with ThreadPoolExecutor(max_workers=1) as pool:
+    with ThreadPoolExecutor(max_workers=in_flight) as pool:
         for g in range(n_groups):
             if png and init_clouds:   # init_pc: the whole-world cloud before the first iteration (nirrt_star_png_2d.py:58)
                 t_r = time.perf_counter()

@@ -358,11 +358,44 @@ struct ArenaPool {
     }
 };
 ArenaPool g_pool;
+
+// Launch scratch (argument tables, counters, traces of nirrt_run): blocks are kept and handed out again, rounded up to powers of
+// two.  hipFree waits for the whole device - with two batches launched from two host threads the thread that finished first sat
+// in its cleanup until the other thread's persistent kernel had ended.
+struct ScratchPool {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void *> idle;   // (device, bytes) -> block
+    static size_t round_up(size_t b) { size_t r = 256; while (r < b) r <<= 1; return r; }
+    hipError_t take(int device, size_t bytes, void **out, size_t *got)
+    {
+        const size_t r = round_up(bytes);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = idle.find({device, r});
+            if (it != idle.end()) { *out = it->second; *got = r; idle.erase(it); return hipSuccess; }
+        }
+        *got = r;
+        return hipMalloc(out, r);
+    }
+    void give(int device, size_t bytes, void *p)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        idle.insert({{device, bytes}, p});
+    }
+    void trim()
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto &kv : idle) { (void)hipSetDevice(kv.first.first); (void)hipFree(kv.second); }
+        idle.clear();
+    }
+};
+ScratchPool g_scratch;
 }
 
 extern "C" int nirrt_pool_trim(void)
 {
     g_pool.trim();
+    g_scratch.trim();
     return NIRRT_OK;
 }
 
@@ -990,8 +1023,9 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
     }
     const bool need_py = (a->flags & NIRRT_F_IRRT) && D == 2;
     if (need_py && (!a->py_words || !a->n_py)) { g_err = "nirrt_run: 2D IRRT* sampling needs py_words"; return NIRRT_E_ARG; }
-    std::vector<void *> to_free;
-    auto cleanup = [&]() { for (void *p : to_free) (void)hipFree(p); };
+    std::vector<std::pair<void *, size_t>> to_free;
+    const int dev_id = t0->device;
+    auto cleanup = [&]() { for (auto &p : to_free) g_scratch.give(dev_id, p.second, p.first); to_free.clear(); };
 #define HIPCHK_R(expr)                                                                        \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
@@ -1002,8 +1036,9 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         }                                                                                     \
     } while (0)
     auto dalloc = [&](size_t bytes, void **out) -> hipError_t {
-        hipError_t e = hipMalloc(out, bytes ? bytes : 8);
-        if (e == hipSuccess) to_free.push_back(*out);
+        size_t got = 0;
+        hipError_t e = g_scratch.take(dev_id, bytes ? bytes : 8, out, &got);
+        if (e == hipSuccess) to_free.push_back({*out, got});
         return e;
     };
     // Launch groups.  By default the whole batch runs on one kernel instantiation (run_variant).  With lanes_hint the
@@ -1127,10 +1162,11 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
     HIPCHK_R(hipStreamSynchronize(st));
     std::vector<long long> done(nt), npu(nt), pyu(nt);
     std::vector<int> stop(nt);
-    HIPCHK_R(hipMemcpy(done.data(), d_done, sizeof(long long) * nt, hipMemcpyDeviceToHost));
-    HIPCHK_R(hipMemcpy(npu.data(), d_npu, sizeof(long long) * nt, hipMemcpyDeviceToHost));
-    HIPCHK_R(hipMemcpy(pyu.data(), d_pyu, sizeof(long long) * nt, hipMemcpyDeviceToHost));
-    HIPCHK_R(hipMemcpy(stop.data(), d_stop, sizeof(int) * nt, hipMemcpyDeviceToHost));
+    HIPCHK_R(hipMemcpyAsync(done.data(), d_done, sizeof(long long) * nt, hipMemcpyDeviceToHost, st));
+    HIPCHK_R(hipMemcpyAsync(npu.data(), d_npu, sizeof(long long) * nt, hipMemcpyDeviceToHost, st));
+    HIPCHK_R(hipMemcpyAsync(pyu.data(), d_pyu, sizeof(long long) * nt, hipMemcpyDeviceToHost, st));
+    HIPCHK_R(hipMemcpyAsync(stop.data(), d_stop, sizeof(int) * nt, hipMemcpyDeviceToHost, st));
+    HIPCHK_R(hipStreamSynchronize(st));
     if (a->cost_trace) {
         if (identity) HIPCHK_R(hipMemcpy(a->cost_trace, d_trace, sizeof(double) * nt * (size_t)a->iters, hipMemcpyDeviceToHost));
         else

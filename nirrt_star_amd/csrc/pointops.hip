@@ -597,6 +597,75 @@ extern "C" int nirrt_guidance_clouds(const nirrt_cloud_job *jobs, int n_jobs, in
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
+// The network's input block of a guidance cloud (pointnet2_wrapper.py:43-58), assembled where the cloud already is: xyz in
+// float32 shifted to the centroid and scaled by the largest norm (pc_normalize, pointnet2_utils.py:13-18), the start / goal
+// indicator channels (get_point_cloud_mask_around_points, point_cloud_mask_utils.py:20-31: float64 distance strictly inside
+// the radius) and the "neither" channel.  The arithmetic follows numpy's: np.mean over axis 0 of an (N, 3) float32 array adds
+// the rows in order (one thread per coordinate walks the cloud), the norm is (x^2 + y^2) + z^2, no contraction.
+// One workgroup per cloud; rows[] picks the clouds of one size n out of the batch's (n_clouds, stride_pts, 3) f64 block.
+// ------------------------------------------------------------------------------------------------
+#define NI_NT 256
+__global__ __launch_bounds__(NI_NT) void k_net_input(const double *__restrict__ clouds, long long stride_pts, const int *__restrict__ rows,
+                                                     int n, const double *__restrict__ starts, const double *__restrict__ goals,
+                                                     double radius, float *__restrict__ out)
+{
+    extern __shared__ float ni_lds[];          // 3 * n coordinates + reduction slots
+    float *px = ni_lds, *py = px + n, *pz = py + n;
+    __shared__ float mean[3];
+    __shared__ float red[NI_NT / 64];
+    const int b = blockIdx.x, row = rows[b], tid = threadIdx.x;
+    const double *c = clouds + (long long)row * stride_pts * 3;
+    const double sx = starts[3 * b], sy = starts[3 * b + 1], sz = starts[3 * b + 2];
+    const double gx = goals[3 * b], gy = goals[3 * b + 1], gz = goals[3 * b + 2];
+    float *o = out + (long long)b * 6 * n;
+    for (int i = tid; i < n; i += NI_NT) {
+        const double x = c[3 * i], y = c[3 * i + 1], z = c[3 * i + 2];
+        px[i] = (float)x; py[i] = (float)y; pz[i] = (float)z;
+        double dx = x - sx, dy = y - sy, dz = z - sz;
+        const float sm = sqrt((dx * dx + dy * dy) + dz * dz) < radius ? 1.f : 0.f;
+        dx = x - gx; dy = y - gy; dz = z - gz;
+        const float gm = sqrt((dx * dx + dy * dy) + dz * dz) < radius ? 1.f : 0.f;
+        o[3 * n + i] = sm;
+        o[4 * n + i] = gm;
+        o[5 * n + i] = (sm + gm) == 0.f ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (tid < 3) {
+        const float *p = tid == 0 ? px : tid == 1 ? py : pz;
+        float acc = 0.f;
+        for (int i = 0; i < n; i++) acc = acc + p[i];
+        mean[tid] = acc / (float)n;
+    }
+    __syncthreads();
+    const float mx = mean[0], my = mean[1], mz = mean[2];
+    float big = 0.f;
+    for (int i = tid; i < n; i += NI_NT) {
+        const float x = px[i] - mx, y = py[i] - my, z = pz[i] - mz;
+        px[i] = x; py[i] = y; pz[i] = z;
+        big = fmaxf(big, sqrtf((x * x + y * y) + z * z));
+    }
+    for (int off = 32; off; off >>= 1) big = fmaxf(big, __shfl_xor(big, off));
+    if ((tid & 63) == 0) red[tid >> 6] = big;
+    __syncthreads();
+    big = red[0];
+    for (int w = 1; w < NI_NT / 64; w++) big = fmaxf(big, red[w]);
+    for (int i = tid; i < n; i += NI_NT) {
+        o[i] = px[i] / big;
+        o[n + i] = py[i] / big;
+        o[2 * n + i] = pz[i] / big;
+    }
+}
+
+extern "C" int nirrt_pn2_net_input(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n, const double *starts,
+                                   const double *goals, double radius, float *out, void *stream)
+{
+    if (n_rows <= 0 || n <= 0 || n > 12288 || stride_pts < n) return -1;
+    hipLaunchKernelGGL(k_net_input, dim3((unsigned)n_rows), dim3(NI_NT), sizeof(float) * 3 * (size_t)n, (hipStream_t)stream, clouds,
+                       (long long)stride_pts, rows, n, starts, goals, radius, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Input rows of the levels whose MLP runs as library GEMMs (SA3, SA4, every feature-propagation level): ONE pass that writes
 // the GEMM's A matrix, instead of torch gathers + multiply + sum + cat (five kernels and four intermediate tensors per level).
 // float4 throughout: channel counts are multiples of 4 (the host checks and otherwise keeps the torch path).

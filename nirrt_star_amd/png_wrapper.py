@@ -115,6 +115,12 @@ class PNGWrapper:
             score = torch.softmax(logp, dim=2)[:, :, 1]
             return pred.cpu().numpy(), score.cpu().numpy()
 
+    def classify_device(self, x, fps_starts=None):
+        """input blocks already on the device (pointops.net_input): x f32 (B, 6, N) -> path_pred int64 (B, N), left on the device"""
+        with torch.no_grad():
+            logp, _ = self.model(x, fps_starts=fps_starts)
+            return logp.argmax(dim=2)
+
     def _graph_forward(self, x, fps_starts):
         """B = 1: the forward of a cloud of this size captured once into a HIP graph (static input / start-index buffers) and
         replayed.  The FPS start indices are drawn here, on the CPU generator and in the order the model itself would draw them

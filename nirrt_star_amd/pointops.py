@@ -42,8 +42,9 @@ def _lib():
                                        C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]
         L.nirrt_pn2_group_rows.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.nirrt_pn2_fp_rows.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+        L.nirrt_pn2_net_input.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp, C.c_double, vp, vp]
         for f in (L.nirrt_pn2_fps, L.nirrt_pn2_ball_query, L.nirrt_pn2_three_nn, L.nirrt_fps_f64, L.nirrt_fps_f64_batch,
-                  L.nirrt_pn2_sa_mlp, L.nirrt_pn2_group_rows, L.nirrt_pn2_fp_rows):
+                  L.nirrt_pn2_sa_mlp, L.nirrt_pn2_group_rows, L.nirrt_pn2_fp_rows, L.nirrt_pn2_net_input):
             f.restype = C.c_int
         L._pn2_ready = True
     return L
@@ -93,6 +94,21 @@ def three_nn(xyz1, xyz2):
     _check(_lib().nirrt_pn2_three_nn(xyz1.contiguous().data_ptr(), xyz2.contiguous().data_ptr(), B, N, S, d.data_ptr(),
                                      i.data_ptr(), _stream(xyz1)), "three_nn")
     return d, i
+
+
+def net_input(clouds, rows, n, starts, goals, radius):
+    """the network's input blocks of resident clouds (k_net_input): clouds f64 (n_clouds, stride, 3) on the device, rows = the
+    clouds to take (all of n points), starts / goals (len(rows), 3) f64 -> x f32 (len(rows), 6, n), bit-equal to
+    PNGWrapper.network_input + get_point_cloud_mask_around_points on the host"""
+    _need_cuda("net_input", clouds)
+    dev = clouds.device
+    rows_t = torch.as_tensor(rows, dtype=torch.int32).to(dev)
+    st = torch.as_tensor(starts, dtype=torch.float64).reshape(-1, 3).to(dev)
+    gl = torch.as_tensor(goals, dtype=torch.float64).reshape(-1, 3).to(dev)
+    out = torch.empty(len(rows_t), 6, int(n), dtype=torch.float32, device=dev)
+    _check(_lib().nirrt_pn2_net_input(clouds.data_ptr(), clouds.shape[1], rows_t.data_ptr(), len(rows_t), int(n), st.data_ptr(),
+                                      gl.data_ptr(), float(radius), out.data_ptr(), _stream(clouds)), "net_input")
+    return out
 
 
 def group_rows(feats, xyz, new_xyz, gidx):

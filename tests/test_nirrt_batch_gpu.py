@@ -153,6 +153,13 @@ def test_batched_real_wrapper_classifies_all_due_clouds_in_one_forward():
         return inner(clouds, sm, gm, fps_starts)
 
     w.classify_batch = counting
+    inner_dev = w.classify_device
+
+    def counting_dev(x, fps_starts=None):       # the batched refresh hands over input blocks assembled on the device
+        sizes.append(x.shape[0])
+        return inner_dev(x, fps_starts)
+
+    w.classify_device = counting_dev
     recs, traces = es.plan_batch(probs, list(range(6)), _args("nirrt_star", 2, 4000, 300), 0, wrapper=w)
     assert sizes[0] == 6 and max(sizes) <= 6
     for rec, tr in zip(recs, traces):
@@ -167,3 +174,48 @@ def test_batched_real_wrapper_classifies_all_due_clouds_in_one_forward():
     p6, s6 = inner([pc] * 6, [sm] * 6, [gm] * 6, fps_starts=st)
     p1, s1 = inner([pc], [sm], [gm], fps_starts=[t[:1] for t in st])
     assert np.max(np.abs(s6 - s1[0])) <= 1e-3 and np.mean(p6 == p1[0]) >= 0.99
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [2, 3])
+def test_device_assembled_network_input_changes_no_result(dim, monkeypatch):
+    """the batched refresh with input blocks assembled on the device (k_net_input, predictions handed to the trees without a
+    host round trip) against the same run with the numpy assembly (NIRRT_HOST_INPUT=1): identical cost traces and clouds"""
+    from nirrt_star_amd import eval_sharded as es, png_wrapper, worlds
+    mk = (lambda i: worlds.problem_2d(worlds.random_world_2d(60 + i, "b30"), 0)) if dim == 2 else (lambda i: worlds.problem_3d(worlds.random_world_3d(60 + i)))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NIRRT_HOST_INPUT", mode)
+        if dim == 3:
+            np.random.seed(5)
+        probs = [mk(i) for i in range(5)]
+        w = (png_wrapper.PNGWrapper if dim == 2 else png_wrapper.PNGWrapper3D)(root_dir=synthetic_checkpoint_root(dim), device="cuda")
+        calls = []
+        inner = w.classify_device
+        w.classify_device = lambda x, fps_starts=None: (calls.append(x.shape[0]), inner(x, fps_starts))[1]
+        out[mode] = (es.plan_batch(probs, list(range(5)), _args("nirrt_star", dim, 3000, 400), 0, wrapper=w), len(calls))
+    (r0, t0), n0 = out["0"]
+    (r1, t1), n1 = out["1"]
+    assert n0 > 0 and n1 == 0
+    for a, b in zip(t0, t1):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    assert [r[1] for r in r0] == [r[1] for r in r1]
+
+
+@pytest.mark.gpu
+def test_launch_groups_change_no_result(monkeypatch):
+    """a guided batch split into groups that are launched from worker threads (NIRRT_BATCH_GROUPS / _INFLIGHT, two launches on the
+    device at once) against the default single group: trees are independent, so identical traces"""
+    from nirrt_star_amd import eval_sharded as es, png_wrapper, worlds
+    out = {}
+    for mode, env in (("one", {}), ("split", {"NIRRT_BATCH_GROUPS": "3", "NIRRT_BATCH_INFLIGHT": "2", "NIRRT_BATCH_OVERLAP_MIN": "1",
+                                               "NIRRT_BATCH_WINDOW": "700"})):
+        for k in ("NIRRT_BATCH_GROUPS", "NIRRT_BATCH_INFLIGHT", "NIRRT_BATCH_OVERLAP_MIN", "NIRRT_BATCH_WINDOW"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        probs = [worlds.problem_2d(worlds.random_world_2d(80 + i, "b30"), 0) for i in range(7)]
+        # (labels that do not depend on the batch: a real forward's GEMMs sum in a different order for a different batch size)
+        out[mode] = es.plan_batch(probs, list(range(7)), _args("nirrt_star", 2, 3000, 400), 0, wrapper=DiagonalFake(2))
+    for a, b in zip(out["one"][1], out["split"][1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)

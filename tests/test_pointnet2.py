@@ -206,3 +206,34 @@ def test_gpu_fp_rows_equal_torch_interpolation(c1, c2, s):
     if c1:
         assert torch.equal(got[:, :c1], ref[:, :c1])
     assert torch.allclose(got[:, c1:], ref[:, c1:], rtol=1e-6, atol=1e-6), float((got - ref).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [2, 3])
+def test_gpu_net_input_bit_equal_to_host_assembly(dim):
+    """k_net_input against PNGWrapper.network_input + get_point_cloud_mask_around_points (numpy, the reference's arithmetic)"""
+    from nirrt_star_amd import pointops, png_wrapper, pointcloud as pcu
+    rng = np.random.RandomState(11 + dim)
+    sizes = [2048, 2048, 1777, 1777, 2048, 100]
+    stride = 2048
+    block = np.zeros((len(sizes), stride, 3))
+    starts, goals = [], []
+    for j, n in enumerate(sizes):
+        block[j, :n, :dim] = rng.uniform(0, 224, (n, dim))
+        starts.append(block[j, rng.randint(n), :].copy() + 0.25)
+        goals.append(block[j, rng.randint(n), :].copy() - 0.5)
+    if dim == 2:
+        for v in starts + goals:
+            v[2] = 0.0
+    dev_block = torch.from_numpy(block).cuda()
+    radius = 10.0
+    for n in sorted(set(sizes)):
+        rows = [j for j, m in enumerate(sizes) if m == n]
+        got = pointops.net_input(dev_block, rows, n, np.stack([starts[j] for j in rows]), np.stack([goals[j] for j in rows]), radius).cpu().numpy()
+        for k, j in enumerate(rows):
+            c = block[j, :n, :dim]
+            sm = pcu.get_point_cloud_mask_around_points(c, starts[j][np.newaxis, :dim], radius).astype(np.float32)
+            gm = pcu.get_point_cloud_mask_around_points(c, goals[j][np.newaxis, :dim], radius).astype(np.float32)
+            ref = png_wrapper.PNGWrapper.network_input(c.astype(np.float32), sm, gm)
+            assert sm.sum() > 0 and gm.sum() > 0
+            assert np.array_equal(got[k], ref), (n, j, np.abs(got[k] - ref).max())
