@@ -335,6 +335,7 @@ struct LdsData {
     unsigned char rg_flag[GRID_RG_MAX + 4];
     struct {                      // arguments / results of wg_query_fn
         double pn[3], q[3], r, floor_m, cand;
+        int lazy;                 // collision filter of the Near members deferred to the members that can matter (wg_query_fn)
         int n, want, new_idx, lds_cap, ni, cj;
     } qa;
     struct {                      // state of the loop body handed from phase to phase (it_extend / it_connect / it_book)
@@ -1285,6 +1286,7 @@ NIRRT_FN __device__ void wg_query_fn()
     // everything the loop compares with is the same in every lane: scalar registers
     const double r = uni(s.qa.r), floor_m = uni(s.qa.floor_m);
     const int new_idx = uni(s.qa.new_idx), lds_cap = uni(s.qa.lds_cap);
+    const bool lazy = uni(s.qa.lazy) != 0;
     const double r2 = r * r, r2lo = r2 * BAND_LO, r2hi = r2 * BAND_HI;
     const double pnx = uni(s.qa.pn[0]), pny = uni(s.qa.pn[1]), pnz = D == 3 ? uni(s.qa.pn[2]) : 0.;
     const double qx = uni(s.qa.q[0]), qy = uni(s.qa.q[1]), qz = D == 3 ? uni(s.qa.q[2]) : 0.;
@@ -1434,9 +1436,14 @@ NIRRT_FN __device__ void wg_query_fn()
             if (!exact) { dj = dist_scan_cold<D>(dx, dy, dz); exact = true; }
             hit = dj <= r;
         }
+        // The Near set is the collision-free hits (find_near_neighbors, rrt_star_2d.py:101-110).  lazy (the persistent loops): the
+        // segment test runs only for a hit that can still become this lane's choose_parent candidate; the others go to the stash
+        // untested and it_connect tests the few of them that reach cost(new) - a member is used in exactly those two places.  (3D
+        // trees with thousands of Near members spent 90 % of their time testing every member against every obstacle in reach.)
+        const double c = p.c + dj;
         bool col = false;
         if (n_ob > 0) {                         // uniform
-            if (hit) {
+            if (hit && (!lazy || c <= ba * (1.0 + 0x1p-40))) {
                 double l0[3], l1[3];
                 l0[0] = fmin(pnx, p.x); l1[0] = fmax(pnx, p.x); l0[1] = fmin(pny, p.y); l1[1] = fmax(pny, p.y);
                 if (D == 3) { l0[D - 1] = fmin(pnz, p.z); l1[D - 1] = fmax(pnz, p.z); }
@@ -1452,7 +1459,6 @@ NIRRT_FN __device__ void wg_query_fn()
         // with sqrt(v) (within 2 ulp of d_j) and settles it exactly only when another member comes within 2^-40 of it; a
         // lane's best is evaluated exactly ONCE, after the visit.  (Evaluating at every new per-lane minimum put a call - and
         // with it a drain of the loads in flight - into nearly every trip.)
-        const double c = p.c + dj;
         const bool better = member && c < ba * (1.0 - 0x1p-40);             // clearly better than the lane's best
         const bool close = member && !better && c <= ba * (1.0 + 0x1p-40);   // too close to call: the reference's values decide
         ba = better ? c : ba;
@@ -1630,10 +1636,10 @@ NIRRT_FN __device__ void wg_query_fn()
 template <int D, int NT>
 __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, const double *pn, double r, int new_idx,
                                          const double *q, int *ni, NearResult *nr, int lds_cap,
-                                         double floor_m = -__builtin_inf())
+                                         double floor_m = -__builtin_inf(), bool lazy = false)
 {
     if (threadIdx.x == 0) {   // the arguments are the same in every thread
-        s.qa.n = n; s.qa.want = (pn ? 1 : 0) | (q ? 2 : 0);
+        s.qa.n = n; s.qa.want = (pn ? 1 : 0) | (q ? 2 : 0); s.qa.lazy = lazy ? 1 : 0;
         s.qa.r = r; s.qa.floor_m = floor_m; s.qa.new_idx = new_idx; s.qa.lds_cap = lds_cap;
 #pragma unroll
         for (int k = 0; k < 3; k++) { s.qa.pn[k] = (pn && k < D) ? pn[k] : 0.; s.qa.q[k] = (q && k < D) ? q[k] : 0.; }
@@ -2225,8 +2231,27 @@ NIRRT_FN __device__ void it_connect()
     int k_out = 0, reparented_out = 0, n_rewired_out = 0;
     {
         {
-            const int k = nr.k;            // Near members
+            // Near members.  lazy query: nr.k counts hits, filtered or not; the set is non-empty iff choose_parent has a candidate
+            // (a lane filters its hits until one is free), and rewire filters its candidates below
+            const bool lazy = uni(s.qa.lazy) != 0;
+            const int k = lazy ? (nr.cand < __builtin_inf() ? (nr.k > 0 ? nr.k : 1) : 0) : nr.k;
             const int ks = nr.n_stash;     // ... of which on the stash
+            const int n_ob = uni(s.ob_n);  // obstacles in reach of the Near ball (listed by the query)
+            // is_collision(new, vertex id) against the query's obstacle list, one lane
+            auto blocked = [&](int id) -> bool {
+                if (!lazy || n_ob == 0) return false;
+                const VRec vr = ldg(&t.vrec[id]);
+                const double pz = D == 3 ? node_new[D - 1] : 0., vz = D == 3 ? vr.z : 0.;
+                double l0[3], l1[3];
+                l0[0] = fmin(node_new[0], vr.x); l1[0] = fmax(node_new[0], vr.x); l0[1] = fmin(node_new[1], vr.y); l1[1] = fmax(node_new[1], vr.y);
+                if (D == 3) { l0[D - 1] = fmin(pz, vz); l1[D - 1] = fmax(pz, vz); }
+                bool col = false;
+                for (int j = 0; j < n_ob && !col; j++) {
+                    const int o = s.ob_list[j];
+                    if (seg_aabb_pass<D, NT>(s, o, l0, l1)) col = seg_obstacle_cold<D>(o, node_new[0], node_new[1], pz, vr.x, vr.y, vz);
+                }
+                return col;
+            };
             PROF(2);
             int reparented = 0, n_rewired = 0;
             // curr_node_new_cost (rrt_star_2d.py:45 "same point" / :51)
@@ -2298,8 +2323,8 @@ NIRRT_FN __device__ void it_connect()
                 __syncthreads();
                 for (int base = 0; base < k_lds; base += NT) {
                     const int a = base + tid;
-                    const bool c = a < k_lds && s.pool[s.stash_off + a] >= thr;
                     const int id = a < k_lds ? ids[a] : 0;
+                    const bool c = a < k_lds && s.pool[s.stash_off + a] >= thr && !blocked(id);
                     __syncthreads();
                     if (c) {
                         const int p = atomicAdd(&s.n_cand, 1);
@@ -2314,8 +2339,11 @@ NIRRT_FN __device__ void it_connect()
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         if (mg[u] >= thr) {
-                            const int p = atomicAdd(&s.n_cand, 1);
-                            if (p < list_cap) ids[p] = t.nr_idx[a0 + u * NT - cap_lds]; else s.cand_listed = 0;
+                            const int id = t.nr_idx[a0 + u * NT - cap_lds];
+                            if (!blocked(id)) {
+                                const int p = atomicAdd(&s.n_cand, 1);
+                                if (p < list_cap) ids[p] = id; else s.cand_listed = 0;
+                            }
                         }
                     }
                 }
@@ -2564,7 +2592,7 @@ NIRRT_FN __device__ void it_connect()
                     if (!listed_all) {   // candidates that found no room on the list: straight from the spilled stash, every round
                         for (int a = cap_lds + tid; a < ks; a += NT) {
                             const int id = t.nr_idx[a - cap_lds];
-                            if (id > last && id < first && t.nr_m[a - cap_lds] >= thr && passes(id)) first = id;
+                            if (id > last && id < first && t.nr_m[a - cap_lds] >= thr && passes(id) && !blocked(id)) first = id;
                         }
                     }
                     first = uni(block_min_int<NT>(s, first));
@@ -2661,7 +2689,8 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
             const double lb_new = __builtin_sqrt(dist2<D>(d_root));
             const double floor_m = lb_new - (1e-9 + 1e-11 * lb_new);
             const int n = uni(s.it.n);
-            wg_query<D, NT>(s, t, n, node_new, uni(s.it.r_query), new_idx, q_next, &next_ni, nullptr, uni(s.stash_cap), floor_m);
+            // (the step kernel reports the size of the filtered Near set: it filters every hit; the loops only need the set's uses)
+            wg_query<D, NT>(s, t, n, node_new, uni(s.it.r_query), new_idx, q_next, &next_ni, nullptr, uni(s.stash_cap), floor_m, res == nullptr);
             alg += n;
             it_connect<D, NT>();
             // goal bookkeeping only concerns vertices within step_len of the goal (wg_goal_candidate / InGoalRegion test the same

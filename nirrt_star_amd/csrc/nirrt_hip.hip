@@ -368,6 +368,7 @@ struct ScratchPool {
     static size_t round_up(size_t b) { size_t r = 256; while (r < b) r <<= 1; return r; }
     hipError_t take(int device, size_t bytes, void **out, size_t *got)
     {
+        if (bytes > ((size_t)64 << 20)) { *got = 0; return hipMalloc(out, bytes); }   // word slabs of host-fed runs: exact, not kept
         const size_t r = round_up(bytes);
         {
             std::lock_guard<std::mutex> g(mu);
@@ -379,6 +380,7 @@ struct ScratchPool {
     }
     void give(int device, size_t bytes, void *p)
     {
+        if (bytes == 0) { (void)hipFree(p); return; }
         std::lock_guard<std::mutex> g(mu);
         idle.insert({{device, bytes}, p});
     }

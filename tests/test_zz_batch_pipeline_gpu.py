@@ -1,8 +1,8 @@
 """GPU: the pipelined form of the batched guided planners (nirrt_star_amd/batch.py run_batch with two half-batches whose
 launches are issued from a worker thread while the other half's clouds are refreshed) gives every tree the result of the
 planner class run alone - the same check as tests/test_nirrt_batch_gpu.py::test_batched_guided_planners_equal_the_planner_class,
-with the split forced onto a 4-problem batch (NIRRT_BATCH_OVERLAP_MIN=1; the default splits from 2048 problems, which only
-bench.py reaches).  Reference: nirrt_star_png_2d.py:56-174 (planning / planning_random), eval_planning_2d.py:83-136.
+with the split forced onto a 4-problem batch (NIRRT_BATCH_GROUPS=2, NIRRT_BATCH_OVERLAP_MIN=1; by default a guided batch runs as
+one group since round 3).  Reference: nirrt_star_png_2d.py:56-174 (planning / planning_random), eval_planning_2d.py:83-136.
 (Named to run last: it is the one test of the suite that drives the library from two threads.)"""
 import random
 from types import SimpleNamespace as NS
@@ -31,6 +31,7 @@ class DiagonalFake(FakePNG):
 def test_two_pipelined_half_batches_equal_the_planner_class(monkeypatch):
     from nirrt_star_amd import batch, eval_sharded as es, planners, worlds
     monkeypatch.setenv("NIRRT_BATCH_OVERLAP_MIN", "1")
+    monkeypatch.setenv("NIRRT_BATCH_GROUPS", "2")       # (round 3: one group is the default; the split is an option)
     probs = [worlds.problem_2d(worlds.random_world_2d(20 + i, "b30"), 0) for i in range(4)]
     pids = [11, 12, 13, 14]
     args = NS(problem="random_2d", planner="nirrt_star", iter_max=3000, iter_after_initial=200, step_len=10, clearance=3,
