@@ -53,7 +53,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--trees", type=int, default=8192, help="problems per GPU per step (4096 = 16 one-wave workgroups per CU, all resident; more queue up "
+    ap.add_argument("--trees", type=int, default=8192, help="problems per GPU per step (3072 = 12 one-wave workgroups per CU are resident; more queue up "
                                                              "behind them and even out the heavy-tailed per-tree run times)")
     ap.add_argument("--iters", type=int, default=50000, help="planner iterations per problem (tree capacity)")
     ap.add_argument("--dim", type=int, default=2)
@@ -450,7 +450,7 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (tree) / f32 (PointNet++)", "data": "synthetic",
                "config": {"workload": "%s_star -n pointnet2%s random_%dd, %d problems/GPU x %d iters, 2048-point guidance clouds, batched "
-                                      "PointNet++ refresh (synthetic weights), host-side cloud candidates inside the timed step, generator look-ahead resident before it"
+                                      "PointNet++ refresh (synthetic weights; cloud candidates, down-sampling, network input and predictions on the device, inside the timed step), generator look-ahead resident before it"
                                       % ("nirrt", " -c bfs" if args.algo == "nirrt_c" else "", D, B, iters),
                           "key": config_key(args), "trees_per_gpu": B, "iters": iters, "dim": D,
                           "launches_per_step": float(np.mean(launches)), "forwards_per_step": (guidance.calls - f0) / args.steps,
@@ -470,7 +470,8 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
 SECONDARY = [   # (label, bench arguments): each runs `--steps 1 --warmup 0` in a process of its own
     ("rrt_2d", ["--algo", "rrt"]),
     ("rrt_3d", ["--algo", "rrt", "--dim", "3"]),
-    ("irrt_3d", ["--algo", "irrt", "--dim", "3", "--trees", "4096"]),
+    # (problems whose straight start-goal segment is free - the degenerate, thousands-of-Near-members class - on 256 lanes)
+    ("irrt_3d", ["--algo", "irrt", "--dim", "3", "--trees", "4096", "--free-lanes", "256"]),
     ("irrt_2d_b30r16", ["--algo", "irrt", "--world", "b30r16"]),
     ("nirrt_2d", ["--algo", "nirrt", "--trees", "4096"]),
     # config 3 as composed (-c bfs): the neural-connect rounds run a breadth-first search per cloud on the HOST (bfs_connect.py,

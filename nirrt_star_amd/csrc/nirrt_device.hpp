@@ -68,7 +68,12 @@ __device__ __forceinline__ void stg(GAS T *p, const T &v)
 struct Hop4;
 struct Topo;
 #ifndef NIRRT_WAVES_PER_EU
-#define NIRRT_WAVES_PER_EU 4   // second __launch_bounds__ argument of the persistent kernels (register budget 512 / this)
+#define NIRRT_WAVES_PER_EU 3   // second __launch_bounds__ argument of the persistent kernels (register budget 512 / this).
+// 3 waves per SIMD = 168 VGPRs = 12 one-wave trees per CU (3072 per GPU).  At 4 (128 VGPRs, 4096 trees resident) the four phase
+// functions spilled 100+ registers per iteration: the launch's WRITE_SIZE was the scratch frames, 27 KB per iteration in 2D and
+// 35.8 KB in 3D - exactly (224 + 176 + 96) / (256 + 192 + 112) bytes per lane x 64 - against ~1.2 KB of tree updates; frames at
+// 168 VGPRs: 48 + 32 + 16 bytes.  Per-tree time 4.28 -> 2.70 s (IRRT* 2D), launch 11.7 -> 10.0 s; RRT* 2D 54 -> 63.5 M it/s,
+// 3D 45 -> 58.7 M it/s.  (2 waves per SIMD, no spills at all: 2.37 s per tree but only 2048 slots - launch 11.6 s.)
 #endif
 // Out-of-line device functions (NIRRT_FN) get their register budget from the kernels that reach them: the compiler gives a
 // callee the union of its callers' waves-per-EU ranges, so EVERY kernel of the library carries the same second launch
@@ -199,7 +204,7 @@ struct __attribute__((aligned(32))) GSlot {
 
 // The part of a tree descriptor the loop body touches: copied into LDS when a kernel starts (hot_enter) and written back when
 // it ends (hot_leave), so that a pointer or a counter of the tree costs an LDS read instead of a dependent scalar load from HBM
-// (16 trees per CU x ~700 B of descriptor do not live in the scalar cache).
+// (12 - 16 trees per CU x ~700 B of descriptor do not live in the scalar cache).
 template <template <typename> class P>
 struct TreeHotT {
     typename P<Topo>::type topo;     // topo[cap]: parent chain (4 hops), child-list links, flags

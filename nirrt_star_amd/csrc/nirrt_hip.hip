@@ -71,7 +71,7 @@ struct RunSampleDev {
 };
 
 // Three instantiations of every kernel; nirrt_run picks by batch size so that the CU's 16 wave slots are busy:
-//   slim   64 threads (one wave per tree, 16 trees per CU = every wave slot): batches of more than 2048 trees;
+//   slim   64 threads (one wave per tree, 12 trees per CU = every wave slot at 168 VGPRs): batches of more than 2048 trees;
 //   narrow 128 threads (8 trees per CU): with the grid index an iteration is a chain of short dependent phases, so trees
 //          in flight per CU is what counts (measured on 2048 problems: 1.2x IRRT*, 1.7x RRT* over 256-thread workgroups;
 //          256 was best while the O(n) scans dominated);
@@ -111,7 +111,7 @@ namespace slim {
 static_assert(NT_WIDE / 64 <= LDS_NW_MAX && NT_NARROW / 64 <= LDS_NW_MAX, "LdsData reduction slots: raise LDS_NW_MAX");
 static_assert(offsetof(TreeHotH, pc) > offsetof(TreeHotH, CL_C) && offsetof(TreeHotH, g_rec) > offsetof(TreeHotH, c_update),
               "nirrt_set_informed / nirrt_set_cloud patch contiguous field ranges of the descriptor");
-static_assert(sizeof(LdsData) <= 10240, "LdsData must fit 16 times into a CU's 160 KB of LDS (16 one-wave trees per CU)");
+static_assert(sizeof(LdsData) <= 10240, "LdsData must fit 16 times into a CU's 160 KB of LDS (up to 16 one-wave trees per CU)");
 // nirrt_run: batches larger than the 2048 workgroup slots of the 128-thread kernels run one wave per tree (16 trees per
 // CU with 10 KB of LDS): measured on 4096 problems 12.8 vs 10.9 M it/s (IRRT*), 39.0 vs 26.3 M it/s (RRT*); at 2048
 // problems the 128-thread kernels win (IRRT* 10.9 vs 8.6) or tie (RRT*).  NIRRT_SLIM_MIN_TREES overrides the threshold.

@@ -28,7 +28,7 @@ print("factors", f_fetch, f_write)
 PY
   cp $R/profiles/r03_traffic_calibration.json $out/ ;;
 traffic)
-  for cfg in "" "--algo rrt" "--algo rrt --dim 3" "--algo irrt --dim 3 --trees 4096" "--algo nirrt --trees 4096"; do
+  for cfg in "" "--algo rrt" "--algo rrt --dim 3" "--algo irrt --dim 3 --trees 4096" "--algo irrt --world b30r16" "--algo nirrt --trees 4096" "--algo nirrt --dim 3 --trees 1024"; do
     python $R/scripts/collect_traffic.py $cfg > $out/traffic_$(echo $cfg | tr -d ' -').txt 2>&1
   done
   cp $R/profiles/r03_traffic.json $R/profiles/r03_pmc_*.csv $out/ 2>/dev/null ;;
@@ -45,8 +45,10 @@ sq)
 pn2)
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/pn2_b256 -o p -- python $R/scripts/pn2_forward_only.py 256 > $out/pn2_b256.txt 2>&1
   find $out/pn2_b256 -name "*kernel_trace.csv" -delete
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --kernel-include-regex "k_sa_mlp|Cijk" --output-format csv -d $out/pn2_pmc -o p -- python $R/scripts/pn2_forward_only.py 256 > $out/pn2_pmc.txt 2>&1
-  find $out/pn2_pmc -name "*kernel_trace.csv" -delete ;;
+  python $R/scripts/sa_mlp_bench.py 256 > $out/sa_mlp_bench.txt 2>&1
+  $R/scripts/pmc_pn2.sh r03 > $out/pn2_pmc.txt 2>&1
+  cp $R/gpurun_out/pmc_pn2_r03/summary.txt $out/pn2_pmc_summary.txt
+  ;;
 esac
 done
 ls -R $out | head -60
