@@ -28,12 +28,12 @@ print("factors", f_fetch, f_write)
 PY
   cp $R/profiles/r03_traffic_calibration.json $out/ ;;
 traffic)
-  for cfg in "" "--algo rrt" "--algo rrt --dim 3" "--algo irrt --dim 3 --trees 4096" "--algo irrt --world b30r16" "--algo nirrt --trees 4096" "--algo nirrt --dim 3 --trees 1024"; do
+  for cfg in "" "--algo rrt" "--algo irrt --dim 3 --trees 4096 --free-lanes 256" "--algo irrt --world b30r16" "--algo nirrt --trees 4096" "--algo rrt --dim 3" "--algo nirrt --dim 3 --trees 1024"; do
     python $R/scripts/collect_traffic.py $cfg > $out/traffic_$(echo $cfg | tr -d ' -').txt 2>&1
   done
   cp $R/profiles/r03_traffic.json $R/profiles/r03_pmc_*.csv $out/ 2>/dev/null ;;
 stats)
-  for cfg in "" "--algo irrt --dim 3 --trees 4096"; do
+  for cfg in "" "--algo irrt --dim 3 --trees 4096 --free-lanes 256"; do
     n=$(echo $cfg | tr -d ' -'); [ -z "$n" ] && n=irrt2d
     rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$n -o p -- python $R/bench.py --no-cpu-baseline --no-ttfs --no-secondary --steps 1 --warmup 0 $cfg > $out/bench_profiled_$n.json 2> $out/bench_profiled_$n.err
     find $out/stats_$n -name "*kernel_trace.csv" -delete
