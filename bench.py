@@ -279,6 +279,8 @@ def main():
         hint = first_hint
         tot = {"kernel_ms": 0.0, "stats": np.zeros((B, _hip.N_STATS), dtype=np.int64), "alg_elems": np.zeros(B, dtype=np.int64),
                "iters_done": np.zeros(B, dtype=np.int64), "seconds": np.zeros(B), "wide": 0, "narrow": 0}
+        if hint is not None:   # --free-lanes: lane hints of the first (only) launch
+            tot["wide"], tot["narrow"] = int(np.sum(hint == 256)), int(np.sum(hint == 128))
         for si, n_it in enumerate(seg_len):
             nt_s = [(np_tab[b][0] + 4 * int(used_np[b]), np_tab[b][1] - int(used_np[b])) for b in order]
             pt_s = [(py_tab[b][0] + 4 * int(used_py[b]), py_tab[b][1] - int(used_py[b])) for b in order] if py_tab else None
