@@ -237,3 +237,22 @@ def test_gpu_net_input_bit_equal_to_host_assembly(dim):
             ref = png_wrapper.PNGWrapper.network_input(c.astype(np.float32), sm, gm)
             assert sm.sum() > 0 and gm.sum() > 0
             assert np.array_equal(got[k], ref), (n, j, np.abs(got[k] - ref).max())
+
+
+def test_numpy_reduction_orders_the_device_input_assembly_relies_on():
+    """k_net_input (csrc/pointops.hip) restates pc_normalize with the evaluation order numpy uses for it: np.mean over axis 0 of
+    a C-contiguous (N, 3) float32 array adds the rows in index order (no pairwise blocking on the outer axis), the row norm is
+    (x^2 + y^2) + z^2.  Pinned here on the CPU so that a numpy whose reductions work differently is noticed without a GPU."""
+    from nirrt_star_amd.pointnet2 import pc_normalize
+    rng = np.random.RandomState(5)
+    for n in (7, 100, 1777, 2048):
+        a = (rng.uniform(0, 224, (n, 3))).astype(np.float32)
+        acc = np.zeros(3, dtype=np.float32)
+        for i in range(n):
+            acc = acc + a[i]
+        mean = acc / np.float32(n)
+        assert np.array_equal(mean, np.mean(a, axis=0))
+        c = a - mean
+        norm = np.sqrt((c[:, 0] * c[:, 0] + c[:, 1] * c[:, 1]) + c[:, 2] * c[:, 2])
+        assert np.array_equal(norm, np.sqrt(np.sum(c ** 2, axis=1)))
+        assert np.array_equal(c / np.max(norm), pc_normalize(a))
