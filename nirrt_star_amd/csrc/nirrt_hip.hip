@@ -1151,13 +1151,18 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
     float ms_max = 0.f;
     for (Group &g : groups) {
         HIPCHK_R(hipStreamSynchronize(g.st));
+    }
+    for (Group &g : groups) {
+        // first group's start -> this group's end: groups that each fill the GPU run one after the other, whatever their streams
         float ms = 0.f;
-        HIPCHK_R(hipEventElapsedTime(&ms, g.e0, g.e1));
+        HIPCHK_R(hipEventElapsedTime(&ms, groups[0].e0, g.e1));
         ms_max = std::max(ms_max, ms);
+    }
+    for (Group &g : groups) {
         (void)hipEventDestroy(g.e0);
         (void)hipEventDestroy(g.e1);
     }
-    if (a->kernel_ms) *a->kernel_ms = ms_max;   // the groups start together: the longest one is the launch's device time
+    if (a->kernel_ms) *a->kernel_ms = ms_max;   // device time of the launch: start of the first group to the end of the last
     hipLaunchKernelGGL(k_collect, dim3((n_trees + 255) / 256), dim3(256), 0, st, (TreeDev *const *)d_ptrs, n_trees, d_col + nt * COLLECT_W);
     std::vector<long long> col(2 * nt * COLLECT_W);
     HIPCHK_R(hipMemcpyAsync(col.data(), d_col, sizeof(long long) * col.size(), hipMemcpyDeviceToHost, st));
