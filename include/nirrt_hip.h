@@ -107,6 +107,11 @@ int nirrt_reset(nirrt_tree *t);
  * 4096, 0 = one allocation per tree; no counterpart in the reference, whose arrays are numpy's): hand the chunks that hold no
  * live tree back to the driver - a process that is done with one batch and starts helpers that need the memory calls this */
 int nirrt_pool_trim(void);
+/* Host helper: n raw 32-bit outputs of an MT19937 generator - numpy's legacy RandomState (np.random.seed, what rrt_base_2d.py /
+ * rrt_star_2d.py draw from) and CPython's random.Random (irrt_star_2d.py's informed sampling) are this generator, and nirrt_run
+ * consumes their raw outputs (np_words / py_words).  key (624 words) and *pos (0..624, 624 = block used up) are the generator's
+ * state as get_state() / getstate() expose it; both are updated in place to the state after n outputs.  No device involved. */
+int nirrt_mt19937_fill(uint32_t *key, int32_t *pos, int64_t n, uint32_t *out);
 /* the same for every tree of a batch (same device and dim) in ONE launch, one workgroup per tree: the planner objects of an
  * evaluation set are single-use in the reference (demo_planning_2d.py:90); a benchmark step re-plans the same problems */
 int nirrt_reset_batch(nirrt_tree *const *trees, int32_t n_trees);

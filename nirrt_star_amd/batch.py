@@ -56,7 +56,6 @@ class ProblemStreams:
         self._rs = np.random.RandomState(self.seed)
         self._pyg = random.Random(self.seed)
         self._torch = None
-        self._scratch = np.random.RandomState(0)
         self._npc = {"host": None, "dev": None, "off": 0, "pending": 0, "touched": False}
         self._pyc = {"host": None, "dev": None, "off": 0, "pending": 0, "touched": False}
 
@@ -99,16 +98,16 @@ class ProblemStreams:
 
     # ---- raw outputs ahead of the current position (nothing is consumed) ----
     def _gen(self, is_np, n):
+        """the next n raw outputs of the numpy / python stream; the generator itself stays where it is.  Both are MT19937
+        (CPython: getrandbits(32 k) = k consecutive outputs, least significant word first): the words come from the library's
+        host-side generator (nirrt_mt19937_fill) started in a copy of the stream's state."""
         if is_np:
-            st = self._rs.get_state()
-            w = self._rs.randint(0, 1 << 32, size=int(n), dtype=np.uint32)
-            self._rs.set_state(st)
-            return w
-        # CPython's generator is the same MT19937 (getrandbits(32 k) = k consecutive outputs, least significant word first):
-        # its state is copied into a numpy RandomState, which produces the outputs 3-4x faster than a 25-Mbit Python int
-        st = self._pyg.getstate()[1]
-        self._scratch.set_state(("MT19937", np.array(st[:624], dtype=np.uint32), int(st[624])))
-        return self._scratch.randint(0, 1 << 32, size=int(n), dtype=np.uint32)
+            st = self._rs.get_state(legacy=True)
+            key, pos = st[1], int(st[2])
+        else:
+            st = self._pyg.getstate()[1]
+            key, pos = np.array(st[:624], dtype=np.uint32), int(st[624])
+        return _hip.mt19937_outputs(key, pos, n)[0]
 
     def _window(self, c, is_np, n, device):
         n = int(n)

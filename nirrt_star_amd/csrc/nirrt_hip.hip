@@ -394,6 +394,45 @@ struct ScratchPool {
 ScratchPool g_scratch;
 }
 
+/* MT19937 outputs in bulk (host): numpy's legacy RandomState and CPython's random.Random are this generator, and the loops
+ * consume their raw 32-bit outputs.  key: the 624 state words, *pos: position inside the block (624 = used up), both updated in
+ * place the way the generators themselves would be after n outputs (pass copies to peek). */
+extern "C" int nirrt_mt19937_fill(uint32_t *key, int32_t *pos, int64_t n, uint32_t *out)
+{
+    if (!key || !pos || n < 0 || (n > 0 && !out) || *pos < 0 || *pos > 624) return NIRRT_E_ARG;
+    int p = *pos;
+    for (int64_t i = 0; i < n;) {
+        if (p >= 624) {
+            // the next block: three stretches whose inputs are all in place (the reference implementation's loop, unrolled by range)
+            int k = 0;
+            for (; k < 624 - 397; k++) {
+                const uint32_t y = (key[k] & 0x80000000u) | (key[k + 1] & 0x7fffffffu);
+                key[k] = key[k + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            for (; k < 623; k++) {
+                const uint32_t y = (key[k] & 0x80000000u) | (key[k + 1] & 0x7fffffffu);
+                key[k] = key[k + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            const uint32_t y = (key[623] & 0x80000000u) | (key[0] & 0x7fffffffu);
+            key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            p = 0;
+        }
+        const int64_t take = std::min<int64_t>(624 - p, n - i);
+        for (int64_t j = 0; j < take; j++) {
+            uint32_t y = key[p + j];
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= y >> 18;
+            out[i + j] = y;
+        }
+        p += (int)take;
+        i += take;
+    }
+    *pos = p;
+    return NIRRT_OK;
+}
+
 extern "C" int nirrt_pool_trim(void)
 {
     g_pool.trim();

@@ -1,6 +1,7 @@
 """ProblemStreams (nirrt_star_amd/batch.py): the kept look-ahead of generator outputs equals a fresh peek at every
 position, also after somebody else drew from the numpy generator (cloud candidates, pointcloud.py)."""
 import numpy as np
+import pytest
 
 from nirrt_star_amd.batch import ProblemStreams
 
@@ -49,3 +50,29 @@ def test_advancing_jumps_through_the_lookahead_like_generate_and_discard():
             assert a.rs.get_state()[2] in (b.rs.get_state()[2], 624)
         assert a.rs.random_sample() == b.rs.random_sample() and a.py.random() == b.py.random()
         assert a.rs.normal() == b.rs.normal() and a.py.gauss(0, 1) == b.py.gauss(0, 1)
+
+
+def test_native_mt19937_fill_equals_numpy_and_cpython():
+    """nirrt_mt19937_fill (host code of the library): the raw outputs, and the state it leaves behind, are numpy's RandomState's
+    and CPython's random.Random's - from any position inside a block, across block boundaries, for n = 0"""
+    import random
+    from nirrt_star_amd import _hip
+    for seed, skip, n in ((1, 0, 5), (2, 3, 624), (3, 611, 2000), (4, 624 * 2 + 7, 1), (5, 10, 0)):
+        rs = np.random.RandomState(seed)
+        rs.randint(0, 1 << 32, size=skip, dtype=np.uint32)
+        st = rs.get_state(legacy=True)
+        want = rs.randint(0, 1 << 32, size=n, dtype=np.uint32)
+        got, key, pos = _hip.mt19937_outputs(st[1], st[2], n)
+        after = rs.get_state(legacy=True)
+        assert np.array_equal(got, want)
+        if n:
+            assert pos == after[2] and np.array_equal(key, after[1])
+        r = random.Random(seed)
+        if skip:
+            r.getrandbits(32 * skip)
+        ps = r.getstate()[1]
+        v = r.getrandbits(32 * n) if n else 0
+        got, _, _ = _hip.mt19937_outputs(np.array(ps[:624], dtype=np.uint32), ps[624], n)
+        assert [int(x) for x in got] == [(v >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
+    with pytest.raises(ValueError):
+        _hip.mt19937_outputs(np.zeros(10, dtype=np.uint32), 0, 4)
