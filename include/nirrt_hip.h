@@ -14,13 +14,17 @@
  *     arrays the reference passes around); the library owns device memory until nirrt_destroy.
  *   - one tree = one opaque handle = one HIP stream; a handle is not thread-safe.
  *   - vertices cross the boundary as (n, dim) row-major float64 (the reference's
- *     `self.vertices[:n]`), parents as int64 (`self.vertex_parents[:n]`).  In HBM the tree is a
- *     flat SoA: x[cap], y[cap](, z[cap]) f64 + parent[cap] i32, plus derived copies the kernels keep in
- *     step (float32 twins ordered by grid cell, packed records).
- *   - nearest_neighbor / find_near_neighbors answers come from a uniform-grid index on large trees and
- *     from whole scans on small ones; both give exactly the reference's answers (ties, ordering).
- *     Environment knobs read by nirrt_create: NIRRT_GRID_MIN, NIRRT_GRID_REBUILD, NIRRT_GRID_G;
- *     by nirrt_run: NIRRT_WIDE_MAX_TREES.
+ *     `self.vertices[:n]`), parents as int64 (`self.vertex_parents[:n]`).  In HBM a tree is ONE device range (its arena)
+ *     holding records, not coordinate columns: a 32-byte vertex record {x, y, z, cost(v)} and a 64-byte
+ *     tree record {four hops of the parent chain with their edge lengths, child-list links, flags} per vertex, a 32-byte slot
+ *     record per vertex of the two-level uniform-grid index (cell-ordered part, coarse level over the recent insertions,
+ *     unsorted rest), the solution / goal-candidate lists, the Near-radius table, the guidance cloud and the tree's two
+ *     MT19937 generators.  Everything is float64 / int32 on the device; there are no float32 copies.
+ *   - nearest_neighbor / find_near_neighbors answers come from the grid index on large trees and from whole scans on small
+ *     ones; both give exactly the reference's answers (ties, ordering).
+ *     Environment knobs read by nirrt_create: NIRRT_GRID_MIN (smallest indexed tree), NIRRT_GRID_REBUILD / NIRRT_GRID_REBUILD2
+ *     (rebuild intervals of the two levels), NIRRT_GRID_G / NIRRT_GRID_G2 (cells per axis), NIRRT_POOL_CHUNK_MB (arena pool);
+ *     by nirrt_run: NIRRT_WIDE_MAX_TREES, NIRRT_SLIM_MIN_TREES, NIRRT_FORCE_VARIANT.
  *   - all planner arithmetic is float64 and follows the reference's per-call-site formulas
  *     (SURVEY.md Appendix A); integer bookkeeping (indices, parents, n) is exact.
  */
@@ -115,6 +119,23 @@ int nirrt_mt19937_fill(uint32_t *key, int32_t *pos, int64_t n, uint32_t *out);
 /* the same for every tree of a batch (same device and dim) in ONE launch, one workgroup per tree: the planner objects of an
  * evaluation set are single-use in the reference (demo_planning_2d.py:90); a benchmark step re-plans the same problems */
 int nirrt_reset_batch(nirrt_tree *const *trees, int32_t n_trees);
+/* The tree's OWN generators.  The reference draws from two process-global MT19937 generators inside the loop: numpy's legacy
+ * RandomState (SampleFree rrt_base_2d.py:46-52, 3D SampleUnitBall irrt_star_3d.py:146-158, SamplePointCloud
+ * nirrt_star_png_2d.py:129-130) and CPython's random (2D SampleUnitBall irrt_star_2d.py:146-151).  Every tree carries its own
+ * pair in HBM: nirrt_set_generators = np.random.set_state / random.setstate (key (n_trees, 624) words + pos (n_trees,) in
+ * 0..624, as get_state() / getstate() expose them; a NULL key table leaves that stream alone), nirrt_get_generators = the
+ * state after whatever the device consumed, in the very representation get_state() would show (the block of the last
+ * consumed output, pos in 1..624).  nirrt_run with np_words == NULL draws from them: the twist runs in the tree's wave
+ * (three stretches of the recurrence over 64 lanes), outputs are tempered on read; nothing is generated on the host. */
+int nirrt_set_generators(nirrt_tree *const *trees, int32_t n_trees, const uint32_t *np_key, const int32_t *np_pos,
+                         const uint32_t *py_key, const int32_t *py_pos);
+int nirrt_get_generators(nirrt_tree *const *trees, int32_t n_trees, uint32_t *np_key, int32_t *np_pos, uint32_t *py_key,
+                         int32_t *py_pos);
+/* the next n_words raw outputs of every tree's numpy (which = 0) / python (which = 1) generator, produced on the device and
+ * consumed (rng.random_sample / rng.uniform of the guidance-cloud candidates, datasets/point_cloud_mask_utils.py:81-131, read
+ * them in place): tree i's words at out + i * stride; out is a DEVICE pointer if out_on_device != 0, else host memory */
+int nirrt_generator_words(nirrt_tree *const *trees, int32_t n_trees, int32_t which, int64_t n_words, uint32_t *out, int64_t stride,
+                          int32_t out_on_device);
 /* test/bring-up helper: load a frozen tree (vertices (n,dim) f64, parents (n,) i64); vertex 0 must be x_start - the tree is
  * rooted at the start state like the reference's (rrt_base_2d.py:27) - else NIRRT_E_ARG */
 int nirrt_upload(nirrt_tree *t, int64_t n, const double *vertices, const int64_t *parents);
@@ -173,12 +194,15 @@ int nirrt_extend(nirrt_tree *t, int64_t nearest_idx, const double *node_new, uin
  *                     (RRT*: SampleFree, rrt_base_2d.py:46-52).
  *   samples == NULL : sampling happens in the kernel (SampleFree / SampleInformedSubset,
  *                     irrt_star_2d.py:99-151, irrt_star_3d.py:95-158) and consumes raw MT19937
- *                     32-bit outputs of the two host generators the reference uses, exactly as
- *                     numpy's legacy RandomState / CPython's `random` would:
+ *                     32-bit outputs of the two generators the reference uses, exactly as
+ *                     numpy's legacy RandomState / CPython's `random` would.
+ *                     np_words == NULL (the normal case): the outputs come from the trees' own generators
+ *                       (nirrt_set_generators), twisted and tempered in the kernel; a stream never runs dry
+ *                       (NIRRT_E_STREAM only if ONE draw rejects 2^22 outputs: free space empty).
+ *                     np_words != NULL: outputs produced by the caller -
  *                       np_words[i] : stream of numpy's global RandomState  (n_np per tree)
  *                       py_words[i] : stream of python's `random` module    (n_py per tree)
- *                     On return np_used[i] / py_used[i] say how many words each tree consumed so the
- *                     host can advance its generators by exactly that much.
+ *                     On return np_used[i] / py_used[i] say how many words each tree consumed.
  * cost_trace (optional, (n_trees, iters) f64): entry k = best cost AFTER iteration k, which is what
  *   planning_random's path_len_list holds at index k in both planners -
  *   F_IRRT: find_best_path_solution (irrt_star_2d.py:239-241 after its [1:] shift);

@@ -25,7 +25,7 @@ EXPORTS = [
     "nirrt_download", "nirrt_num_vertices", "nirrt_nearest", "nirrt_collision_batch", "nirrt_points_in_obs",
     "nirrt_near", "nirrt_cost", "nirrt_search_goal_parent", "nirrt_best_solution", "nirrt_solutions",
     "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed", "nirrt_debug_prof", "nirrt_set_cloud", "nirrt_reset_batch", "nirrt_pool_trim", "nirrt_set_cloud_batch",
-    "nirrt_mt19937_fill",
+    "nirrt_mt19937_fill", "nirrt_set_generators", "nirrt_get_generators", "nirrt_generator_words",
 ]
 
 
@@ -102,6 +102,9 @@ def load():
     L.nirrt_reset_batch.argtypes = [C.POINTER(vp), C.c_int32]
     L.nirrt_pool_trim.argtypes = []
     L.nirrt_mt19937_fill.argtypes = [vp, C.POINTER(C.c_int32), C.c_int64, vp]
+    L.nirrt_set_generators.argtypes = [C.POINTER(vp), C.c_int32, vp, vp, vp, vp]
+    L.nirrt_get_generators.argtypes = [C.POINTER(vp), C.c_int32, vp, vp, vp, vp]
+    L.nirrt_generator_words.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int64, vp, C.c_int64, C.c_int32]
     L.nirrt_set_cloud_batch.argtypes = [C.POINTER(vp), C.c_int32, vp, C.c_int64, C.POINTER(C.c_int32), vp, C.c_int64, C.c_double,
                                         C.c_double, dp, C.POINTER(C.c_int32)]
     L.nirrt_upload.argtypes = [vp, C.c_int64, dp, ip]
@@ -352,6 +355,79 @@ def mt19937_outputs(key, pos, n):
     return out, k, int(p.value)
 
 
+def np_state(rs=None):
+    """(key uint32[624], pos) of a numpy legacy RandomState (default: the process-global one the reference draws from)"""
+    st = (rs if rs is not None else np.random).get_state()
+    return np.ascontiguousarray(st[1], dtype=np.uint32), int(st[2])
+
+
+def py_state(rnd=None):
+    """(key uint32[624], pos) of a CPython random.Random (default: the module-level generator)"""
+    import random
+    st = (rnd if rnd is not None else random).getstate()[1]
+    return np.array(st[:624], dtype=np.uint32), int(st[624])
+
+
+def set_np_state(key, pos, rs=None):
+    tgt = rs if rs is not None else np.random
+    st = tgt.get_state()
+    tgt.set_state((st[0], np.asarray(key, dtype=np.uint32), int(pos), st[3], st[4]))
+
+
+def set_py_state(key, pos, rnd=None):
+    import random
+    tgt = rnd if rnd is not None else random
+    st = tgt.getstate()
+    tgt.setstate((st[0], tuple(int(v) for v in key) + (int(pos),), st[2]))
+
+
+def set_generators(trees, np_states=None, py_states=None):
+    """np.random.set_state / random.setstate for the trees' own generators: per-tree (key[624], pos) pairs; None leaves a
+    stream alone"""
+    nt = len(trees)
+    handles = (C.c_void_p * nt)(*[t.h for t in trees])
+
+    def tab(states):
+        if states is None:
+            return None, None, None, None
+        k = np.ascontiguousarray(np.stack([np.asarray(s[0], dtype=np.uint32) for s in states]))
+        p = np.array([int(s[1]) for s in states], dtype=np.int32)
+        assert k.shape == (nt, 624)
+        return k, p, k.ctypes.data, p.ctypes.data
+
+    nk, npos, nka, npa = tab(np_states)
+    pk, ppos, pka, ppa = tab(py_states)
+    _check(load().nirrt_set_generators(handles, nt, nka, npa, pka, ppa))
+
+
+def get_generators(trees, want_np=True, want_py=True):
+    """-> (np_keys (nt, 624), np_pos (nt,), py_keys, py_pos): the generators' states as get_state() / getstate() would show
+    them after what the device consumed"""
+    nt = len(trees)
+    handles = (C.c_void_p * nt)(*[t.h for t in trees])
+    nk = np.zeros((nt, 624), dtype=np.uint32) if want_np else None
+    npos = np.zeros(nt, dtype=np.int32) if want_np else None
+    pk = np.zeros((nt, 624), dtype=np.uint32) if want_py else None
+    ppos = np.zeros(nt, dtype=np.int32) if want_py else None
+    _check(load().nirrt_get_generators(handles, nt, nk.ctypes.data if want_np else None, npos.ctypes.data if want_np else None,
+                                       pk.ctypes.data if want_py else None, ppos.ctypes.data if want_py else None))
+    return nk, npos, pk, ppos
+
+
+def generator_words(trees, which, n_words, device_ptr=None, stride=None):
+    """the next n_words raw outputs of every tree's numpy (which=0) / python (which=1) generator, produced on the device and
+    consumed; returns a (nt, n_words) uint32 array, or writes to device memory (device_ptr, stride in words) and returns None"""
+    nt = len(trees)
+    handles = (C.c_void_p * nt)(*[t.h for t in trees])
+    if device_ptr is None:
+        out = np.zeros((nt, int(n_words)), dtype=np.uint32)
+        _check(load().nirrt_generator_words(handles, nt, int(which), int(n_words), out.ctypes.data, int(n_words), 0))
+        return out
+    _check(load().nirrt_generator_words(handles, nt, int(which), int(n_words), C.c_void_p(int(device_ptr)),
+                                        int(stride if stride is not None else n_words), 1))
+    return None
+
+
 def pool_trim():
     """device chunks that hold no live tree go back to the driver (see nirrt_pool_trim)"""
     _check(load().nirrt_pool_trim())
@@ -405,8 +481,9 @@ def run_replay(trees, samples, flags=0, want_trace=False, device_ptr=None, iters
             "alg_elems": alg, "stats": stats}
 
 
-def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=False, on_device=False, iters_each=None, lanes_hint=None):
-    """Device-resident loop with in-kernel sampling.  np_words / py_words: per-tree uint32 arrays of
+def run_sampling(trees, iters, np_words=None, py_words=None, flags=0, want_trace=False, on_device=False, iters_each=None, lanes_hint=None):
+    """Device-resident loop with in-kernel sampling.  np_words = None (the normal case): every tree draws from its own
+    generators resident in HBM (set_generators / get_generators).  Otherwise np_words / py_words: per-tree uint32 arrays of
     raw MT19937 outputs (numpy legacy global stream / python `random`); with on_device=True they are
     per-tree (device_address, n_words) pairs of buffers already resident in HBM (e.g. slices of a
     torch.cuda tensor).  Returns dict with iters_done, np_used, py_used (words consumed), status
@@ -444,9 +521,10 @@ def run_sampling(trees, iters, np_words, py_words=None, flags=0, want_trace=Fals
         keep.append(hint)
         a.lanes_hint = hint.ctypes.data_as(C.POINTER(C.c_int32))
     a.samples = None
-    a.np_words, a.n_np = table(np_words)
-    if py_words is not None:
-        a.py_words, a.n_py = table(py_words)
+    if np_words is not None:      # None: the trees' own generators (set_generators) produce the words on the device
+        a.np_words, a.n_np = table(np_words)
+        if py_words is not None:
+            a.py_words, a.n_py = table(py_words)
     done = np.zeros(nt, dtype=np.int64)
     np_used = np.zeros(nt, dtype=np.int64)
     py_used = np.zeros(nt, dtype=np.int64)

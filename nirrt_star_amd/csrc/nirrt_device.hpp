@@ -285,12 +285,27 @@ struct TreeHotT {
 using TreeHotH = TreeHotT<gp_plain>;    // as stored in HBM and as the host fills it in
 using TreeHot = TreeHotT<gp_global>;    // the device code's view (same layout)
 
+// The tree's OWN generators, resident in its arena: stream 0 = numpy's legacy RandomState, stream 1 = CPython's random.Random
+// (both MT19937; the reference draws from the process-global ones inside the loop: rrt_base_2d.py:46-52, irrt_star_2d.py:121-151).
+// A stream is the endless sequence of the generator's 32-bit outputs; pos counts outputs from the start of block 0 (the state
+// nirrt_set_generators handed over), block b = the 624 state words after b twists.  The last two blocks are kept (key[s][b & 1])
+// so that a speculative draw can be undone across a block boundary; the state as get_state() shows it is (key of the block
+// holding output pos - 1, pos inside it in 1..624).
+#define MT_N 624
+struct MtGen {
+    long long pos[2];
+    int gen[2];              // highest block produced so far
+    int pad[2];
+    unsigned key[2][2][MT_N];
+};
+
 // the whole descriptor in HBM: hot part first, then what only kernel prologues / epilogues and the host touch
 struct TreeDev : TreeHotH {
     long long stat[NSTAT];   // counters since creation / reset (ST_*); a launch reports the difference
     double rnd[MAX_OBS][4];  // cx, cy, cz, r
     double box[MAX_OBS][6];  // x, y, z, w, h, d
     long long prof[24];      // NIRRT_PROFILE: wall_clock64 ticks (100 MHz) per phase
+    MtGen *mt;               // the tree's generators (inside its arena)
 };
 static_assert(sizeof(TreeHot) % 8 == 0 && sizeof(TreeHot) == sizeof(TreeHotH), "hot_enter / hot_leave copy 8-byte words");
 
@@ -300,8 +315,13 @@ static_assert(sizeof(TreeHot) % 8 == 0 && sizeof(TreeHot) == sizeof(TreeHotH), "
 // Generator state of one tree between draws: stream positions and the 64-word windows (see WordStream in
 // nirrt_hip.hip) live in LDS, so the persistent loop carries no sampler registers across the loop-body call.
 struct StreamState {
-    const GAS unsigned *w;
+    const GAS unsigned *w;   // word mode: the caller's raw outputs; generator mode: the two key blocks of the stream (MtGen::key[s])
     long long n, pos, base;
+    long long pos0;          // position when the kernel started (words used by the launch = pos - pos0)
+    int genmode;             // 1: the tree's own MT19937 generator produces the words (n is a per-draw limit, see draw_call)
+    int gen;                 // generator mode: highest block produced so far
+    int wn;                  // words in the register window (64; fewer at the end of a generator block)
+    int pad;
     unsigned buf[64];
 };
 

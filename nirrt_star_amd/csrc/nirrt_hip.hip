@@ -25,23 +25,92 @@ struct RunDev {
     long long *iters_done;  // (n_trees,)
 };
 
-// Raw 32-bit outputs of a host generator, consumed in order.  Executed by ALL lanes of wave 0 with identical values:
+// MT19937: the 624 state words after one more twist (genrand's refill), one wave, all 64 lanes.  Lane l holds words l, l + 64,
+// ... of the block (ten registers, the last row 48 words wide).  Word i needs old[i], old[i + 1] and word (i + 397) mod 624,
+// which is an OLD word for i < 227 and a NEW one - word i - 227, three to four rows back - from there on: rows are produced in
+// order, the neighbours come through ds_bpermute / v_readlane, nothing goes through memory until the block is complete.
+static __device__ __noinline__ void mt_next_block(const GAS unsigned *old_k, GAS unsigned *new_k)
+{
+    const int l = threadIdx.x & 63;
+    unsigned o[10], nw[10];
+#pragma unroll
+    for (int r = 0; r < 10; r++) o[r] = (64 * r + l) < MT_N ? old_k[64 * r + l] : 0u;
+    auto lane_of = [](unsigned v, int src) -> unsigned { return (unsigned)__builtin_amdgcn_ds_bpermute((src & 63) << 2, (int)v); };
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        // old[i + 1]: the next lane of this row, lane 0 of the next row for l == 63; word 623 pairs with the NEW word 0
+        unsigned o1 = lane_of(o[r], l + 1);
+        if (r < 9) { const unsigned nx = (unsigned)__builtin_amdgcn_readlane((int)o[r + 1], 0); o1 = l == 63 ? nx : o1; }
+        else { const unsigned n0 = (unsigned)__builtin_amdgcn_readlane((int)nw[0], 0); o1 = l == 47 ? n0 : o1; }
+        const unsigned y = (o[r] & 0x80000000u) | (o1 & 0x7fffffffu);
+        unsigned m;
+        if (r <= 2) {          // i + 397 = 64 (r + 6) + l + 13: old rows r + 6 / r + 7
+            const unsigned a = lane_of(o[r + 6], l + 13), b = lane_of(o[r + 7], l + 13);
+            m = l + 13 < 64 ? a : b;
+        } else if (r == 3) {   // i < 227 <=> l < 35: old word i + 397 (row 9, lane l + 13); else new word i - 227 (row 0, lane l - 35)
+            const unsigned a = lane_of(o[9], l + 13), b = lane_of(nw[0], l - 35);
+            m = l < 35 ? a : b;
+        } else {               // new word i - 227 = 64 (r - 4) + l + 29: rows r - 4 / r - 3
+            const unsigned a = lane_of(nw[r - 4], l + 29), b = lane_of(nw[r - 3], l - 35);
+            m = l < 35 ? a : b;
+        }
+        nw[r] = m ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < 10; r++)
+        if (64 * r + l < MT_N) new_k[64 * r + l] = nw[r];
+    __threadfence_block();   // the window refill that follows reads the block back (other lanes' words)
+}
+
+__device__ __forceinline__ unsigned mt_temper(unsigned y)
+{
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+// Raw 32-bit outputs of a generator, consumed in order.  Executed by ALL lanes of wave 0 with identical values:
 // lane i keeps word base+i of a 64-word window in a register, a word is fetched with v_readlane, and the window is
 // refilled with one coalesced load when the position leaves it (so a draw costs no memory round trip most of the time).
+// Word mode: the outputs were produced by the caller (w[0 .. n)).  Generator mode: the tree's own MT19937 stream (MtGen) -
+// w points at the stream's two key blocks, a refill tempers the state words of the block the position is in and produces
+// the next block when the position enters it; n is the limit of the current draw (see draw_call).
 struct WordStream {
     const GAS unsigned *w;
     long long n, pos;
     long long base;   // first word of the window, -1: nothing loaded
     unsigned reg;     // this lane's word of the window
+    int wn;           // words in the window
+    int gen;          // generator mode: highest block produced so far
+    int genmode;
     __device__ __forceinline__ bool has(long long k) const { return pos + k <= n; }
+    __device__ __noinline__ void refill()
+    {
+        base = pos;
+        const int lane = threadIdx.x & 63;
+        if (!genmode) {
+            const long long i = base + (long long)lane;
+            wn = 64;
+            reg = i < n ? w[i] : 0u;
+            return;
+        }
+        const long long b = pos / MT_N;               // wave-uniform; b is gen - 1, gen or gen + 1
+        const int j = (int)(pos - b * MT_N);
+        if (b > gen) {
+            mt_next_block(w + (gen & 1) * MT_N, const_cast<GAS unsigned *>(w) + ((gen + 1) & 1) * MT_N);
+            gen++;
+        }
+        wn = MT_N - j < 64 ? MT_N - j : 64;
+        reg = mt_temper(lane < wn ? w[(int)(b & 1) * MT_N + j + lane] : 0u);
+    }
     __device__ __forceinline__ unsigned next_word()
     {
         long long rel = pos - base;
-        if (base < 0 || rel < 0 || rel >= 64) {   // wave-uniform
-            base = pos;
+        if (base < 0 || rel < 0 || rel >= wn) {   // wave-uniform
+            refill();
             rel = 0;
-            const long long i = base + (long long)(threadIdx.x & 63);
-            reg = i < n ? w[i] : 0u;
         }
         const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)reg, __builtin_amdgcn_readfirstlane((int)rel));
         pos++;
@@ -52,13 +121,16 @@ struct WordStream {
         unsigned a = next_word() >> 5, b = next_word() >> 6;
         return (a * 67108864.0 + b) / 9007199254740992.0;
     }
+    // generator mode: the block that holds output pos - 1 (what get_state() shows) must stay in the two-block ring while a
+    // draw that may be undone runs: such a draw may not enter block anchor + 2
+    __device__ __forceinline__ long long undo_limit() const { return ((pos > 0 ? (pos - 1) / MT_N : 0) + 2) * MT_N; }
 };
 
 struct RunSampleDev {
     unsigned flags;
     int pad;
     long long iters;
-    const unsigned *const *np_words;
+    const unsigned *const *np_words;   // nullptr: generator mode - the trees' own MT19937 streams (MtGen) produce the words
     const long long *n_np;
     const unsigned *const *py_words;
     const long long *n_py;
@@ -210,6 +282,7 @@ struct nirrt_tree {
     Scratch *scratch_dev;  // device alias of the same memory
     double *pc_dev;        // guidance cloud (nirrt_set_cloud): pc_own (inside the arena, PC_OWN_POINTS points) or an allocation of its own
     double *pc_own;
+    MtGen *mt;             // the tree's generators (inside the arena)
     long long last_n;      // num_vertices as of the last call that reported it (kernel-variant choice only)
 };
 
@@ -433,6 +506,165 @@ extern "C" int nirrt_mt19937_fill(uint32_t *key, int32_t *pos, int64_t n, uint32
     return NIRRT_OK;
 }
 
+// ---- the trees' own generators ------------------------------------------------------------------------------------
+// one wave per tree; keys: (n, 624) words per stream, pos: (n,) - a stream whose key pointer is null is left alone
+__global__ __launch_bounds__(64) void k_set_generators(TreeDev *const *trees, const unsigned *np_key, const int *np_pos,
+                                                       const unsigned *py_key, const int *py_pos)
+{
+    MtGen *m = trees[blockIdx.x]->mt;
+    const int l = threadIdx.x;
+    for (int g = 0; g < 2; g++) {
+        const unsigned *key = g == 0 ? np_key : py_key;
+        const int *pos = g == 0 ? np_pos : py_pos;
+        if (!key) continue;
+        for (int i = l; i < MT_N; i += 64) m->key[g][0][i] = key[(size_t)blockIdx.x * MT_N + i];
+        if (l == 0) { m->pos[g] = pos[blockIdx.x]; m->gen[g] = 0; }
+    }
+}
+
+// the state as the generator's own get_state() / getstate() would show it: the block that holds the last consumed output and
+// the position inside it (1..624; 0 only if nothing was consumed from a state handed over at position 0)
+__global__ __launch_bounds__(64) void k_get_generators(TreeDev *const *trees, unsigned *np_key, int *np_pos, unsigned *py_key, int *py_pos)
+{
+    const MtGen *m = trees[blockIdx.x]->mt;
+    const int l = threadIdx.x;
+    for (int g = 0; g < 2; g++) {
+        unsigned *key = g == 0 ? np_key : py_key;
+        int *pos = g == 0 ? np_pos : py_pos;
+        if (!key) continue;
+        const long long p = m->pos[g];
+        const long long blk = p > 0 ? (p - 1) / MT_N : 0;
+        for (int i = l; i < MT_N; i += 64) key[(size_t)blockIdx.x * MT_N + i] = m->key[g][blk & 1][i];
+        if (l == 0) pos[blockIdx.x] = (int)(p - blk * MT_N);
+    }
+}
+
+// the next n outputs of stream `which` of every tree, written to out + tree * stride; the streams move on by n
+__global__ __launch_bounds__(64) void k_generator_words(TreeDev *const *trees, int which, long long n, unsigned *out, long long stride)
+{
+    MtGen *m = trees[blockIdx.x]->mt;
+    const int l = threadIdx.x;
+    WordStream ws = {(const GAS unsigned *)&m->key[which][0][0], 0, m->pos[which], -1, 0u, 0, m->gen[which], 1};
+    unsigned *o = out + (size_t)blockIdx.x * (size_t)stride;
+    long long done = 0;
+    while (done < n) {   // a window (the rest of a block, at most 64 outputs) per trip
+        ws.refill();
+        const long long take = ws.wn < n - done ? ws.wn : n - done;
+        if (l < take) o[done + l] = ws.reg;
+        done += take;
+        ws.pos += take;
+    }
+    if (l == 0) { m->pos[which] = ws.pos; m->gen[which] = ws.gen; }
+}
+
+namespace {
+// trees of one device -> device array of their descriptors (launch scratch from the pool)
+struct TreeList {
+    TreeDev **d = nullptr;
+    size_t got = 0;
+    int device = 0;
+    ~TreeList() { if (d) g_scratch.give(device, got, d); }
+};
+}
+static int tree_list(nirrt_tree *const *trees, int32_t n_trees, const char *who, TreeList &tl)
+{
+    if (!trees || n_trees <= 0) { g_err = std::string(who) + ": no trees"; return NIRRT_E_ARG; }
+    nirrt_tree *t0 = trees[0];
+    for (int i = 0; i < n_trees; i++)
+        if (!trees[i] || trees[i]->device != t0->device) { g_err = std::string(who) + ": all trees must live on one device"; return NIRRT_E_ARG; }
+    HIPCHK(hipSetDevice(t0->device));
+    for (int i = 0; i < n_trees; i++) HIPCHK(hipStreamSynchronize(trees[i]->stream));
+    std::vector<TreeDev *> ptrs((size_t)n_trees);
+    for (int i = 0; i < n_trees; i++) ptrs[(size_t)i] = trees[i]->dev;
+    tl.device = t0->device;
+    HIPCHK(g_scratch.take(t0->device, sizeof(TreeDev *) * (size_t)n_trees, (void **)&tl.d, &tl.got));
+    HIPCHK(hipMemcpyAsync(tl.d, ptrs.data(), sizeof(TreeDev *) * (size_t)n_trees, hipMemcpyHostToDevice, t0->stream));
+    return NIRRT_OK;
+}
+
+/* np.random.set_state / random.setstate for the trees' own generators: (key, pos) as get_state() / getstate() expose them */
+extern "C" int nirrt_set_generators(nirrt_tree *const *trees, int32_t n_trees, const uint32_t *np_key, const int32_t *np_pos,
+                                    const uint32_t *py_key, const int32_t *py_pos)
+{
+    TreeList tl;
+    int rc = tree_list(trees, n_trees, "nirrt_set_generators", tl);
+    if (rc) return rc;
+    if ((np_key && !np_pos) || (py_key && !py_pos)) { g_err = "nirrt_set_generators: a key table needs its positions"; return NIRRT_E_ARG; }
+    for (int i = 0; i < n_trees; i++)
+        if ((np_key && (np_pos[i] < 0 || np_pos[i] > MT_N)) || (py_key && (py_pos[i] < 0 || py_pos[i] > MT_N))) {
+            g_err = "nirrt_set_generators: position outside 0..624";
+            return NIRRT_E_ARG;
+        }
+    hipStream_t st = trees[0]->stream;
+    const size_t kb = sizeof(uint32_t) * MT_N * (size_t)n_trees, pb = sizeof(int32_t) * (size_t)n_trees;
+    char *slab = nullptr;
+    size_t got = 0;
+    HIPCHK(g_scratch.take(tl.device, 2 * (kb + pb) + 1024, (void **)&slab, &got));
+    unsigned *d_k[2] = {(unsigned *)slab, (unsigned *)(slab + kb)};
+    int *d_p[2] = {(int *)(slab + 2 * kb), (int *)(slab + 2 * kb + ((pb + 255) & ~(size_t)255))};
+    hipError_t e = hipSuccess;
+    if (np_key) { e = hipMemcpyAsync(d_k[0], np_key, kb, hipMemcpyHostToDevice, st); if (e == hipSuccess) e = hipMemcpyAsync(d_p[0], np_pos, pb, hipMemcpyHostToDevice, st); }
+    if (e == hipSuccess && py_key) { e = hipMemcpyAsync(d_k[1], py_key, kb, hipMemcpyHostToDevice, st); if (e == hipSuccess) e = hipMemcpyAsync(d_p[1], py_pos, pb, hipMemcpyHostToDevice, st); }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_set_generators, dim3(n_trees), dim3(64), 0, st, (TreeDev *const *)tl.d, np_key ? d_k[0] : nullptr, d_p[0],
+                           py_key ? d_k[1] : nullptr, d_p[1]);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    g_scratch.give(tl.device, got, slab);
+    if (e != hipSuccess) { g_err = std::string("nirrt_set_generators: ") + hipGetErrorString(e); return NIRRT_E_HIP; }
+    return NIRRT_OK;
+}
+
+/* np.random.get_state / random.getstate of the trees' own generators */
+extern "C" int nirrt_get_generators(nirrt_tree *const *trees, int32_t n_trees, uint32_t *np_key, int32_t *np_pos, uint32_t *py_key,
+                                    int32_t *py_pos)
+{
+    TreeList tl;
+    int rc = tree_list(trees, n_trees, "nirrt_get_generators", tl);
+    if (rc) return rc;
+    if ((np_key && !np_pos) || (py_key && !py_pos)) { g_err = "nirrt_get_generators: a key table needs its positions"; return NIRRT_E_ARG; }
+    hipStream_t st = trees[0]->stream;
+    const size_t kb = sizeof(uint32_t) * MT_N * (size_t)n_trees, pb = sizeof(int32_t) * (size_t)n_trees;
+    char *slab = nullptr;
+    size_t got = 0;
+    HIPCHK(g_scratch.take(tl.device, 2 * (kb + pb) + 1024, (void **)&slab, &got));
+    unsigned *d_k[2] = {(unsigned *)slab, (unsigned *)(slab + kb)};
+    int *d_p[2] = {(int *)(slab + 2 * kb), (int *)(slab + 2 * kb + ((pb + 255) & ~(size_t)255))};
+    hipLaunchKernelGGL(k_get_generators, dim3(n_trees), dim3(64), 0, st, (TreeDev *const *)tl.d, np_key ? d_k[0] : nullptr, d_p[0],
+                       py_key ? d_k[1] : nullptr, d_p[1]);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && np_key) { e = hipMemcpyAsync(np_key, d_k[0], kb, hipMemcpyDeviceToHost, st); if (e == hipSuccess) e = hipMemcpyAsync(np_pos, d_p[0], pb, hipMemcpyDeviceToHost, st); }
+    if (e == hipSuccess && py_key) { e = hipMemcpyAsync(py_key, d_k[1], kb, hipMemcpyDeviceToHost, st); if (e == hipSuccess) e = hipMemcpyAsync(py_pos, d_p[1], pb, hipMemcpyDeviceToHost, st); }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    g_scratch.give(tl.device, got, slab);
+    if (e != hipSuccess) { g_err = std::string("nirrt_get_generators: ") + hipGetErrorString(e); return NIRRT_E_HIP; }
+    return NIRRT_OK;
+}
+
+/* the next n_words raw outputs of every tree's numpy (which = 0) or python (which = 1) generator, produced on the device */
+extern "C" int nirrt_generator_words(nirrt_tree *const *trees, int32_t n_trees, int32_t which, int64_t n_words, uint32_t *out,
+                                     int64_t stride, int32_t out_on_device)
+{
+    if ((which != 0 && which != 1) || n_words < 0 || stride < n_words || (n_words > 0 && !out)) { g_err = "nirrt_generator_words: bad arguments"; return NIRRT_E_ARG; }
+    TreeList tl;
+    int rc = tree_list(trees, n_trees, "nirrt_generator_words", tl);
+    if (rc || n_words == 0) return rc;
+    hipStream_t st = trees[0]->stream;
+    unsigned *d_out = out;
+    size_t got = 0;
+    const size_t bytes = sizeof(uint32_t) * (size_t)stride * (size_t)n_trees;
+    if (!out_on_device) HIPCHK(g_scratch.take(tl.device, bytes, (void **)&d_out, &got));
+    hipLaunchKernelGGL(k_generator_words, dim3(n_trees), dim3(64), 0, st, (TreeDev *const *)tl.d, (int)which, (long long)n_words, d_out,
+                       (long long)stride);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && !out_on_device) e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (!out_on_device) g_scratch.give(tl.device, got, d_out);
+    if (e != hipSuccess) { g_err = std::string("nirrt_generator_words: ") + hipGetErrorString(e); return NIRRT_E_HIP; }
+    return NIRRT_OK;
+}
+
 extern "C" int nirrt_pool_trim(void)
 {
     g_pool.trim();
@@ -525,7 +757,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     t->cap = (int)(cfg->iter_max + 1);
     t->device = cfg->device_id;
     t->stream = nullptr;
-    t->arena = nullptr; t->arena_bytes = 0; t->arena_pooled = false; t->pc_own = nullptr; t->dev = nullptr; t->self_dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->pc_dev = nullptr;
+    t->arena = nullptr; t->arena_bytes = 0; t->arena_pooled = false; t->pc_own = nullptr; t->mt = nullptr; t->dev = nullptr; t->self_dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->pc_dev = nullptr;
     const int D = t->dim;
     auto fail = [&](int rc) { nirrt_destroy(t); return rc; };
 #define HIPCHK_T(expr)                                                                        \
@@ -561,6 +793,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         want(&t->self_dev, 1);
         want(&t->near_r, (size_t)t->cap + 1);
         want(&t->pc_own, (size_t)PC_OWN_POINTS * 3);
+        want(&t->mt, 1);
         want(&h.vrec, np);
         want(&h.topo, np);
         want(&h.g_rec, np); want(&h.g_idx, np); want(&h.pos, np);
@@ -582,6 +815,8 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         for (const Piece &pc : pieces) { *pc.dst = (char *)t->arena + off; off += (pc.bytes + A - 1) / A * A; }
     }
     HIPCHK_T(hipMemset(h.vrec, 0, sizeof(VRec) * np));
+    HIPCHK_T(hipMemset(t->mt, 0, sizeof(MtGen)));   // (generator 5489-less: all-zero state until nirrt_set_generators)
+    h.mt = t->mt;
     HIPCHK_T(hipMemset(h.topo, 0, sizeof(Topo) * np));
     h.cap = t->cap;
     h.dim = D;
@@ -1058,12 +1293,14 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
     nirrt_tree *t0 = trees[0];
     const int D = t0->dim;
     hipStream_t st = t0->stream;
-    if (!a->np_words || !a->n_np || !a->np_used || !a->py_used || !a->iters_done) {
-        g_err = "nirrt_run: sampling mode needs np_words, n_np, np_used, py_used, iters_done";
+    const bool gen_mode = a->np_words == nullptr;   // the trees' own generators (nirrt_set_generators) produce the words
+    if (!a->np_used || !a->py_used || !a->iters_done || (!gen_mode && !a->n_np)) {
+        g_err = "nirrt_run: sampling mode needs np_used, py_used, iters_done (+ n_np with np_words)";
         return NIRRT_E_ARG;
     }
+    if (gen_mode && a->py_words) { g_err = "nirrt_run: py_words without np_words (generator mode uses the trees' own streams for both)"; return NIRRT_E_ARG; }
     const bool need_py = (a->flags & NIRRT_F_IRRT) && D == 2;
-    if (need_py && (!a->py_words || !a->n_py)) { g_err = "nirrt_run: 2D IRRT* sampling needs py_words"; return NIRRT_E_ARG; }
+    if (!gen_mode && need_py && (!a->py_words || !a->n_py)) { g_err = "nirrt_run: 2D IRRT* sampling needs py_words"; return NIRRT_E_ARG; }
     std::vector<std::pair<void *, size_t>> to_free;
     const int dev_id = t0->device;
     auto cleanup = [&]() { for (auto &p : to_free) g_scratch.give(dev_id, p.second, p.first); to_free.clear(); };
@@ -1177,7 +1414,7 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         const int o = g.b0;
         rd.iters_each = d_each ? d_each + o : nullptr;
         rd.flags = a->flags; rd.pad = 0; rd.iters = a->iters;
-        rd.np_words = d_npp + o; rd.n_np = d_nnp + o; rd.py_words = a->py_words ? d_pyp + o : nullptr; rd.n_py = d_npy + o;
+        rd.np_words = gen_mode ? nullptr : d_npp + o; rd.n_np = d_nnp + o; rd.py_words = a->py_words ? d_pyp + o : nullptr; rd.n_py = d_npy + o;
         rd.np_used = d_npu + o; rd.py_used = d_pyu + o; rd.cost_trace = d_trace ? d_trace + (size_t)o * (size_t)a->iters : nullptr;
         rd.iters_done = d_done + o; rd.stop_code = d_stop + o;
         HIPCHK_R(hipEventCreate(&g.e0));

@@ -10,10 +10,10 @@ Public state after planning, like the reference: .vertices ((1+iter_max, D) f64)
 
 Where the loop runs (``mode``):
   "resident" (default for RRT*/IRRT*): the whole `for k in range(iter_max)` runs in ONE persistent
-      kernel; sampling happens in the kernel from the raw MT19937 outputs of the process-global
-      numpy / python generators, which are then advanced by exactly what was consumed
-      (nirrt_star_amd/sampling.py) - `np.random.seed(s); random.seed(s)` therefore mean what they
-      mean for the reference.  NIRRT* runs the same way: its sampling policy (cloud / informed / free) is in
+      kernel; sampling happens in the kernel from the process-global numpy / python generators, whose
+      MT19937 states move into the tree for the launch (twist and tempering run on the device) and
+      back afterwards - `np.random.seed(s); random.seed(s)` therefore mean what they mean for the
+      reference, and get_state() afterwards shows what the reference's own loop would have left.  NIRRT* runs the same way: its sampling policy (cloud / informed / free) is in
       the kernel too, which returns to the host only when the guidance cloud is due for a PointNet++ refresh.
   "step": host Python loop; sampling with the reference's own numpy / random calls, one fused HIP
       kernel per iteration (nearest -> steer -> ... -> rewire).
@@ -161,49 +161,52 @@ class _HipPlanner:
         self._vcache = {0: self.x_start.copy()}
 
     def _resident(self, iters, flags, want_trace=False):
-        """run `iters` loop bodies in the persistent kernel, feeding it the global generators'
-        upcoming raw outputs and advancing them afterwards; resumes if a word budget runs dry."""
+        """run `iters` loop bodies in the persistent kernel.  The reference draws from the process-global generators inside
+        its loop; here their states move into the tree (np.random.get_state() / random.getstate() -> nirrt_set_generators), the
+        kernel draws from them where they are (twist and tempering on the device), and they move back afterwards - the
+        global generators end up exactly where the reference's own loop would have left them."""
         D = self.dim
         done_total = 0
         traces = []
         ms = 0.0
         need_py = D == 2 and (flags & _hip.F_IRRT)
-        grow = 1   # window multiplier: raised when not even ONE draw fitted into the words handed over
-        while done_total < iters:
-            left = iters - done_total
-            npw = sampling.peek_np_words((min(left, 65536) * D * 2 * (40 if (D == 3 and flags & _hip.F_IRRT) else 4) + 4096) * grow)
-            pyw = sampling.peek_py_words((min(left, 65536) * 16 + 4096) * grow) if need_py else None
-            res = _hip.run_sampling([self.tree], left, [npw], [pyw] if need_py else None, flags=flags, want_trace=want_trace)
-            d = int(res["iters_done"][0])
-            sampling.advance_np_words(int(res["np_used"][0]))
+        _hip.set_generators([self.tree], [_hip.np_state()], [_hip.py_state()] if need_py else None)
+
+        def hand_back():
+            nk, npos, pk, ppos = _hip.get_generators([self.tree], want_py=bool(need_py))
+            _hip.set_np_state(nk[0], npos[0])
             if need_py:
-                sampling.advance_py_words(int(res["py_used"][0]))
-            ms += res["kernel_ms"]
-            if want_trace:
-                traces.append(res["cost_trace"][0, :d])
-            before = done_total
-            done_total += d
-            for kk in range(before // _PRINT_EVERY + 1, done_total // _PRINT_EVERY + 1):
-                self._progress(kk * _PRINT_EVERY)
-            st = int(res["status"][0])
-            if st == _hip.E_CAPACITY:
-                raise IndexError("tree capacity (1+iter_max vertices) exceeded")   # the reference raises IndexError here too
-            if st == _hip.E_ARG:
-                raise ValueError("high <= 0")   # empty predicted cloud: np.random.randint(0, 0) in the reference
-            if st == _hip.E_CLOUD:
-                self._refresh_cloud_on_device()
-                continue
-            if st == 0 and d < left:   # STOP_FIRST fired
-                break
-            if d == 0 and st == _hip.E_STREAM:
-                # the very first draw of the launch exhausted the window (rejection sampling in a nearly full world):
-                # hand over a larger one next time instead of re-offering the same words for ever
-                grow *= 4
-                if grow > 1024:
-                    raise _hip.NirrtError("sampling cannot make progress: one draw needs more than %d generator words "
-                                          "(free space empty?)" % len(npw))
-            elif d > 0:
-                grow = 1
+                _hip.set_py_state(pk[0], ppos[0])
+
+        try:
+            while done_total < iters:
+                left = iters - done_total
+                res = _hip.run_sampling([self.tree], left, None, None, flags=flags, want_trace=want_trace)
+                d = int(res["iters_done"][0])
+                ms += res["kernel_ms"]
+                if want_trace:
+                    traces.append(res["cost_trace"][0, :d])
+                before = done_total
+                done_total += d
+                for kk in range(before // _PRINT_EVERY + 1, done_total // _PRINT_EVERY + 1):
+                    self._progress(kk * _PRINT_EVERY)
+                st = int(res["status"][0])
+                if st == _hip.E_CAPACITY:
+                    raise IndexError("tree capacity (1+iter_max vertices) exceeded")   # the reference raises IndexError here too
+                if st == _hip.E_ARG:
+                    raise ValueError("high <= 0")   # empty predicted cloud: np.random.randint(0, 0) in the reference
+                if st == _hip.E_CLOUD:
+                    hand_back()                     # update_point_cloud draws its candidates from the global generator
+                    self._refresh_cloud_on_device()
+                    _hip.set_generators([self.tree], [_hip.np_state()], None)
+                    continue
+                if st == _hip.E_STREAM:
+                    # one draw rejected 2^22 generator outputs in a row (the reference would spin for ever in SampleFree)
+                    raise _hip.NirrtError("sampling cannot make progress: one draw rejected 2^22 generator outputs (free space empty?)")
+                if st == 0 and d < left:   # STOP_FIRST fired
+                    break
+        finally:
+            hand_back()
         self.last_kernel_ms = ms
         self._sync()
         return done_total, (np.concatenate(traces) if want_trace and traces else np.zeros(0))
