@@ -10,8 +10,10 @@ kernel.  `--algo rrt` runs plain RRT* on the same problems (uniform sampling, no
 `--dim 3` the random_3d worlds (boxes + balls), `--world b30r16` the r in [16, 24] circles of SURVEY.md §8d.
 
 One "step" = one pass of that loop over the whole batch (B x iters iterations), starting from fresh
-one-vertex trees.  Inputs (the raw MT19937 outputs of each problem's seeded numpy / python generators)
-are resident in HBM before the timed region.  N GPUs = N processes (torch.distributed / RCCL), each
+one-vertex trees and freshly seeded generators: each problem's numpy / python MT19937 states (2 x 2.5 KB, seeded
+like the reference seeds its process-global ones) are uploaded inside the step and every output the loop
+consumes is produced by the tree's own wave (twist + tempering on the device) - no generator output exists
+on the host or in HBM ahead of time.  N GPUs = N processes (torch.distributed / RCCL), each
 with its own B problems (weak scaling); the only collectives are the timing protocol's barrier /
 max-reduce and a gather of per-rank iteration counts.  `--gpus N` without a launcher re-executes itself
 under `python -m torch.distributed.run --nproc-per-node N` (the driver's own torchrun launch is used as is).
@@ -125,27 +127,36 @@ def make_problem(args, pid, cache=None):
 
 
 def word_budgets(args):
+    """raw generator outputs the ORACLE is handed per problem (oracle/cpu_bench.py, scripts/perf_*.py, the full-size tests): the
+    C restatement consumes pre-drawn words; the device draws from the trees' own generators and needs no budget"""
     D, it = args.dim, args.iters
     if args.algo == "rrt":
         return it * D * 2 * 4 + 4096, 0          # four SampleFree attempts per iteration (crowded worlds reject 2 of 3)
     if D == 2:
         # SampleFree (4 words per attempt) until the first solution, then python-random unit disk.  In the r in [16, 24] worlds
-        # only ~39 % of the range is free (10 words per sample, 14 in the most crowded ones) and a tree without a solution
-        # keeps drawing that way for the whole run
-        # ... and once it has one, the informed sampler's unit-disk points (5.1 python words each) are rejected at the same
-        # rate: 13 words per sample on average, 18+ in the most crowded worlds (measured: 17 % of the trees ran out of a
-        # 14-word budget, having done 82 % of their iterations on average)
+        # only ~39 % of the range is free (10 words per sample, 14 in the most crowded ones), and the informed sampler's
+        # unit-disk points (5.1 python words each) are rejected at the same rate: 13 words per sample on average, 18+ in the
+        # most crowded worlds
         crowded = getattr(args, "world", "b30") == "b30r16"
         return it * (24 if crowded else 12) + 4096, it * (48 if crowded else 14) + 4096
     return it * 6 * 40 + 4096, 0                 # 3D informed sampling stays on the numpy stream
 
 
 def problem_words(args, pid, n_np, n_py):
-    """raw generator outputs of problem `pid`: np.random.seed(1000 + pid); random.seed(1000 + pid)"""
+    """raw generator outputs of problem `pid`: np.random.seed(1000 + pid); random.seed(1000 + pid) (oracle side only)"""
     from nirrt_star_amd import sampling
     np.random.seed(1000 + pid)
     random.seed(1000 + pid)
     return sampling.peek_np_words(n_np), (sampling.peek_py_words(n_py) if n_py else None)
+
+
+def problem_generators(pids):
+    """(numpy states, python states) of the problems' generators right after `np.random.seed(1000 + pid); random.seed(1000 + pid)`
+    (what the reference's evaluation loop does before planning a problem): per problem a (key[624], pos) pair"""
+    from nirrt_star_amd import _hip
+    np_st = [_hip.np_state(np.random.RandomState(1000 + pid)) for pid in pids]
+    py_st = [_hip.py_state(random.Random(1000 + pid)) for pid in pids]
+    return np_st, py_st
 
 
 def respawn_under_torchrun(args):
@@ -243,29 +254,11 @@ def main():
             first_order = sorted(range(B), key=lambda b: (not free_line[b], b))
         if args.free_lanes:
             first_hint = np.array([args.free_lanes if free_line[b] else 0 for b in first_order], dtype=np.int32)
-    # inputs: each problem's generator outputs (np.random.seed(s); random.seed(s)), resident in HBM
+    # inputs: each problem's two generators seeded like the reference seeds its process-global ones (np.random.seed(s);
+    # random.seed(s)).  Only the 2 x 2.5 KB states exist on the host; every output is produced on the device inside the loop.
     t_inputs = time.perf_counter()
-    n_np, n_py = word_budgets(args)
-    py_stride = max(n_py, 1)
-    d_np = torch.empty((B, n_np), dtype=torch.int32, device=dev)
-    d_py = torch.empty((B, py_stride), dtype=torch.int32, device=dev)
-    CH = 256   # generated and uploaded in chunks: the host never holds more than ~1 GB of the ~16 GB of words
-    for c0 in range(0, B, CH):
-        c1 = min(B, c0 + CH)
-        h_np = np.empty((c1 - c0, n_np), dtype=np.uint32)
-        h_py = np.empty((c1 - c0, py_stride), dtype=np.uint32)
-        for b in range(c0, c1):
-            w_np, w_py = problem_words(args, probs[b]["pid"], n_np, n_py)
-            h_np[b - c0] = w_np
-            if n_py:
-                h_py[b - c0] = w_py
-        d_np[c0:c1].copy_(torch.from_numpy(h_np.view(np.int32)))
-        d_py[c0:c1].copy_(torch.from_numpy(h_py.view(np.int32)))
-    np_tab = [(d_np.data_ptr() + 4 * n_np * b, n_np) for b in range(B)]
-    py_tab = [(d_py.data_ptr() + 4 * py_stride * b, n_py) for b in range(B)] if n_py else None
-    torch.cuda.synchronize()
-    del h_np, h_py
-    input_generation_s = time.perf_counter() - t_inputs   # host MT19937 outputs of every problem + upload (outside the timed region)
+    np_states, py_states = problem_generators([pr["pid"] for pr in probs])
+    input_generation_s = time.perf_counter() - t_inputs   # host: seeding 2 B generators (outside the timed region; the upload is inside)
 
     seg_len = [args.pilot, iters - args.pilot] if 0 < args.pilot < iters and B > 1 else [iters]
     n_seg = len(seg_len)
@@ -273,21 +266,17 @@ def main():
     def one_step():
         """one pass of the loop over the whole batch = n_seg launches; returns the sums / last-launch views the report needs"""
         _hip.reset_batch(trees)
-        used_np = np.zeros(B, dtype=np.int64)
-        used_py = np.zeros(B, dtype=np.int64)
+        _hip.set_generators(trees, np_states, py_states)      # np.random.seed(s); random.seed(s) of every problem
         order = list(first_order)
         hint = first_hint
         tot = {"kernel_ms": 0.0, "stats": np.zeros((B, _hip.N_STATS), dtype=np.int64), "alg_elems": np.zeros(B, dtype=np.int64),
-               "iters_done": np.zeros(B, dtype=np.int64), "seconds": np.zeros(B), "wide": 0, "narrow": 0}
+               "iters_done": np.zeros(B, dtype=np.int64), "seconds": np.zeros(B), "wide": 0, "narrow": 0, "words": 0}
         if hint is not None:   # --free-lanes: lane hints of the first (only) launch
             tot["wide"], tot["narrow"] = int(np.sum(hint == 256)), int(np.sum(hint == 128))
         for si, n_it in enumerate(seg_len):
-            nt_s = [(np_tab[b][0] + 4 * int(used_np[b]), np_tab[b][1] - int(used_np[b])) for b in order]
-            pt_s = [(py_tab[b][0] + 4 * int(used_py[b]), py_tab[b][1] - int(used_py[b])) for b in order] if py_tab else None
-            r = _hip.run_sampling([trees[b] for b in order], n_it, nt_s, pt_s, flags=flags, on_device=True, lanes_hint=hint)
+            r = _hip.run_sampling([trees[b] for b in order], n_it, flags=flags, lanes_hint=hint)
             idx = np.asarray(order)
-            used_np[idx] += r["np_used"]
-            used_py[idx] += r["py_used"]
+            tot["words"] += int(r["np_used"].sum()) + int(r["py_used"].sum())
             secs = (r["stats"][:, 15] - r["stats"][:, 14]) / 1e8
             tot["kernel_ms"] += r["kernel_ms"]
             tot["stats"][idx] += r["stats"]
@@ -369,11 +358,11 @@ def main():
             "reference_python_survey_container_its": REF_PY[args.algo],
         }
         if short:
-            out["warning"] = ("%d of %d trees stopped before iteration %d (generator words ran out): `value` counts only the iterations "
+            out["warning"] = ("%d of %d trees stopped before iteration %d (a draw rejected 2^22 generator outputs, or a tree ran out of capacity): `value` counts only the iterations "
                               "that ran" % (short, B, iters))
         if not args.no_ttfs:
-            out["time_to_first_solution"] = time_to_first_solution(args, trees, np_tab, py_tab, flags)
-            out["single_tree"] = single_tree_latency(args, trees, np_tab, py_tab, flags)
+            out["time_to_first_solution"] = time_to_first_solution(args, trees, np_states, py_states, flags)
+            out["single_tree"] = single_tree_latency(args, trees, np_states, py_states, flags)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         if world == 1 and not args.no_secondary:
@@ -381,7 +370,6 @@ def main():
             for t_ in trees:
                 t_.close()
             trees = []
-            del d_np, d_py
             torch.cuda.empty_cache()
             _hip.pool_trim()
             out["secondary"] = secondary_runs(args)
@@ -509,21 +497,22 @@ def secondary_runs(args):
     return out
 
 
-def single_tree_latency(args, trees, np_tab, py_tab, flags):
+def single_tree_latency(args, trees, np_states, py_states, flags):
     """ONE problem planned alone for the full iteration count (what demo_planning_2d.py:85-90 does): the whole GPU serves one
     tree, 256-thread kernels; HIP-event time of the launch, median over the first 3 problems of the batch."""
     from nirrt_star_amd import _hip
     ms, n_fin = [], []
     for b in range(min(3, len(trees))):
         trees[b].reset()
-        r = _hip.run_sampling([trees[b]], args.iters, [np_tab[b]], [py_tab[b]] if py_tab else None, flags=flags, on_device=True)
+        _hip.set_generators([trees[b]], [np_states[b]], [py_states[b]])
+        r = _hip.run_sampling([trees[b]], args.iters, flags=flags)
         ms.append(r["kernel_ms"])
         n_fin.append(int(trees[b].n))
     return {"problems": len(ms), "iterations": args.iters, "median_seconds": float(np.median(ms)) * 1e-3,
             "iterations_per_second": args.iters / (float(np.median(ms)) * 1e-3), "final_vertices": n_fin}
 
 
-def time_to_first_solution(args, trees, np_tab, py_tab, flags):
+def time_to_first_solution(args, trees, np_states, py_states, flags):
     """Measured, not interpolated: NIRRT_F_STOP_FIRST launches on the first problems of the batch.  `single` = one
     problem per launch (the whole GPU serves one tree, 256-thread kernels): HIP-event time of the launch.  `batch` =
     the same problems in ONE launch: per-tree device clock (stats[14..15]) from the start of the tree's loop to the
@@ -535,7 +524,8 @@ def time_to_first_solution(args, trees, np_tab, py_tab, flags):
     single_ms, single_it = [], []
     for b in range(n_single):
         trees[b].reset()
-        r = _hip.run_sampling([trees[b]], cap, [np_tab[b]], [py_tab[b]] if py_tab else None, flags=fl, want_trace=True, on_device=True)
+        _hip.set_generators([trees[b]], [np_states[b]], [py_states[b]])
+        r = _hip.run_sampling([trees[b]], cap, flags=fl, want_trace=True)
         it = int(r["iters_done"][0])
         if it > 0 and np.isfinite(r["cost_trace"][0, it - 1]):
             single_ms.append(r["kernel_ms"])
@@ -543,8 +533,8 @@ def time_to_first_solution(args, trees, np_tab, py_tab, flags):
     sub = list(range(n_batch))
     for b in sub:
         trees[b].reset()
-    r = _hip.run_sampling([trees[b] for b in sub], cap, [np_tab[b] for b in sub], [py_tab[b] for b in sub] if py_tab else None,
-                          flags=fl, want_trace=True, on_device=True)
+    _hip.set_generators([trees[b] for b in sub], [np_states[b] for b in sub], [py_states[b] for b in sub])
+    r = _hip.run_sampling([trees[b] for b in sub], cap, flags=fl, want_trace=True)
     its = r["iters_done"]
     found = np.array([its[j] > 0 and np.isfinite(r["cost_trace"][j, its[j] - 1]) for j in range(len(sub))])
     secs = (r["stats"][:, 15] - r["stats"][:, 14]) / 1e8

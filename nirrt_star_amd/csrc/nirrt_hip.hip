@@ -86,7 +86,7 @@ struct WordStream {
     int gen;          // generator mode: highest block produced so far
     int genmode;
     __device__ __forceinline__ bool has(long long k) const { return pos + k <= n; }
-    __device__ __noinline__ void refill()
+    __device__ __forceinline__ void refill()   // (inline: an out-of-line member would force the stream's state out of registers)
     {
         base = pos;
         const int lane = threadIdx.x & 63;
