@@ -401,17 +401,10 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
         t.set_informed(*frames[-1])
         trees.append(t)
 
-    # inputs: every step starts from freshly seeded generators; their look-ahead of raw outputs (what the loop's first window
-    # asks for) is produced and made resident in HBM BEFORE the timed region, like the word tables of the other workloads
+    # inputs: every step starts from freshly seeded generators (np.random.seed(s); random.seed(s); torch.manual_seed(s) per
+    # problem); run_batch hands their states to the trees inside the timed step, every output is produced on the device
     dev = torch.device("cuda", local_rank)
-    n_np0 = (min(iters, 65536) * (8 if D == 2 else 240) + 4096)
-    n_py0 = (min(iters, 65536) * 16 + 4096) if D == 2 else 0
-    primed = []
-    for _ in range(args.warmup + args.steps):
-        ss = [batch.ProblemStreams(1000 + pr["pid"]) for pr in probs]
-        for s_ in ss:
-            s_.prime(n_np0, n_py0, dev)
-        primed.append(ss)
+    primed = [[batch.ProblemStreams(1000 + pr["pid"]) for pr in probs] for _ in range(args.warmup + args.steps)]
 
     def one_step():
         _hip.reset_batch(trees)
@@ -440,7 +433,7 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (tree) / f32 (PointNet++)", "data": "synthetic",
                "config": {"workload": "%s_star -n pointnet2%s random_%dd, %d problems/GPU x %d iters, 2048-point guidance clouds, batched "
-                                      "PointNet++ refresh (synthetic weights; cloud candidates, down-sampling, network input and predictions on the device, inside the timed step), generator look-ahead resident before it"
+                                      "PointNet++ refresh (synthetic weights; generators, cloud candidates, down-sampling, network input and predictions on the device, inside the timed step)"
                                       % ("nirrt", " -c bfs" if args.algo == "nirrt_c" else "", D, B, iters),
                           "key": config_key(args), "trees_per_gpu": B, "iters": iters, "dim": D,
                           "launches_per_step": float(np.mean(launches)), "forwards_per_step": (guidance.calls - f0) / args.steps,

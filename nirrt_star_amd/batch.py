@@ -3,8 +3,8 @@ bench.py): RRT* / IRRT* / NRRT* / NIRRT*[-C] trees advance together in persisten
 from ITS OWN seeded generator pair, exactly like one reference process per problem would consume
 `np.random.seed(s); random.seed(s); torch.manual_seed(s)`.
 
-What the host does between launches:
-  * a tree whose word window ran dry (NIRRT_E_STREAM) gets the next window of its generators and resumes;
+The generators themselves live in the trees (nirrt_set_generators): the loop and the cloud generation draw from them in
+HBM, no generator output is produced on the host.  What the host does between launches:
   * NIRRT* trees whose best cost dropped below pc_update_cost_ratio * c_update (NIRRT_E_CLOUD, nirrt_star_png_2d.py:114-116)
     get a new guidance cloud: candidates are drawn from the tree's OWN numpy stream (so the stream position is what the
     reference's single process would have), all due clouds are down-sampled in one launch (k_fps_f64, one workgroup per
@@ -23,180 +23,79 @@ from . import _hip
 from . import pointcloud as pcu
 
 
-def _untemper(y):
-    """MT19937 outputs -> the state words they were tempered from (vectorised inverse of genrand's four xor-shifts)"""
-    y = np.array(y, dtype=np.uint32)
-    y ^= y >> np.uint32(18)
-    y ^= (y << np.uint32(15)) & np.uint32(0xEFC60000)
-    t = y.copy()
-    for _ in range(4):
-        t = y ^ ((t << np.uint32(7)) & np.uint32(0x9D2C5680))
-    y = t
-    t = y.copy()
-    for _ in range(2):
-        t = y ^ (t >> np.uint32(11))
-    return t
-
-
 class ProblemStreams:
     """the generator pair of ONE problem: numpy legacy RandomState + python Random (+ torch CPU generator for the FPS
     start indices of its PointNet++ forwards), all seeded like the reference seeds its process-global ones.
 
-    The kernels consume raw 32-bit MT19937 outputs, a launch needs a window of them ahead of the current position, and a
-    batch is resumed many times (cloud refreshes): the look-ahead is therefore generated ONCE and kept - on the host and as a
-    resident copy in HBM that launches (and the device-side cloud generation) read in place (`window_np/py(n, device)` ->
-    (address, count)).  What the device consumed is booked with advance_np/py(): the position inside the look-ahead moves at
-    once, the host generator itself follows lazily - by an O(1) state jump - when somebody looks at it (`rs` / `py`: host-side
-    cloud candidates, the end of a run) or the look-ahead has to be regenerated.  `rs` / `py` always return the generator at
-    the problem's true position; if a caller draws from them, the window is found again inside the look-ahead by its next
-    outputs."""
+    The numpy / python generators LIVE ON THE DEVICE while a tree plans the problem: run_batch hands their states to the tree
+    (nirrt_set_generators), the persistent loop and the device-side cloud generation draw from them in HBM (twist and
+    tempering in the tree's wave; no output is ever produced on the host), and the host objects fall behind.  `rs` / `py`
+    return the host generator AT THE PROBLEM'S TRUE POSITION: the state is fetched from the tree first
+    (nirrt_get_generators), and because the caller may draw from it, it is handed back to the tree before the next launch
+    (`push_if_touched`)."""
 
     def __init__(self, seed):
         self.seed = int(seed)
         self._rs = np.random.RandomState(self.seed)
         self._pyg = random.Random(self.seed)
         self._torch = None
-        self._npc = {"host": None, "dev": None, "off": 0, "pending": 0, "touched": False}
-        self._pyc = {"host": None, "dev": None, "off": 0, "pending": 0, "touched": False}
+        self._tree = None                 # the tree that owns the states right now (None: the host objects are current)
+        self._behind = [False, False]     # the device has drawn since the host object was last synchronised
+        self._touched = [False, False]    # the host object was handed out since: the tree needs its state back
+
+    # ---- ownership ----
+    def bound_to(self, tree):
+        return self._tree is tree
+
+    def bind(self, tree):
+        """(run_batch) the tree takes over; the caller uploads np_state() / py_state() in one batched call"""
+        self._tree = tree
+        self._behind = [False, False]
+        self._touched = [False, False]
+
+    def np_state(self):
+        return _hip.np_state(self._rs)
+
+    def py_state(self):
+        return _hip.py_state(self._pyg)
+
+    def device_drew(self, np_too=True, py_too=True):
+        if self._tree is not None:
+            self._behind[0] = self._behind[0] or np_too
+            self._behind[1] = self._behind[1] or py_too
+
+    def absorb(self, np_st=None, py_st=None):
+        """states fetched from the tree (batched by the caller)"""
+        if np_st is not None:
+            _hip.set_np_state(np_st[0], np_st[1], self._rs)
+            self._behind[0] = False
+        if py_st is not None:
+            _hip.set_py_state(py_st[0], py_st[1], self._pyg)
+            self._behind[1] = False
+
+    def _pull(self, which):
+        if self._tree is not None and self._behind[which]:
+            nk, npos, pk, ppos = _hip.get_generators([self._tree], want_np=which == 0, want_py=which == 1)
+            if which == 0:
+                self.absorb(np_st=(nk[0], npos[0]))
+            else:
+                self.absorb(py_st=(pk[0], ppos[0]))
 
     # ---- the generators themselves ----
     @property
     def rs(self):
-        self._settle(self._npc, True)
-        self._npc["touched"] = True      # the caller may draw from it
+        self._pull(0)
+        self._touched[0] = self._tree is not None     # the caller may draw from it
         return self._rs
 
     @property
     def py(self):
-        self._settle(self._pyc, False)
-        self._pyc["touched"] = True
+        self._pull(1)
+        self._touched[1] = self._tree is not None
         return self._pyg
 
-    def _set_from_outputs(self, is_np, last624):
-        """any 624 consecutive outputs determine an MT19937 generator: state rebuilt from them, position 624 = "block used up\""""
-        key = _untemper(last624)
-        if is_np:
-            st = self._rs.get_state(legacy=True)
-            self._rs.set_state((st[0], key, 624, st[3], st[4]))
-        else:
-            st = self._pyg.getstate()
-            self._pyg.setstate((st[0], tuple(int(v) for v in key) + (624,), st[2]))
-
-    def _settle(self, c, is_np):
-        """move the host generator past the outputs the device consumed since it was last looked at"""
-        n = c["pending"]
-        if not n:
-            return
-        c["pending"] = 0
-        end = c["off"]            # already counts the pending outputs
-        if c["host"] is not None and 624 <= end <= len(c["host"]):
-            self._set_from_outputs(is_np, c["host"][end - 624:end])
-        elif is_np:
-            self._rs.randint(0, 1 << 32, size=int(n), dtype=np.uint32)
-        else:
-            self._pyg.getrandbits(32 * int(n))
-
-    # ---- raw outputs ahead of the current position (nothing is consumed) ----
-    def _gen(self, is_np, n):
-        """the next n raw outputs of the numpy / python stream; the generator itself stays where it is.  Both are MT19937
-        (CPython: getrandbits(32 k) = k consecutive outputs, least significant word first): the words come from the library's
-        host-side generator (nirrt_mt19937_fill) started in a copy of the stream's state."""
-        if is_np:
-            st = self._rs.get_state(legacy=True)
-            key, pos = st[1], int(st[2])
-        else:
-            st = self._pyg.getstate()[1]
-            key, pos = np.array(st[:624], dtype=np.uint32), int(st[624])
-        return _hip.mt19937_outputs(key, pos, n)[0]
-
-    def _window(self, c, is_np, n, device):
-        n = int(n)
-        if c["touched"]:
-            # somebody held the generator itself (cloud candidates drawn on the host): find its next outputs in the look-ahead
-            c["touched"] = False
-            if c["host"] is not None:
-                found = -1
-                probe = self._gen(is_np, 8)
-                h, o = c["host"], c["off"]
-                if np.array_equal(h[o:o + 8], probe):
-                    found = o
-                else:
-                    for k in np.flatnonzero(h[o:len(h) - 7] == probe[0]):
-                        if np.array_equal(h[o + k:o + k + 8], probe):
-                            found = o + int(k)
-                            break
-                if found < 0:
-                    c["host"] = c["dev"] = None
-                else:
-                    c["off"] = found
-        if c["host"] is None or len(c["host"]) - c["off"] < n:
-            # from the current position; replaces what was left.  Rare: windows shrink as a run proceeds, and the numpy
-            # look-ahead carries headroom for the candidates of the cloud refreshes in between
-            self._settle(c, is_np)
-            c["host"] = self._gen(is_np, n + (min(n // 2, 1 << 20) + 131072 if is_np else 0))
-            c["dev"] = None
-            c["off"] = 0
-        if device is None:
-            return c["host"][c["off"]:c["off"] + n]
-        if c["dev"] is None:
-            import torch
-            c["dev"] = torch.from_numpy(c["host"].view(np.int32)).to(device)
-        return (c["dev"].data_ptr() + 4 * c["off"], n)
-
-    def window_np(self, n, device=None):
-        """the next n outputs of the numpy stream: host array, or (device address, n) of the resident copy"""
-        return self._window(self._npc, True, n, device)
-
-    def window_py(self, n, device=None):
-        """the next n 32-bit outputs of the python stream"""
-        return self._window(self._pyc, False, n, device)
-
-    def prime(self, n_np, n_py, device):
-        """produce and upload the look-ahead before a run starts (bench: inputs resident before the timed region)"""
-        self.window_np(n_np, device)
-        if n_py:
-            self.window_py(n_py, device)
-
-    def peek_np(self, n):
-        self._settle(self._npc, True)
-        return self._gen(True, n)
-
-    def peek_py(self, n):
-        self._settle(self._pyc, False)
-        return self._gen(False, n)
-
-    # ---- consuming: "n outputs later" ----
-    def _advance(self, c, is_np, n):
-        n = int(n)
-        if not n:
-            return
-        if c["touched"]:               # position inside the look-ahead unknown until the next window: move the generator itself
-            self._settle(c, is_np)
-            if is_np:
-                self._rs.randint(0, 1 << 32, size=n, dtype=np.uint32)
-            else:
-                self._pyg.getrandbits(32 * n)
-            return
-        c["pending"] += n
-        if c["host"] is not None:
-            c["off"] += n
-            if c["off"] > len(c["host"]):      # ran past the look-ahead (cannot happen for windows handed out): settle by drawing
-                over = c["off"] - len(c["host"])
-                c["off"] = len(c["host"])
-                c["pending"] -= over
-                self._settle(c, is_np)
-                if is_np:
-                    self._rs.randint(0, 1 << 32, size=over, dtype=np.uint32)
-                else:
-                    self._pyg.getrandbits(32 * over)
-                c["host"] = c["dev"] = None
-                c["off"] = 0
-
-    def advance_np(self, n):
-        self._advance(self._npc, True, n)
-
-    def advance_py(self, n):
-        self._advance(self._pyc, False, n)
+    def touched(self):
+        return self._touched[0] or self._touched[1]
 
     def fps_start(self, n_points):
         """the reference's `torch.randint(0, N, (B,))` of one forward over ONE cloud (pointnet2_utils.py:77), from this
@@ -205,6 +104,43 @@ class ProblemStreams:
         if self._torch is None:
             self._torch = torch.Generator().manual_seed(self.seed)
         return torch.randint(0, int(n_points), (1,), generator=self._torch, dtype=torch.long)
+
+
+def hand_over(trees, streams, only_touched=False):
+    """generator states host -> trees in ONE call: every stream not yet owned by its tree (a fresh problem), and every
+    stream whose host object was handed out since the last launch (host-side cloud candidates)"""
+    np_i, py_i = [], []
+    for i, (t, s) in enumerate(zip(trees, streams)):
+        if not s.bound_to(t):
+            if only_touched:
+                continue
+            s.bind(t)
+            np_i.append(i)
+            py_i.append(i)
+        else:
+            if s._touched[0]:
+                np_i.append(i)
+            if s._touched[1]:
+                py_i.append(i)
+            s._touched = [False, False]
+    both = [i for i in np_i if i in set(py_i)]
+    only_np = [i for i in np_i if i not in set(both)]
+    only_py = [i for i in py_i if i not in set(both)]
+    if both:
+        _hip.set_generators([trees[i] for i in both], [streams[i].np_state() for i in both], [streams[i].py_state() for i in both])
+    if only_np:
+        _hip.set_generators([trees[i] for i in only_np], [streams[i].np_state() for i in only_np], None)
+    if only_py:
+        _hip.set_generators([trees[i] for i in only_py], None, [streams[i].py_state() for i in only_py])
+
+
+def fetch_np(trees, streams, idx):
+    """the numpy generators of the problems `idx` brought up to date on the host in one call (host-side candidates)"""
+    idx = [i for i in idx if streams[i]._tree is not None and streams[i]._behind[0]]
+    if idx:
+        nk, npos, _, _ = _hip.get_generators([trees[i] for i in idx], want_py=False)
+        for k, i in enumerate(idx):
+            streams[i].absorb(np_st=(nk[k], npos[k]))
 
 
 class Guidance:
@@ -229,10 +165,12 @@ class Guidance:
         self.seconds = {"candidates": 0.0, "downsample": 0.0, "classify": 0.0, "set_cloud": 0.0}   # host wall time per refresh stage
 
     # ---- cloud generation -------------------------------------------------------------------------------------------
-    def _host_clouds(self, idx, problems, streams, c_best, frames):
-        """candidates from the problem's own numpy generator on the host + one batched down-sampling launch (the 3D ellipsoid
-        candidates go through sin / cos and stay with the host's libm; also the path when no resident look-ahead is wanted)"""
+    def _host_clouds(self, idx, problems, trees, streams, c_best, frames):
+        """candidates from the problem's own numpy generator on the host + one batched down-sampling launch (NIRRT_HOST_CLOUDS=1:
+        the host path the reference-generated fixtures pin).  The generators come back from their trees first and return
+        there before the next launch (hand_over)."""
         from . import pointops
+        fetch_np(trees, streams, idx)
         cands = []
         for i in idx:
             pr, rng = problems[i], streams[i].rs
@@ -259,19 +197,22 @@ class Guidance:
         masks = pointops.farthest_point_down_sample_f64_batch(cands, self.n_points, self.device_id)
         return [c[m] for c, m in zip(cands, masks)]          # (n_b, 3) each
 
-    def _device_jobs(self, idx, problems, streams, c_best, frames, dev):
-        """nirrt_cloud_job of every problem in idx (2D: whole image / ellipse; 3D: whole box), reading the generator outputs from
-        the problem's resident look-ahead at its current position"""
+    def cloud_words(self):
+        """generator outputs one cloud's candidates consume: n_raw points x dim doubles x 2 words"""
+        n_raw = self.n_points * self.scale
+        return n_raw, 2 * (2 if self.dim == 2 else 3) * n_raw
+
+    def _device_jobs(self, idx, problems, word_addr, c_best, frames, dev):
+        """nirrt_cloud_job of every problem in idx (2D: whole image / ellipse; 3D: whole box / ellipsoid); word_addr[k] = device
+        address of the generator outputs job k reads (nirrt_generator_words of the problem's tree)"""
         import torch
         from . import pointops
-        n_raw = self.n_points * self.scale
-        n_words = 2 * (2 if self.dim == 2 else 3) * n_raw
+        n_raw, n_words = self.cloud_words()
         jobs = []
-        for i in idx:
+        for k, i in enumerate(idx):
             pr = problems[i]
             j = pointops.CloudJob()
-            addr, _ = streams[i].window_np(n_words, dev)
-            j.words = addr
+            j.words = int(word_addr[k])
             if self.dim == 2:
                 if "_free_tab_dev" not in pr:
                     pr["_free_tab_dev"] = torch.from_numpy(pcu.free_block_table(pr["binary_mask"])).to(dev)
@@ -322,20 +263,27 @@ class Guidance:
         dev = torch.device("cuda", self.device_id)
         nd = len(due)
         on_dev = [j for j, i in enumerate(due) if self.device_clouds and not (self.dim == 3 and c_best[i] < np.inf)]
-        on_host = [j for j in range(nd) if j not in set(on_dev)]
+        on_dev_set = set(on_dev)
+        on_host = [j for j in range(nd) if j not in on_dev_set]
         clouds_dev = torch.zeros((nd, self.n_points, 3), dtype=torch.float64, device=dev)
         n_out = np.zeros(nd, dtype=np.int32)
         clouds = [None] * nd
         if on_dev:
             idx = [due[j] for j in on_dev]
-            jobs, n_raw, n_words = self._device_jobs(idx, problems, streams, c_best, frames, dev)
+            # what rng.random_sample / rng.uniform would consume, produced by the problems' own generators where they live
+            n_raw, n_words = self.cloud_words()
+            words = torch.empty((len(idx), n_words), dtype=torch.int32, device=dev)
+            _hip.generator_words([trees[i] for i in idx], 0, n_words, device_ptr=words.data_ptr(), stride=n_words)
+            for i in idx:
+                streams[i].device_drew(py_too=False)
+            jobs, n_raw, n_words = self._device_jobs(idx, problems, [words.data_ptr() + 4 * n_words * k for k in range(len(idx))],
+                                                     c_best, frames, dev)
             sub = clouds_dev if len(on_dev) == nd else torch.zeros((len(on_dev), self.n_points, 3), dtype=torch.float64, device=dev)
             n_cand, n_o = pointops.guidance_clouds(jobs, n_raw, self.n_points, sub, self.device_id)
             for k, j in enumerate(on_dev):
                 i = due[j]
                 if self.dim == 2 and not (c_best[i] < np.inf) and n_cand[k] < self.n_points:
                     raise ValueError("farthest_point_down_sample: %d candidates for %d samples (problem %d)" % (n_cand[k], self.n_points, i))
-                streams[i].advance_np(n_words)      # what rng.random_sample / rng.uniform would have consumed
                 n_out[j] = n_o[k]
             if sub is not clouds_dev:
                 clouds_dev[torch.as_tensor(on_dev, device=dev)] = sub
@@ -344,7 +292,7 @@ class Guidance:
                 clouds[j] = host[k, : n_out[j], : self.dim]
         t1 = time.perf_counter()
         if on_host:
-            pts = self._host_clouds([due[j] for j in on_host], problems, streams, c_best, frames)
+            pts = self._host_clouds([due[j] for j in on_host], problems, trees, streams, c_best, frames)
             for k, j in enumerate(on_host):
                 clouds[j] = pts[k][:, : self.dim]
                 n_out[j] = len(pts[k])
@@ -409,21 +357,18 @@ class Guidance:
 
 
 def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, frames=None, want_trace=True, stop_first=False,
-              np_per_iter=None, py_per_iter=None, window=65536, init_clouds=True, pad=4096, overlap_min=None):
+              window=65536, init_clouds=True, overlap_min=None):
     """`iters` loop bodies for every tree of the batch (fewer for trees that stop: first solution with stop_first, full
-    tree).  Returns dict(traces = per-tree best cost after each iteration, iters_done, kernel_ms, launches, stats).
-    The per-tree generators in `streams` end up advanced by exactly what each tree consumed."""
+    tree), in persistent launches of at most `window` iterations.  Returns dict(traces = per-tree best cost after each
+    iteration, iters_done, kernel_ms, launches, stats).  Every problem's generators move into its tree for the run (streams[i]
+    -> trees[i]); `streams[i].rs` / `.py` afterwards show them advanced by exactly what the tree consumed."""
     B = len(trees)
     irrt = bool(flags & _hip.F_IRRT)
     png = guidance is not None
     need_py = dim == 2 and irrt
-    if np_per_iter is None:
-        np_per_iter = (2 * dim * 4) if not irrt else (8 if dim == 2 else 6 * 40)
-    if py_per_iter is None:
-        py_per_iter = 16
+    hand_over(trees, streams)
     run_flags = flags | (_hip.F_STOP_FIRST if stop_first else 0) | (_hip.F_PNG if png else 0)
     remaining = np.full(B, int(iters), dtype=np.int64)
-    grow = np.ones(B, dtype=np.int64)
     traces = [[] for _ in range(B)]
     c_best = np.full(B, np.inf)
     finished = np.zeros(B, dtype=bool)
@@ -436,18 +381,18 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
     dev = torch.device("cuda", trees[0].device_id)
 
     import time
-    prof = {"windows": 0.0, "wait_launch": 0.0, "book": 0.0, "refresh": 0.0}
+    prof = {"generators": 0.0, "wait_launch": 0.0, "book": 0.0, "refresh": 0.0}
 
     def launch(act):
-        """windows of generator outputs (read in place from each problem's resident look-ahead) + the arguments of one
-        persistent launch over the trees `act`"""
-        rem = remaining[act].copy()
+        """the arguments of one persistent launch over the trees `act` (each draws from its own generators, in HBM); host
+        generators that were handed out since the last launch (host-side cloud candidates) go back to their trees first"""
+        rem = np.minimum(remaining[act], window)
         t_w = time.perf_counter()
-        npw = [streams[i].window_np((min(int(r), window) * np_per_iter + pad) * int(grow[i]), dev) for i, r in zip(act, rem)]
-        pyw = [streams[i].window_py((min(int(r), window) * py_per_iter + pad) * int(grow[i]), dev) for i, r in zip(act, rem)] if need_py else None
-        prof["windows"] += time.perf_counter() - t_w
-        return lambda: _hip.run_sampling([trees[i] for i in act], int(rem.max()), npw, pyw, flags=run_flags, want_trace=want_trace,
-                                         iters_each=rem, on_device=True)
+        hand_over([trees[i] for i in act], [streams[i] for i in act], only_touched=True)
+        for i in act:
+            streams[i].device_drew(py_too=need_py)
+        prof["generators"] += time.perf_counter() - t_w
+        return lambda: _hip.run_sampling([trees[i] for i in act], int(rem.max()), flags=run_flags, want_trace=want_trace, iters_each=rem)
 
     def absorb(act, r):
         """book a finished launch, refresh the clouds that are due; returns the trees of `act` that go on"""
@@ -458,9 +403,6 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
         due = []
         for j, i in enumerate(act):
             d = int(r["iters_done"][j])
-            streams[i].advance_np(int(r["np_used"][j]))
-            if need_py:
-                streams[i].advance_py(int(r["py_used"][j]))
             if want_trace and d:
                 tr = r["cost_trace"][j, :d]
                 traces[i].append(tr.copy())
@@ -480,12 +422,9 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
                 # launch's counters: no extra launch per stopped tree
                 c_best[i] = float(r["stats"][j, 17:18].view(np.float64)[0])
                 due.append(i)
-            elif st == _hip.E_STREAM:
-                if d == 0:   # not even one draw fitted into the window: widen it (free space nearly empty ...)
-                    grow[i] *= 4
-                    if grow[i] > 4096:
-                        failed[i] = "sampling cannot make progress (free space empty?)"
-                        finished[i] = True
+            elif st == _hip.E_STREAM:   # one draw rejected 2^22 generator outputs in a row
+                failed[i] = "sampling cannot make progress (free space empty?)"
+                finished[i] = True
             elif st == _hip.E_CAPACITY:
                 failed[i] = "tree capacity exceeded"
                 finished[i] = True

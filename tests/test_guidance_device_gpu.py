@@ -8,59 +8,94 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _streams(seed, n_words):
+def _device_side(pr, dim, seed):
+    """a tree that owns the problem's generators (seeded like the host-side twin) + the host twin"""
+    from nirrt_star_amd import _hip, batch
+    t = _hip.HipTree(dim, 100, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], 3 if dim == 2 else 2, pr["env"])
+    sd, sh = batch.ProblemStreams(seed), batch.ProblemStreams(seed)
+    batch.hand_over([t], [sd])
+    return t, sd, sh
+
+
+def _device_cloud(g, t, sd, pr, cbest, frame):
     import torch
-    from nirrt_star_amd import batch
-    st = batch.ProblemStreams(seed)
-    st.prime(n_words + 4096, 0, torch.device("cuda", 0))
-    return st
+    from nirrt_star_amd import _hip, pointops
+    dev = torch.device("cuda", 0)
+    n_raw, n_words = g.cloud_words()
+    words = torch.empty((1, n_words), dtype=torch.int32, device=dev)
+    _hip.generator_words([t], 0, n_words, device_ptr=words.data_ptr(), stride=n_words)
+    sd.device_drew(py_too=False)
+    jobs, n_raw, nw = g._device_jobs([0], [pr], [words.data_ptr()], [cbest], [frame], dev)
+    out = torch.zeros((1, g.n_points, 3), dtype=torch.float64, device="cuda")
+    n_cand, n_out = pointops.guidance_clouds(jobs, n_raw, g.n_points, out, 0)
+    return out.cpu().numpy()[0, : n_out[0]]
 
 
 @pytest.mark.parametrize("world,pair", [(0, 0), (3, 1), (7, 2)])
 def test_device_clouds_2d_equal_host_clouds(world, pair):
-    import torch
-    from nirrt_star_amd import batch, pointcloud as pcu, sampling, worlds
+    from nirrt_star_amd import _hip, batch, pointcloud as pcu, sampling, worlds
     pr = worlds.problem_2d(worlds.random_world_2d(world, "b30"), pair)
     g = batch.Guidance(None, 2, 10)
     frame = sampling.informed_frame(pr["x_start"], pr["x_goal"])
-    n_words = 2 * 2 * g.n_points * g.scale
     xs, xg = np.asarray(pr["x_start"], dtype=np.float64), np.asarray(pr["x_goal"], dtype=np.float64)
     for cbest in (np.inf, 1.6 * frame[0], 1.05 * frame[0]):
-        sd, sh = _streams(1000 + world, 4 * n_words), _streams(1000 + world, 4 * n_words)
+        t, sd, sh = _device_side(pr, 2, 1000 + world)
         for _ in range(2):    # two clouds in a row: the generator position carries over
-            jobs, n_raw, nw = g._device_jobs([0], [pr], [sd], [cbest], [frame], torch.device("cuda", 0))
-            out = torch.zeros((1, g.n_points, 3), dtype=torch.float64, device="cuda")
-            from nirrt_star_amd import pointops
-            n_cand, n_out = pointops.guidance_clouds(jobs, n_raw, g.n_points, out, 0)
-            sd.advance_np(nw)
-            dev_cloud = out.cpu().numpy()[0, : n_out[0], :2]
+            dev_cloud = _device_cloud(g, t, sd, pr, cbest, frame)[:, :2]
             if cbest < np.inf:
                 host_cloud = pcu.ellipsoid_point_cloud_sampling(xs, xg, cbest / frame[0], pr["binary_mask"], g.n_points, g.n_points * g.scale, sh.rs)
-                cand = None
             else:
                 host_cloud = pcu.generate_rectangle_point_cloud(pr["binary_mask"], g.n_points, g.scale, sh.rs)
             assert dev_cloud.shape == host_cloud.shape
             assert np.array_equal(dev_cloud, host_cloud)
-            # both generators sit at the same position afterwards
-            assert np.array_equal(sd.peek_np(8), sh.peek_np(8))
+            # the tree's generator sits where the host twin's does: same get_state()
+            k_d, p_d = _hip.np_state(sd.rs)
+            k_h, p_h = _hip.np_state(sh.rs)
+            assert p_d == p_h and np.array_equal(k_d, k_h)
+        t.close()
 
 
 def test_device_cloud_3d_box_equals_host_cloud():
-    import torch
-    from nirrt_star_amd import batch, pointcloud as pcu, pointops, sampling, worlds
+    from nirrt_star_amd import _hip, batch, pointcloud as pcu, sampling, worlds
     np.random.seed(4)
     pr = worlds.problem_3d(worlds.random_world_3d(4))
     g = batch.Guidance(None, 3, 10)
     frame = sampling.informed_frame(pr["x_start"], pr["x_goal"])
-    n_words = 2 * 3 * g.n_points * g.scale
-    sd, sh = _streams(77, 2 * n_words), _streams(77, 2 * n_words)
-    jobs, n_raw, nw = g._device_jobs([0], [pr], [sd], [np.inf], [frame], torch.device("cuda", 0))
-    out = torch.zeros((1, g.n_points, 3), dtype=torch.float64, device="cuda")
-    n_cand, n_out = pointops.guidance_clouds(jobs, n_raw, g.n_points, out, 0)
-    sd.advance_np(nw)
+    t, sd, sh = _device_side(pr, 3, 77)
+    dev_cloud = _device_cloud(g, t, sd, pr, np.inf, frame)
     host_cloud = pcu.generate_rectangle_point_cloud_3d(pr["env"], g.n_points, g.scale, clearance=0, rng=sh.rs)
-    assert np.array_equal(out.cpu().numpy()[0, : n_out[0]], host_cloud)
-    assert np.array_equal(sd.peek_np(8), sh.peek_np(8))
+    assert np.array_equal(dev_cloud, host_cloud)
+    k_d, p_d = _hip.np_state(sd.rs)
+    k_h, p_h = _hip.np_state(sh.rs)
+    assert p_d == p_h and np.array_equal(k_d, k_h)
+    t.close()
+
+
+def test_generators_move_between_host_and_tree():
+    """ProblemStreams: a draw on the host between two device draws is honoured (the state goes back to the tree before the
+    next launch), and an untouched host object is simply behind until somebody looks at it"""
+    import random
+    from nirrt_star_amd import _hip, batch, worlds
+    pr = worlds.problem_2d(worlds.random_world_2d(2, "b30"), 0)
+    t = _hip.HipTree(2, 100, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], 3, pr["env"])
+    s = batch.ProblemStreams(11)
+    ref_np, ref_py = np.random.RandomState(11), random.Random(11)
+    batch.hand_over([t], [s])
+    w = _hip.generator_words([t], 0, 1000)[0]
+    s.device_drew()
+    assert np.array_equal(w, ref_np.randint(0, 1 << 32, size=1000, dtype=np.uint32))
+    assert s.rs.random_sample() == ref_np.random_sample()          # fetched from the tree, then drawn on the host
+    assert s.touched()
+    batch.hand_over([t], [s], only_touched=True)                   # ... and back
+    assert not s.touched()
+    w = _hip.generator_words([t], 0, 700)[0]
+    s.device_drew()
+    assert np.array_equal(w, ref_np.randint(0, 1 << 32, size=700, dtype=np.uint32))
+    w = _hip.generator_words([t], 1, 10)[0]
+    v = ref_py.getrandbits(320)
+    assert [int(x) for x in w] == [(v >> (32 * i)) & 0xFFFFFFFF for i in range(10)]
+    assert s.py.random() == ref_py.random() and s.rs.random_sample() == ref_np.random_sample()
+    t.close()
 
 
 def test_set_cloud_batch_equals_per_tree_set_cloud():
