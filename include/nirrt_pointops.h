@@ -69,20 +69,22 @@ int nirrt_fps_f64(const double *pts, int N, int num_samples, unsigned char *sel,
 int nirrt_fps_f64_batch(const double *pts, int n_clouds, const int *cnt, const int *num_samples, unsigned char *sel, int device_id);
 
 /* Guidance clouds generated on the device: generate_rectangle_point_cloud / ellipsoid_point_cloud_sampling
- * (datasets/point_cloud_mask_utils.py:35-73, 104-174) and generate_rectangle_point_cloud_3d (datasets_3d/point_cloud_mask_utils_3d.py:
- * 83-113) for n_jobs problems at once - candidates from each problem's numpy generator outputs (resident in HBM, consumed like
+ * (datasets/point_cloud_mask_utils.py:35-73, 104-174) and generate_rectangle_point_cloud_3d / ellipsoid_point_cloud_sampling_3d
+ * (datasets_3d/point_cloud_mask_utils_3d.py:83-113, 132-200) for n_jobs problems at once - candidates from each problem's numpy generator outputs (resident in HBM, consumed like
  * rng.random_sample / rng.uniform would: 2 words per double), free-space filter, farthest-point down-sampling, survivors in their
  * original order.  jobs: HOST array whose pointers are DEVICE addresses; clouds: DEVICE (n_jobs, n_points, 3) f64 out; n_cand /
  * n_out: HOST out (candidates after the filters / points of the cloud).  The caller advances the problem's generator by
- * 2 * (2 or 3) * n_raw words.  (The 3D ellipsoid candidates go through sin / cos: they stay with the host's libm.) */
+ * 2 * (2 or 3) * n_raw words.  The 3D ellipsoid candidates (ellipsoid_point_cloud_sampling_3d, point_cloud_mask_utils_3d.py:
+ * 132-200) go through the device's sin / cos: equal to the host's within a few ulp (<= 1e-9 on the coordinates), not bit for bit. */
 typedef struct nirrt_cloud_job {
     const uint32_t *words;     /* DEVICE */
     const uint8_t *free_tab;   /* DEVICE, 2D: (h + 1) x (w + 1), 1 = the 2 x 2 pixel block around the integer position is free */
     const double *balls;       /* DEVICE, 3D: (n_ball, 4) */
     const double *boxes;       /* DEVICE, 3D: (n_box, 6) */
-    int32_t mode;              /* 0 whole image (2D), 1 ellipse (2D), 2 whole box (3D) */
+    int32_t mode;              /* 0 whole image (2D), 1 ellipse (2D), 2 whole box (3D), 3 ellipsoid (3D); one batch = 2D jobs or 3D jobs */
     int32_t w, h, n_ball, n_box, pad;
-    double a[8];               /* mode 0: w, h; mode 1: (C.L)[0][0], [0][1], [1][0], [1][1], x_center[0], [1]; mode 2: lo[3], (hi - lo)[3] */
+    double a[20];              /* mode 0: w, h; mode 1: (C.L)[0][0], [0][1], [1][0], [1][1], x_center[0], [1]; mode 2: lo[3], (hi - lo)[3];
+                                  mode 3: C.L row-major [9], x_center [3], range lo [3], range hi [3] */
     double clearance;
 } nirrt_cloud_job;
 int nirrt_guidance_clouds(const nirrt_cloud_job *jobs, int n_jobs, int n_raw, int n_points, double *clouds, int *n_cand, int *n_out,

@@ -237,9 +237,18 @@ class Guidance:
                 j.mode, j.balls, j.boxes, j.n_ball, j.n_box = 2, balls.data_ptr(), boxes.data_ptr(), int(balls.shape[0]), int(boxes.shape[0])
                 lo = np.array([env.x_range[0] + 0, env.y_range[0] + 0, env.z_range[0] + 0], dtype=np.float64)
                 hi = np.array([env.x_range[1] - 0, env.y_range[1] - 0, env.z_range[1] - 0], dtype=np.float64)
-                diff = hi - lo
-                for k in range(3):
-                    j.a[k], j.a[3 + k] = float(lo[k]), float(diff[k])
+                if c_best[i] < np.inf:      # ellipsoid-restricted cloud (point_cloud_mask_utils_3d.py:132-200)
+                    xs, xg = np.asarray(pr["x_start"], dtype=np.float64), np.asarray(pr["x_goal"], dtype=np.float64)
+                    CL, xc = pcu.ellipsoid_transform_3d(xs, xg, c_best[i] / frames[i][0])
+                    j.mode = 3
+                    for k in range(9):
+                        j.a[k] = float(CL[k // 3, k % 3])
+                    for k in range(3):
+                        j.a[9 + k], j.a[12 + k], j.a[15 + k] = float(xc[k]), float(lo[k]), float(hi[k])
+                else:
+                    diff = hi - lo
+                    for k in range(3):
+                        j.a[k], j.a[3 + k] = float(lo[k]), float(diff[k])
                 j.clearance = 0.0
             jobs.append(j)
         return jobs, n_raw, n_words
@@ -262,7 +271,7 @@ class Guidance:
         t0 = time.perf_counter()
         dev = torch.device("cuda", self.device_id)
         nd = len(due)
-        on_dev = [j for j, i in enumerate(due) if self.device_clouds and not (self.dim == 3 and c_best[i] < np.inf)]
+        on_dev = [j for j, i in enumerate(due) if self.device_clouds]
         on_dev_set = set(on_dev)
         on_host = [j for j in range(nd) if j not in on_dev_set]
         clouds_dev = torch.zeros((nd, self.n_points, 3), dtype=torch.float64, device=dev)

@@ -413,16 +413,19 @@ extern "C" int nirrt_fps_f64(const double *pts, int N, int num_samples, unsigned
 // (k_fps_f64) and compacted without a host round trip.  Arithmetic restated op by op: legacy RandomState doubles
 // (a = w0 >> 5, b = w1 >> 6, (a * 2^26 + b) / 2^53), uniform(lo, hi) = lo + (hi - lo) * u, the ellipse transform as numpy's
 // dgemm evaluates it for K = 3 (fma chain in k order: fma(a1, s1, a0 * s0), the z term adds an exact zero), np.linalg.norm
-// (axis) = sqrt(x*x + y*y), astype(int) = truncation.  The 3D ellipsoid candidates go through sin / cos and stay on the host.
+// (axis) = sqrt(x*x + y*y), astype(int) = truncation.  The 3D ellipsoid candidates (point_cloud_mask_utils_3d.py:132-200) go
+// through sin / cos: the device's own (OCML), so they agree with the host's to a few ulp, not bit for bit - like the informed
+// samples of the 3D loop.
 // ------------------------------------------------------------------------------------------------
 struct nirrt_cloud_job {
     const unsigned *words;          // DEVICE: generator outputs from the problem's current position (>= 2 * n_doubles of them)
     const unsigned char *free_tab;  // DEVICE, 2D: (h + 1) x (w + 1) table "the 2 x 2 pixel block around this integer position is free"
     const double *balls;            // DEVICE, 3D: (n_ball, 4) cx, cy, cz, r
     const double *boxes;            // DEVICE, 3D: (n_box, 6) x, y, z, w, h, d
-    int mode;                       // 0: whole image (2D), 1: ellipse (2D), 2: whole box (3D)
+    int mode;                       // 0: whole image (2D), 1: ellipse (2D), 2: whole box (3D), 3: ellipsoid (3D)
     int w, h, n_ball, n_box, pad;
-    double a[8];                    // mode 0: w, h; mode 1: CL00, CL01, CL10, CL11, cx, cy; mode 2: lo[3], hi - lo [3]
+    double a[20];                   // mode 0: w, h; mode 1: CL00, CL01, CL10, CL11, cx, cy; mode 2: lo[3], hi - lo [3];
+                                    // mode 3: C.L row-major [9], x_center [3], range lo [3], range hi [3]
     double clearance;               // 3D obstacle inflation
 };
 
@@ -449,11 +452,26 @@ __global__ __launch_bounds__(CAND_NT) void k_cloud_candidates(const nirrt_cloud_
         double x = 0., y = 0., z = 0.;
         bool keep = false;
         if (i < n_raw) {
-            if (jb.mode == 2) {
-                x = jb.a[0] + jb.a[3] * mt_double(jb.words, 3ll * i);
-                y = jb.a[1] + jb.a[4] * mt_double(jb.words, 3ll * i + 1);
-                z = jb.a[2] + jb.a[5] * mt_double(jb.words, 3ll * i + 2);
+            if (jb.mode >= 2) {
                 bool inside = false;
+                if (jb.mode == 2) {
+                    x = jb.a[0] + jb.a[3] * mt_double(jb.words, 3ll * i);
+                    y = jb.a[1] + jb.a[4] * mt_double(jb.words, 3ll * i + 1);
+                    z = jb.a[2] + jb.a[5] * mt_double(jb.words, 3ll * i + 2);
+                } else {
+                    // rng.uniform(0, 1, n), rng.uniform(0, pi, n), rng.uniform(0, 2 pi, n): three arrays drawn one after the other;
+                    // spherical coordinates -> unit ball -> (C.L) . s + x_center, then the range test
+                    const double PI = 3.141592653589793;
+                    const double rr = 0.0 + (1.0 - 0.0) * mt_double(jb.words, (long long)i);
+                    const double th = 0.0 + (PI - 0.0) * mt_double(jb.words, (long long)n_raw + i);
+                    const double ph = 0.0 + (2 * PI - 0.0) * mt_double(jb.words, 2ll * n_raw + i);
+                    const double st = sin(th), ct = cos(th), sp = sin(ph), cp = cos(ph);
+                    const double s0 = rr * st * cp, s1 = rr * st * sp, s2 = rr * ct;
+                    x = __builtin_fma(jb.a[2], s2, __builtin_fma(jb.a[1], s1, jb.a[0] * s0)) + jb.a[9];
+                    y = __builtin_fma(jb.a[5], s2, __builtin_fma(jb.a[4], s1, jb.a[3] * s0)) + jb.a[10];
+                    z = __builtin_fma(jb.a[8], s2, __builtin_fma(jb.a[7], s1, jb.a[6] * s0)) + jb.a[11];
+                    inside = !(jb.a[12] <= x && x <= jb.a[15] && jb.a[13] <= y && y <= jb.a[16] && jb.a[14] <= z && z <= jb.a[17]);
+                }
                 for (int o = 0; o < jb.n_ball; o++) {
                     const double *c = jb.balls + 4 * o;
                     const double rc = c[3] + jb.clearance;
@@ -544,6 +562,8 @@ extern "C" int nirrt_guidance_clouds(const nirrt_cloud_job *jobs, int n_jobs, in
                                      int *n_out, int device_id)
 {
     if (!jobs || !clouds || !n_cand || !n_out || n_jobs <= 0 || n_raw <= 0 || n_points <= 0 || n_raw > FPS64_NT * FPS64_MAX_PER_THREAD) return -1;
+    for (int b = 0; b < n_jobs; b++)   // one batch = one dimensionality (the down-sampling kernel takes has_z for the whole launch)
+        if (jobs[b].mode < 0 || jobs[b].mode > 3 || (jobs[b].mode >= 2) != (jobs[0].mode >= 2)) return -1;
     if (hipSetDevice(device_id) != hipSuccess) return -4;
     const long long total = (long long)n_jobs * n_raw;
     const size_t a256 = 255;
@@ -581,10 +601,10 @@ extern "C" int nirrt_guidance_clouds(const nirrt_cloud_job *jobs, int n_jobs, in
         // k_fps_f64 leaves clouds with cnt <= num_samples alone (k_cloud_compact keeps all of their points)
         if (n_raw <= 20 * FPS64_NT)
             hipLaunchKernelGGL(k_fps_f64<20>, dim3(n_jobs), dim3(FPS64_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
-                               (const int *)d_cnt, (const int *)d_ns, ds, jobs[0].mode == 2 ? 1 : 0);
+                               (const int *)d_cnt, (const int *)d_ns, ds, jobs[0].mode >= 2 ? 1 : 0);
         else
             hipLaunchKernelGGL(k_fps_f64<32>, dim3(n_jobs), dim3(FPS64_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
-                               (const int *)d_cnt, (const int *)d_ns, ds, jobs[0].mode == 2 ? 1 : 0);
+                               (const int *)d_cnt, (const int *)d_ns, ds, jobs[0].mode >= 2 ? 1 : 0);
         hipLaunchKernelGGL(k_cloud_compact, dim3(n_jobs), dim3(CAND_NT), 0, 0, (const double *)d, total, n_raw, (const int *)d_cnt, n_points,
                            (const unsigned char *)ds, clouds, d_nout);
         if (hipGetLastError() != hipSuccess || hipMemcpy(n_cand, d_cnt, sizeof(int) * (size_t)n_jobs, hipMemcpyDeviceToHost) != hipSuccess ||

@@ -192,6 +192,20 @@ def _rotation_to_world_3d(x_start, x_goal, L):
     return U @ np.diag([1, 1, np.linalg.det(U) * np.linalg.det(V)]) @ V.T
 
 
+def ellipsoid_transform_3d(start_point, goal_point, max_min_ratio):
+    """the constants of ellipsoid_candidates_3d's transform, formed like the reference forms them (point_cloud_mask_utils_3d.py:
+    137-150): (C.L (3, 3), x_center (3,)) - what the device-side candidate generation takes"""
+    c_min = np.linalg.norm(goal_point - start_point)
+    C = _rotation_to_world_3d(start_point, goal_point, c_min)
+    x_center = (start_point + goal_point) / 2.
+    c_max = c_min * max_min_ratio
+    eps = 1e-6 if c_max ** 2 - c_min ** 2 < 0 else 0
+    r = np.zeros(3)
+    r[0] = c_max / 2
+    r[1] = r[2] = np.sqrt(c_max ** 2 - c_min ** 2 + eps) / 2
+    return np.dot(C, np.diag(r)), x_center
+
+
 def ellipsoid_candidates_3d(start_point, goal_point, max_min_ratio, env, n_raw_samples=10000, clearance=0, rng=None):
     """point_cloud_mask_utils_3d.py:132-195: ellipsoid-restricted candidates before any down-sampling -> (m, 3)"""
     rng = np.random if rng is None else rng

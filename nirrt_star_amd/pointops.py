@@ -219,7 +219,7 @@ class CloudJob(C.Structure):
     """nirrt_cloud_job of include/nirrt_pointops.h"""
     _fields_ = [("words", C.c_void_p), ("free_tab", C.c_void_p), ("balls", C.c_void_p), ("boxes", C.c_void_p),
                 ("mode", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("n_ball", C.c_int32), ("n_box", C.c_int32), ("pad", C.c_int32),
-                ("a", C.c_double * 8), ("clearance", C.c_double)]
+                ("a", C.c_double * 20), ("clearance", C.c_double)]
 
 
 def guidance_clouds(jobs, n_raw, n_points, clouds, device_id=0):

@@ -71,6 +71,29 @@ def test_device_cloud_3d_box_equals_host_cloud():
     t.close()
 
 
+@pytest.mark.parametrize("world,ratio", [(4, 1.8), (9, 1.2), (15, 1.02)])
+def test_device_cloud_3d_ellipsoid_equals_host_cloud_within_libm(world, ratio):
+    """ellipsoid_point_cloud_sampling_3d (point_cloud_mask_utils_3d.py:132-200): the candidates go through sin / cos - OCML on
+    the device, the host's libm / numpy SIMD in the reference - so the bar is the floating-point one: same candidates kept, same
+    points selected by the down-sampling, coordinates within 1e-9, generator at the same state"""
+    from nirrt_star_amd import _hip, batch, pointcloud as pcu, sampling, worlds
+    np.random.seed(world)
+    pr = worlds.problem_3d(worlds.random_world_3d(world))
+    g = batch.Guidance(None, 3, 10)
+    frame = sampling.informed_frame(pr["x_start"], pr["x_goal"])
+    xs, xg = np.asarray(pr["x_start"], dtype=np.float64), np.asarray(pr["x_goal"], dtype=np.float64)
+    t, sd, sh = _device_side(pr, 3, 300 + world)
+    for _ in range(2):
+        dev_cloud = _device_cloud(g, t, sd, pr, ratio * frame[0], frame)
+        host_cloud = pcu.ellipsoid_point_cloud_sampling_3d(xs, xg, ratio, pr["env"], g.n_points, g.n_points * g.scale, clearance=0, rng=sh.rs)
+        assert dev_cloud.shape == host_cloud.shape and len(dev_cloud) > 100
+        assert np.max(np.abs(dev_cloud - host_cloud)) <= 1e-9
+        k_d, p_d = _hip.np_state(sd.rs)
+        k_h, p_h = _hip.np_state(sh.rs)
+        assert p_d == p_h and np.array_equal(k_d, k_h)
+    t.close()
+
+
 def test_generators_move_between_host_and_tree():
     """ProblemStreams: a draw on the host between two device draws is honoured (the state goes back to the tree before the
     next launch), and an untouched host object is simply behind until somebody looks at it"""
