@@ -240,7 +240,8 @@ typedef struct nirrt_run_args {
                             when the tree's loop started / ended, [16] = alg_elems, [17] sampling mode: bit pattern (IEEE double) of
                             the best cost on the tree when its loop ended - what a NIRRT_E_CLOUD stop compared with
                             update_cost_ratio * c_update, so that the host needs no extra launch per stopped tree -
-                            [18..19] reserved */
+                            [18] rewire rounds that re-parented something, [19] vertices re-parented one at a time
+                            (candidate list larger than its LDS room) */
     const int64_t *iters_each; /* optional (n_trees,), sampling mode: tree i runs at most iters_each[i] <= iters iterations
                             (trees of one batch resumed after stopping at different iterations, e.g. NIRRT_E_CLOUD);
                             cost_trace rows stay `iters` long */

@@ -65,7 +65,7 @@ N_STATS = 20
 ST_ITERS, ST_T0, ST_T1, ST_CBEST = 13, 14, 15, 17   # slots 14 / 15 / 17 are absolute values of a launch, the rest are deltas
 STAT_NAMES = ["visited", "visit_bytes", "members", "spilled", "hop_records", "rewire_candidates", "rewired", "recosted",
               "list_entries", "inserted", "rebuilt", "revisits", "whole_tree_visits", "iterations", "t0_ticks", "t1_ticks",
-              "alg_elems", "c_best_bits", "r18", "r19"]
+              "alg_elems", "c_best_bits", "rewire_rounds", "rewired_one_by_one"]
 
 
 def useful_bytes(stats, dim):

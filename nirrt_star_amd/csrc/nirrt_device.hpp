@@ -127,6 +127,8 @@ struct Topo;
 #define ST_T0 14         // wall_clock64 (100 MHz) when the tree's loop started / ended
 #define ST_T1 15
 #define ST_CBEST 17      // bit pattern of the best cost when a sampling loop ended (absolute, like T0 / T1; what NIRRT* compared with ratio * c_update)
+#define ST_RROUNDS 18    // rewire rounds that re-parented something (batched path)
+#define ST_RSEQ 19       // vertices re-parented one at a time (candidate list did not fit / small-limits build)
 #define ST_ALG 16        // vertices the REFERENCE algorithm scans for the same iterations: n per nearest_neighbor + n per find_near_neighbors
 #define NSTAT NIRRT_N_STATS
 
@@ -211,6 +213,10 @@ struct TreeHotT {
     typename P<VRec>::type vrec;     // vrec[cap]: coordinates + exact cost by vertex index (random access, download)
     typename P<int>::type bfs_q;     // scratch queue for subtree traversals
     typename P<int>::type bfs_fc;    // ... first child of each queue entry (-2: not known, read the record)
+    // rewire: tie_stamp[v] == rw_stamp <=> v is a Near member of THIS pass that is collision-free and fails the reference's test
+    // by less than the list threshold (a "near-tie").  Such members stay off the candidate list; if an earlier re-parenting of
+    // the pass re-costs one of them, the re-costing finds the stamp and puts it on the list for an exact re-test.
+    typename P<int>::type tie_stamp;
     typename P<double>::type chain_g;   // edge lengths of the chain new -> root beyond the first CHAIN_MAX (which live in LDS)
     int cap;
     int n;          // num_vertices
@@ -267,7 +273,7 @@ struct TreeHotT {
     int g_ncell;             // g_G ^ dim
     int g_min;               // smallest tree that gets indexed (GRID_MIN_VERTICES; env NIRRT_GRID_MIN)
     int g_every;             // rebuild interval in vertices (GRID_REBUILD_EVERY; env NIRRT_GRID_REBUILD)
-    int pad3;
+    int rw_stamp;            // number of the current rewire pass (see tie_stamp)
     double g_rho;            // running estimate of the nearest-vertex distance of the samples (first box of a nearest query)
     double g_inv_h[3];       // cells per unit length, per axis
     double g_margin[3];      // slack added to every query box
@@ -1778,8 +1784,11 @@ __device__ __forceinline__ unsigned char *cand_state(LdsData &s) { return reinte
 // source before the member's turn; a source with a higher index comes after it and must not change the member's test).
 #define BFS_FRONT 32   // frontier entries kept in LDS per level (6 * BFS_FRONT ints: two buffers of vertex / first child / source)
 template <int D, int NT>
-NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int through_in, int n_list_in, int front_off_in)
+NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int through_in, int n_list_in, int front_off_in, int stamp_in)
 {
+    // stamp != 0: the candidate list holds passing members only; a re-costed vertex that carries the pass's near-tie stamp
+    // (and hangs below a source of lower index) joins the list for an exact re-test (s.n_cand grows; at most list_cap entries)
+    const int stamp = uni(stamp_in);
     // front_off >= 0: byte offset (from the Near stash's margin area) of 6 * BFS_FRONT ints the traversal may use for its
     // frontier: a level of up to BFS_FRONT vertices then costs ONE memory round trip (the records of its children) instead
     // of re-reading the queue and the parents' records first - what counts for the long chains of degenerate trees
@@ -1790,6 +1799,9 @@ NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int 
     int *fr = front_off >= 0 ? reinterpret_cast<int *>(cand_state(s) + front_off) : nullptr;
     const int tid = threadIdx.x;
     const int ns = uni(t.g_ns2);   // vertices below it have their slot in pos[]
+#ifdef NIRRT_PROFILE
+    long long rq0_ = wall_clock64();
+#endif
     int head = 0, tail = n_src, level = 0, cur = 0;
     bool in_lds = false;   // the sources come from the global queue (their child lists have just been edited: read afresh)
     while (head < tail) {   // one BFS level per trip; uniform
@@ -1825,6 +1837,9 @@ NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int 
         level++;
         __syncthreads();
     }
+#ifdef NIRRT_PROFILE
+    { const long long n_ = wall_clock64(); if (tid == 0) { s.tree_g->prof[11] += n_ - rq0_; s.tree_g->prof[23] += level; } rq0_ = n_; }
+#endif
     int nrec = 0;
     for (int base = walk_from; base < tail; base += NT * WALK_R) {
         int idx[WALK_R], who[WALK_R], slot[WALK_R], src[WALK_R];
@@ -1851,12 +1866,19 @@ NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int 
                 t.vrec[who[r]].cost = acc[r];
                 t.g_rec[slot[r]].cost = acc[r];
                 const int li = t.topo[who[r]].flags;
+                const int ts = stamp ? t.tie_stamp[who[r]] : 0;
                 if (li & 1) t.sol_dirty = 1;
                 if (li & 2) t.gc_dirty = 1;
                 if (n_list > 0 && src[r] < who[r]) {
-                    const int *ids = stash_ids(s);
+                    int *ids = stash_ids(s);
+                    bool listed = false;
                     for (int a = 0; a < n_list; a++)
-                        if (ids[a] == who[r] && !(cand_state(s)[a] & CAND_DONE)) cand_state(s)[a] = CAND_DIRTY;
+                        if (ids[a] == who[r]) { listed = true; if (!(cand_state(s)[a] & CAND_DONE)) cand_state(s)[a] = CAND_DIRTY; }
+                    if (!listed && stamp && ts == stamp) {
+                        const int p = atomicAdd(&s.n_cand, 1);
+                        if (p < s.stash_cap) { ids[p] = who[r]; cand_state(s)[p] = CAND_DIRTY; }
+                        else t.status = NIRRT_E_CAPACITY;   // more re-tests than the list holds (64 places are kept free for them)
+                    }
                 }
             }
         }
@@ -1868,9 +1890,10 @@ NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int 
 }
 
 template <int D, int NT>
-__device__ __forceinline__ void wg_recost_queue(Lds<NT> &s, TreeHot &t, int n_src, int walk_from, int through, int n_list, int front_off = -1)
+__device__ __forceinline__ void wg_recost_queue(Lds<NT> &s, TreeHot &t, int n_src, int walk_from, int through, int n_list, int front_off = -1,
+                                                int stamp = 0)
 {
-    wg_recost_queue_fn<D, NT>(n_src, walk_from, through, n_list, front_off);
+    wg_recost_queue_fn<D, NT>(n_src, walk_from, through, n_list, front_off, stamp);
 }
 
 // one re-parented vertex v: its own cost and everything below it
@@ -2343,31 +2366,107 @@ NIRRT_FN __device__ void it_connect()
                 // The stash is compacted IN PLACE to the candidates - the members whose margin reaches cost(new), few unless the
                 // tree is degenerate; candidates from the spilled part are appended while there is room.  (One trip = read a
                 // slice, barrier, write: a write lands at or below the slice just read.)
+                // Pass 1 classifies the stash entries whose margin reaches cost(new) WITHOUT touching the stash: collision filter and,
+                // if there are many of them, the reference's test with the member's current cost.  A degenerate tree (free straight segment: hundreds of
+                // members within 1e-10 of cost(new)) has a few passing members among hundreds of near-ties, and more candidates
+                // than the list holds used to send every re-parenting down the one-at-a-time path (7.5 of 10 per iteration in the
+                // slowest tree of the bench).  Now the list takes the PASSING members only (`fresh`); the near-ties get the pass's
+                // stamp in tie_stamp[] and come back only if an earlier re-parenting re-costs them (wg_recost_queue_fn).
+                auto passes_now = [&](int id) -> bool {
+                    const VRec vr = ldg(&t.vrec[id]);
+                    return vr.cost > new_cost + dist_scan_cold<D>(vr.x - node_new[0], vr.y - node_new[1], D == 3 ? vr.z - node_new[D - 1] : 0.);
+                };
                 __syncthreads();
-                if (tid == 0) { s.n_cand = 0; s.cand_listed = 1; }
+                if (tid == 0) { s.n_cand = 0; s.cand_listed = 1; s.bc_i[1] = 0; s.bc_i[2] = 0; }
                 __syncthreads();
-                for (int base = 0; base < k_lds; base += NT) {
-                    const int a = base + tid;
-                    const int id = a < k_lds ? ids[a] : 0;
-                    const bool c = a < k_lds && s.pool[s.stash_off + a] >= thr && !blocked(id);
-                    __syncthreads();
-                    if (c) {
-                        const int p = atomicAdd(&s.n_cand, 1);
-                        if (p < list_cap) ids[p] = id; else s.cand_listed = 0;
+                unsigned m_pass = 0u, m_tie = 0u;   // this lane's entries of the LDS part, one bit per trip (<= 13 trips of 64 lanes)
+                {
+                    // 1a: who is a candidate at all (margin + collision filter)
+                    int trip = 0, nc_ = 0;
+                    for (int base = 0; base < k_lds; base += NT, trip++) {
+                        const int a = base + tid;
+                        if (a < k_lds && s.pool[s.stash_off + a] >= thr && !blocked(ids[a])) { m_tie |= 1u << trip; nc_++; }
                     }
-                    __syncthreads();
+                    // spilled part (large Near sets only): the verdict replaces the margin - +inf passing, DBL_MAX candidate / near-tie,
+                    // -inf neither - so that the later passes (and the one-at-a-time path, which asks `>= thr`) need not repeat the tests
+                    for (int a0 = cap_lds + tid; a0 < ks; a0 += 4 * NT) {   // 4 entries per lane in flight
+                        double mg[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) mg[u] = a0 + u * NT < ks ? t.nr_m[a0 + u * NT - cap_lds] : -__builtin_inf();
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (a0 + u * NT < ks) {
+                                double code = -__builtin_inf();
+                                if (mg[u] >= thr && !blocked(t.nr_idx[a0 + u * NT - cap_lds])) { code = 1.7976931348623157e308; nc_++; }
+                                t.nr_m[a0 + u * NT - cap_lds] = code;
+                            }
+                        }
+                    }
+                    if (nc_) atomicAdd(&s.bc_i[2], nc_);
                 }
-                for (int a0 = cap_lds + tid; a0 < ks; a0 += 4 * NT) {   // spilled part (large Near sets only): 4 entries per lane in flight
-                    double mg[4];
+                __syncthreads();
+                const int n_candidates = uni(s.bc_i[2]);
+                int n_passing = 0;
+                // 1b (only when the candidates would crowd the list): the reference's test for each of them
+                const bool classify = cap_lds >= 128 && n_candidates > 64;
+                if (classify) {
+                    int trip = 0, np_ = 0;
+                    for (int base = 0; base < k_lds; base += NT, trip++) {
+                        if (((m_tie >> trip) & 1u) && passes_now(ids[base + tid])) { m_tie &= ~(1u << trip); m_pass |= 1u << trip; np_++; }
+                    }
+                    for (int a0 = cap_lds + tid; a0 < ks; a0 += 4 * NT) {
+                        double mg[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) mg[u] = a0 + u * NT < ks ? t.nr_m[a0 + u * NT - cap_lds] : -__builtin_inf();
+                        for (int u = 0; u < 4; u++) mg[u] = a0 + u * NT < ks ? t.nr_m[a0 + u * NT - cap_lds] : -__builtin_inf();
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (mg[u] >= thr) {
-                            const int id = t.nr_idx[a0 + u * NT - cap_lds];
-                            if (!blocked(id)) {
-                                const int p = atomicAdd(&s.n_cand, 1);
-                                if (p < list_cap) ids[p] = id; else s.cand_listed = 0;
+                        for (int u = 0; u < 4; u++) {
+                            if (mg[u] >= thr && passes_now(t.nr_idx[a0 + u * NT - cap_lds])) { t.nr_m[a0 + u * NT - cap_lds] = __builtin_inf(); np_++; }
+                        }
+                    }
+                    if (np_) atomicAdd(&s.bc_i[1], np_);
+                    __syncthreads();
+                    n_passing = uni(s.bc_i[1]);
+                }
+                // fresh: passing members only on the list, 64 places kept free for near-ties that come back
+                const bool fresh = classify && n_passing <= cap_lds - 64;
+                int stamp = 0;
+                if (fresh) {
+                    stamp = uni(t.rw_stamp) + 1;
+                    __syncthreads();
+                    if (tid == 0) t.rw_stamp = stamp;
+                }
+                // Pass 2: the stash is compacted IN PLACE to the list (one trip = read a slice, barrier, write: a write lands at or
+                // below the slice just read); entries from the spilled part are appended while there is room.
+                {
+                    int trip = 0;
+                    for (int base = 0; base < k_lds; base += NT, trip++) {
+                        const int a = base + tid;
+                        const int id = a < k_lds ? ids[a] : 0;
+                        const bool ps = (m_pass >> trip) & 1u, ti = (m_tie >> trip) & 1u;
+                        const bool c = fresh ? ps : (ps || ti);
+                        __syncthreads();
+                        if (c) {
+                            const int p = atomicAdd(&s.n_cand, 1);
+                            if (p < list_cap) ids[p] = id; else s.cand_listed = 0;
+                        }
+                        if (fresh && ti) t.tie_stamp[id] = stamp;
+                        __syncthreads();
+                    }
+                    for (int a0 = cap_lds + tid; a0 < ks; a0 += 4 * NT) {
+                        double mg[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) mg[u] = a0 + u * NT < ks ? t.nr_m[a0 + u * NT - cap_lds] : -__builtin_inf();
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (mg[u] >= thr) {
+                                const int id = t.nr_idx[a0 + u * NT - cap_lds];
+                                const bool ps = mg[u] == __builtin_inf();
+                                if (fresh ? ps : true) {
+                                    const int p = atomicAdd(&s.n_cand, 1);
+                                    if (p < list_cap) ids[p] = id; else s.cand_listed = 0;
+                                } else {
+                                    t.tie_stamp[id] = stamp;
+                                }
                             }
                         }
                     }
@@ -2379,9 +2478,9 @@ NIRRT_FN __device__ void it_connect()
                 // list (more candidates than the stash has room for): the LDS part cannot be trusted to be complete ->
                 // every round re-tests the spilled stash too (slow, rare).
                 const bool listed_all = uni(s.cand_listed) != 0;
-                const int n_list = n_cand < list_cap ? n_cand : list_cap;
+                int n_list = n_cand < list_cap ? n_cand : list_cap;   // (fresh: grows when a stamped near-tie is re-costed)
                 for (int a = tid; a < n_list; a += NT) state[a] = CAND_DIRTY;
-                if (tid == 0) s.stat[ST_ROUNDS] += n_cand;
+                if (tid == 0) s.stat[ST_ROUNDS] += n_candidates;
                 __syncthreads();
                 int last = -1;
                 if (dup && tid == 0) s.new_fc = tnear.fc;   // head of an existing vertex's child list (a fresh vertex's is in LDS already)
@@ -2421,6 +2520,7 @@ NIRRT_FN __device__ void it_connect()
                         }
                         s.bc_i[7] = fast;
                         s.stat[ST_REWIRED] += 1;
+                        s.stat[ST_RSEQ] += 1;
                     }
                     n_rewired++;
                     __syncthreads();
@@ -2452,7 +2552,6 @@ NIRRT_FN __device__ void it_connect()
                     // behind the chunk arrays: the frontier buffers of the subtree traversal, if the margin area has the room
                     const int front_off = (((cap_lds + 7) & ~7) + 768 + 24 * BFS_FRONT <= 8 * cap_lds) ? ((cap_lds + 7) & ~7) + 768 : -1;
                     const int lane = tid & 63;
-                    const bool single = n_list <= 64;   // every candidate has its own lane of wave 0: records stay in registers across the phases
                     const int ns_ = uni(t.g_ns2);   // vertices below it have their slot in pos[]
                     const double bound = new_cost - (1e-9 + 1e-11 * new_cost);   // an ancestor that passes costs more than cost(new)
                     const int clen = s.chain_len;
@@ -2463,6 +2562,8 @@ NIRRT_FN __device__ void it_connect()
                         __syncthreads();
                         if (tid == 0) { s.bc_i[5] = 0; s.bc_i[4] = 0; s.bc_i[7] = 0; }
                         __syncthreads();
+                        if (fresh) { const int nc = uni(s.n_cand); n_list = nc < list_cap ? nc : list_cap; }
+                        const bool single = n_list <= 64;   // every candidate has its own lane of wave 0: records stay in registers across the phases
                         // phase A: test what changed
                         for (int base = 0; base < n_list; base += NT) {
                             const int a = base + tid;
@@ -2484,7 +2585,9 @@ NIRRT_FN __device__ void it_connect()
                         }
                         __syncthreads();
                         const int n_pass = uni(s.bc_i[5]);
+                        PROF(21);
                         if (n_pass == 0) break;
+                        if (tid == 0) s.stat[ST_RROUNDS] += 1;
                         // phase B: a passing member with a passing ancestor of lower index waits for that one
                         for (int base = 0; base < n_list; base += NT) {
                             const int a = base + tid;
@@ -2519,12 +2622,35 @@ NIRRT_FN __device__ void it_connect()
                             }
                         }
                         __syncthreads();
+                        PROF(22);
                         // phase C: re-parent the others, 64 at a time (wave 0): unlink (runs of adjacent siblings resolved in LDS),
                         // new records + costs, then the whole chunk is pushed onto new's child list
-                        for (int base = 0; base < n_list; base += 64) {
-                            const int a = base + tid;
-                            const bool mine = tid < 64 && a < n_list && state[a] == CAND_PASS;
-                            if (!block_any(mine)) continue;   // (uniform) nothing to re-parent among these 64
+                        // A long list (hundreds of near-tie candidates in degenerate trees) holds its few passing members anywhere:
+                        // their list positions are compacted first (into the traversal's frontier buffer, idle until the
+                        // re-costing), so that they are re-parented in ceil(n / 64) chunks instead of one chunk per stretch of 64
+                        // list positions that happens to hold one - every chunk waits for its stores three times
+                        int *go_a = (!single && front_off >= 0) ? reinterpret_cast<int *>(state + front_off) : nullptr;
+                        int n_go = -1;
+                        if (go_a) {
+                            if (tid == 0) s.bc_i[3] = 0;
+                            __syncthreads();
+                            for (int base = 0; base < n_list; base += NT) {
+                                const int a = base + tid;
+                                if (a < n_list && state[a] == CAND_PASS) {
+                                    const int p = atomicAdd(&s.bc_i[3], 1);
+                                    if (p < 6 * BFS_FRONT) go_a[p] = a;
+                                }
+                            }
+                            __syncthreads();
+                            n_go = uni(s.bc_i[3]);
+                            if (n_go > 6 * BFS_FRONT) n_go = -1;   // (more than the buffer holds: chunks by list position)
+                        }
+                        for (int base = 0; base < (n_go >= 0 ? n_go : n_list); base += 64) {
+                            int a = base + tid;
+                            bool mine;
+                            if (n_go >= 0) { mine = tid < 64 && a < n_go; a = mine ? go_a[a] : 0; }
+                            else mine = tid < 64 && a < n_list && state[a] == CAND_PASS;
+                            if (n_go < 0 && !block_any(mine)) continue;   // (uniform) nothing to re-parent among these 64
                             int v = -1, pv = -1, nx = -1, old_p = -1, fc = -1, flg = 0;
                             if (mine) {
                                 v = ids[a];
@@ -2598,7 +2724,7 @@ NIRRT_FN __device__ void it_connect()
                         PROF(9);
                         n_rewired += uni(s.bc_i[7]);
                         const int n_src = uni(s.bc_i[4]);
-                        if (n_src > 0) wg_recost_queue<D, NT>(s, t, n_src, n_src, new_idx, n_list, front_off);   // uniform
+                        if (n_src > 0) wg_recost_queue<D, NT>(s, t, n_src, n_src, new_idx, n_list, front_off, stamp);   // uniform
                         for (int a = tid; a < n_list; a += NT)
                             if (state[a] & CAND_BLOCKED) state[a] = (unsigned char)CAND_DIRTY;
                         PROF(10);

@@ -803,6 +803,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         want(&h.gc_idx, np); want(&h.gc_dist, np); want(&h.gc_col, np);
         want(&h.nr_idx, np); want(&h.nr_m, np);
         want(&h.bfs_q, np); want(&h.bfs_fc, np); want(&h.chain_g, np);
+        want(&h.tie_stamp, np);
         want(&h.g_cnt, (size_t)std::max(h.g_ncell, h.g_ncell2)); want(&h.g_rank, np);   // (both levels' rebuilds count in it)
         const size_t A = 256;
         size_t total = 0;
@@ -815,6 +816,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         for (const Piece &pc : pieces) { *pc.dst = (char *)t->arena + off; off += (pc.bytes + A - 1) / A * A; }
     }
     HIPCHK_T(hipMemset(h.vrec, 0, sizeof(VRec) * np));
+    HIPCHK_T(hipMemset(h.tie_stamp, 0, sizeof(int) * np));   // (a pooled arena carries an earlier tree's stamps)
     HIPCHK_T(hipMemset(t->mt, 0, sizeof(MtGen)));   // (generator 5489-less: all-zero state until nirrt_set_generators)
     h.mt = t->mt;
     HIPCHK_T(hipMemset(h.topo, 0, sizeof(Topo) * np));
@@ -922,6 +924,7 @@ extern "C" int nirrt_upload(nirrt_tree *t, int64_t n, const double *vertices, co
         ax[(size_t)i].a[0] = (int)parents[i];
     }
     HIPCHK(hipMemcpy(t->host.topo, ax.data(), sizeof(Topo) * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(t->host.tie_stamp, 0, sizeof(int) * ((size_t)t->cap + SCAN_PAD)));   // the descriptor push below restarts rw_stamp at 0
     t->host.n = (int)n;
     t->last_n = n;
     t->host.n_sol = 0;
