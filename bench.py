@@ -67,11 +67,14 @@ def parse(argv=None):
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline processes (0 = min(host cores, 32))")
     ap.add_argument("--no-ttfs", action="store_true")
     ap.add_argument("--pilot", type=int, default=0,
-                    help="a step's iterations run as two launches: this many first, then the rest with the trees ordered by the Near-set "
-                         "size the pilot measured (largest first) and the largest on wider workgroups; 0 = one launch")
-    ap.add_argument("--wide-frac", type=float, default=0.01, help="share of the batch (largest Near sets in the pilot) run on 256 lanes")
-    ap.add_argument("--narrow-frac", type=float, default=0.03, help="next share of the batch run on 128 lanes")
-    ap.add_argument("--first-frac", type=float, default=0.04, help="share of the batch (largest Near sets in the pilot) dispatched first; the rest keeps its order")
+                    help="a step's iterations run as two launches: this many first, then the rest re-scheduled like --segments does; 0 = off")
+    ap.add_argument("--segments", type=int, default=1, help="a step's iterations run as this many launches of equal length; between them the "
+                                                           "trees are re-ordered (longest first by the last segment's device time) and re-sized "
+                                                           "(--wide-visits / --narrow-visits)")
+    ap.add_argument("--wide-visits", type=float, default=0.0, help="trees whose visits covered at least this many index slots per iteration in the "
+                                                                    "last segment continue on 256 lanes (0 = never)")
+    ap.add_argument("--narrow-visits", type=float, default=0.0, help="... on 128 lanes")
+    ap.add_argument("--no-reorder", action="store_true", help="keep the dispatch order between segments")
     ap.add_argument("--free-first", type=int, default=1, help="1: problems with a free start-goal segment are dispatched first in the first launch")
     ap.add_argument("--free-lanes", type=int, default=0, choices=[0, 64, 128, 256],
                     help="workgroup size for the problems with a free start-goal segment (their Near sets grow to thousands of members: the "
@@ -226,7 +229,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    from nirrt_star_amd import _hip, build, sampling
+    from nirrt_star_amd import _hip, batch, build, sampling
     build.build()
     if args.algo.startswith("nirrt"):
         return bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work)
@@ -260,43 +263,23 @@ def main():
     np_states, py_states = problem_generators([pr["pid"] for pr in probs])
     input_generation_s = time.perf_counter() - t_inputs   # host: seeding 2 B generators (outside the timed region; the upload is inside)
 
-    seg_len = [args.pilot, iters - args.pilot] if 0 < args.pilot < iters and B > 1 else [iters]
+    # a step's iterations as `--segments` launches of equal length (or --pilot P: P, then the rest); between launches the host
+    # re-schedules from the device's own measurements (nirrt_star_amd.batch.run_scheduled)
+    if 0 < args.pilot < iters and B > 1:
+        seg_len = [args.pilot, iters - args.pilot]
+    elif args.segments > 1 and B > 1:
+        q = iters // args.segments
+        seg_len = [q] * (args.segments - 1) + [iters - q * (args.segments - 1)]
+    else:
+        seg_len = [iters]
     n_seg = len(seg_len)
 
     def one_step():
-        """one pass of the loop over the whole batch = n_seg launches; returns the sums / last-launch views the report needs"""
+        """one pass of the loop over the whole batch = n_seg launches; returns the sums the report needs"""
         _hip.reset_batch(trees)
         _hip.set_generators(trees, np_states, py_states)      # np.random.seed(s); random.seed(s) of every problem
-        order = list(first_order)
-        hint = first_hint
-        tot = {"kernel_ms": 0.0, "stats": np.zeros((B, _hip.N_STATS), dtype=np.int64), "alg_elems": np.zeros(B, dtype=np.int64),
-               "iters_done": np.zeros(B, dtype=np.int64), "seconds": np.zeros(B), "wide": 0, "narrow": 0, "words": 0}
-        if hint is not None:   # --free-lanes: lane hints of the first (only) launch
-            tot["wide"], tot["narrow"] = int(np.sum(hint == 256)), int(np.sum(hint == 128))
-        for si, n_it in enumerate(seg_len):
-            r = _hip.run_sampling([trees[b] for b in order], n_it, flags=flags, lanes_hint=hint)
-            idx = np.asarray(order)
-            tot["words"] += int(r["np_used"].sum()) + int(r["py_used"].sum())
-            secs = (r["stats"][:, 15] - r["stats"][:, 14]) / 1e8
-            tot["kernel_ms"] += r["kernel_ms"]
-            tot["stats"][idx] += r["stats"]
-            tot["alg_elems"][idx] += r["alg_elems"]
-            tot["iters_done"][idx] += r["iters_done"]
-            tot["seconds"][idx] += secs
-            if si + 1 < n_seg and B > 1:
-                rank = np.argsort(-r["stats"][:, 2], kind="stable")      # positions in this launch, largest Near sets first
-                n_first = int(B * args.first_frac)
-                head = [order[j] for j in rank[:n_first]]                # only the heaviest go first: a CU full of heavy trees
-                chosen = set(head)                                      # slows every one of them down
-                order = head + [b for b in order if b not in chosen]
-                n_w, n_n = int(B * args.wide_frac), int(B * args.narrow_frac)
-                hint = np.zeros(B, dtype=np.int32)
-                hint[:n_w] = 256
-                hint[n_w:n_w + n_n] = 128
-                tot["wide"], tot["narrow"] = n_w, n_n
-                if not hint.any():
-                    hint = None
-        return tot
+        return batch.run_scheduled(trees, seg_len, flags, order=first_order, hint=first_hint, wide_visits=args.wide_visits,
+                                   narrow_visits=args.narrow_visits, reorder=not args.no_reorder)
 
     for _ in range(args.warmup):
         one_step()
@@ -348,7 +331,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "wasted_traffic_ratio": (traffic / useful_b) if traffic else None,
-                         "kernel": "k_run_sample<%d>" % D, "kernel_ms": k_ms, "kernel_ms_is": "sum of the step's %d launches (pilot + rest)" % n_seg if n_seg > 1 else "the step's launch",
+                         "kernel": "k_run_sample<%d>" % D, "kernel_ms": k_ms, "kernel_ms_is": "sum of the step's %d launches" % n_seg if n_seg > 1 else "the step's launch",
                          "useful_bytes_per_launch": useful_b, "visited_index_bytes_per_launch": float(np.mean(visit_b)),
                          "per_iteration": {"visited_slots": per_it[0], "visit_bytes": per_it[1], "near_members": per_it[2],
                                            "members_spilled": per_it[3], "chain_records": per_it[4], "rewire_candidates": per_it[5],

@@ -143,6 +143,56 @@ def fetch_np(trees, streams, idx):
             streams[i].absorb(np_st=(nk[k], npos[k]))
 
 
+def run_scheduled(trees, seg_len, flags, order=None, hint=None, wide_visits=0.0, narrow_visits=0.0, reorder=True):
+    """RRT* / IRRT* on a batch whose trees draw from their own generators, as len(seg_len) persistent launches of seg_len[k]
+    iterations each.  Between two launches the HOST re-schedules the independent problems from what the device measured in the
+    launch before (problems, generators and results are untouched: a tree resumes exactly where it stopped):
+      * dispatch order = longest first by the device time of the last segment - a launch lasts as long as its last tree, and
+        trees dispatched late should be the short ones;
+      * a tree whose fused nearest / Near visits covered >= wide_visits slots per iteration moves to a 256-lane workgroup
+        (>= narrow_visits: 128 lanes): its visit is the whole iteration and scales with the lanes (a 3D tree with 14 000 visited
+        slots per iteration: 450 us per iteration on one wave, 190 us on four).  Lane groups run at the same time.
+    `order` / `hint`: dispatch order / lane hints (by position in `order`) of the FIRST launch.
+    Returns the sums over the segments: kernel_ms, stats (B, N_STATS), alg_elems, iters_done, seconds, status, words; wide /
+    narrow = trees on 256 / 128 lanes in the last launch."""
+    B = len(trees)
+    order = list(range(B)) if order is None else list(order)
+    tot = {"kernel_ms": 0.0, "stats": np.zeros((B, _hip.N_STATS), dtype=np.int64), "alg_elems": np.zeros(B, dtype=np.int64),
+           "iters_done": np.zeros(B, dtype=np.int64), "seconds": np.zeros(B), "status": np.zeros(B, dtype=np.int32), "words": 0,
+           "wide": int(np.sum(np.asarray(hint) == 256)) if hint is not None else 0,
+           "narrow": int(np.sum(np.asarray(hint) == 128)) if hint is not None else 0}
+    for si, n_it in enumerate(seg_len):
+        live = [b for b in order if tot["status"][b] == 0]
+        if not live:
+            break
+        if len(live) != len(order):      # (a stopped tree leaves the batch; hints follow their trees)
+            keep = {b: (hint[j] if hint is not None else 0) for j, b in enumerate(order)}
+            order = live
+            hint = np.array([keep[b] for b in order], dtype=np.int32) if hint is not None else None
+        r = _hip.run_sampling([trees[b] for b in order], int(n_it), flags=flags, lanes_hint=hint)
+        idx = np.asarray(order)
+        secs = (r["stats"][:, _hip.ST_T1] - r["stats"][:, _hip.ST_T0]) / 1e8
+        tot["kernel_ms"] += r["kernel_ms"]
+        tot["stats"][idx] += r["stats"]
+        tot["alg_elems"][idx] += r["alg_elems"]
+        tot["iters_done"][idx] += r["iters_done"]
+        tot["seconds"][idx] += secs
+        tot["status"][idx] = r["status"]
+        tot["words"] += int(r["np_used"].sum()) + int(r["py_used"].sum())
+        if si + 1 < len(seg_len) and B > 1:
+            visits = r["stats"][:, 0] / np.maximum(1, r["stats"][:, _hip.ST_ITERS])
+            rank = np.argsort(-secs, kind="stable") if reorder else np.arange(len(order))
+            order = [order[j] for j in rank]
+            h = np.zeros(len(order), dtype=np.int32)
+            if wide_visits > 0:
+                h[visits[rank] >= wide_visits] = 256
+            if narrow_visits > 0:
+                h[(visits[rank] >= narrow_visits) & (h == 0)] = 128
+            hint = h if h.any() else None
+            tot["wide"], tot["narrow"] = int(np.sum(h == 256)), int(np.sum(h == 128))
+    return tot
+
+
 class Guidance:
     """NIRRT* / NRRT* point-cloud guidance of a batch: policy scalars + the (batched) cloud refresh"""
 

@@ -1291,6 +1291,28 @@ static void report_stats(const nirrt_run_args *a, int i, const long long *after,
     }
 }
 
+// Lane groups of one nirrt_run call must run AT THE SAME TIME (the few wide workgroups of the heavy trees next to the many
+// one-wave trees).  Tree streams do not guarantee that: thousands of them share the handful of hardware queues, and two
+// launches that land on the same queue run one after the other (measured: the 64-lane group started the moment the 256-lane
+// group ended).  Three streams per device, created back to back (consecutive streams get consecutive hardware queues), the
+// first with the highest priority - it carries the widest, longest-running trees.
+static hipStream_t *group_streams(int device)
+{
+    static std::mutex mu;
+    static hipStream_t st[16][3];
+    static bool made[16] = {false};
+    std::lock_guard<std::mutex> g(mu);
+    const int d = device & 15;
+    if (!made[d]) {
+        int lo = 0, hi = 0;   // (numerically lower = higher priority)
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
+        for (int i = 0; i < 3; i++)
+            if (hipStreamCreateWithPriority(&st[d][i], hipStreamNonBlocking, i == 0 ? hi : lo) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        made[d] = true;
+    }
+    return st[d];
+}
+
 static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *a)
 {
     nirrt_tree *t0 = trees[0];
@@ -1346,6 +1368,10 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         for (int i = 0; i < n_trees; i++)
             if (want[(size_t)i] == v) perm.push_back(i);
         if ((int)perm.size() > b0) groups.push_back(Group{v, b0, (int)perm.size(), trees[perm[(size_t)b0]]->stream, nullptr, nullptr});
+    }
+    if (groups.size() > 1) {
+        if (hipStream_t *gs = group_streams(t0->device))
+            for (size_t gi = 0; gi < groups.size(); gi++) groups[gi].st = gs[gi];
     }
     bool identity = true;
     for (int j = 0; j < n_trees; j++) identity = identity && perm[(size_t)j] == j;

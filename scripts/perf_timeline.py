@@ -19,8 +19,9 @@ free_line = [not t.is_collision(pr["x_start"], pr["x_goal"]) for t, pr in zip(tr
 order = sorted(range(B), key=lambda b: (not free_line[b], b)) if args.free_first else list(range(B))
 np_st, py_st = bench.problem_generators([pr["pid"] for pr in probs])
 _hip.set_generators(trees, np_st, py_st)
-r = _hip.run_sampling([trees[b] for b in order], iters, flags=_hip.F_IRRT if args.algo == "irrt" else 0)
+hint = np.array([args.free_lanes if free_line[b] else 0 for b in order], dtype=np.int32) if args.free_lanes else None
+r = _hip.run_sampling([trees[b] for b in order], iters, flags=_hip.F_IRRT if args.algo == "irrt" else 0, lanes_hint=hint)
 st = r["stats"]
 os.makedirs("gpurun_out", exist_ok=True)
-np.savez("gpurun_out/timeline.npz", t0=st[:, 14], t1=st[:, 15], order=np.array(order), free=np.array(free_line), kernel_ms=r["kernel_ms"], stats=st)
+np.savez("gpurun_out/timeline.npz", t0=st[:, 14], t1=st[:, 15], order=np.array(order), free=np.array(free_line), hint=hint if hint is not None else np.zeros(1), kernel_ms=r["kernel_ms"], stats=st)
 print("kernel_ms", r["kernel_ms"])
