@@ -45,6 +45,11 @@ int nirrt_pn2_sa_mlp(const float *feats, const float *xyz, const float *new_xyz,
 int nirrt_pn2_net_input(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n, const double *starts,
                         const double *goals, double radius, float *out, void *stream);
 
+/* the same block with GIVEN indicator channels: start_masks / goal_masks DEVICE bytes, cloud `row` at + row * mask_stride (the
+ * masks of the neural-connect rounds are re-seeded at boundary points, pointnet2_wrapper_connect_bfs.py:181-216) */
+int nirrt_pn2_net_input_masks(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n,
+                              const uint8_t *start_masks, const uint8_t *goal_masks, int64_t mask_stride, float *out, void *stream);
+
 /* Input rows of the set-abstraction levels whose MLP runs as library GEMMs: sample_and_group's concatenation
  * (pointnet2_utils.py:247-250) in one pass.  DEVICE pointers as for nirrt_pn2_sa_mlp; C a multiple of 4;
  * out f32 (B * S * K, C + 4) = [feats[b, gidx], xyz[b, gidx] - new_xyz[b, s], 0] (the zero column keeps rows 16-byte aligned). */
@@ -89,6 +94,32 @@ typedef struct nirrt_cloud_job {
 } nirrt_cloud_job;
 int nirrt_guidance_clouds(const nirrt_cloud_job *jobs, int n_jobs, int n_raw, int n_points, double *clouds, int *n_cand, int *n_out,
                           int device_id);
+
+/* Neural connect for a batch of clouds (PNGWrapper.generate_connected_path_points, wrapper{,_3d}/pointnet_pointnet2/
+ * pointnet2_wrapper_connect_bfs.py:76-240, with bfs_point_cloud_visualization / get_boundary_mask /
+ * select_heuristic_boundary_point of wrapper/utils/bfs_connect_heuristic.py:80-139, 5-29, 142-181), one workgroup per cloud.
+ * The reference's float32 numpy arithmetic is restated op by op (float32 differences, (d0^2 + d1^2) [+ d2^2], correctly rounded
+ * sqrt, strict `< radius`).  jobs: HOST array whose pointers are DEVICE addresses; n <= 2048 points.
+ *   nirrt_connect_round: path_mask |= pred; breadth-first reachability start -> goal (then goal -> start) over the predicted
+ *     points; has_path[b] = 1 ends the rounds of cloud b; otherwise boundary masks (jobs[b].boundary, (2, n)) and the heuristic
+ *     boundary point of each search: seed_idx (n_jobs, 2), -1 = no boundary point; tie (n_jobs, 2) != 0: two boundary points
+ *     share a key of the rank heuristic - numpy's argsort is not stable, the caller repeats that choice with numpy on the
+ *     boundary mask.  has_path / seed_idx / tie: HOST outputs.
+ *   nirrt_connect_masks: start / goal masks of the next classification from seeds (HOST (n_jobs, 2)): -2 = the start / goal
+ *     state (the masks before the first round), -1 = keep the mask, >= 0 = that cloud point. */
+typedef struct nirrt_connect_job {
+    const double *cloud;     /* DEVICE (n, 3) f64, z = 0 for planar clouds (the float32 cloud of the reference = its rounding) */
+    const uint8_t *pred;     /* DEVICE (n,): this round's path_pred != 0 */
+    uint8_t *path_mask;      /* DEVICE (n,) in / out: path_pred_mask, the union of the predictions so far */
+    uint8_t *start_mask;     /* DEVICE (n,) in / out */
+    uint8_t *goal_mask;      /* DEVICE (n,) in / out */
+    uint8_t *boundary;       /* DEVICE (2, n) out */
+    int32_t n, dim;
+    double start[3], goal[3];
+} nirrt_connect_job;
+int nirrt_connect_round(const nirrt_connect_job *jobs, int n_jobs, double radius, int32_t *has_path, int32_t *seed_idx, int32_t *tie,
+                        int device_id);
+int nirrt_connect_masks(const nirrt_connect_job *jobs, int n_jobs, double radius, const int32_t *seed_idx, int device_id);
 
 #ifdef __cplusplus
 }

@@ -366,7 +366,16 @@ class Guidance:
 
         preds = [None] * nd
         pred_dev = None
-        if self.connect:
+        if self.connect and self.device_input and hasattr(self.wrapper, "classify_device"):
+            # neural connect on the device: every round = one forward per cloud size + ONE launch of searches / heuristics
+            from .png_wrapper import connect_rounds_device
+            _, runs, pred_dev = connect_rounds_device(self.wrapper, clouds_dev, n_out, xs_l, xg_l, self.radius, self.max_trials,
+                                                      fps_starts_for, self.dim, self.device_id)
+            pred_host = pred_dev.cpu().numpy().astype(np.float32)
+            for j in range(nd):
+                preds[j] = pred_host[j, : n_out[j]]
+            self.calls += int(runs.max()) if nd else 0
+        elif self.connect:
             res = self.wrapper.generate_connected_path_points_batch([c.astype(np.float32) for c in clouds], xs_l, xg_l, self.radius,
                                                                     self.max_trials, fps_starts_for)
             for j, (_, runs, mask) in enumerate(res):

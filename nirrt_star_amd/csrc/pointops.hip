@@ -625,9 +625,12 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 // One workgroup per cloud; rows[] picks the clouds of one size n out of the batch's (n_clouds, stride_pts, 3) f64 block.
 // ------------------------------------------------------------------------------------------------
 #define NI_NT 256
+// smask / gmask != nullptr: the indicator channels are given (one byte per point, row `row` at + row * mask_stride) - the masks of
+// the neural-connect rounds are re-seeded at boundary points (k_connect_masks) instead of following from the start / goal states
 __global__ __launch_bounds__(NI_NT) void k_net_input(const double *__restrict__ clouds, long long stride_pts, const int *__restrict__ rows,
                                                      int n, const double *__restrict__ starts, const double *__restrict__ goals,
-                                                     double radius, float *__restrict__ out)
+                                                     double radius, float *__restrict__ out, const unsigned char *__restrict__ smask,
+                                                     const unsigned char *__restrict__ gmask, long long mask_stride)
 {
     extern __shared__ float ni_lds[];          // 3 * n coordinates + reduction slots
     float *px = ni_lds, *py = px + n, *pz = py + n;
@@ -635,16 +638,23 @@ __global__ __launch_bounds__(NI_NT) void k_net_input(const double *__restrict__ 
     __shared__ float red[NI_NT / 64];
     const int b = blockIdx.x, row = rows[b], tid = threadIdx.x;
     const double *c = clouds + (long long)row * stride_pts * 3;
-    const double sx = starts[3 * b], sy = starts[3 * b + 1], sz = starts[3 * b + 2];
-    const double gx = goals[3 * b], gy = goals[3 * b + 1], gz = goals[3 * b + 2];
+    const bool given = smask != nullptr;
+    const double sx = given ? 0. : starts[3 * b], sy = given ? 0. : starts[3 * b + 1], sz = given ? 0. : starts[3 * b + 2];
+    const double gx = given ? 0. : goals[3 * b], gy = given ? 0. : goals[3 * b + 1], gz = given ? 0. : goals[3 * b + 2];
     float *o = out + (long long)b * 6 * n;
     for (int i = tid; i < n; i += NI_NT) {
         const double x = c[3 * i], y = c[3 * i + 1], z = c[3 * i + 2];
         px[i] = (float)x; py[i] = (float)y; pz[i] = (float)z;
-        double dx = x - sx, dy = y - sy, dz = z - sz;
-        const float sm = sqrt((dx * dx + dy * dy) + dz * dz) < radius ? 1.f : 0.f;
-        dx = x - gx; dy = y - gy; dz = z - gz;
-        const float gm = sqrt((dx * dx + dy * dy) + dz * dz) < radius ? 1.f : 0.f;
+        float sm, gm;
+        if (given) {
+            sm = smask[(long long)row * mask_stride + i] ? 1.f : 0.f;
+            gm = gmask[(long long)row * mask_stride + i] ? 1.f : 0.f;
+        } else {
+            double dx = x - sx, dy = y - sy, dz = z - sz;
+            sm = sqrt((dx * dx + dy * dy) + dz * dz) < radius ? 1.f : 0.f;
+            dx = x - gx; dy = y - gy; dz = z - gz;
+            gm = sqrt((dx * dx + dy * dy) + dz * dz) < radius ? 1.f : 0.f;
+        }
         o[3 * n + i] = sm;
         o[4 * n + i] = gm;
         o[5 * n + i] = (sm + gm) == 0.f ? 1.f : 0.f;
@@ -681,8 +691,241 @@ extern "C" int nirrt_pn2_net_input(const double *clouds, int64_t stride_pts, con
 {
     if (n_rows <= 0 || n <= 0 || n > 12288 || stride_pts < n) return -1;
     hipLaunchKernelGGL(k_net_input, dim3((unsigned)n_rows), dim3(NI_NT), sizeof(float) * 3 * (size_t)n, (hipStream_t)stream, clouds,
-                       (long long)stride_pts, rows, n, starts, goals, radius, out);
+                       (long long)stride_pts, rows, n, starts, goals, radius, out, (const unsigned char *)nullptr, (const unsigned char *)nullptr, 0ll);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int nirrt_pn2_net_input_masks(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n,
+                                         const uint8_t *start_masks, const uint8_t *goal_masks, int64_t mask_stride, float *out, void *stream)
+{
+    if (n_rows <= 0 || n <= 0 || n > 12288 || stride_pts < n || mask_stride < n || !start_masks || !goal_masks) return -1;
+    hipLaunchKernelGGL(k_net_input, dim3((unsigned)n_rows), dim3(NI_NT), sizeof(float) * 3 * (size_t)n, (hipStream_t)stream, clouds,
+                       (long long)stride_pts, rows, n, (const double *)nullptr, (const double *)nullptr, 0.0, out, start_masks, goal_masks,
+                       (long long)mask_stride);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Neural connect (wrapper/pointnet_pointnet2/pointnet2_wrapper_connect_bfs.py:76-240 with the helpers of
+// wrapper/utils/bfs_connect_heuristic.py:5-29, 80-139, 142-181), one workgroup per cloud, every open cloud of a batch in one
+// launch.  The reference works on the float32 cloud with numpy: np.linalg.norm(axis) of float32 differences = correctly rounded
+// float32 sqrt of the float32 sum (d0^2 + d1^2) [+ d2^2], compared with the radius in float32 - restated here op by op.
+//   * breadth-first search from one end over {end, other end, points predicted "path" so far}, edge <=> distance < radius: only
+//     the SET reached matters (has_path <=> the other end is adjacent to the end or to a reached point; without a path the
+//     reached set is the end's whole component, whatever the visiting order), so the search runs level by level in parallel;
+//   * boundary = reached points with a not-predicted point strictly within the radius;
+//   * next seed = the boundary point with the smallest (rank of g + h, ascending) + (rank of g, descending), first on ties of
+//     that sum.  numpy's argsort is not stable: equal keys are reported (tie) and the caller repeats the choice for that cloud
+//     with numpy itself;
+//   * start / goal masks of the next classification = points strictly within the radius of the seeds (k_connect_masks).
+// ------------------------------------------------------------------------------------------------
+struct nirrt_connect_job {
+    const double *cloud;        // DEVICE (n, 3) f64 (z = 0 for planar clouds)
+    const unsigned char *pred;  // DEVICE (n,): this round's path_pred != 0
+    unsigned char *path_mask;   // DEVICE (n,) in / out: union of the predictions so far (path_pred_mask)
+    unsigned char *start_mask;  // DEVICE (n,) in / out: start / goal masks of the NEXT classification
+    unsigned char *goal_mask;
+    unsigned char *boundary;    // DEVICE (2, n) out: boundary masks of the two searches (start -> goal, goal -> start)
+    int n, dim;
+    double start[3], goal[3];
+};
+#define CN_NT 256
+#define CN_MAX 2048
+
+__device__ __forceinline__ float cn_dist(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return sqrtf((dx * dx + dy * dy) + dz * dz);   // (planar clouds: dz == 0 adds an exact zero)
+}
+
+__global__ __launch_bounds__(CN_NT) void k_connect_round(const nirrt_connect_job *jobs, float radius, int *has_path, int *seed_idx, int *tie)
+{
+    __shared__ float px[CN_MAX], py[CN_MAX], pz[CN_MAX];
+    __shared__ unsigned char um[CN_MAX], vis[CN_MAX], bf[CN_MAX];
+    __shared__ unsigned short fr[2][CN_MAX], bidx[CN_MAX];
+    __shared__ float kg[CN_MAX], ks[CN_MAX];
+    __shared__ int cnt[2], flag, best_score, best_k;
+    const nirrt_connect_job jb = jobs[blockIdx.x];
+    const int tid = threadIdx.x, n = jb.n;
+    for (int i = tid; i < n; i += CN_NT) {
+        px[i] = (float)jb.cloud[3 * i]; py[i] = (float)jb.cloud[3 * i + 1]; pz[i] = jb.dim == 3 ? (float)jb.cloud[3 * i + 2] : 0.f;
+        const unsigned char u = (unsigned char)((jb.path_mask[i] | jb.pred[i]) ? 1 : 0);   // ((mask + pred) > 0)
+        um[i] = u;
+        jb.path_mask[i] = u;
+    }
+    if (tid == 0) { has_path[blockIdx.x] = 0; seed_idx[2 * blockIdx.x] = -1; seed_idx[2 * blockIdx.x + 1] = -1; tie[2 * blockIdx.x] = 0; tie[2 * blockIdx.x + 1] = 0; }
+    const float sxyz[3] = {(float)jb.start[0], (float)jb.start[1], jb.dim == 3 ? (float)jb.start[2] : 0.f};
+    const float gxyz[3] = {(float)jb.goal[0], (float)jb.goal[1], jb.dim == 3 ? (float)jb.goal[2] : 0.f};
+    __syncthreads();
+    for (int d = 0; d < 2; d++) {
+        const float ax = d == 0 ? sxyz[0] : gxyz[0], ay = d == 0 ? sxyz[1] : gxyz[1], az = d == 0 ? sxyz[2] : gxyz[2];
+        const float bx = d == 0 ? gxyz[0] : sxyz[0], by = d == 0 ? gxyz[1] : sxyz[1], bz = d == 0 ? gxyz[2] : sxyz[2];
+        // ---- the component of end a among the predicted points ----
+        if (tid == 0) { cnt[0] = 0; cnt[1] = 0; flag = cn_dist(ax, ay, az, bx, by, bz) < radius ? 1 : 0; }
+        __syncthreads();
+        for (int i = tid; i < n; i += CN_NT) {
+            const bool hit = um[i] && cn_dist(px[i], py[i], pz[i], ax, ay, az) < radius;
+            vis[i] = hit ? 1 : 0;
+            if (hit) fr[0][atomicAdd(&cnt[0], 1)] = (unsigned short)i;
+        }
+        __syncthreads();
+        int cur = 0;
+        for (;;) {
+            const int nf = cnt[cur];
+            if (nf == 0) break;
+            for (int i = tid; i < n; i += CN_NT) {
+                if (um[i] && !vis[i]) {
+                    const float x = px[i], y = py[i], z = pz[i];
+                    bool hit = false;
+                    for (int f = 0; f < nf && !hit; f++) {
+                        const int q = fr[cur][f];
+                        hit = cn_dist(x, y, z, px[q], py[q], pz[q]) < radius;
+                    }
+                    if (hit) { vis[i] = 1; fr[cur ^ 1][atomicAdd(&cnt[cur ^ 1], 1)] = (unsigned short)i; }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) cnt[cur] = 0;
+            cur ^= 1;
+            __syncthreads();
+        }
+        // has_path: the other end is adjacent to this end or to a reached point
+        for (int i = tid; i < n; i += CN_NT)
+            if (vis[i] && cn_dist(px[i], py[i], pz[i], bx, by, bz) < radius) flag = 1;
+        __syncthreads();
+        if (flag) {   // (uniform) connected: the rounds end here (pointnet2_wrapper_connect_bfs.py:178-179)
+            if (tid == 0) has_path[blockIdx.x] = 1;
+            return;
+        }
+        // ---- boundary: reached points with a not-predicted point strictly within the radius ----
+        for (int i = tid; i < n; i += CN_NT) {
+            bool b = false;
+            if (vis[i]) {
+                const float x = px[i], y = py[i], z = pz[i];
+                for (int q = 0; q < n && !b; q++) b = !um[q] && cn_dist(x, y, z, px[q], py[q], pz[q]) < radius;
+            }
+            bf[i] = b ? 1 : 0;
+            jb.boundary[(size_t)d * n + i] = b ? 1 : 0;
+        }
+        __syncthreads();
+        if (tid == 0) {   // boundary points in index order (np.where)
+            int nb = 0;
+            for (int i = 0; i < n; i++) if (bf[i]) bidx[nb++] = (unsigned short)i;
+            cnt[1] = nb; best_score = 0x7fffffff; best_k = 0x7fffffff;
+        }
+        __syncthreads();
+        const int nb = cnt[1];
+        if (nb > 0) {
+            // g = |b - a|, h = |b - other end| (float32), key = g + h
+            for (int k = tid; k < nb; k += CN_NT) {
+                const int i = bidx[k];
+                const float g = cn_dist(px[i], py[i], pz[i], ax, ay, az), h = cn_dist(px[i], py[i], pz[i], bx, by, bz);
+                kg[k] = g; ks[k] = g + h;
+            }
+            __syncthreads();
+            bool any_tie = false;
+            for (int k = tid; k < nb; k += CN_NT) {
+                const float g = kg[k], s_ = ks[k];
+                int tr = 0, gr = 0;
+                for (int j = 0; j < nb; j++) {
+                    const float gj = kg[j], sj = ks[j];
+                    tr += sj < s_ ? 1 : 0;
+                    gr += gj > g ? 1 : 0;
+                    if (j != k && (sj == s_ || gj == g)) any_tie = true;
+                }
+                atomicMin(&best_score, tr + gr);
+                fr[0][k] = (unsigned short)(tr + gr);   // (the frontier lists are dead; the keys are still being read by other threads)
+            }
+            __syncthreads();
+            for (int k = tid; k < nb; k += CN_NT)
+                if ((int)fr[0][k] == best_score) atomicMin(&best_k, k);   // np.argmax: the first maximum of -(rank sum)
+            if (any_tie) tie[2 * blockIdx.x + d] = 1;
+            __syncthreads();
+            if (tid == 0) seed_idx[2 * blockIdx.x + d] = bidx[best_k];
+        }
+        __syncthreads();
+    }
+}
+
+// start / goal masks of the next classification: seed -2 = the start / goal state itself (the masks before the first round), -1 =
+// keep the mask (no boundary point: pointnet2_wrapper_connect_bfs.py:181-183), >= 0: that cloud point
+__global__ __launch_bounds__(CN_NT) void k_connect_masks(const nirrt_connect_job *jobs, float radius, const int *seed_idx)
+{
+    const nirrt_connect_job jb = jobs[blockIdx.x];
+    for (int d = 0; d < 2; d++) {
+        const int sd = seed_idx[2 * blockIdx.x + d];
+        if (sd == -1) continue;
+        float ax, ay, az;
+        if (sd == -2) {
+            const double *p = d == 0 ? jb.start : jb.goal;
+            ax = (float)p[0]; ay = (float)p[1]; az = jb.dim == 3 ? (float)p[2] : 0.f;
+        } else {
+            ax = (float)jb.cloud[3 * sd]; ay = (float)jb.cloud[3 * sd + 1]; az = jb.dim == 3 ? (float)jb.cloud[3 * sd + 2] : 0.f;
+        }
+        unsigned char *m = d == 0 ? jb.start_mask : jb.goal_mask;
+        for (int i = threadIdx.x; i < jb.n; i += CN_NT) {
+            const float x = (float)jb.cloud[3 * i], y = (float)jb.cloud[3 * i + 1], z = jb.dim == 3 ? (float)jb.cloud[3 * i + 2] : 0.f;
+            m[i] = cn_dist(x, y, z, ax, ay, az) < radius ? 1 : 0;
+        }
+    }
+}
+
+static FpsScratch g_connect_scratch[16];
+static int connect_stage(const nirrt_connect_job *jobs, int n_jobs, int n_ints, int device_id, nirrt_connect_job **d_jobs, int **d_ints)
+{
+    if (!jobs || n_jobs <= 0) return -1;
+    for (int b = 0; b < n_jobs; b++)
+        if (jobs[b].n <= 0 || jobs[b].n > CN_MAX || (jobs[b].dim != 2 && jobs[b].dim != 3)) return -1;
+    if (hipSetDevice(device_id) != hipSuccess) return -4;
+    const size_t b_job = (sizeof(nirrt_connect_job) * (size_t)n_jobs + 255) & ~(size_t)255;
+    const size_t need = b_job + sizeof(int) * (size_t)n_ints * (size_t)n_jobs + 256;
+    FpsScratch &sc = g_connect_scratch[device_id & 15];
+    if (sc.cap < need) {
+        if (sc.p) (void)hipFree(sc.p);
+        sc.p = nullptr; sc.cap = 0;
+        if (hipMalloc(&sc.p, 2 * need) != hipSuccess) return -2;
+        sc.cap = 2 * need;
+    }
+    *d_jobs = (nirrt_connect_job *)sc.p;
+    *d_ints = (int *)((char *)sc.p + b_job);
+    return hipMemcpy(*d_jobs, jobs, sizeof(nirrt_connect_job) * (size_t)n_jobs, hipMemcpyHostToDevice) == hipSuccess ? 0 : -2;
+}
+
+// one neural-connect round for n_jobs clouds (their new predictions in jobs[].pred): has_path (n_jobs,), seed_idx (n_jobs, 2) and
+// tie (n_jobs, 2) are HOST outputs; the boundary masks stay on the device (jobs[].boundary)
+extern "C" int nirrt_connect_round(const nirrt_connect_job *jobs, int n_jobs, double radius, int32_t *has_path, int32_t *seed_idx,
+                                   int32_t *tie, int device_id)
+{
+    if (!has_path || !seed_idx || !tie) return -1;
+    std::lock_guard<std::mutex> hold(g_fps_mu);
+    nirrt_connect_job *d_jobs = nullptr;
+    int *d = nullptr;
+    int rc = connect_stage(jobs, n_jobs, 5, device_id, &d_jobs, &d);
+    if (rc) return rc;
+    int *d_has = d, *d_seed = d + n_jobs, *d_tie = d + 3 * n_jobs;
+    hipLaunchKernelGGL(k_connect_round, dim3(n_jobs), dim3(CN_NT), 0, 0, (const nirrt_connect_job *)d_jobs, (float)radius, d_has, d_seed, d_tie);
+    if (hipGetLastError() != hipSuccess || hipMemcpy(has_path, d_has, sizeof(int) * (size_t)n_jobs, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(seed_idx, d_seed, sizeof(int) * 2 * (size_t)n_jobs, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(tie, d_tie, sizeof(int) * 2 * (size_t)n_jobs, hipMemcpyDeviceToHost) != hipSuccess)
+        return -2;
+    return 0;
+}
+
+// start / goal masks from seeds (HOST (n_jobs, 2): -2 start / goal state, -1 keep, >= 0 cloud point)
+extern "C" int nirrt_connect_masks(const nirrt_connect_job *jobs, int n_jobs, double radius, const int32_t *seed_idx, int device_id)
+{
+    if (!seed_idx) return -1;
+    std::lock_guard<std::mutex> hold(g_fps_mu);
+    nirrt_connect_job *d_jobs = nullptr;
+    int *d = nullptr;
+    int rc = connect_stage(jobs, n_jobs, 2, device_id, &d_jobs, &d);
+    if (rc) return rc;
+    for (int b = 0; b < n_jobs; b++)
+        for (int k = 0; k < 2; k++)
+            if (seed_idx[2 * b + k] < -2 || seed_idx[2 * b + k] >= jobs[b].n) return -1;
+    if (hipMemcpy(d, seed_idx, sizeof(int) * 2 * (size_t)n_jobs, hipMemcpyHostToDevice) != hipSuccess) return -2;
+    hipLaunchKernelGGL(k_connect_masks, dim3(n_jobs), dim3(CN_NT), 0, 0, (const nirrt_connect_job *)d_jobs, (float)radius, (const int *)d);
+    return hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess ? 0 : -2;
 }
 
 // ------------------------------------------------------------------------------------------------

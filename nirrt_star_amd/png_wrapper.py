@@ -194,6 +194,65 @@ class PNGWrapper:
         return [(st.has_path, st.trials, st.path_pred_mask) for st in states]
 
 
+def connect_rounds_device(wrapper, clouds_dev, n_out, starts, goals, radius, max_trial_attempts, fps_starts_for=None, dim=2,
+                          device_id=0):
+    """generate_connected_path_points for a batch of clouds that are resident on the device (pointnet2_wrapper_connect_bfs.py:
+    76-240): round r classifies, in ONE forward per cloud size, every cloud that is not connected yet (input blocks assembled on
+    the device from the masks the round before left there), then ONE launch runs the breadth-first searches, boundary masks and
+    seed heuristics of all of them (nirrt_connect_round) and one more writes the next masks.  The host sees a few integers per
+    cloud and round.  clouds_dev f64 (nd, P, 3), n_out (nd,) points per cloud, starts / goals per cloud.
+    Returns (has_path bool (nd,), num_png_runs int (nd,), path_pred_mask uint8 tensor (nd, P) on the device)."""
+    from . import pointops
+    from .bfs_connect import select_heuristic_boundary_point
+    nd, P = int(clouds_dev.shape[0]), int(clouds_dev.shape[1])
+    dev = clouds_dev.device
+    n_out = np.asarray(n_out, dtype=np.int64)
+    path = torch.zeros((nd, P), dtype=torch.uint8, device=dev)
+    smask, gmask = torch.zeros_like(path), torch.zeros_like(path)
+    pred = torch.zeros_like(path)
+    boundary = torch.zeros((nd, 2, P), dtype=torch.uint8, device=dev)
+    jobs = []
+    for j in range(nd):
+        jb = pointops.ConnectJob()
+        jb.cloud, jb.pred, jb.path_mask = clouds_dev[j].data_ptr(), pred[j].data_ptr(), path[j].data_ptr()
+        jb.start_mask, jb.goal_mask, jb.boundary = smask[j].data_ptr(), gmask[j].data_ptr(), boundary[j].data_ptr()
+        jb.n, jb.dim = int(n_out[j]), int(dim)
+        for k in range(dim):
+            jb.start[k], jb.goal[k] = float(starts[j][k]), float(goals[j][k])
+        jobs.append(jb)
+    pointops.connect_masks(jobs, radius, np.full((nd, 2), -2, dtype=np.int32), device_id)      # masks around the start / goal states
+    has = np.zeros(nd, dtype=bool)
+    trials = np.zeros(nd, dtype=np.int64)
+    for _ in range(int(max_trial_attempts)):
+        open_ = [j for j in range(nd) if not has[j]]
+        if not open_:
+            break
+        for size in sorted(set(int(n_out[j]) for j in open_)):
+            grp = [j for j in open_ if n_out[j] == size]
+            x = pointops.net_input_masks(clouds_dev, grp, size, smask, gmask)
+            p = wrapper.classify_device(x, fps_starts=fps_starts_for(grp) if fps_starts_for else None)
+            pred[torch.as_tensor(grp, device=dev), :size] = (p != 0).to(torch.uint8)
+        hp, seeds, ties = pointops.connect_round([jobs[j] for j in open_], radius, device_id)
+        trials[open_] += 1
+        for k, j in enumerate(open_):
+            if hp[k]:
+                has[j] = True
+                continue
+            for d in (0, 1):
+                if ties[k, d]:     # equal keys among the boundary points: numpy's own (unstable) argsort decides, like in the reference
+                    pc32 = clouds_dev[j, : n_out[j], :dim].cpu().numpy().astype(np.float32)
+                    nj = int(n_out[j])
+                    bm = boundary[j].reshape(-1)[d * nj:(d + 1) * nj].cpu().numpy().astype(np.float32)   # (2, n) packed
+                    a = np.asarray(starts[j] if d == 0 else goals[j]).astype(np.float32)
+                    b = np.asarray(goals[j] if d == 0 else starts[j]).astype(np.float32)
+                    bi, _, _ = select_heuristic_boundary_point(pc32, bm, a, b)
+                    seeds[k, d] = -1 if bi is None else int(bi)
+        still = [k for k, j in enumerate(open_) if not hp[k]]
+        if still:
+            pointops.connect_masks([jobs[open_[k]] for k in still], radius, seeds[still], device_id)
+    return has, trials, path
+
+
 class ConnectState:
     """one cloud's progress through the neural-connect rounds: the union of the predictions so far, the start / goal masks
     the NEXT classification uses, and whether start and goal are connected through predicted points yet"""

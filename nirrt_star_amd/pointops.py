@@ -43,6 +43,9 @@ def _lib():
         L.nirrt_pn2_group_rows.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.nirrt_pn2_fp_rows.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.nirrt_pn2_net_input.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp, C.c_double, vp, vp]
+        L.nirrt_pn2_net_input_masks.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp, C.c_int64, vp, vp]
+        L.nirrt_connect_round.argtypes = [vp, C.c_int, C.c_double, vp, vp, vp, C.c_int]
+        L.nirrt_connect_masks.argtypes = [vp, C.c_int, C.c_double, vp, C.c_int]
         for f in (L.nirrt_pn2_fps, L.nirrt_pn2_ball_query, L.nirrt_pn2_three_nn, L.nirrt_fps_f64, L.nirrt_fps_f64_batch,
                   L.nirrt_pn2_sa_mlp, L.nirrt_pn2_group_rows, L.nirrt_pn2_fp_rows, L.nirrt_pn2_net_input):
             f.restype = C.c_int
@@ -109,6 +112,49 @@ def net_input(clouds, rows, n, starts, goals, radius):
     _check(_lib().nirrt_pn2_net_input(clouds.data_ptr(), clouds.shape[1], rows_t.data_ptr(), len(rows_t), int(n), st.data_ptr(),
                                       gl.data_ptr(), float(radius), out.data_ptr(), _stream(clouds)), "net_input")
     return out
+
+
+def net_input_masks(clouds, rows, n, start_masks, goal_masks):
+    """net_input with GIVEN indicator channels: start_masks / goal_masks uint8 (n_clouds, stride) on the device (the masks of
+    the neural-connect rounds) -> x f32 (len(rows), 6, n)"""
+    _need_cuda("net_input_masks", clouds)
+    dev = clouds.device
+    assert start_masks.dtype == torch.uint8 and goal_masks.dtype == torch.uint8 and start_masks.is_contiguous() and goal_masks.is_contiguous()
+    assert start_masks.shape == goal_masks.shape and start_masks.shape[0] == clouds.shape[0]
+    rows_t = torch.as_tensor(rows, dtype=torch.int32).to(dev)
+    out = torch.empty(len(rows_t), 6, int(n), dtype=torch.float32, device=dev)
+    _check(_lib().nirrt_pn2_net_input_masks(clouds.data_ptr(), clouds.shape[1], rows_t.data_ptr(), len(rows_t), int(n),
+                                            start_masks.data_ptr(), goal_masks.data_ptr(), start_masks.shape[1], out.data_ptr(),
+                                            _stream(clouds)), "net_input_masks")
+    return out
+
+
+class ConnectJob(C.Structure):
+    """nirrt_connect_job of include/nirrt_pointops.h"""
+    _fields_ = [("cloud", C.c_void_p), ("pred", C.c_void_p), ("path_mask", C.c_void_p), ("start_mask", C.c_void_p),
+                ("goal_mask", C.c_void_p), ("boundary", C.c_void_p), ("n", C.c_int32), ("dim", C.c_int32),
+                ("start", C.c_double * 3), ("goal", C.c_double * 3)]
+
+
+def connect_round(jobs, radius, device_id=0):
+    """one neural-connect round of len(jobs) clouds on the device -> (has_path (n,), seed_idx (n, 2), tie (n, 2)) int32"""
+    import numpy as np
+    n = len(jobs)
+    arr = (ConnectJob * n)(*jobs)
+    has, seed, tie = np.zeros(n, dtype=np.int32), np.zeros((n, 2), dtype=np.int32), np.zeros((n, 2), dtype=np.int32)
+    torch.cuda.current_stream(torch.device("cuda", device_id)).synchronize()
+    _check(_lib().nirrt_connect_round(C.cast(arr, C.c_void_p), n, float(radius), has.ctypes.data, seed.ctypes.data, tie.ctypes.data, int(device_id)), "connect_round")
+    return has, seed, tie
+
+
+def connect_masks(jobs, radius, seed_idx, device_id=0):
+    """start / goal masks of the next classification from seeds (n, 2): -2 start / goal state, -1 keep, >= 0 cloud point"""
+    import numpy as np
+    n = len(jobs)
+    arr = (ConnectJob * n)(*jobs)
+    seed = np.ascontiguousarray(seed_idx, dtype=np.int32).reshape(n, 2)
+    torch.cuda.current_stream(torch.device("cuda", device_id)).synchronize()
+    _check(_lib().nirrt_connect_masks(C.cast(arr, C.c_void_p), n, float(radius), seed.ctypes.data, int(device_id)), "connect_masks")
 
 
 def group_rows(feats, xyz, new_xyz, gidx):

@@ -77,6 +77,29 @@ class FakePNG:
         return True, 1, pred.astype(np.float32)
 
 
+def seed_grow_classifier(grow, calls=None):
+    """the deterministic classifier of the neural-connect fixtures (tests/golden/make_golden.py, same function there): a point
+    is "path" iff it lies within `grow` of a point of the start or goal mask - several rounds are needed to connect"""
+    def classify(pc_, start_mask, goal_mask):
+        pc_ = np.asarray(pc_)
+        seeds = pc_[(np.asarray(start_mask) + np.asarray(goal_mask)) > 0]
+        d = np.linalg.norm(pc_[:, None] - seeds[None], axis=2).min(axis=1) if len(seeds) else np.full(len(pc_), np.inf)
+        if calls is not None:
+            calls.append((np.asarray(start_mask, dtype=np.float32).copy(), np.asarray(goal_mask, dtype=np.float32).copy()))
+        return (d < grow).astype(np.int64), (1.0 / (1.0 + d)).astype(np.float32)
+    return classify
+
+
+def stub_connect_wrapper(dim, grow, calls=None):
+    """PNGWrapper / PNGWrapper3D without a network: generate_connected_path_points is the package's, the classifier the seed-growing one"""
+    from nirrt_star_amd import png_wrapper
+    w = object.__new__(png_wrapper.PNGWrapper if dim == 2 else png_wrapper.PNGWrapper3D)
+    classify = seed_grow_classifier(grow, calls)
+    w.classify_path_points = classify
+    w.classify_batch = lambda clouds, sm, gm, fps_starts=None: (np.stack([classify(c, s, g_)[0] for c, s, g_ in zip(clouds, sm, gm)]), None)
+    return w
+
+
 _CK_ROOTS = {}
 
 

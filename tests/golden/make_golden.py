@@ -550,6 +550,103 @@ def connect_fixture():
     save("connect_ref", **out)
 
 
+def seed_grow_classifier(grow, calls=None):
+    """deterministic stand-in for the network that needs several neural-connect rounds: a point is "path" iff it lies within
+    `grow` of a point of the start or goal mask (same function in tests/conftest.py)"""
+    def classify(pc_, start_mask, goal_mask):
+        seeds = pc_[(np.asarray(start_mask) + np.asarray(goal_mask)) > 0]
+        d = np.linalg.norm(pc_[:, None] - seeds[None], axis=2).min(axis=1) if len(seeds) else np.full(len(pc_), np.inf)
+        if calls is not None:
+            calls.append((np.asarray(start_mask, dtype=np.float32).copy(), np.asarray(goal_mask, dtype=np.float32).copy()))
+        return (d < grow).astype(np.int64), (1.0 / (1.0 + d)).astype(np.float32)
+    return classify
+
+
+def connect_fixture3d():
+    """a20 in 3D: the helpers of wrapper/utils/bfs_connect_heuristic.py on a 3D cloud and the multi-round loop of the 3D wrapper
+    class (wrapper_3d/pointnet_pointnet2/pointnet2_wrapper_connect_bfs.py:76-...) with the seed-growing classifier."""
+    from datasets_3d.point_cloud_mask_utils_3d import generate_rectangle_point_cloud_3d
+    from wrapper.utils.bfs_connect_heuristic import (bfs_point_cloud_visualization, get_boundary_mask,
+                                                     select_heuristic_boundary_point)
+    from wrapper_3d.pointnet_pointnet2.pointnet2_wrapper_connect_bfs import PNGWrapper as RefWrapper3D
+    out = {}
+    np.random.seed(9)
+    pr, _ = make_problem(3, "ref3d", 9, 0)
+    env3 = RefEnv3D(pr["env_dict"])
+    np.random.seed(41)
+    pc = generate_rectangle_point_cloud_3d(env3, 2048, over_sample_scale=5).astype(np.float32)
+    xs, xg = np.array(pr["x_start"], dtype=np.float64), np.array(pr["x_goal"], dtype=np.float64)
+    out["pc"], out["xs"], out["xg"] = pc, xs, xg
+    out["env"] = env_json(pr["env_dict"])
+    RADIUS = 6      # (the planners use step_len = 10; 2048 points in a 50^3 box are ~4 apart, so the helpers get a tighter radius here)
+    ab = (xg - xs).astype(np.float32)
+    tt = np.clip(((pc - xs.astype(np.float32)) @ ab) / (ab @ ab), 0, 1)
+    dline = np.linalg.norm(pc - (xs.astype(np.float32) + tt[:, None] * ab), axis=1)
+    corridor = (dline < 10).astype(np.float32)
+    blobs = ((np.linalg.norm(pc - xs.astype(np.float32), axis=1) < 13) | (np.linalg.norm(pc - xg.astype(np.float32), axis=1) < 13)).astype(np.float32)
+    for tag, pm in (("corridor", corridor), ("blobs", blobs)):
+        for dtag, a, b in (("sg", xs, xg), ("gs", xg, xs)):
+            has, line, vis = bfs_point_cloud_visualization(pc, pm, a.astype(np.float32), b.astype(np.float32), RADIUS)
+            bm = get_boundary_mask(pc, vis, 1 - pm, RADIUS)
+            bi, bp, heur = select_heuristic_boundary_point(pc, bm, a.astype(np.float32), b.astype(np.float32))
+            k = "%s_%s" % (tag, dtag)
+            out[k + "_mask"] = pm
+            out[k + "_has"] = np.array(bool(has))
+            out[k + "_visited"] = np.asarray(vis, dtype=np.float32)
+            out[k + "_boundary"] = np.asarray(bm, dtype=np.float32)
+            out[k + "_bidx"] = np.array(-1 if bi is None else int(bi))
+            print("   connect3d %s: has=%s visited %d boundary %d seed %s" % (k, has, int(vis.sum()), int(bm.sum()), bi))
+    out["radius"] = np.array(float(RADIUS))
+    calls = []
+    w = object.__new__(RefWrapper3D)
+    w.classify_path_points = seed_grow_classifier(8.0, calls)
+    for tag, trials, rad in (("loop5", 5, 6), ("loop2", 2, 6)):
+        del calls[:]
+        ok, runs, mask = w.generate_connected_path_points(pc, xs, xg, pr["env_dict"], rad, trials)
+        out[tag + "_ok"], out[tag + "_runs"], out[tag + "_mask"] = np.array(bool(ok)), np.array(int(runs)), np.asarray(mask, dtype=np.float32)
+        out[tag + "_start_masks"] = np.stack([c[0] for c in calls])
+        out[tag + "_goal_masks"] = np.stack([c[1] for c in calls])
+        print("   connect3d %s: ok=%s runs=%d path points %d" % (tag, ok, runs, int(mask.sum())))
+    save("connect_ref3d", **out)
+
+
+def nirrtc_bfs_fixture(name, dim, world_seed, iters, seed, grow):
+    """NIRRT*-PNG(C) whole run in which the neural-connect loop REALLY runs: the reference planner
+    (path_planning_classes{,_3d}/nirrt_star_png_c_{2d,3d}.py) with the reference's own connect wrapper class
+    (generate_connected_path_points and the bfs helpers are the reference's code) whose network is replaced by the seed-growing
+    classifier.  Pins the 3D instantiation of the loop inside a planner run (NIRRT*-C 3D had no reference-run fixture)."""
+    if dim == 2:
+        from path_planning_classes.nirrt_star_png_c_2d import NIRRTStarPNGC2D as PC
+        from wrapper.pointnet_pointnet2.pointnet2_wrapper_connect_bfs import PNGWrapper as WC
+    else:
+        from path_planning_classes_3d.nirrt_star_png_c_3d import NIRRTStarPNGC3D as PC
+        from wrapper_3d.pointnet_pointnet2.pointnet2_wrapper_connect_bfs import PNGWrapper as WC
+    t0 = time.time()
+    pr, clearance = make_problem(dim, "b30", world_seed, 0)
+    calls = []
+    w = object.__new__(WC)
+    w.classify_path_points = seed_grow_classifier(grow, calls)
+    common = [pr["x_start"], pr["x_goal"], STEP_LEN, pr["search_radius"], iters, pr["env_dict"], w]
+    if dim == 2:
+        common.append(pr["binary_mask"])
+    planner = PC(*common, clearance, 2048, 5, 0.5, 0.9, 5)
+    np.random.seed(seed)
+    random.seed(seed)
+    with quiet():
+        planner.planning()
+    n = planner.num_vertices
+    path = np.array(planner.path, dtype=np.float64).reshape(-1, dim) if len(planner.path) else np.zeros((0, dim))
+    save(name, env=env_json(pr["env_dict"]), dim=np.array(dim), algo=np.array("nirrt_c"), grow=np.array(float(grow)),
+         seed=np.array(seed), iter_max=np.array(iters), step_len=np.array(float(STEP_LEN)), clearance=np.array(float(clearance)),
+         search_radius=np.array(float(pr["search_radius"])), x_start=np.array(pr["x_start"], dtype=np.float64),
+         x_goal=np.array(pr["x_goal"], dtype=np.float64), n=np.array(n), vertices=planner.vertices[:n].copy(),
+         parents=planner.vertex_parents[:n].astype(np.int64), path=path, path_len=np.array(float(planner.get_path_len(planner.path))),
+         path_solutions=np.array(planner.path_solutions, dtype=np.int64), n_classifications=np.array(len(calls)),
+         num_png_calls=np.array(int(planner.num_png_calls) if hasattr(planner, "num_png_calls") else -1),
+         binary_mask=(pr["binary_mask"].astype(np.uint8) if dim == 2 else np.zeros(0, np.uint8)))
+    print("   %s: n=%d path_len=%.4f classifications %d (%.1fs)" % (name, n, float(planner.get_path_len(planner.path)), len(calls), time.time() - t0))
+
+
 def block_gap_fixture():
     """Block / gap evaluation problems: the reference's generator script run in a scratch directory with a seeded
     numpy generator (its JSON output is the fixture), and the problem dicts its own loader builds for a few of them.
@@ -767,6 +864,9 @@ JOBS = {
     "blockgap_rrt_gap": lambda: block_gap_run("blockgap_rrt_gap", "rrt", "gap", 250, 2002, 6000),
     "guidance_clouds": guidance_fixture,
     "connect_ref": connect_fixture,
+    "connect_ref3d": connect_fixture3d,
+    "run_nirrtc3d_bfs_1500": lambda: nirrtc_bfs_fixture("run_nirrtc3d_bfs_1500", 3, 11, 1500, 1021, 8.0),
+    "run_nirrtc2d_bfs_1500": lambda: nirrtc_bfs_fixture("run_nirrtc2d_bfs_1500", 2, 16, 1500, 1022, 28.0),
     "run_nrrtc2d_1500": lambda: nrrt_fixture("run_nrrtc2d_1500", 2, 13, 1500, 1013, connect=True),
     "run_nrrtc3d_1500": lambda: nrrt_fixture("run_nrrtc3d_1500", 3, 7, 1500, 1007, connect=True),
     "random_nirrt2d": lambda: nirrt_fixture("random_nirrt2d", 2, False, 14, 4000, 1014, random_after=300),
