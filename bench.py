@@ -61,10 +61,13 @@ def parse(argv=None):
     ap.add_argument("--dim", type=int, default=2)
     ap.add_argument("--algo", default="irrt", choices=["irrt", "rrt", "nirrt", "nirrt_c"],
                     help="nirrt / nirrt_c: NIRRT*-PNG[(C)] with PointNet++ guidance (BASELINE configs 3-4) through the batched driver")
-    ap.add_argument("--world", default="b30", choices=sorted(WORLDS))
+    ap.add_argument("--world", default="b30r16", choices=sorted(WORLDS),
+                    help="b30r16 = SURVEY.md 8(d)'s primary world (30 circles r in [16, 24], start / goal in one free component); b30 = its "
+                         "lighter fallback (r in [8, 12])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=12000, help="iterations each CPU-baseline process runs (per repetition)")
-    ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline processes (0 = min(host cores, 32))")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline processes (0 = every host core)")
+    ap.add_argument("--no-cpu-full", action="store_true", help="skip the ONE full-length single-core oracle run reported beside the sample")
     ap.add_argument("--no-ttfs", action="store_true")
     ap.add_argument("--pilot", type=int, default=0,
                     help="a step's iterations run as two launches: this many first, then the rest re-scheduled like --segments does; 0 = off")
@@ -234,6 +237,7 @@ def main():
     if args.algo.startswith("nirrt"):
         return bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work)
 
+    full_proc = start_cpu_full_run(args) if (rank == 0 and not args.no_cpu_baseline and not args.no_cpu_full) else None
     probs = make_problems(args, rank)
     D, B, iters = args.dim, len(probs), args.iters   # (strong scaling: this rank's share of the fixed set)
     flags = _hip.F_IRRT if args.algo == "irrt" else 0
@@ -316,6 +320,7 @@ def main():
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "input_generation_s": input_generation_s,
+            "end_to_end_value": total_iters / (elapsed_max + input_generation_s),   # incl. seeding every problem's generators on the host
             "config": {"workload": ("%s_star random_2d (%s: %s; clearance 3, step_len 10), %d problems/GPU x %d iters, "
                                     "device-resident batched loop with in-kernel sampling" % (args.algo, args.world, WORLDS[args.world], B, iters))
                        if D == 2 else ("%s_star random_3d (50^3, 6-9 boxes + 6-9 balls; clearance 2, step_len 10), %d problems/GPU x %d iters, "
@@ -347,7 +352,7 @@ def main():
             out["time_to_first_solution"] = time_to_first_solution(args, trees, np_states, py_states, flags)
             out["single_tree"] = single_tree_latency(args, trees, np_states, py_states, flags)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, full_proc)
         if world == 1 and not args.no_secondary:
             # the other BASELINE configurations as short runs in processes of their own: this one's trees and inputs go first
             for t_ in trees:
@@ -434,16 +439,16 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
 
 
 SECONDARY = [   # (label, bench arguments): each runs `--steps 1 --warmup 0` in a process of its own
-    ("rrt_2d", ["--algo", "rrt"]),
+    ("rrt_2d", ["--algo", "rrt", "--world", "b30"]),
     ("rrt_3d", ["--algo", "rrt", "--dim", "3"]),
-    # (problems whose straight start-goal segment is free - the degenerate, thousands-of-Near-members class - on 256 lanes)
-    ("irrt_3d", ["--algo", "irrt", "--dim", "3", "--trees", "4096", "--free-lanes", "256"]),
-    ("irrt_2d_b30r16", ["--algo", "irrt", "--world", "b30r16"]),
-    ("nirrt_2d", ["--algo", "nirrt", "--trees", "4096"]),
-    # config 3 as composed (-c bfs): the neural-connect rounds run a breadth-first search per cloud on the HOST (bfs_connect.py,
-    # like the reference) - a small batch keeps the line within minutes; it is not a throughput configuration
-    ("nirrt_c_2d (config 3)", ["--algo", "nirrt_c", "--trees", "64"]),
-    ("nirrt_3d (config 4)", ["--algo", "nirrt", "--dim", "3", "--trees", "1024"]),
+    # (trees whose visits cover thousands of index slots per iteration - the degenerate, near-straight-line class - move to 256 lanes)
+    ("irrt_3d", ["--algo", "irrt", "--dim", "3", "--trees", "4096", "--segments", "5", "--wide-visits", "4000"]),
+    ("irrt_2d_b30 (r in [8, 12])", ["--algo", "irrt", "--world", "b30"]),
+    ("nirrt_2d", ["--algo", "nirrt", "--trees", "4096", "--world", "b30"]),
+    ("nirrt_c_2d (config 3)", ["--algo", "nirrt_c", "--trees", "2048", "--world", "b30"]),
+    ("nirrt_3d (config 4)", ["--algo", "nirrt", "--dim", "3", "--trees", "2048"]),
+    # BASELINE config 5 as written, on ONE GPU: the fixed 1000-problem evaluation set (the anchor of the strong-scaling curve)
+    ("irrt_2d eval set (config 5, N = 1)", ["--algo", "irrt", "--scaling", "strong", "--problems", "1000"]),
 ]
 
 
@@ -467,6 +472,8 @@ def secondary_runs(args):
                           "roofline_frac": rf.get("frac"), "traffic": rf.get("traffic"), "key": cfg.get("key"),
                           "trees_per_gpu": cfg.get("trees_per_gpu"), "trees_stopped_early": cfg.get("trees_stopped_early", cfg.get("failed")),
                           "per_tree_seconds": cfg.get("per_tree_seconds"), "host_seconds": cfg.get("host_seconds_last_step"),
+                          "launches_per_step": cfg.get("launches_per_step"), "trees_on_256_lanes": cfg.get("trees_on_256_lanes"),
+                          "problem_set": cfg.get("problem_set"),
                           "warning": d.get("warning"), "wall_s": time.perf_counter() - t0}
         except subprocess.TimeoutExpired:
             out[label] = {"error": "timed out after 900 s"}
@@ -537,14 +544,44 @@ def measured_traffic(args):
         return None, None
 
 
-def cpu_baseline(args):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def start_cpu_full_run(args):
+    """ONE problem (problem 0 of the batch) for the FULL iteration count on one host core, started when the bench starts and
+    collected at its end (the oracle's per-iteration cost grows with the tree: ~minutes for 50 000 iterations)"""
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--algo", args.algo, "--dim", str(args.dim),
+           "--world", args.world, "--iters", str(args.iters), "--cap", str(args.iters), "--pid", "0"]
+    return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+
+
+def cpu_baseline(args, full_proc=None):
     """The oracle (C port of the reference loop, incl. sampling and the reference's un-cached cost walks) on this box's
-    host cores: C independent processes (oracle/cpu_bench.py), process i plans problem i of the batch for --cpu-iters
-    iterations from its own seeded generators.  One repetition's value = iterations of all processes / wall time of the
-    slowest; --cpu-reps repetitions, the MEDIAN is reported."""
-    procs = args.cpu_procs or min(os.cpu_count() or 1, 32)
+    host cores: C independent processes (oracle/cpu_bench.py; C = every host core), process i plans problem i of the batch for
+    --cpu-iters iterations from its own seeded generators.  One repetition's value = iterations of all processes / wall time of
+    the slowest; --cpu-reps repetitions, the MEDIAN is reported.  Beside it: one full-length single-core run (full_run)."""
+    procs = args.cpu_procs or (os.cpu_count() or 1)
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--algo", args.algo, "--dim", str(args.dim),
            "--world", args.world, "--iters", str(min(args.cpu_iters, args.iters)), "--cap", str(args.iters)]
+    full = None
+    if full_proc is not None:      # it has had the whole GPU part of the bench to itself; now it shares the cores with the sample
+        try:
+            outp = full_proc.communicate(timeout=900)[0]
+            if full_proc.returncode == 0:
+                r = json.loads(outp.strip().splitlines()[-1])
+                full = {"iterations": r["iters"], "seconds": r["seconds"], "iterations_per_second": r["iters"] / r["seconds"],
+                        "final_vertices": r["n"], "what": "problem 0 of the batch, all %d iterations, one core (oracle loop only)" % r["iters"]}
+        except subprocess.TimeoutExpired:
+            full_proc.kill()
+            full = {"error": "not finished 900 s after the GPU part"}
     reps = []
     t_all = time.perf_counter()
     for _ in range(max(1, args.cpu_reps)):
@@ -564,12 +601,14 @@ def cpu_baseline(args):
         return None
     reps.sort(key=lambda r: r["value"])
     m = reps[len(reps) // 2]
-    return {"value": m["value"], "unit": "iterations/s", "cores": m["cores"], "kind": "port", "repetitions": len(reps),
+    return {"value": m["value"], "unit": "iterations/s", "cores": m["cores"], "host_cores": os.cpu_count(), "cpu_model": cpu_model(),
+            "kind": "port", "repetitions": len(reps),
             "values_of_repetitions": [r["value"] for r in reps],
             "single_core_median": m["single_core_median"], "single_core_min": m["single_core_min"], "single_core_max": m["single_core_max"],
-            "sample": "median of %d repetitions of: %d processes x first %d of %d iterations of problems 0..%d of the batch (oracle loop only, "
-                      "%.1f s for the slowest process of the median repetition, %.1f s for everything incl. start-up); the per-iteration cost "
-                      "grows with the tree, so a truncated sample flatters the CPU"
+            "full_run": full,
+            "sample": "median of %d repetitions of: %d processes (one per host core) x first %d of %d iterations of problems 0..%d of the batch "
+                      "(oracle loop only, %.1f s for the slowest process of the median repetition, %.1f s for everything incl. start-up); the "
+                      "per-iteration cost grows with the tree, so the truncated sample flatters the CPU - full_run is one problem at full length"
                       % (len(reps), m["cores"], m["iters"], args.iters, m["cores"] - 1, m["loop_s"], wall)}
 
 

@@ -107,9 +107,11 @@ int nirrt_device_count(int *count);
 int nirrt_create(const nirrt_config *cfg, nirrt_tree **out);
 int nirrt_destroy(nirrt_tree *t);
 int nirrt_reset(nirrt_tree *t);
-/* Trees of at least 1 MB are carved out of multi-GB device chunks that stay with the process (NIRRT_POOL_CHUNK_MB, default
- * 4096, 0 = one allocation per tree; no counterpart in the reference, whose arrays are numpy's): hand the chunks that hold no
- * live tree back to the driver - a process that is done with one batch and starts helpers that need the memory calls this */
+/* Trees of at least 1 MB are carved out of multi-GB device chunks (NIRRT_POOL_CHUNK_MB, default 4096, 0 = one allocation per
+ * tree; no counterpart in the reference, whose arrays are numpy's).  A destroyed tree's block serves the next tree that fits it;
+ * a chunk whose last tree is destroyed starts over empty, and all but one idle chunk per device go back to the driver right away.
+ * nirrt_pool_trim hands the remaining idle chunks back too - a process that is done with a batch and starts helpers that need the
+ * memory calls this */
 int nirrt_pool_trim(void);
 /* Host helper: n raw 32-bit outputs of an MT19937 generator - numpy's legacy RandomState (np.random.seed, what rrt_base_2d.py /
  * rrt_star_2d.py draw from) and CPython's random.Random (irrt_star_2d.py's informed sampling) are this generator, and nirrt_run

@@ -356,8 +356,10 @@ static int push_desc(nirrt_tree *t)
 // Tree arenas come out of large device chunks (NIRRT_POOL_CHUNK_MB, default 4096; 0 = one hipMalloc per tree): thousands of
 // separately mapped 12 MB allocations cost one address-translation entry per 2 MB each, while a few multi-GB chunks are
 // mapped with large fragments - the loop is a latency-bound chase across ~100 GB of trees, and translation misses are part of
-// every round trip.  Bump allocation inside a chunk, exact-size free lists per device (trees of one batch have one size);
-// chunks stay with the process.
+// every round trip.  Bump allocation inside a chunk, free lists by size per device (an idle block serves a request of up to
+// its own size, down to half of it).  A chunk whose last tree is destroyed starts over empty, and all but one idle chunk per
+// device go back to the driver at once (nirrt_pool_trim returns that one too): a long-lived process that plans batches of
+// varying iter_max neither grows without bound nor starves other users of the device (torch) of memory.
 #include <map>
 #include <mutex>
 namespace {
@@ -378,16 +380,21 @@ struct ArenaPool {
             if ((const char *)p >= c.base && (const char *)p < c.base + c.size) return &c;
         return nullptr;
     }
-    // returns nullptr when pooling is off or the request is small / larger than a chunk (the caller then uses hipMalloc)
-    void *take(int device, size_t bytes)
+    // returns nullptr when pooling is off or the request is small / larger than a chunk (the caller then uses hipMalloc);
+    // *got = size of the block handed out (>= bytes: an idle block of another tree size is reused if it is large enough)
+    void *take(int device, size_t bytes, size_t *got)
     {
         const size_t cb = chunk_bytes();
+        *got = bytes;
         if (cb == 0 || bytes < ((size_t)1 << 20) || bytes > cb) return nullptr;
         std::lock_guard<std::mutex> g(mu);
-        auto &fl = free_list[{device, bytes}];
-        if (!fl.empty()) {
-            void *p = fl.back();
-            fl.pop_back();
+        // the smallest idle block of this device that fits
+        auto it = free_list.lower_bound({device, bytes});
+        while (it != free_list.end() && it->first.first == device && it->second.empty()) ++it;
+        if (it != free_list.end() && it->first.first == device && it->first.second <= 2 * bytes) {   // (not a block twice the size: it would pin the room of two trees)
+            void *p = it->second.back();
+            it->second.pop_back();
+            *got = it->first.second;
             owner(p)->live++;
             return p;
         }
@@ -410,8 +417,25 @@ struct ArenaPool {
     void give(int device, size_t bytes, void *p)
     {
         std::lock_guard<std::mutex> g(mu);
-        owner(p)->live--;
-        free_list[{device, bytes}].push_back(p);
+        Chunk *c = owner(p);
+        c->live--;
+        if (c->live > 0) { free_list[{device, bytes}].push_back(p); return; }
+        // the chunk's last tree is gone: it starts over empty (its idle blocks are forgotten) - a process that creates and destroys
+        // trees of many sizes does not grow without bound, and the chunk can serve any size again
+        for (auto &kv : free_list) {
+            auto &v = kv.second;
+            v.erase(std::remove_if(v.begin(), v.end(), [&](void *q) { return (char *)q >= c->base && (char *)q < c->base + c->size; }), v.end());
+        }
+        c->used = 0;
+        // more than one idle chunk per device is more than the next batch needs to start: the others go back to the driver
+        int idle = 0;
+        for (const Chunk &k : chunks) idle += (k.device == device && k.live == 0) ? 1 : 0;
+        if (idle > 1) {
+            const Chunk dead = *c;
+            chunks.erase(chunks.begin() + (c - chunks.data()));
+            (void)hipSetDevice(dead.device);
+            (void)hipFree(dead.base);
+        }
     }
     // chunks none of whose arenas is in use go back to the driver
     void trim()
@@ -809,9 +833,9 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         size_t total = 0;
         for (const Piece &pc : pieces) total += (pc.bytes + A - 1) / A * A;
         t->arena_bytes = total;
-        t->arena = g_pool.take(t->device, total);
+        t->arena = g_pool.take(t->device, total, &t->arena_bytes);   // (arena_bytes = the block's size: what goes back to the pool)
         t->arena_pooled = t->arena != nullptr;
-        if (!t->arena) HIPCHK_T(hipMalloc(&t->arena, total));
+        if (!t->arena) { t->arena_bytes = total; HIPCHK_T(hipMalloc(&t->arena, total)); }
         size_t off = 0;
         for (const Piece &pc : pieces) { *pc.dst = (char *)t->arena + off; off += (pc.bytes + A - 1) / A * A; }
     }

@@ -27,12 +27,12 @@ def test_default_arguments_follow_the_driver_contract(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "2"])
     a = b.parse()
     assert (a.gpus, a.steps, a.warmup) == (8, 3, 2)
-    assert b.config_key(a) == "irrt_2d_b30_%dx50000" % a.trees
+    assert a.world == "b30r16" and b.config_key(a) == "irrt_2d_b30r16_%dx50000" % a.trees      # SURVEY 8(d)'s primary world
 
 
 def test_problem_set_is_disjoint_across_ranks_and_sized_like_the_survey(monkeypatch):
     b = _bench()
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--trees", "6"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--trees", "6", "--world", "b30"])
     a = b.parse()
     p0, p1 = b.make_problems(a, 0), b.make_problems(a, 1)
     assert [p["pid"] for p in p0] == list(range(6)) and [p["pid"] for p in p1] == list(range(6, 12))
@@ -46,7 +46,7 @@ def test_problem_set_is_disjoint_across_ranks_and_sized_like_the_survey(monkeypa
 
 def test_primary_world_of_the_survey_has_large_circles_and_connected_start_goal(monkeypatch):
     b = _bench()
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--trees", "2", "--world", "b30r16"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--trees", "2"])
     a = b.parse()
     for p in b.make_problems(a, 0):
         assert len(p["env_dict"]["circle_obstacles"]) == 30
@@ -82,7 +82,7 @@ def test_cpu_baseline_process_runs_the_oracle_on_a_batch_problem():
 
 def test_traffic_entry_is_used_only_for_the_exact_configuration(tmp_path, monkeypatch):
     b = _bench()
-    tab = {"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", "entries": {"irrt_2d_b30_4096x50000": {"traffic_bytes": 5e13, "collected": "2026-09-28",
+    tab = {"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", "entries": {"irrt_2d_b30r16_4096x50000": {"traffic_bytes": 5e13, "collected": "2026-09-28",
                                                                                                     "kernel": "slim::k_run_sample<2>"}}}
     f = tmp_path / "t.json"
     f.write_text(json.dumps(tab))
