@@ -194,7 +194,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     if have_gpu:
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under a launcher (RANK / MASTER_PORT in the environment) a process group exists even for ONE rank: the timing protocol's
+    # barrier / all_reduce then run through RCCL as they do at N > 1 (a one-GPU box cannot host two RCCL ranks)
+    grouped = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if have_gpu:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -205,14 +208,14 @@ def main():
     def barrier():
         if have_gpu:
             torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         if have_gpu:
             torch.cuda.synchronize()
 
     def reduce_time_and_work(elapsed, work):
         tot = torch.tensor([elapsed, float(work)], dtype=torch.float64, device=dev)
-        if world > 1:
+        if grouped:
             tmax = tot.clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -227,7 +230,7 @@ def main():
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "work_all_ranks": total, "config": {"workload": config_key(args)}}))
-        if world > 1:
+        if grouped:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -319,6 +322,7 @@ def main():
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "process_group": (dist.get_backend() if grouped else None),
             "input_generation_s": input_generation_s,
             "end_to_end_value": total_iters / (elapsed_max + input_generation_s),   # incl. seeding every problem's generators on the host
             "config": {"workload": ("%s_star random_2d (%s: %s; clearance 3, step_len 10), %d problems/GPU x %d iters, "
@@ -362,7 +366,7 @@ def main():
             _hip.pool_trim()
             out["secondary"] = secondary_runs(args)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
@@ -433,7 +437,7 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
                             "kernel_ms": float(np.mean(k_ms)), "kernel_share_of_step": float(np.mean(k_ms)) / (elapsed_max / args.steps * 1e3),
                             "useful_bytes_per_step": useful_b, "near_members_per_iteration": float(st[:, 2].sum() / max(1.0, st[:, 13].sum()))}}
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -32,8 +32,12 @@ def gather_records(local, world_size, rank, device="cpu"):
     import torch
     import torch.distributed as dist
     local = np.asarray(local, dtype=np.float64).reshape(-1, RECORD_LEN)
-    if world_size == 1:
+    if not (dist.is_available() and dist.is_initialized()):      # no launcher, one rank: nothing to gather from
+        if world_size != 1:
+            raise RuntimeError("gather_records: %d ranks but no process group" % world_size)
         return local[np.argsort(local[:, 0])]
+    # (a process group of ONE rank still goes through the collectives: `torchrun --nproc-per-node 1` is how the RCCL path is
+    #  exercised on a one-GPU box - RCCL refuses two ranks on one device)
     m = torch.tensor([len(local)], dtype=torch.int64, device=device)
     mx = m.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -93,6 +97,14 @@ def _batch_setup(problems, pids, args, device_id, cap, wrapper):
         t.set_informed(*frames[-1])
         trees.append(t)
         streams.append(batch.ProblemStreams(1000 + pid))
+    # dispatch order inside the persistent launches = longest first by the one predictor that is known before planning: a free
+    # straight start-goal segment (informed set collapsed onto it, Near sets of thousands of members: 2-3x the median run time)
+    if informed and len(trees) > 1:
+        free = [not t.is_collision(pr["x_start"], pr["x_goal"]) for t, pr in zip(trees, problems)]
+        order = sorted(range(len(trees)), key=lambda i: (not free[i], i))
+        trees, streams, frames = [trees[i] for i in order], [streams[i] for i in order], [frames[i] for i in order]
+    else:
+        order = list(range(len(trees)))
     guidance = None
     if planner.startswith("n"):
         if wrapper is None:
@@ -100,7 +112,7 @@ def _batch_setup(problems, pids, args, device_id, cap, wrapper):
         guidance = batch.Guidance(wrapper, dim, args.step_len, args.pc_n_points, args.pc_over_sample_scale, args.pc_sample_rate,
                                   args.pc_update_cost_ratio, connect=planner.endswith("_c"),
                                   connect_max_trial_attempts=args.connect_max_trial_attempts, informed=informed, device_id=device_id)
-    return dim, flags, trees, streams, frames, guidance
+    return dim, flags, trees, streams, frames, guidance, order
 
 
 def _raise_failures(res, pids):
@@ -111,10 +123,12 @@ def _raise_failures(res, pids):
 def plan_batch(problems, pids, args, device_id, wrapper=None):
     """planning_random for a batch of problems: persistent launches until every tree has its first solution (or spent
     iter_max iterations), then iter_after_initial more for the solved ones.  Each problem uses its own seeded generators
-    (1000 + problem id); word windows are refilled and guidance clouds refreshed between launches (nirrt_star_amd/batch.py)."""
+    (1000 + problem id), resident in its tree; guidance clouds are refreshed between launches (nirrt_star_amd/batch.py).  Inside the
+    launches the problems with a free start-goal segment are dispatched first; records and traces come back in the caller's order."""
     from . import batch
     cap = args.iter_max + args.iter_after_initial
-    dim, flags, trees, streams, frames, guidance = _batch_setup(problems, pids, args, device_id, cap, wrapper)
+    dim, flags, trees, streams, frames, guidance, order = _batch_setup(problems, pids, args, device_id, cap, wrapper)
+    problems, pids = [problems[i] for i in order], [pids[i] for i in order]      # dispatch order from here on; undone at the end
     r1 = batch.run_batch(trees, streams, args.iter_max, flags, dim, problems, guidance, frames, want_trace=True, stop_first=True)
     _raise_failures(r1, pids)
     traces = list(r1["traces"])
@@ -128,7 +142,8 @@ def plan_batch(problems, pids, args, device_id, wrapper=None):
     recs = [make_record(pid, tr, t.n) for pid, tr, t in zip(pids, traces, trees)]
     for t in trees:
         t.close()
-    return recs, traces
+    back = np.argsort(order)      # results in the caller's order
+    return [recs[j] for j in back], [traces[j] for j in back]
 
 
 def result_lists(kind, traces, thresholds=None):
@@ -149,9 +164,9 @@ def result_lists(kind, traces, thresholds=None):
 def gather_results(local, world_size, rank):
     """local: list of (problem id, path_len_list) -> rank 0 gets all of them sorted by id (variable-length lists travel
     as pickled objects: one gather at the end of the run, off the data path)"""
-    if world_size == 1:
-        return sorted(local)
     import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return sorted(local)
     out = [None] * world_size if rank == 0 else None
     dist.gather_object(local, out, dst=0)
     if rank != 0:
@@ -197,7 +212,8 @@ def plan_batch_block_gap(problems, pids, thresholds, args, device_id, wrapper=No
     only depends on the iterations before it and every problem owns its generators, so truncating the cost trace at
     the first sub-threshold entry gives exactly the list the reference's early-exit loop returns."""
     from . import batch
-    dim, flags, trees, streams, frames, guidance = _batch_setup(problems, pids, args, device_id, args.iter_max, wrapper)
+    dim, flags, trees, streams, frames, guidance, order = _batch_setup(problems, pids, args, device_id, args.iter_max, wrapper)
+    problems, pids, thresholds = [problems[i] for i in order], [pids[i] for i in order], [thresholds[i] for i in order]
     traces = [np.zeros(0) for _ in trees]
     active = list(range(len(trees)))
     done_iters = 0
@@ -216,7 +232,8 @@ def plan_batch_block_gap(problems, pids, thresholds, args, device_id, wrapper=No
     recs = [make_block_gap_record(pid, tr, thr, t.n) for pid, tr, thr, t in zip(pids, traces, thresholds, trees)]
     for t in trees:
         t.close()
-    return recs, traces
+    back = np.argsort(order)      # results in the caller's order
+    return [recs[j] for j in back], [traces[j] for j in back]
 
 
 def main():
@@ -259,7 +276,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("eval_sharded needs MI355X GPUs (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torchrun (also with ONE rank): RCCL process group
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from . import problems as P
@@ -317,7 +335,7 @@ def main():
         with open(args.out, "w") as f:
             json.dump({"summary": summary, "records": allr.tolist()}, f)
         print(json.dumps(summary))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,7 +1,10 @@
-"""The sharded evaluation harness END TO END on one rank: `python -m nirrt_star_amd.eval_sharded
---max_problems 16` - argument handling, problem loading, the batched device loop, the RCCL-side gather on `cuda`, the
-summary JSON and the reference-format result pickle (eval_planning_2d.py:99-136) - and the same problems through
-plan_batch directly must give the same records."""
+"""The sharded evaluation harness END TO END on one rank: `python -m nirrt_star_amd.eval_sharded --max_problems 16` - argument
+handling, problem loading, the batched device loop, the summary JSON and the reference-format result pickle
+(eval_planning_2d.py:99-136) - and the same problems through plan_batch directly must give the same records.
+Run plainly there is no process group and nothing is gathered (one rank).  Run under `torchrun --nproc-per-node 1` the harness
+builds an RCCL process group of one rank and the records DO travel through dist.all_reduce / dist.gather / gather_object on
+`cuda` tensors - the only way to execute that branch on a one-GPU box (RCCL refuses two ranks on one device: "Duplicate GPU
+detected"); same for bench.py's barrier / all_reduce timing protocol."""
 import json
 import os
 import pickle
@@ -16,13 +19,19 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_eval_sharded_main_end_to_end(tmp_path):
+@pytest.mark.parametrize("launcher", ["plain", "torchrun-1"])
+def test_eval_sharded_main_end_to_end(tmp_path, launcher):
     out = tmp_path / "res.json"
     pk = tmp_path / "res.pickle"
-    env = dict(os.environ, PYTHONPATH=ROOT)
-    cmd = [sys.executable, "-m", "nirrt_star_amd.eval_sharded", "--problem", "random_2d", "-p", "irrt_star", "--max_problems", "16",
-           "--iter_max", "3000", "--batch", "8", "--out", str(out), "--pickle_out", str(pk)]
-    p = subprocess.run(cmd, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    tail = ["-m", "nirrt_star_amd.eval_sharded", "--problem", "random_2d", "-p", "irrt_star", "--max_problems", "16",
+            "--iter_max", "3000", "--batch", "8", "--out", str(out), "--pickle_out", str(pk)]
+    if launcher == "plain":
+        cmd = [sys.executable] + tail
+    else:      # an RCCL process group of one rank: init_process_group("nccl"), all_reduce, gather, gather_object, barrier on cuda
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", "29533"] + tail
+    p = subprocess.run(cmd, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     summary = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert summary["problems"] == 16 and summary["world_size"] == 1 and summary["solved"] > 0
@@ -34,6 +43,8 @@ def test_eval_sharded_main_end_to_end(tmp_path):
         cfgs = pickle.load(f)
     assert len(cfgs) == 16 and all("result" in c and "env_dict" in c for c in cfgs)
     assert all(len(c["result"]) > 0 for c in cfgs)
+    if launcher != "plain":
+        return
     # the same 16 problems through the batch function in this process: identical records (seeded, deterministic)
     from types import SimpleNamespace as NS
     from nirrt_star_amd import eval_sharded as es, problems as P
@@ -46,3 +57,17 @@ def test_eval_sharded_main_end_to_end(tmp_path):
     r = np.array(r).reshape(-1, es.RECORD_LEN)
     order = np.argsort(recs[:, 0])
     assert np.array_equal(np.nan_to_num(recs[order], posinf=1e300), np.nan_to_num(r, posinf=1e300))
+
+
+def test_bench_timing_protocol_under_a_one_rank_rccl_group(tmp_path):
+    """bench.py launched by torchrun with ONE rank: process group "nccl", barrier + all_reduce(MAX / SUM) of the timing protocol
+    on cuda tensors, one JSON line"""
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--trees", "96", "--iters", "3000", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-ttfs", "--no-secondary"]
+    p = subprocess.run(cmd, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["process_group"] == "nccl"
+    assert d["config"]["trees_stopped_early"] == 0
