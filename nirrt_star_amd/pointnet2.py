@@ -39,9 +39,13 @@ FP_SPECS = [  # attribute, in_channel, mlp   (pointnet2.py:15-18)
 ]
 
 
+FUSED_EPILOGUE = hasattr(torch, "_addmm_activation")   # private torch entry point: guarded (tests compare both evaluations)
+
+
 def _affine_relu(b, x, w):
-    """relu(x @ w.T + b) as one library GEMM; on the GPU the bias and the ReLU ride in the GEMM's epilogue (hipBLASLt)"""
-    if x.is_cuda:
+    """relu(x @ w.T + b) as one library GEMM; on the GPU the bias and the ReLU ride in the GEMM's epilogue (hipBLASLt) when this
+    torch build has the fused entry point, else addmm followed by relu (scores within the L4 tolerance either way)"""
+    if x.is_cuda and FUSED_EPILOGUE:
         return torch._addmm_activation(b, x, w.t())
     return F.relu(torch.addmm(b, x, w.t()))
 

@@ -122,18 +122,46 @@ def test_generators_move_between_host_and_tree():
 
 
 def test_set_cloud_batch_equals_per_tree_set_cloud():
-    """nirrt_set_cloud_batch: the kept points and policy scalars land in the trees exactly like nirrt_set_cloud's"""
+    """nirrt_set_cloud_batch: the kept points (dim-strided in the tree's arena) and the policy scalars land in the trees exactly
+    like nirrt_set_cloud's - checked through what the loop DOES with them: trees set either way, seeded alike, draw the same
+    samples from their clouds and grow the same tree (SamplePointCloud, nirrt_star_png_2d.py:129-130)"""
+    import random
     import torch
-    from nirrt_star_amd import _hip, worlds
+    from nirrt_star_amd import _hip, sampling, worlds
     pr = worlds.problem_2d(worlds.random_world_2d(1, "b30"), 0)
     rs = np.random.RandomState(3)
-    trees = [_hip.HipTree(2, 200, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], 3, pr["env"]) for _ in range(3)]
-    clouds = torch.from_numpy(rs.uniform(5, 200, size=(3, 64, 3))).cuda()
-    n_pts = np.array([64, 10, 0], dtype=np.int32)
-    pred = torch.from_numpy((rs.uniform(size=(3, 64)) < 0.4).astype(np.uint8)).cuda()
-    kept = _hip.set_cloud_batch(trees, clouds.data_ptr(), 64 * 3, n_pts, pred.data_ptr(), 64, 0.5, 0.9, [70.0, 80.0, np.inf])
-    pc, pb = clouds.cpu().numpy(), pred.cpu().numpy()
-    for b in range(3):
-        assert kept[b] == int(pb[b, : n_pts[b]].sum())
-    for t in trees:
+
+    def trees3():
+        ts = [_hip.HipTree(2, 400, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], 3, pr["env"]) for _ in range(3)]
+        for t in ts:
+            t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
+        _hip.set_generators(ts, [_hip.np_state(np.random.RandomState(50 + k)) for k in range(3)], [_hip.py_state(random.Random(50 + k)) for k in range(3)])
+        return ts
+
+    pts = rs.uniform(20, 200, size=(3, 64, 3))
+    pts[:, :, 2] = 0.0
+    clouds = torch.from_numpy(pts).cuda()
+    n_pts = np.array([64, 10, 64], dtype=np.int32)
+    pb = (rs.uniform(size=(3, 64)) < 0.4).astype(np.uint8)
+    pb[2, :] = 0
+    pb[2, 5] = 1                       # a one-point prediction: np.random.randint(0, 1) draws nothing
+    pred = torch.from_numpy(pb).cuda()
+    c_upd = [np.inf, np.inf, np.inf]
+    a = trees3()
+    kept = _hip.set_cloud_batch(a, clouds.data_ptr(), 64 * 3, n_pts, pred.data_ptr(), 64, 0.7, 0.9, c_upd)
+    b = trees3()
+    for k, t in enumerate(b):
+        sel = pts[k, : n_pts[k], :2][pb[k, : n_pts[k]] != 0]
+        assert kept[k] == len(sel)
+        t.set_cloud(sel, 0.7, 0.9, c_upd[k])
+    flags = _hip.F_IRRT | _hip.F_PNG
+    ra = _hip.run_sampling(a, 400, flags=flags, want_trace=True)
+    rb = _hip.run_sampling(b, 400, flags=flags, want_trace=True)
+    assert np.array_equal(ra["status"], rb["status"]) and np.array_equal(ra["iters_done"], rb["iters_done"])
+    assert np.array_equal(ra["np_used"], rb["np_used"]) and np.array_equal(ra["py_used"], rb["py_used"])
+    for ta, tb in zip(a, b):
+        va, pa = ta.download()
+        vb, pb_ = tb.download()
+        assert np.array_equal(pa, pb_) and np.array_equal(va, vb) and len(va) > 20
+    for t in a + b:
         t.close()
