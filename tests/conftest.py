@@ -13,14 +13,22 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
-    # The package has only the HIP point operators and no hook for others.  On a host WITHOUT a GPU (the CPU suite) the
-    # module's functions are replaced from here by the oracle's torch / numpy ones for the whole session; on a GPU box
-    # nothing is replaced, so a CPU tensor that reaches the operators inside a `-m gpu` test raises (the one explicit
-    # exception is the CPU calibration of the synthetic checkpoint, synthetic_checkpoint_root below).
-    if not _gpu_visible():
-        from nirrt_star_amd import pointops
-        from oracle import pointops_ref
-        pointops_ref.patched(pointops).start()
+    config.addinivalue_line("markers", "oracle_pointops: CPU test that runs the network / down-sampling through the oracle's point operators")
+
+
+@pytest.fixture(autouse=True)
+def _oracle_pointops_where_asked(request):
+    """The package has only the HIP point operators and no hook for others.  A CPU test that needs a forward or a down-sampling
+    on a host WITHOUT a GPU says so (`@pytest.mark.oracle_pointops`) and gets the oracle's torch / numpy operators patched into
+    the module for ITS duration only; every other test - and every test on a GPU box - sees the product as it is, so a call
+    that should not reach the point operators fails loudly instead of being served by the oracle."""
+    if request.node.get_closest_marker("oracle_pointops") is None or _gpu_visible():
+        yield
+        return
+    from nirrt_star_amd import pointops
+    from oracle import pointops_ref
+    with pointops_ref.patched(pointops):
+        yield
 
 
 def _gpu_visible():

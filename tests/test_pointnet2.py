@@ -33,6 +33,7 @@ def _check(g, m, device, tol):
     assert np.max(np.abs(l4.cpu().numpy() - g["l4"])) <= tol * max(1.0, float(np.abs(g["l4"]).max()))
 
 
+@pytest.mark.oracle_pointops
 def test_cpu_unfolded_and_folded_match_reference():
     g = load_golden("pointnet2_ref")
     m = _model(g, "cpu")
@@ -47,6 +48,7 @@ def test_state_dict_layout_is_the_reference_one():
     assert keys[0] == "sa1.conv_blocks.0.0.weight" and "fp1.mlp_bns.2.running_var" in keys and keys[-1] == "conv2.bias"
 
 
+@pytest.mark.oracle_pointops
 def test_wrapper_roundtrip_cpu(tmp_path):
     """PNGWrapper on CPU with a synthetic checkpoint in the reference format: classify + neural connect run end to end."""
     from nirrt_star_amd import png_wrapper
