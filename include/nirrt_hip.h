@@ -47,7 +47,7 @@ extern "C" {
 
 #define NIRRT_MAX_OBSTACLES 64 /* per kind (round / box) */
 #define NIRRT_OBSTACLE_POOL 640 /* = 4 * 64 + 6 * 64: the tables live in LDS, 4 * n_round + 6 * n_box doubles of them */
-#define NIRRT_N_STATS 20       /* per-tree counters of a nirrt_run launch, see nirrt_run_args.stats */
+#define NIRRT_N_STATS 24       /* per-tree counters of a nirrt_run launch, see nirrt_run_args.stats */
 #define NIRRT_NEAR_CAPACITY 0 /* unlimited: Near-set scratch is sized like the tree */
 
 typedef struct nirrt_tree nirrt_tree;
@@ -243,7 +243,9 @@ typedef struct nirrt_run_args {
                             the best cost on the tree when its loop ended - what a NIRRT_E_CLOUD stop compared with
                             update_cost_ratio * c_update, so that the host needs no extra launch per stopped tree -
                             [18] rewire rounds that re-parented something, [19] vertices re-parented one at a time
-                            (candidate list larger than its LDS room) */
+                            (candidate list larger than its LDS room), [20] device ticks the tree's loop was running (the launch may
+                            share its workgroups among the trees in time slices: then [14] / [15] span the idle time in between),
+                            [21..23] reserved */
     const int64_t *iters_each; /* optional (n_trees,), sampling mode: tree i runs at most iters_each[i] <= iters iterations
                             (trees of one batch resumed after stopping at different iterations, e.g. NIRRT_E_CLOUD);
                             cost_trace rows stay `iters` long */
@@ -251,6 +253,11 @@ typedef struct nirrt_run_args {
                             batch's default.  Trees with different sizes are launched as concurrent groups on their own streams:
                             a tree known to be heavy (large Near sets) gets more lanes instead of holding up the launch on one
                             wave.  Results never depend on it. */
+    int64_t slice_iters;   /* sampling mode with the trees' own generators, more trees than the GPU holds at once: the resident
+                            workgroups share ALL trees round-robin in time slices of this many iterations (every tree advances at the
+                            same pace, so the launch does not end with a long drain of half-empty compute units).  0 = the library
+                            chooses (iters / 16, at least 1024; env NIRRT_SLICE overrides, 0 there = off), < 0 = off (one workgroup
+                            per tree for the whole launch).  Results never depend on it. */
 } nirrt_run_args;
 int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *args);
 

@@ -59,13 +59,14 @@ class RunArgs(C.Structure):
                 ("py_used", C.POINTER(C.c_int64)), ("iters_done", C.POINTER(C.c_int64)),
                 ("status", C.POINTER(C.c_int32)), ("kernel_ms", C.POINTER(C.c_double)),
                 ("scan_elems", C.POINTER(C.c_int64)), ("alg_elems", C.POINTER(C.c_int64)),
-                ("stats", C.POINTER(C.c_int64)), ("iters_each", C.POINTER(C.c_int64)), ("lanes_hint", C.POINTER(C.c_int32))]
+                ("stats", C.POINTER(C.c_int64)), ("iters_each", C.POINTER(C.c_int64)), ("lanes_hint", C.POINTER(C.c_int32)),
+                ("slice_iters", C.c_int64)]
 
-N_STATS = 20
-ST_ITERS, ST_T0, ST_T1, ST_CBEST = 13, 14, 15, 17   # slots 14 / 15 / 17 are absolute values of a launch, the rest are deltas
+N_STATS = 24
+ST_ITERS, ST_T0, ST_T1, ST_CBEST, ST_BUSY = 13, 14, 15, 17, 20   # slots 14 / 15 / 17 are absolute values of a launch, the rest are deltas
 STAT_NAMES = ["visited", "visit_bytes", "members", "spilled", "hop_records", "rewire_candidates", "rewired", "recosted",
               "list_entries", "inserted", "rebuilt", "revisits", "whole_tree_visits", "iterations", "t0_ticks", "t1_ticks",
-              "alg_elems", "c_best_bits", "rewire_rounds", "rewired_one_by_one"]
+              "alg_elems", "c_best_bits", "rewire_rounds", "rewired_one_by_one", "busy_ticks", "r21", "r22", "r23"]
 
 
 def useful_bytes(stats, dim):
@@ -481,7 +482,8 @@ def run_replay(trees, samples, flags=0, want_trace=False, device_ptr=None, iters
             "alg_elems": alg, "stats": stats}
 
 
-def run_sampling(trees, iters, np_words=None, py_words=None, flags=0, want_trace=False, on_device=False, iters_each=None, lanes_hint=None):
+def run_sampling(trees, iters, np_words=None, py_words=None, flags=0, want_trace=False, on_device=False, iters_each=None, lanes_hint=None,
+                 slice_iters=0):
     """Device-resident loop with in-kernel sampling.  np_words = None (the normal case): every tree draws from its own
     generators resident in HBM (set_generators / get_generators).  Otherwise np_words / py_words: per-tree uint32 arrays of
     raw MT19937 outputs (numpy legacy global stream / python `random`); with on_device=True they are
@@ -521,6 +523,7 @@ def run_sampling(trees, iters, np_words=None, py_words=None, flags=0, want_trace
         keep.append(hint)
         a.lanes_hint = hint.ctypes.data_as(C.POINTER(C.c_int32))
     a.samples = None
+    a.slice_iters = int(slice_iters)     # 0: the library decides whether / how to time-slice a batch larger than the GPU; < 0: never
     if np_words is not None:      # None: the trees' own generators (set_generators) produce the words on the device
         a.np_words, a.n_np = table(np_words)
         if py_words is not None:

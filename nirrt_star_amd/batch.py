@@ -171,7 +171,7 @@ def run_scheduled(trees, seg_len, flags, order=None, hint=None, wide_visits=0.0,
             hint = np.array([keep[b] for b in order], dtype=np.int32) if hint is not None else None
         r = _hip.run_sampling([trees[b] for b in order], int(n_it), flags=flags, lanes_hint=hint)
         idx = np.asarray(order)
-        secs = (r["stats"][:, _hip.ST_T1] - r["stats"][:, _hip.ST_T0]) / 1e8
+        secs = r["stats"][:, _hip.ST_BUSY] / 1e8      # (device time inside the loop; a time-sliced launch idles a tree between its slices)
         tot["kernel_ms"] += r["kernel_ms"]
         tot["stats"][idx] += r["stats"]
         tot["alg_elems"][idx] += r["alg_elems"]

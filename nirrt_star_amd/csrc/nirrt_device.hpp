@@ -129,6 +129,7 @@ struct Topo;
 #define ST_CBEST 17      // bit pattern of the best cost when a sampling loop ended (absolute, like T0 / T1; what NIRRT* compared with ratio * c_update)
 #define ST_RROUNDS 18    // rewire rounds that re-parented something (batched path)
 #define ST_RSEQ 19       // vertices re-parented one at a time (candidate list did not fit / small-limits build)
+#define ST_BUSY 20       // device ticks (100 MHz) the tree's loop was running (= T1 - T0 unless the launch was time-sliced)
 #define ST_ALG 16        // vertices the REFERENCE algorithm scans for the same iterations: n per nearest_neighbor + n per find_near_neighbors
 #define NSTAT NIRRT_N_STATS
 

@@ -142,6 +142,15 @@ struct RunSampleDev {
     const long long *iters_each;   // optional per-tree iteration budgets (<= iters)
 };
 
+// time-sliced launches (k_run_pool): the work queue of a launch group
+struct PoolDev {
+    int n_trees, pad;
+    long long quantum;
+    int *ticket;     // next slice to hand out
+    int *progress;   // per tree: slices completed
+    int *fin;        // per tree: run ended early (nothing left for later slices)
+};
+
 // Three instantiations of every kernel; nirrt_run picks by batch size so that the CU's 16 wave slots are busy:
 //   slim   64 threads (one wave per tree, 12 trees per CU = every wave slot at 168 VGPRs): batches of more than 2048 trees;
 //   narrow 128 threads (8 trees per CU): with the grid index an iteration is a chain of short dependent phases, so trees
@@ -1337,6 +1346,25 @@ static hipStream_t *group_streams(int device)
     return st[d];
 }
 
+// workgroups of the time-sliced loop that are resident at once (occupancy of the kernel x compute units)
+static int resident_workgroups(Variant v, int D, int device)
+{
+    int per_cu = 0, cus = 0;
+    const void *fn = nullptr;
+    int threads = NT_SLIM;
+    switch (v) {
+    case V_SLIM: fn = D == 2 ? (const void *)slim::k_run_pool<2> : (const void *)slim::k_run_pool<3>; threads = NT_SLIM; break;
+    case V_NARROW: fn = D == 2 ? (const void *)narrow::k_run_pool<2> : (const void *)narrow::k_run_pool<3>; threads = NT_NARROW; break;
+    default: fn = D == 2 ? (const void *)wide::k_run_pool<2> : (const void *)wide::k_run_pool<3>; threads = NT_WIDE; break;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return per_cu * cus;
+}
+
 static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *a)
 {
     nirrt_tree *t0 = trees[0];
@@ -1472,8 +1500,28 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         rd.iters_done = d_done + o; rd.stop_code = d_stop + o;
         HIPCHK_R(hipEventCreate(&g.e0));
         HIPCHK_R(hipEventCreate(&g.e1));
-        HIPCHK_R(hipEventRecord(g.e0, g.st));
-        LAUNCH_V(g.v, D, k_run_sample, g.b1 - g.b0, g.st, (TreeDev *const *)(d_ptrs + o), rd);
+        // more trees than the GPU holds at once: a resident set of workgroups shares them in time slices (k_run_pool)
+        const int n_g = g.b1 - g.b0;
+        int resident = gen_mode ? resident_workgroups(g.v, D, t0->device) : 0;
+        if (const int forced = env_int("NIRRT_POOL_RESIDENT", 0)) resident = std::min(resident, forced);   // (tests: a small resident set)
+        long long slice = a->slice_iters;
+        if (slice == 0) {
+            const long long e = env_int("NIRRT_SLICE", -1);
+            slice = e >= 0 ? e : std::max<long long>(1024, (a->iters + 15) / 16);
+            if (e == 0) slice = -1;
+        }
+        if (resident > 0 && n_g > resident && slice > 0 && slice < a->iters) {
+            int *d_pool = nullptr;
+            HIPCHK_R(dalloc(sizeof(int) * (2 * (size_t)n_g + 64), (void **)&d_pool));
+            HIPCHK_R(hipMemsetAsync(d_pool, 0, sizeof(int) * (2 * (size_t)n_g + 64), g.st));
+            PoolDev pd;
+            pd.n_trees = n_g; pd.pad = 0; pd.quantum = slice; pd.ticket = d_pool; pd.progress = d_pool + 64; pd.fin = d_pool + 64 + n_g;
+            HIPCHK_R(hipEventRecord(g.e0, g.st));
+            LAUNCH_V(g.v, D, k_run_pool, resident, g.st, (TreeDev *const *)(d_ptrs + o), rd, pd);
+        } else {
+            HIPCHK_R(hipEventRecord(g.e0, g.st));
+            LAUNCH_V(g.v, D, k_run_sample, n_g, g.st, (TreeDev *const *)(d_ptrs + o), rd);
+        }
         HIPCHK_R(hipEventRecord(g.e1, g.st));
         HIPCHK_R(hipGetLastError());
     }

@@ -1,0 +1,65 @@
+"""GPU: time-sliced launches (k_run_pool, nirrt_run_args.slice_iters): a resident set of workgroups shares all trees of a batch
+in slices of a few iterations, a tree's slices running on whatever workgroup (CU, XCD) is free.  Every result must equal the
+launch with one workgroup per tree: trees, best-cost traces, iterations done, generator outputs consumed and final generator
+states - with and without NIRRT_F_STOP_FIRST, with per-tree budgets, in 2D and 3D."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from test_hip_parity import make_hip_tree
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(g, B, iters, seed0):
+    from nirrt_star_amd import _hip, sampling
+    trees = [make_hip_tree(g, iter_max=iters) for _ in range(B)]
+    frame = sampling.informed_frame(g["x_start"], g["x_goal"])
+    for t in trees:
+        t.set_informed(*frame)
+    seeds = [int(g["seed"])] + [seed0 + i for i in range(B - 1)]
+    _hip.set_generators(trees, [_hip.np_state(np.random.RandomState(s)) for s in seeds], [_hip.py_state(random.Random(s)) for s in seeds])
+    return trees
+
+
+@pytest.mark.parametrize("name,irrt,stop_first", [("run_irrt2d_3000", True, False), ("run_irrt2d_3000", True, True), ("run_rrt3d_3000", False, False),
+                                                  ("run_irrt3d_3000", True, False)])
+def test_time_sliced_launch_equals_one_workgroup_per_tree(name, irrt, stop_first, monkeypatch):
+    from nirrt_star_amd import _hip
+    g = load_golden(name)
+    B, iters = 41, 3000
+    flags = (_hip.F_IRRT if irrt else 0) | (_hip.F_STOP_FIRST if stop_first else 0)
+    each = np.full(B, iters, dtype=np.int64)
+    each[5], each[17], each[40] = 1, 1234, 2999       # per-tree budgets (trees resumed after stopping at different iterations)
+    out = {}
+    for mode in ("plain", "sliced"):
+        if mode == "sliced":
+            monkeypatch.setenv("NIRRT_POOL_RESIDENT", "7")     # 7 resident workgroups share the 41 trees
+        else:
+            monkeypatch.delenv("NIRRT_POOL_RESIDENT", raising=False)
+        trees = _batch(g, B, iters, 7000)
+        r = _hip.run_sampling(trees, iters, flags=flags, want_trace=True, iters_each=each, slice_iters=(-1 if mode == "plain" else 137))
+        st = _hip.get_generators(trees)
+        out[mode] = (r, [t.download() for t in trees], [t.solutions for t in trees], st)
+        for t in trees:
+            t.close()
+    (r0, d0, s0, g0), (r1, d1, s1, g1) = out["plain"], out["sliced"]
+    assert np.array_equal(r0["iters_done"], r1["iters_done"]) and np.array_equal(r0["status"], r1["status"])
+    assert np.array_equal(r0["np_used"], r1["np_used"]) and np.array_equal(r0["py_used"], r1["py_used"])
+    for b in range(B):
+        k = int(r0["iters_done"][b])
+        assert np.array_equal(r0["cost_trace"][b, :k], r1["cost_trace"][b, :k])
+        assert np.array_equal(d0[b][1], d1[b][1]) and np.array_equal(d0[b][0], d1[b][0])
+        assert np.array_equal(s0[b], s1[b])
+    for a, b_ in zip(g0, g1):
+        assert np.array_equal(a, b_)
+    if not stop_first:
+        assert np.array_equal(d1[0][1], g["parents"])       # tree 0 is the reference's run
+        assert r1["iters_done"][17] == 1234 and r1["iters_done"][5] == 1
+    else:
+        assert (r1["iters_done"] <= each).all() and (r1["iters_done"] < iters).any()
+    # the counters add up over the slices; busy time is reported per tree
+    assert np.array_equal(r0["stats"][:, 13], r1["stats"][:, 13]) and np.array_equal(r0["stats"][:, 9], r1["stats"][:, 9])
+    assert (r1["stats"][:, _hip.ST_BUSY] > 0).all()
