@@ -82,7 +82,7 @@ def parse(argv=None):
     ap.add_argument("--free-lanes", type=int, default=0, choices=[0, 64, 128, 256],
                     help="workgroup size for the problems with a free start-goal segment (their Near sets grow to thousands of members: the "
                          "visit is arithmetic-bound and scales with the lanes); 0 = like the others")
-    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "r03_traffic.json"),
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "r04_traffic.json"),
                     help="PMC traffic table written by scripts/collect_traffic.py (an entry is used only if its key names this exact configuration)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group / timing protocol only, no GPU work (CPU test of --gpus N)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -340,7 +340,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "wasted_traffic_ratio": (traffic / useful_b) if traffic else None,
-                         "kernel": "k_run_sample<%d>" % D, "kernel_ms": k_ms, "kernel_ms_is": "sum of the step's %d launches" % n_seg if n_seg > 1 else "the step's launch",
+                         "kernel": "k_run_pool<%d> (time-sliced; k_run_sample<%d> when the batch fits the GPU at once)" % (D, D), "kernel_ms": k_ms, "kernel_ms_is": "sum of the step's %d launches" % n_seg if n_seg > 1 else "the step's launch",
                          "useful_bytes_per_launch": useful_b, "visited_index_bytes_per_launch": float(np.mean(visit_b)),
                          "per_iteration": {"visited_slots": per_it[0], "visit_bytes": per_it[1], "near_members": per_it[2],
                                            "members_spilled": per_it[3], "chain_records": per_it[4], "rewire_candidates": per_it[5],
@@ -421,6 +421,7 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
     if rank == 0:
         st = r["stats"].astype(np.float64)
         useful_b = _hip.useful_bytes(r["stats"], D)
+        traffic, traffic_src = measured_traffic(args)
         out = {"metric": "RRT* iters/sec (50k-node tree), random_%dd" % D, "value": total_iters / elapsed_max, "unit": "iterations/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (tree) / f32 (PointNet++)", "data": "synthetic",
@@ -433,7 +434,8 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
                           "mean_final_vertices": float(np.mean([t.n for t in trees])), "failed": len(r["failed"]),
                           "host_seconds_last_step": {k: round(v, 3) for k, v in r["host_seconds"].items()}},
                "roofline": {"bound": "hbm", "achieved": useful_b / (k_ms[-1] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": useful_b / (k_ms[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_run_sample<%d>" % D,
+                            "frac": useful_b / (k_ms[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                            "wasted_traffic_ratio": (traffic / useful_b) if traffic else None, "kernel": "k_run_sample<%d>" % D,
                             "kernel_ms": float(np.mean(k_ms)), "kernel_share_of_step": float(np.mean(k_ms)) / (elapsed_max / args.steps * 1e3),
                             "useful_bytes_per_step": useful_b, "near_members_per_iteration": float(st[:, 2].sum() / max(1.0, st[:, 13].sum()))}}
         print(json.dumps(out))

@@ -257,7 +257,7 @@ typedef struct nirrt_run_args {
                             workgroups share ALL trees round-robin in time slices of this many iterations (every tree advances at the
                             same pace, so the launch does not end with a long drain of half-empty compute units; a tree whose slice
                             is still running when its next turn comes simply keeps its workgroup - nobody waits).  0 = the library
-                            chooses (iters / 48, at least 512; env NIRRT_SLICE overrides, 0 there = off), < 0 = off (one workgroup
+                            chooses (iters / 48, at least 128; env NIRRT_SLICE overrides, 0 there = off), < 0 = off (one workgroup
                             per tree for the whole launch).  Results never depend on it. */
 } nirrt_run_args;
 int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *args);

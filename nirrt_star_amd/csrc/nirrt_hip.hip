@@ -1508,7 +1508,7 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         long long slice = a->slice_iters;
         if (slice == 0) {
             const long long e = env_int("NIRRT_SLICE", -1);
-            slice = e >= 0 ? e : std::max<long long>(512, (a->iters + 47) / 48);   // (measured at 50 000 iterations: 3125 -> 49.4, 1024 -> 50.9, 512 -> 51.0 M it/s)
+            slice = e >= 0 ? e : std::max<long long>(128, (a->iters + 47) / 48);   // (measured at 50 000 iterations: 3125 -> 49.4, 1024 -> 50.9, 512 -> 51.0 M it/s)
             if (e == 0) slice = -1;
         }
         if (resident > 0 && n_g > resident && slice > 0 && slice < a->iters) {

@@ -3,7 +3,7 @@
 separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only), kernel-filtered, then
     traffic_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
 (FETCH_SIZE is in KiB and on gfx950 reports half of the bytes of wide reads - doubled as the guide says; WRITE_SIZE is
-uncalibrated).  Writes / updates profiles/r03_traffic.json: one entry per configuration key (bench.py config_key) with the
+uncalibrated).  Writes / updates profiles/<round>_traffic.json: one entry per configuration key (bench.py config_key) with the
 raw counters, the date, the command and the kernel name, and copies the raw counter CSV rows next to it.
 
     python scripts/collect_traffic.py [bench.py arguments, e.g. --trees 8192 --algo irrt]      (on the GPU box)
@@ -17,6 +17,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = os.environ.get("NIRRT_ROUND", "r04")   # prefix of the files written under profiles/
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
@@ -45,7 +46,7 @@ def main():
         rows.sort(key=lambda r: -float(r["Counter_Value"]))
         # one step = several launches (segments x workgroup-size groups): the step's traffic is the sum over all of them
         raw[counter] = dict(rows[0], Counter_Value=str(sum(float(r["Counter_Value"]) for r in rows)), dispatches=str(len(rows)))
-        with open(os.path.join(prof_dir, "r03_pmc_%s_%s.csv" % (key, counter)), "w") as fh:
+        with open(os.path.join(prof_dir, "%s_pmc_%s_%s.csv" % (ROUND, key, counter)), "w") as fh:
             keep = ["Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count",
                     "SGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
             w = csv.DictWriter(fh, fieldnames=keep, extrasaction="ignore")
@@ -64,14 +65,14 @@ def main():
         if "factors" in cal:
             f_fetch, f_write = float(cal["factors"]["fetch"]), float(cal["factors"]["write"])
             calib_src = "profiles/r03_traffic_calibration.json"
-    path = os.path.join(prof_dir, "r03_traffic.json")
+    path = os.path.join(prof_dir, "%s_traffic.json" % ROUND)
     tab = {"formula": "traffic_bytes = (f_fetch * FETCH_SIZE_KiB + f_write * WRITE_SIZE_KiB) * 1024, factors per entry (calibrated on this access pattern)", "entries": {}}
     if os.path.exists(path):
         with open(path) as fh:
             tab = json.load(fh)
     tab["entries"][key] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "traffic_bytes": (f_fetch * fetch + f_write * write) * 1024,
                            "f_fetch": f_fetch, "f_write": f_write, "calibration": calib_src,
-                           "kernel": "k_run_sample<%d> (slim / narrow / wide instantiations)" % args.dim,
+                           "kernel": "k_run_pool<%d> / k_run_sample<%d> (slim / narrow / wide instantiations)" % (args.dim, args.dim),
                            "dispatches_summed": int(raw["FETCH_SIZE"]["dispatches"]),
                            "collected": datetime.date.today().isoformat(),
                            "command": "rocprofv3 --pmc <C> --kernel-trace --kernel-include-regex k_run_ -- python bench.py "
@@ -82,7 +83,7 @@ def main():
     import shutil
     shutil.copy(path, out_root)
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        shutil.copy(os.path.join(prof_dir, "r03_pmc_%s_%s.csv" % (key, counter)), out_root)
+        shutil.copy(os.path.join(prof_dir, "%s_pmc_%s_%s.csv" % (ROUND, key, counter)), out_root)
     print(json.dumps(tab["entries"][key]))
 
 

@@ -1,8 +1,10 @@
 #!/bin/bash
-# Round-3 evidence, collected on the GPU box in ONE gpurun call (everything lands under gpurun_out/r03/; copy what is wanted
-# into profiles/):   gpurun --timeout 3600 -- scripts/gpu_profile_r03.sh [stage ...]     stages: calib traffic stats sq pn2
+# A round's evidence, collected on the GPU box in ONE gpurun call (everything lands under gpurun_out/<round>/; copy what is wanted
+# into profiles/):   NIRRT_ROUND=r04 gpurun --timeout 3600 -- scripts/gpu_profile.sh [stage ...]     stages: calib traffic stats sq pn2
 R=$(cd "$(dirname "$0")/.." && pwd)
-out=$R/gpurun_out/r03
+RD=${NIRRT_ROUND:-r04}
+export NIRRT_ROUND=$RD
+out=$R/gpurun_out/$RD
 mkdir -p $out $R/profiles
 stages=${@:-calib traffic stats sq pn2}
 cd /tmp && export TMPDIR=/tmp
@@ -28,12 +30,12 @@ print("factors", f_fetch, f_write)
 PY
   cp $R/profiles/r03_traffic_calibration.json $out/ ;;
 traffic)
-  for cfg in "" "--algo rrt" "--algo irrt --dim 3 --trees 4096 --free-lanes 256" "--algo irrt --world b30r16" "--algo nirrt --trees 4096" "--algo rrt --dim 3" "--algo nirrt --dim 3 --trees 1024"; do
+  for cfg in "" "--algo rrt --world b30" "--algo irrt --dim 3 --trees 4096 --segments 5 --wide-visits 4000" "--algo irrt --world b30" "--algo nirrt --trees 4096 --world b30" "--algo rrt --dim 3" "--algo nirrt --dim 3 --trees 2048" "--algo nirrt_c --trees 2048 --world b30"; do
     python $R/scripts/collect_traffic.py $cfg > $out/traffic_$(echo $cfg | tr -d ' -').txt 2>&1
   done
-  cp $R/profiles/r03_traffic.json $R/profiles/r03_pmc_*.csv $out/ 2>/dev/null ;;
+  cp $R/profiles/${RD}_traffic.json $R/profiles/${RD}_pmc_*.csv $out/ 2>/dev/null ;;
 stats)
-  for cfg in "" "--algo irrt --dim 3 --trees 4096 --free-lanes 256"; do
+  for cfg in "" "--algo irrt --dim 3 --trees 4096 --segments 5 --wide-visits 4000"; do
     n=$(echo $cfg | tr -d ' -'); [ -z "$n" ] && n=irrt2d
     rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$n -o p -- python $R/bench.py --no-cpu-baseline --no-ttfs --no-secondary --steps 1 --warmup 0 $cfg > $out/bench_profiled_$n.json 2> $out/bench_profiled_$n.err
     find $out/stats_$n -name "*kernel_trace.csv" -delete
@@ -46,8 +48,8 @@ pn2)
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/pn2_b256 -o p -- python $R/scripts/pn2_forward_only.py 256 > $out/pn2_b256.txt 2>&1
   find $out/pn2_b256 -name "*kernel_trace.csv" -delete
   python $R/scripts/sa_mlp_bench.py 256 > $out/sa_mlp_bench.txt 2>&1
-  $R/scripts/pmc_pn2.sh r03 > $out/pn2_pmc.txt 2>&1
-  cp $R/gpurun_out/pmc_pn2_r03/summary.txt $out/pn2_pmc_summary.txt
+  $R/scripts/pmc_pn2.sh $RD > $out/pn2_pmc.txt 2>&1
+  cp $R/gpurun_out/pmc_pn2_$RD/summary.txt $out/pn2_pmc_summary.txt
   ;;
 esac
 done
