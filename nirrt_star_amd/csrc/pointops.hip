@@ -1050,6 +1050,17 @@ struct SaMlpArgs {
 // over k is straight-line code: with a run-time bound every ds_read_b128 sat in its own basic block right in front of the eight
 // MFMAs it feeds and its latency was paid every time.  The weight fragments of column tile ct + 16 are read while tile ct
 // multiplies (two register sets, ping-pong).
+// maximum over the 16 lanes of a DPP row; valid in lane 15 of the row (row_shr 1, 2, 4, 8 with the lanes shifted in from outside
+// the row keeping their own value)
+__device__ __forceinline__ float row_max16(float v)
+{
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x111, 0xf, 0xf, false)));   // row_shr:1
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x112, 0xf, 0xf, false)));   // row_shr:2
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x114, 0xf, 0xf, false)));   // row_shr:4
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x118, 0xf, 0xf, false)));   // row_shr:8
+    return v;
+}
+
 template <bool LAST, int KC4>
 __device__ __forceinline__ void sa_layer(float *act, int sa, const float *W, const float *bias, int C_, int lane, int gsz)
 {
@@ -1064,41 +1075,47 @@ __device__ __forceinline__ void sa_layer(float *act, int sa, const float *W, con
     const float *wbase = W + row * sw + kq * kc;
     // fragments + bias of a column tile; `ct` is clamped so that the read-ahead past the last tile stays inside the layer (no
     // branch between two tiles: the compiler may then run the epilogue of one under the MFMAs of the next)
-    auto wload = [&](float4_t (&wf)[KC4], float &bv, int ct) {
+    // The product is formed TRANSPOSED: D^T (16 channels x 16 rows) = W (16 x 4) . A^T (4 x 16) - the weight fragment goes in as the
+    // first operand, the activations as the second (the register contents are the same as for A . W^T: lane l holds
+    // W[ct + l % 16][k(l / 16, step)] and A[l % 16][k(l / 16, step)]).  Lane l then holds FOUR CONSECUTIVE CHANNELS
+    // ct + 4 * (l / 16) + v of row l % 16: the next layer's input row is written with ONE ds_write_b128 per tile instead of four
+    // scattered ds_write_b32 (round 3: 39 % of the LDS-active cycles were bank conflicts of that epilogue), and the bias is a vector.
+    auto wload = [&](float4_t (&wf)[KC4], float4_t &bv, int ct) {
         ct = ct < C_ ? ct : C_ - 16;
 #pragma unroll
         for (int j = 0; j < KC4; j++) wf[j] = *reinterpret_cast<const float4_t *>(wbase + ct * sw + 4 * j);
-        bv = bias[ct + row];
+        bv = *reinterpret_cast<const float4_t *>(bias + ct + 4 * kq);
     };
-    auto mm = [&](const float4_t (&wf)[KC4], float bv, float4_t &acc0, float4_t &acc1) {
-        acc0[0] = bv; acc0[1] = bv; acc0[2] = bv; acc0[3] = bv;
-        acc1 = acc0;
+    auto mm = [&](const float4_t (&wf)[KC4], const float4_t &bv, float4_t &acc0, float4_t &acc1) {
+        acc0 = bv;
+        acc1 = bv;
 #pragma unroll
         for (int j = 0; j < KC4; j++) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j][u], wf[j][u], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j][u], wf[j][u], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][u], a0[j][u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][u], a1[j][u], acc1, 0, 0, 0);
             }
         }
     };
     auto epi = [&](const float4_t &acc0, const float4_t &acc1, int ct) {
+        float4_t r0, r1;
+#pragma unroll
+        for (int v = 0; v < 4; v++) { r0[v] = acc0[v] > 0.f ? acc0[v] : 0.f; r1[v] = acc1[v] > 0.f ? acc1[v] : 0.f; }
         if (!LAST) {
             // (same wave reads and later writes `act`: a0 / a1 were loaded above and LDS operations of a wave complete in order)
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                act[(4 * kq + v) * sa + ct + row] = acc0[v] > 0.f ? acc0[v] : 0.f;
-                act[(16 + 4 * kq + v) * sa + ct + row] = acc1[v] > 0.f ? acc1[v] : 0.f;
-            }
+            *reinterpret_cast<float4_t *>(act + row * sa + ct + 4 * kq) = r0;
+            *reinterpret_cast<float4_t *>(act + (16 + row) * sa + ct + 4 * kq) = r1;
         } else {
-            // maximum over this lane's four rows of each tile (ReLU first); the four lanes of a column leave their partial maxima
-            // in rows kq (first tile) and 16 + kq (second tile) of the - by now dead - activation tile, the caller folds them
-            float m0 = 0.f, m1 = 0.f;
+            // maximum over the 16 rows of each tile = over the 16 lanes that share kq (one DPP row): four row_shr steps leave it
+            // in lane 15 of the row; that lane parks the four channels in row 0 (first tile) / row 16 (second tile) of the - by now
+            // dead - activation tile, the caller reads them from there
 #pragma unroll
-            for (int v = 0; v < 4; v++) { m0 = fmaxf(m0, acc0[v]); m1 = fmaxf(m1, acc1[v]); }
-            const int ms = C_ + 16;                   // 4 * ms <= 16 * sa: the caller sizes sa >= C3 / 4 + 4
-            act[kq * ms + ct + row] = m0;
-            act[16 * sa + kq * ms + ct + row] = m1;
+            for (int v = 0; v < 4; v++) { r0[v] = row_max16(r0[v]); r1[v] = row_max16(r1[v]); }
+            if (row == 15) {
+                *reinterpret_cast<float4_t *>(act + ct + 4 * kq) = r0;
+                *reinterpret_cast<float4_t *>(act + 16 * sa + ct + 4 * kq) = r1;
+            }
         }
     };
     // Two tiles per trip; the fragments of the NEXT trip are read at the end of this one (the scheduler sinks LDS reads towards
@@ -1106,7 +1123,7 @@ __device__ __forceinline__ void sa_layer(float *act, int sa, const float *W, con
     // the tile that needed them; it cannot sink them across the back edge).  The first tile's epilogue runs under the second
     // tile's MFMAs.
     float4_t wA[KC4], wB[KC4], x0, x1, y0, y1;
-    float bA, bB;
+    float4_t bA, bB;
     wload(wA, bA, 0);
     wload(wB, bB, 16);
     int ct = 0;
@@ -1167,7 +1184,7 @@ __global__ __launch_bounds__(64 * SA_WAVES, (KA <= 2 ? 2 : 1)) void k_sa_mlp(SaM
     float *Bs = W3 + C3 * (C2 + 4);           // C1 + C2 + C3 biases
     int kmax = Cin > C1 ? Cin : C1;
     kmax = kmax > C2 ? kmax : C2;
-    kmax = kmax > C3 / 4 ? kmax : C3 / 4;     // (the last layer parks 4 rows of C3 + 16 partial maxima in each half tile)
+    // (the last layer parks the C3 maxima of each tile at the start of the tile - dead by then -: 16 * sa >= C3 floats)
     const int sa = kmax + 4;                  // activation row stride (16-byte aligned rows, 4 banks apart)
     float *act = Bs + C1 + C2 + C3 + (size_t)w * 32 * sa;
     // staging: read W^T (k-major, columns fastest) in storage order - coalesced - and scatter into the [column][k] rows; the grid
@@ -1271,10 +1288,7 @@ __global__ __launch_bounds__(64 * SA_WAVES, (KA <= 2 ? 2 : 1)) void k_sa_mlp(SaM
         for (int h = 0; h < 2; h++) {
             const int c = lane + 64 * h;
             if (c < C3) {
-                const int ms = C3 + 16;
-                float m0 = act[c], m1 = act[16 * sa + c];
-#pragma unroll
-                for (int r = 1; r < 4; r++) { m0 = fmaxf(m0, act[r * ms + c]); m1 = fmaxf(m1, act[16 * sa + r * ms + c]); }
+                const float m0 = act[c], m1 = act[16 * sa + c];    // maxima over the rows of the first / second tile (sa_layer<LAST>)
                 if (gpp == 1) oreg[h] = fmaxf(m0, m1);
                 else { oreg[h] = m0; oreg[2 + h] = m1; }
             }
@@ -1298,7 +1312,6 @@ extern "C" int nirrt_pn2_sa_mlp(const float *feats, const float *xyz, const floa
     int kmax = Cin > C1 ? Cin : C1;
     kmax = kmax > C2 ? kmax : C2;
     const int kin = kmax;                     // widest layer INPUT: picks the instantiation
-    kmax = kmax > C3 / 4 ? kmax : C3 / 4;
     const size_t fixed = (size_t)C1 * (Cin + 4) + (size_t)C2 * (C1 + 4) + (size_t)C3 * (C2 + 4) + C1 + C2 + C3;
     int nw = SA_WAVES;
     size_t lds = 0;
