@@ -1084,7 +1084,8 @@ __device__ __forceinline__ void sa_layer(float *act, int sa, const float *W, con
         ct = ct < C_ ? ct : C_ - 16;
 #pragma unroll
         for (int j = 0; j < KC4; j++) wf[j] = *reinterpret_cast<const float4_t *>(wbase + ct * sw + 4 * j);
-        bv = *reinterpret_cast<const float4_t *>(bias + ct + 4 * kq);
+        if (!LAST) bv = *reinterpret_cast<const float4_t *>(bias + ct + 4 * kq);
+        else { const float b = bias[ct + row]; bv[0] = b; bv[1] = b; bv[2] = b; bv[3] = b; }   // (last layer: not transposed, see epi)
     };
     auto mm = [&](const float4_t (&wf)[KC4], const float4_t &bv, float4_t &acc0, float4_t &acc1) {
         acc0 = bv;
@@ -1093,29 +1094,35 @@ __device__ __forceinline__ void sa_layer(float *act, int sa, const float *W, con
         for (int j = 0; j < KC4; j++) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][u], a0[j][u], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][u], a1[j][u], acc1, 0, 0, 0);
+                if (!LAST) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][u], a0[j][u], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][u], a1[j][u], acc1, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j][u], wf[j][u], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j][u], wf[j][u], acc1, 0, 0, 0);
+                }
             }
         }
     };
     auto epi = [&](const float4_t &acc0, const float4_t &acc1, int ct) {
-        float4_t r0, r1;
-#pragma unroll
-        for (int v = 0; v < 4; v++) { r0[v] = acc0[v] > 0.f ? acc0[v] : 0.f; r1[v] = acc1[v] > 0.f ? acc1[v] : 0.f; }
         if (!LAST) {
+            float4_t r0, r1;
+#pragma unroll
+            for (int v = 0; v < 4; v++) { r0[v] = acc0[v] > 0.f ? acc0[v] : 0.f; r1[v] = acc1[v] > 0.f ? acc1[v] : 0.f; }
             // (same wave reads and later writes `act`: a0 / a1 were loaded above and LDS operations of a wave complete in order)
             *reinterpret_cast<float4_t *>(act + row * sa + ct + 4 * kq) = r0;
             *reinterpret_cast<float4_t *>(act + (16 + row) * sa + ct + 4 * kq) = r1;
         } else {
-            // maximum over the 16 rows of each tile = over the 16 lanes that share kq (one DPP row): four row_shr steps leave it
-            // in lane 15 of the row; that lane parks the four channels in row 0 (first tile) / row 16 (second tile) of the - by now
-            // dead - activation tile, the caller reads them from there
+            // the last layer is NOT transposed (lane l holds rows 4 * (l / 16) + v of column l % 16): the maximum over the rows is a
+            // maximum over this lane's four registers (ReLU first); the four lanes of a column leave their partial maxima in
+            // rows kq (first tile) and 16 + kq (second tile) of the - by now dead - activation tile, the caller folds them.  (With
+            // the transposed product the maximum runs across 16 lanes: 32 DPP steps per column tile pair - measured slower.)
+            float m0 = 0.f, m1 = 0.f;
 #pragma unroll
-            for (int v = 0; v < 4; v++) { r0[v] = row_max16(r0[v]); r1[v] = row_max16(r1[v]); }
-            if (row == 15) {
-                *reinterpret_cast<float4_t *>(act + ct + 4 * kq) = r0;
-                *reinterpret_cast<float4_t *>(act + 16 * sa + ct + 4 * kq) = r1;
-            }
+            for (int v = 0; v < 4; v++) { m0 = fmaxf(m0, acc0[v]); m1 = fmaxf(m1, acc1[v]); }
+            const int ms = C_ + 16;                   // 4 * ms <= 16 * sa: the caller sizes sa >= C3 / 4 + 4
+            act[kq * ms + ct + row] = m0;
+            act[16 * sa + kq * ms + ct + row] = m1;
         }
     };
     // Two tiles per trip; the fragments of the NEXT trip are read at the end of this one (the scheduler sinks LDS reads towards
@@ -1184,7 +1191,7 @@ __global__ __launch_bounds__(64 * SA_WAVES, (KA <= 2 ? 2 : 1)) void k_sa_mlp(SaM
     float *Bs = W3 + C3 * (C2 + 4);           // C1 + C2 + C3 biases
     int kmax = Cin > C1 ? Cin : C1;
     kmax = kmax > C2 ? kmax : C2;
-    // (the last layer parks the C3 maxima of each tile at the start of the tile - dead by then -: 16 * sa >= C3 floats)
+    kmax = kmax > C3 / 4 ? kmax : C3 / 4;     // (the last layer parks 4 rows of C3 + 16 partial maxima in each half tile)
     const int sa = kmax + 4;                  // activation row stride (16-byte aligned rows, 4 banks apart)
     float *act = Bs + C1 + C2 + C3 + (size_t)w * 32 * sa;
     // staging: read W^T (k-major, columns fastest) in storage order - coalesced - and scatter into the [column][k] rows; the grid
@@ -1288,7 +1295,10 @@ __global__ __launch_bounds__(64 * SA_WAVES, (KA <= 2 ? 2 : 1)) void k_sa_mlp(SaM
         for (int h = 0; h < 2; h++) {
             const int c = lane + 64 * h;
             if (c < C3) {
-                const float m0 = act[c], m1 = act[16 * sa + c];    // maxima over the rows of the first / second tile (sa_layer<LAST>)
+                const int ms = C3 + 16;
+                float m0 = act[c], m1 = act[16 * sa + c];
+#pragma unroll
+                for (int r = 1; r < 4; r++) { m0 = fmaxf(m0, act[r * ms + c]); m1 = fmaxf(m1, act[16 * sa + r * ms + c]); }
                 if (gpp == 1) oreg[h] = fmaxf(m0, m1);
                 else { oreg[h] = m0; oreg[2 + h] = m1; }
             }
@@ -1312,6 +1322,7 @@ extern "C" int nirrt_pn2_sa_mlp(const float *feats, const float *xyz, const floa
     int kmax = Cin > C1 ? Cin : C1;
     kmax = kmax > C2 ? kmax : C2;
     const int kin = kmax;                     // widest layer INPUT: picks the instantiation
+    kmax = kmax > C3 / 4 ? kmax : C3 / 4;
     const size_t fixed = (size_t)C1 * (Cin + 4) + (size_t)C2 * (C1 + 4) + (size_t)C3 * (C2 + 4) + C1 + C2 + C3;
     int nw = SA_WAVES;
     size_t lds = 0;
