@@ -65,7 +65,7 @@ def parse(argv=None):
                     help="b30r16 = SURVEY.md 8(d)'s primary world (30 circles r in [16, 24], start / goal in one free component); b30 = its "
                          "lighter fallback (r in [8, 12])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=12000, help="iterations each CPU-baseline process runs (per repetition)")
+    ap.add_argument("--cpu-iters", type=int, default=6000, help="iterations each CPU-baseline process runs (per repetition)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline processes (0 = every host core)")
     ap.add_argument("--no-cpu-full", action="store_true", help="skip the ONE full-length single-core oracle run reported beside the sample")
     ap.add_argument("--no-ttfs", action="store_true")
@@ -90,12 +90,13 @@ def parse(argv=None):
                          "the 1000-problem evaluation set) is sharded round-robin over the ranks (problem i -> rank i mod N)")
     ap.add_argument("--problems", type=int, default=1000, help="size of the fixed problem set of --scaling strong")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other BASELINE configurations (N = 1 only)")
-    ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of the CPU-baseline sample (the median is reported)")
+    ap.add_argument("--cpu-reps", type=int, default=2, help="repetitions of the CPU-baseline sample (the median is reported)")
     return ap.parse_args(argv)
 
 
 def config_key(args):
-    return "%s_%dd_%s_%dx%d" % (args.algo, args.dim, args.world if args.dim == 2 else "ref3d", args.trees, args.iters)
+    size = ("set%d" % args.problems) if getattr(args, "scaling", "weak") == "strong" else str(args.trees)
+    return "%s_%dd_%s_%sx%d" % (args.algo, args.dim, args.world if args.dim == 2 else "ref3d", size, args.iters)
 
 
 def rank_problem_ids(args, rank, world):
