@@ -241,7 +241,7 @@ def main():
     if args.algo.startswith("nirrt"):
         return bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work)
 
-    full_proc = start_cpu_full_run(args) if (rank == 0 and not args.no_cpu_baseline and not args.no_cpu_full) else None
+    full_proc = start_cpu_full_run(args) if (rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_cpu_full) else None
     probs = make_problems(args, rank)
     D, B, iters = args.dim, len(probs), args.iters   # (strong scaling: this rank's share of the fixed set)
     flags = _hip.F_IRRT if args.algo == "irrt" else 0
@@ -356,7 +356,7 @@ def main():
         if not args.no_ttfs:
             out["time_to_first_solution"] = time_to_first_solution(args, trees, np_states, py_states, flags)
             out["single_tree"] = single_tree_latency(args, trees, np_states, py_states, flags)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # (the host-core baseline belongs to the N = 1 line)
             out["cpu_baseline"] = cpu_baseline(args, full_proc)
         if world == 1 and not args.no_secondary:
             # the other BASELINE configurations as short runs in processes of their own: this one's trees and inputs go first

@@ -154,14 +154,16 @@ def test_rrt3d_50k_bit_exact_against_oracle(oracle):
     o.close()
 
 
-@pytest.mark.parametrize("world,pid,iters", [("b30", 3, ITERS), ("b30r16", 1, 20000)])
+@pytest.mark.parametrize("world,pid,iters", [("b30", 3, ITERS), ("b30r16", 1, 20000), ("b30", 5727, 16000)])
 def test_bench_configuration_50k_against_oracle(oracle, monkeypatch, world, pid, iters):
     """The benchmarked configuration itself at full size: 2D IRRT*, 30 circles, 50 000 iterations,
     in-kernel sampling from the problem's own seeded generators, the one-wave-per-tree kernels (`slim`) - one problem of
     bench.py's batch (and one of the r in [16, 24] world) against orc_run_sampling fed with the same words: vertex count,
     parents, solution list, generator words consumed identical; vertices <= 1e-9; best path cost <= 1e-5
     (irrt_star_2d.py:42-97).  The oracle needs 2 - 4 minutes for the 50 000-iteration problem (its cost walks are the
-    reference's, un-cached), so the r in [16, 24] problem stops at 20 000."""
+    reference's, un-cached), so the r in [16, 24] problem stops at 20 000.  Problem 5727 of the b30 batch is DEGENERATE (free
+    straight start-goal segment: hundreds of near-tie rewire candidates per iteration, ~10 re-parentings per rewiring pass): it
+    takes the pass-only candidate list with near-tie stamps (it_connect, round 4) on most of its rewiring passes."""
     from types import SimpleNamespace
     import bench
     from nirrt_star_amd import _hip, sampling
@@ -189,5 +191,8 @@ def test_bench_configuration_50k_against_oracle(oracle, monkeypatch, world, pid,
     assert np.array_equal(np.isfinite(tr), np.isfinite(tro))
     fin = np.isfinite(tr)
     assert np.max(np.abs(tr[fin] - tro[fin])) <= 1e-5
+    if pid == 5727:      # the degenerate tree really went down the new path: crowded candidate lists, few one-at-a-time re-parentings
+        st = res["stats"][0]
+        assert st[5] / iters > 40 and st[6] / iters > 2 and st[19] < 0.5 * st[6]
     t.close()
     o.close()
