@@ -63,3 +63,34 @@ def test_time_sliced_launch_equals_one_workgroup_per_tree(name, irrt, stop_first
     # the counters add up over the slices; busy time is reported per tree
     assert np.array_equal(r0["stats"][:, 13], r1["stats"][:, 13]) and np.array_equal(r0["stats"][:, 9], r1["stats"][:, 9])
     assert (r1["stats"][:, _hip.ST_BUSY] > 0).all()
+
+
+def test_scheduled_segments_with_lane_groups_equal_one_launch():
+    """batch.run_scheduled: a run as three launches with the trees re-ordered (longest first) and some of them moved to 256- /
+    128-lane workgroups between the launches (concurrent lane groups on their own streams) equals the run as one launch: trees,
+    iterations, generator outputs consumed - scheduling never changes a result"""
+    from nirrt_star_amd import _hip, batch
+    g = load_golden("run_irrt2d_3000")
+    B, iters = 24, 3000
+    out = {}
+    for mode in ("one", "scheduled"):
+        trees = _batch(g, B, iters, 9000)
+        if mode == "one":
+            r = batch.run_scheduled(trees, [iters], _hip.F_IRRT)
+        else:
+            # thresholds low enough that trees change lanes after the first segment (Near visits of a few hundred slots per iteration)
+            r = batch.run_scheduled(trees, [700, 800, 1500], _hip.F_IRRT, wide_visits=400.0, narrow_visits=150.0)
+            assert r["wide"] + r["narrow"] > 0
+        st = _hip.get_generators(trees)
+        out[mode] = (r, [t.download() for t in trees], [t.solutions for t in trees], st)
+        for t in trees:
+            t.close()
+    (r0, d0, s0, g0), (r1, d1, s1, g1) = out["one"], out["scheduled"]
+    assert np.array_equal(r0["iters_done"], r1["iters_done"]) and (r1["iters_done"] == iters).all() and not r1["status"].any()
+    assert r0["words"] == r1["words"]
+    for b in range(B):
+        assert np.array_equal(d0[b][1], d1[b][1]) and np.array_equal(d0[b][0], d1[b][0]) and np.array_equal(s0[b], s1[b])
+    for a, b_ in zip(g0, g1):
+        assert np.array_equal(a, b_)
+    assert np.array_equal(d1[0][1], g["parents"])
+    assert (r1["seconds"] > 0).all() and np.array_equal(r0["stats"][:, 13], r1["stats"][:, 13])
