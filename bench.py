@@ -448,8 +448,8 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
 SECONDARY = [   # (label, bench arguments): each runs `--steps 1 --warmup 0` in a process of its own
     ("rrt_2d", ["--algo", "rrt", "--world", "b30"]),
     ("rrt_3d", ["--algo", "rrt", "--dim", "3"]),
-    # (trees whose visits cover thousands of index slots per iteration - the degenerate, near-straight-line class - move to 256 lanes)
-    ("irrt_3d", ["--algo", "irrt", "--dim", "3", "--trees", "4096", "--segments", "5", "--wide-visits", "4000"]),
+    # (trees whose visits cover thousands of index slots per iteration - the degenerate, near-straight-line class - move to 256 / 128 lanes)
+    ("irrt_3d", ["--algo", "irrt", "--dim", "3", "--trees", "4096", "--segments", "3", "--wide-visits", "6000", "--narrow-visits", "2000"]),
     ("irrt_2d_b30 (r in [8, 12])", ["--algo", "irrt", "--world", "b30"]),
     ("nirrt_2d", ["--algo", "nirrt", "--trees", "4096", "--world", "b30"]),
     ("nirrt_c_2d (config 3)", ["--algo", "nirrt_c", "--trees", "2048", "--world", "b30"]),

@@ -30,12 +30,12 @@ print("factors", f_fetch, f_write)
 PY
   cp $R/profiles/r03_traffic_calibration.json $out/ ;;
 traffic)
-  for cfg in "" "--algo rrt --world b30" "--algo irrt --dim 3 --trees 4096 --segments 5 --wide-visits 4000" "--algo irrt --world b30" "--algo nirrt --trees 4096 --world b30" "--algo rrt --dim 3" "--algo nirrt --dim 3 --trees 2048" "--algo nirrt_c --trees 2048 --world b30"; do
+  for cfg in "" "--algo rrt --world b30" "--algo irrt --dim 3 --trees 4096 --segments 3 --wide-visits 6000 --narrow-visits 2000" "--algo irrt --world b30" "--algo nirrt --trees 4096 --world b30" "--algo rrt --dim 3" "--algo nirrt --dim 3 --trees 2048" "--algo nirrt_c --trees 2048 --world b30"; do
     python $R/scripts/collect_traffic.py $cfg > $out/traffic_$(echo $cfg | tr -d ' -').txt 2>&1
   done
   cp $R/profiles/${RD}_traffic.json $R/profiles/${RD}_pmc_*.csv $out/ 2>/dev/null ;;
 stats)
-  for cfg in "" "--algo irrt --dim 3 --trees 4096 --segments 5 --wide-visits 4000"; do
+  for cfg in "" "--algo irrt --dim 3 --trees 4096 --segments 3 --wide-visits 6000 --narrow-visits 2000"; do
     n=$(echo $cfg | tr -d ' -'); [ -z "$n" ] && n=irrt2d
     rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$n -o p -- python $R/bench.py --no-cpu-baseline --no-ttfs --no-secondary --steps 1 --warmup 0 $cfg > $out/bench_profiled_$n.json 2> $out/bench_profiled_$n.err
     find $out/stats_$n -name "*kernel_trace.csv" -delete
