@@ -123,9 +123,11 @@ def hand_over(trees, streams, only_touched=False):
             if s._touched[1]:
                 py_i.append(i)
             s._touched = [False, False]
-    both = [i for i in np_i if i in set(py_i)]
-    only_np = [i for i in np_i if i not in set(both)]
-    only_py = [i for i in py_i if i not in set(both)]
+    py_set = set(py_i)
+    both = [i for i in np_i if i in py_set]
+    both_set = set(both)
+    only_np = [i for i in np_i if i not in both_set]
+    only_py = [i for i in py_i if i not in both_set]
     if both:
         _hip.set_generators([trees[i] for i in both], [streams[i].np_state() for i in both], [streams[i].py_state() for i in both])
     if only_np:
@@ -306,7 +308,7 @@ class Guidance:
     def refresh(self, due, problems, trees, streams, c_best, frames):
         """new clouds for the trees `due` (indices into the batch): c_best[i] = inf draws the whole-world cloud
         (nirrt_star_png_2d.py:132-145), otherwise the ellipse / ellipsoid-restricted one (:146-160).  Clouds are generated, down-
-        sampled and handed to the trees ON the device (candidates from each problem's resident generator look-ahead); the host
+        sampled and handed to the trees ON the device (candidates from outputs of each problem's own generator, produced in its tree); the host
         sees them once, for the network's input block and the caller's records."""
         import time
         import torch
