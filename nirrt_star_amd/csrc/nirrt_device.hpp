@@ -157,6 +157,13 @@ __device__ __forceinline__ double uni(double v)
     int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
+template <class T>
+__device__ __forceinline__ T *uni(T *v)
+{
+    long long b = (long long)v;
+    int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return (T *)(((long long)hi << 32) | (unsigned)lo);
+}
 
 // ------------------------------------------------------------------------------------------------
 // per-tree state in HBM
@@ -371,11 +378,12 @@ struct LdsData {
         int n, want, new_idx, lds_cap, ni, cj;
     } qa;
     struct {                      // state of the loop body handed from phase to phase (it_extend / it_connect / it_book)
-        double node_in[3], node_new[3], edge_new, cost_ni, r_query;
+        double node_in[3], q_next[3], node_new[3], edge_new, cost_ni, r_query;   // q_next: the next iteration's node_rand (has_next)
         long long alg;
+        long long sp_pos[2];      // persistent loops, thread 0: generator positions before the early draw
         nirrt_step_result *res;
         unsigned flags;
-        int host_steer, ni, pref_ni, collided, new_idx, n, dup, inserted, dup_parent, dup_ns, dup_ps, dup_fc, k, reparented, n_rewired;
+        int has_next, host_steer, ni, pref_ni, collided, new_idx, n, dup, inserted, dup_parent, dup_ns, dup_ps, dup_fc, k, reparented, n_rewired;
     } it;
     int n_cand;                   // rewire: members whose stashed margin reaches cost(new) (the stash is compacted to them)
     int cand_listed;              // ... all of them are in the LDS list (else: the spilled part is searched per round)
@@ -914,6 +922,10 @@ __device__ __forceinline__ int block_min_int(Lds<NT> &s, int v)
     return v;
 }
 
+// (the library's reduction reads blockDim for the number of waves, so every function on the call path carries the implicit
+// kernel arguments and the workgroup ids in saved scalar registers; a hand-written ballot + LDS version drops those and measures
+// 2.4 % SLOWER on the default bench - 51.0 vs 52.2 M it/s, same box, twice - so the library's version stays)
+template <int NT>
 __device__ __forceinline__ bool block_any(bool p) { return __syncthreads_or(p ? 1 : 0) != 0; }
 
 // ordered compaction: threads with keep get their output slot (ascending thread order); returns total
@@ -1973,7 +1985,7 @@ NIRRT_FN __device__ bool wg_collision_fn(double ax, double ay, double az, double
     int M = s.n_round + s.n_box;
     bool hit = false;
     for (int o = threadIdx.x; o < M; o += NT) hit = hit || seg_obstacle<D, NT>(s, o, a, b, clr);
-    return block_any(hit);
+    return block_any<NT>(hit);
 }
 template <int D, int NT>
 __device__ __forceinline__ bool wg_collision(const Lds<NT> &s, const double *a, const double *b, double clr)
@@ -2651,7 +2663,7 @@ NIRRT_FN __device__ void it_connect()
                             bool mine;
                             if (n_go >= 0) { mine = tid < 64 && a < n_go; a = mine ? go_a[a] : 0; }
                             else mine = tid < 64 && a < n_list && state[a] == CAND_PASS;
-                            if (n_go < 0 && !block_any(mine)) continue;   // (uniform) nothing to re-parent among these 64
+                            if (n_go < 0 && !block_any<NT>(mine)) continue;   // (uniform) nothing to re-parent among these 64
                             int v = -1, pv = -1, nx = -1, old_p = -1, fc = -1, flg = 0;
                             if (mine) {
                                 v = ids[a];
@@ -2808,22 +2820,18 @@ NIRRT_FN __device__ void it_book()
     __syncthreads();
 }
 
+// One iteration over the arguments thread 0 has left in s.it (node_in, host_steer, ni, pref_ni, flags, res, has_next, q_next);
+// starts with the barrier that publishes them.
+// pref_ni >= 0: nearest_neighbor(node_in) already known from the previous iteration's fused query.
+// has_next: q_next is the next iteration's node_rand; if this iteration runs a Near query its nearest index is
+// left in s.bc_i[6] (else -1) for the caller to pass back as pref_ni (the persistent loops: s.it.pref_ni is set to it as well).
 template <int D, int NT>
-__device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const double *node_in, bool host_steer,
-                                             int nearest_in, unsigned flags, nirrt_step_result *res,
-                                             int pref_ni = -1, const double *q_next = nullptr)
+__device__ __forceinline__ void wg_iteration_body(Lds<NT> &s, TreeHot &t)
 {
-    // pref_ni >= 0: nearest_neighbor(node_in) already known from the previous iteration's fused query.
-    // q_next != nullptr: the next iteration's node_rand; if this iteration runs a Near query its nearest index is
-    // left in s.bc_i[6] (else -1) for the caller to pass back as pref_ni.
     const int tid = threadIdx.x;
-    if (tid == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) s.it.node_in[k] = k < D ? node_in[k] : 0.;
-        s.it.host_steer = host_steer ? 1 : 0; s.it.ni = nearest_in; s.it.pref_ni = pref_ni; s.it.flags = flags; s.it.res = res;
-    }
     __syncthreads();
     it_extend<D, NT>();
+    nirrt_step_result *res = uni(s.it.res);
     int next_ni = -1;
     long long alg = s.it.alg;
     const int new_idx = uni(s.it.new_idx);
@@ -2842,7 +2850,8 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
             const double floor_m = lb_new - (1e-9 + 1e-11 * lb_new);
             const int n = uni(s.it.n);
             // (the step kernel reports the size of the filtered Near set: it filters every hit; the loops only need the set's uses)
-            wg_query<D, NT>(s, t, n, node_new, uni(s.it.r_query), new_idx, q_next, &next_ni, nullptr, uni(s.stash_cap), floor_m, res == nullptr);
+            wg_query<D, NT>(s, t, n, node_new, uni(s.it.r_query), new_idx, uni(s.it.has_next) ? s.it.q_next : nullptr, &next_ni, nullptr,
+                            uni(s.stash_cap), floor_m, res == nullptr);
             alg += n;
             it_connect<D, NT>();
             // goal bookkeeping only concerns vertices within step_len of the goal (wg_goal_candidate / InGoalRegion test the same
@@ -2855,8 +2864,21 @@ __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const doubl
     } else if (res && tid == 0) {
         res->collided = 1;
     }
-    if (tid == 0) { s.stat[ST_ITERS] += 1; s.stat[ST_ALG] += alg; s.bc_i[6] = next_ni; }
+    if (tid == 0) { s.stat[ST_ITERS] += 1; s.stat[ST_ALG] += alg; s.bc_i[6] = next_ni; s.it.pref_ni = next_ni; }
     __syncthreads();
+}
+
+template <int D, int NT>
+__device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const double *node_in, bool host_steer,
+                                             int nearest_in, unsigned flags, nirrt_step_result *res)
+{
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) s.it.node_in[k] = k < D ? node_in[k] : 0.;
+        s.it.host_steer = host_steer ? 1 : 0; s.it.ni = nearest_in; s.it.pref_ni = -1; s.it.flags = flags; s.it.res = res;
+        s.it.has_next = 0;
+    }
+    wg_iteration_body<D, NT>(s, t);
 }
 
 // end-of-iteration report shared by the step kernel and the persistent loops
