@@ -100,7 +100,11 @@ struct Topo;
 #define NEAR_STASH LDS_POOL      // upper limit of Near members whose (index, bound) pair stays in LDS (the pool slots the
 #endif                           // obstacle tables leave free); the rest spills to nr_idx / nr_m.  Test builds set it to 8.
 #ifndef GRID_U
-#define GRID_U 2                 // slots per lane and trip of a grid visit (measured: 2 beats 4 by 12 %, 8 spills)
+#define GRID_U 2                 // slots per lane and trip of a grid visit (measured: 2 beats 4 by 12 %, 8 spills).  Round 4: TWO trips
+                                 // requested ahead of the one being evaluated (three register sets taking turns, loop unrolled by
+                                 // three, no spills in the loop) ran 16 % SLOWER (43.7 vs 52.0 M it/s): more loads in flight per
+                                 // wave only lengthen the queues - the visit is bound by what the memory system delivers for
+                                 // scattered 32-byte records (3.8 TB/s at the HBM), not by the latency one wave sees
 #endif
 #define REBUILD_U 4               // vertices per lane and trip of an index rebuild
 #ifndef LIST_U
