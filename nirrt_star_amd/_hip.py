@@ -92,6 +92,14 @@ def load():
     if not os.path.exists(SO_PATH):
         raise NirrtError("libnirrt_hip.so is not built (%s). Run `python -m nirrt_star_amd.build` "
                          "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm's).
+    # Loaded first, torch's copies also satisfy this library's DT_NEEDED entries; loaded second they would be a SECOND runtime,
+    # whose HSA finds no GPU ("No HIP GPUs are available" from the first torch.cuda call after a tree was created).  The
+    # guidance path needs torch anyway (device memory, PointNet++); a process without torch just loads /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(SO_PATH)
     dp, ip, up = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)
     vp = C.c_void_p

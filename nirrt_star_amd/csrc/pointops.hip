@@ -4,6 +4,7 @@
 // query_ball_point :89-109 (with square_distance :21-42), 3-NN of PointNetFeaturePropagation :295-299.
 // float32 arithmetic, -ffp-contract=off; the dot products of square_distance are a forward FMA chain.
 #include <mutex>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -586,17 +587,19 @@ extern "C" int nirrt_guidance_clouds(const nirrt_cloud_job *jobs, int n_jobs, in
     long long *d_off = (long long *)(base + b_pts + b_sel);
     int *d_cnt = (int *)(base + b_pts + b_sel + b_off), *d_ns = d_cnt + b_int / sizeof(int), *d_nout = d_ns + b_int / sizeof(int);
     nirrt_cloud_job *d_jobs = (nirrt_cloud_job *)(base + b_pts + b_sel + b_off + 3 * b_int);
-    long long *h_off = (long long *)malloc(sizeof(long long) * (size_t)n_jobs);
-    int *h_ns = (int *)malloc(sizeof(int) * (size_t)n_jobs);
-    for (int b = 0; b < n_jobs; b++) { h_off[b] = (long long)b * n_raw; h_ns[b] = n_points; }
+    std::vector<long long> h_off((size_t)n_jobs);
+    std::vector<int> h_ns((size_t)n_jobs, n_points);
+    for (int b = 0; b < n_jobs; b++) h_off[b] = (long long)b * n_raw;
     int rc = 0;
     if (hipMemcpy(d_jobs, jobs, sizeof(nirrt_cloud_job) * (size_t)n_jobs, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_off, h_off, sizeof(long long) * (size_t)n_jobs, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_ns, h_ns, sizeof(int) * (size_t)n_jobs, hipMemcpyHostToDevice) != hipSuccess)
+        hipMemcpy(d_off, h_off.data(), sizeof(long long) * (size_t)n_jobs, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ns, h_ns.data(), sizeof(int) * (size_t)n_jobs, hipMemcpyHostToDevice) != hipSuccess)
         rc = -2;
-    free(h_off);
-    free(h_ns);
     if (!rc) {
+        // The three kernels run on the NULL stream on purpose: the generator outputs they read are complete (nirrt_generator_words
+        // waits for its launch), and the clouds they write are read next by torch's default stream - the legacy stream orders
+        // that without events.  (With NIRRT_BATCH_GROUPS >= 2 - off by default, see batch.run_batch - the launch waits
+        // for the other group's persistent kernel when the tree streams are blocking ones.)
         hipLaunchKernelGGL(k_cloud_candidates, dim3(n_jobs), dim3(CAND_NT), 0, 0, (const nirrt_cloud_job *)d_jobs, n_raw, d, total, d_cnt);
         // k_fps_f64 leaves clouds with cnt <= num_samples alone (k_cloud_compact keeps all of their points)
         if (n_raw <= 20 * FPS64_NT)
