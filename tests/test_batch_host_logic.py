@@ -1,0 +1,219 @@
+"""Host logic of the batched planners without a GPU: who owns a problem's generators when (batch.ProblemStreams / hand_over /
+fetch_np) and how run_scheduled re-orders a batch between two launches.  The library calls are replaced by a fake device that
+keeps the generator states it is given and "draws" by advancing real numpy / CPython generators - the host side must end up
+exactly where a process that drew everything itself ends up (the reference draws from np.random / random in ONE process:
+rrt_base_2d.py:46-52, irrt_star_2d.py:121-151, point_cloud_mask_utils.py:35-73)."""
+import random
+
+import numpy as np
+import pytest
+
+from nirrt_star_amd import _hip, batch
+
+
+class FakeTree:
+    def __init__(self, name):
+        self.name = name
+        self.np_state = None
+        self.py_state = None
+
+
+class FakeDevice:
+    """stands in for nirrt_set_generators / nirrt_get_generators / nirrt_run; counts the calls"""
+
+    def __init__(self):
+        self.set_calls = []
+        self.get_calls = []
+        self.launches = []
+
+    def set_generators(self, trees, np_states=None, py_states=None):
+        self.set_calls.append((len(trees), np_states is not None, py_states is not None))
+        for k, t in enumerate(trees):
+            if np_states is not None:
+                t.np_state = (np.array(np_states[k][0], dtype=np.uint32), int(np_states[k][1]))
+            if py_states is not None:
+                t.py_state = (np.array(py_states[k][0], dtype=np.uint32), int(py_states[k][1]))
+
+    def get_generators(self, trees, want_np=True, want_py=True):
+        self.get_calls.append((len(trees), want_np, want_py))
+        nk = np.stack([t.np_state[0] for t in trees]) if want_np else None
+        npos = np.array([t.np_state[1] for t in trees]) if want_np else None
+        pk = np.stack([t.py_state[0] for t in trees]) if want_py else None
+        ppos = np.array([t.py_state[1] for t in trees]) if want_py else None
+        return nk, npos, pk, ppos
+
+    @staticmethod
+    def draw_on_device(tree, n_np, n_py):
+        """what the kernel does to a tree's generators: n doubles from each"""
+        rs = np.random.RandomState(0)
+        _hip.set_np_state(tree.np_state[0], tree.np_state[1], rs)
+        rs.random_sample(n_np)
+        tree.np_state = _hip.np_state(rs)
+        pg = random.Random(0)
+        _hip.set_py_state(tree.py_state[0], tree.py_state[1], pg)
+        for _ in range(n_py):
+            pg.random()
+        tree.py_state = _hip.py_state(pg)
+
+
+@pytest.fixture
+def dev(monkeypatch):
+    d = FakeDevice()
+    monkeypatch.setattr(_hip, "set_generators", d.set_generators)
+    monkeypatch.setattr(_hip, "get_generators", d.get_generators)
+    return d
+
+
+def test_hand_over_uploads_every_fresh_stream_in_one_call(dev):
+    trees = [FakeTree(i) for i in range(5)]
+    streams = [batch.ProblemStreams(100 + i) for i in range(5)]
+    batch.hand_over(trees, streams)
+    assert dev.set_calls == [(5, True, True)]
+    for i, (t, s) in enumerate(zip(trees, streams)):
+        assert s.bound_to(t)
+        k, p = _hip.np_state(np.random.RandomState(100 + i))
+        assert t.np_state[1] == p and np.array_equal(t.np_state[0], k)
+        k, p = _hip.py_state(random.Random(100 + i))
+        assert t.py_state[1] == p and np.array_equal(t.py_state[0], k)
+    # nothing changed hands since: the next launch uploads nothing
+    batch.hand_over(trees, streams, only_touched=True)
+    assert len(dev.set_calls) == 1
+
+
+def test_host_draws_continue_where_the_device_stopped_and_go_back(dev):
+    """device draws, host draws (cloud candidates), device draws again = one process drawing everything in that order"""
+    tree, s = FakeTree(0), batch.ProblemStreams(7)
+    twin_np, twin_py = np.random.RandomState(7), random.Random(7)
+    batch.hand_over([tree], [s])
+    dev.draw_on_device(tree, 11, 5)
+    twin_np.random_sample(11)
+    [twin_py.random() for _ in range(5)]
+    s.device_drew()
+    # the host object is behind until someone asks for it: ONE fetch, numpy only
+    a = s.rs.uniform(0, 1, 4)
+    assert dev.get_calls == [(1, True, False)]
+    assert np.array_equal(a, twin_np.uniform(0, 1, 4))
+    assert s.touched()
+    # a second look without device draws in between fetches nothing
+    b = s.rs.random_sample(2)
+    assert len(dev.get_calls) == 1 and np.array_equal(b, twin_np.random_sample(2))
+    # before the next launch the touched state goes back to the tree - numpy only, python was never handed out
+    batch.hand_over([tree], [s], only_touched=True)
+    assert dev.set_calls[-1] == (1, True, False) and not s.touched()
+    dev.draw_on_device(tree, 3, 2)
+    twin_np.random_sample(3)
+    [twin_py.random() for _ in range(2)]
+    s.device_drew()
+    assert s.rs.random_sample() == twin_np.random_sample()
+    assert s.py.random() == twin_py.random()
+
+
+def test_device_drew_with_one_stream_only_leaves_the_other_current(dev):
+    tree, s = FakeTree(0), batch.ProblemStreams(3)
+    batch.hand_over([tree], [s])
+    dev.draw_on_device(tree, 8, 0)
+    s.device_drew(py_too=False)       # a 3D tree never touches the python generator
+    s.py.random()
+    assert dev.get_calls == []        # ... so looking at it costs no round trip
+    s.rs.random_sample()
+    assert dev.get_calls == [(1, True, False)]
+
+
+def test_fetch_np_batches_the_streams_that_are_behind(dev):
+    trees = [FakeTree(i) for i in range(4)]
+    streams = [batch.ProblemStreams(20 + i) for i in range(4)]
+    batch.hand_over(trees, streams)
+    for i in (0, 2, 3):
+        dev.draw_on_device(trees[i], 5 + i, 1)
+        streams[i].device_drew()
+    batch.fetch_np(trees, streams, [0, 1, 2])
+    assert dev.get_calls == [(2, True, False)]      # 1 is current, 3 was not asked for
+    for i in (0, 2):
+        twin = np.random.RandomState(20 + i)
+        twin.random_sample(5 + i)
+        assert streams[i]._rs.random_sample() == twin.random_sample()
+    assert streams[3]._behind[0]
+
+
+def test_unbound_stream_is_a_plain_pair_of_generators(dev):
+    s = batch.ProblemStreams(5)
+    assert s.rs.random_sample() == np.random.RandomState(5).random_sample()
+    assert s.py.random() == random.Random(5).random()
+    assert not s.touched() and dev.get_calls == [] and dev.set_calls == []
+    a, b = batch.ProblemStreams(9), batch.ProblemStreams(9)
+    assert int(a.fps_start(2048)) == int(b.fps_start(2048))
+
+
+# ------------------------------------------------------------------------------------------------
+# run_scheduled
+# ------------------------------------------------------------------------------------------------
+def _fake_run(log, secs_of, visits_of, stop_at=None):
+    def run_sampling(trees, iters, flags=0, lanes_hint=None, **kw):
+        names = [t.name for t in trees]
+        log.append({"names": names, "iters": iters, "hint": None if lanes_hint is None else list(lanes_hint)})
+        n = len(trees)
+        stats = np.zeros((n, _hip.N_STATS), dtype=np.int64)
+        status = np.zeros(n, dtype=np.int32)
+        done = np.full(n, iters, dtype=np.int64)
+        for j, b in enumerate(names):
+            stats[j, _hip.ST_ITERS] = iters
+            stats[j, 0] = int(visits_of[b] * iters)
+            stats[j, _hip.ST_BUSY] = int(secs_of[b] * 1e8)
+            if stop_at is not None and b in stop_at and len(log) - 1 == stop_at[b]:
+                status[j] = _hip.E_CAPACITY
+                done[j] = iters // 2
+        return {"kernel_ms": 1000.0 * max(secs_of[b] for b in names), "stats": stats, "alg_elems": done * 10, "iters_done": done,
+                "status": status, "np_used": done * 2, "py_used": done * 4}
+    return run_sampling
+
+
+def test_run_scheduled_dispatches_longest_first_and_widens_heavy_trees(monkeypatch):
+    trees = [FakeTree(i) for i in range(6)]
+    secs = {0: 1.0, 1: 5.0, 2: 2.0, 3: 9.0, 4: 0.5, 5: 3.0}
+    visits = {0: 900, 1: 7000, 2: 2500, 3: 14000, 4: 100, 5: 1999}
+    log = []
+    monkeypatch.setattr(_hip, "run_sampling", _fake_run(log, secs, visits))
+    tot = batch.run_scheduled(trees, [100, 100, 50], 0, wide_visits=6000, narrow_visits=2000)
+    assert [l["iters"] for l in log] == [100, 100, 50]
+    assert log[0]["names"] == [0, 1, 2, 3, 4, 5] and log[0]["hint"] is None
+    # second and third launch: by the device time of the launch before, heavy visits on wider workgroups
+    for l in log[1:]:
+        assert l["names"] == [3, 1, 5, 2, 0, 4]
+        assert l["hint"] == [256, 256, 0, 128, 0, 0]
+    assert tot["wide"] == 2 and tot["narrow"] == 1
+    # sums land on the trees they belong to, whatever the dispatch order was
+    assert np.array_equal(tot["iters_done"], np.full(6, 250))
+    assert np.allclose(tot["seconds"], [3 * secs[b] for b in range(6)])
+    assert tot["kernel_ms"] == pytest.approx(3 * 9000.0)
+    assert tot["words"] == 6 * 250 * 6
+    assert np.array_equal(tot["stats"][:, _hip.ST_ITERS], np.full(6, 250))
+
+
+def test_run_scheduled_without_reorder_keeps_the_order_but_still_widens(monkeypatch):
+    trees = [FakeTree(i) for i in range(3)]
+    log = []
+    monkeypatch.setattr(_hip, "run_sampling", _fake_run(log, {0: 1.0, 1: 3.0, 2: 2.0}, {0: 10, 1: 10, 2: 9000}))
+    batch.run_scheduled(trees, [10, 10], 0, wide_visits=4000, reorder=False)
+    assert log[1]["names"] == [0, 1, 2] and log[1]["hint"] == [0, 0, 256]
+
+
+def test_run_scheduled_drops_a_stopped_tree_and_its_hint_follows_the_others(monkeypatch):
+    trees = [FakeTree(i) for i in range(4)]
+    secs = {0: 4.0, 1: 3.0, 2: 2.0, 3: 1.0}
+    visits = {0: 5000, 1: 10, 2: 5000, 3: 10}
+    log = []
+    monkeypatch.setattr(_hip, "run_sampling", _fake_run(log, secs, visits, stop_at={0: 1}))   # tree 0 fills up in the second launch
+    tot = batch.run_scheduled(trees, [10, 10, 10], 0, wide_visits=4000)
+    assert log[1]["names"] == [0, 1, 2, 3] and log[1]["hint"] == [256, 0, 256, 0]
+    assert log[2]["names"] == [1, 2, 3] and log[2]["hint"] == [0, 256, 0]
+    assert tot["status"][0] == _hip.E_CAPACITY and tot["iters_done"][0] == 15
+    assert list(tot["iters_done"][1:]) == [30, 30, 30]
+
+
+def test_run_scheduled_first_launch_takes_the_callers_order_and_hints(monkeypatch):
+    trees = [FakeTree(i) for i in range(3)]
+    log = []
+    monkeypatch.setattr(_hip, "run_sampling", _fake_run(log, {0: 1.0, 1: 1.0, 2: 1.0}, {0: 1, 1: 1, 2: 1}))
+    tot = batch.run_scheduled(trees, [5], 0, order=[2, 0, 1], hint=np.array([256, 0, 128], dtype=np.int32))
+    assert log[0]["names"] == [2, 0, 1] and log[0]["hint"] == [256, 0, 128]
+    assert tot["wide"] == 1 and tot["narrow"] == 1
