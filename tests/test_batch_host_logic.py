@@ -217,3 +217,107 @@ def test_run_scheduled_first_launch_takes_the_callers_order_and_hints(monkeypatc
     tot = batch.run_scheduled(trees, [5], 0, order=[2, 0, 1], hint=np.array([256, 0, 128], dtype=np.int32))
     assert log[0]["names"] == [2, 0, 1] and log[0]["hint"] == [256, 0, 128]
     assert tot["wide"] == 1 and tot["narrow"] == 1
+
+
+# ------------------------------------------------------------------------------------------------
+# run_batch: launches of at most `window` iterations, per-tree budgets, cloud refreshes, failures
+# ------------------------------------------------------------------------------------------------
+class PlanTree(FakeTree):
+    device_id = 0
+
+
+class FakeGuidance:
+    def __init__(self):
+        self.calls = []
+        self.seconds = {"candidates": 0.0}
+
+    def refresh(self, due, problems, trees, streams, c_best, frames):
+        self.calls.append((list(due), [float(c_best[i]) for i in due]))
+        return {i: (np.zeros((0, 2)), np.zeros(0, dtype=np.int64)) for i in due}
+
+
+def _planner(log, script):
+    """script[name] = list of (iterations the tree really runs, status, best cost after them) per launch the tree takes part in"""
+    step = {}
+
+    def run_sampling(trees, iters, flags=0, want_trace=False, iters_each=None, **kw):
+        n = len(trees)
+        log.append({"names": [t.name for t in trees], "iters": iters, "each": list(iters_each), "flags": flags})
+        done = np.zeros(n, dtype=np.int64)
+        status = np.zeros(n, dtype=np.int32)
+        stats = np.zeros((n, _hip.N_STATS), dtype=np.int64)
+        trace = np.full((n, iters), np.inf)
+        for j, t in enumerate(trees):
+            k = step.get(t.name, 0)
+            step[t.name] = k + 1
+            want, st, cb = script[t.name][k]
+            d = min(want, int(iters_each[j]))
+            done[j], status[j] = d, st
+            trace[j, :d] = cb
+            stats[j, _hip.ST_ITERS] = d
+            stats[j, _hip.ST_T0] = 1000 * len(log)
+            stats[j, _hip.ST_T1] = 1000 * len(log) + 7
+            stats[j, _hip.ST_CBEST] = np.float64(cb).view(np.int64)
+            stats[j, 17] = np.float64(cb).view(np.int64)
+        return {"kernel_ms": 2.0, "iters_done": done, "cost_trace": trace, "stats": stats, "status": status}
+    return run_sampling
+
+
+def test_run_batch_windows_budgets_and_sums(dev, monkeypatch):
+    trees = [PlanTree(i) for i in range(3)]
+    streams = [batch.ProblemStreams(i) for i in range(3)]
+    log = []
+    big = 10 ** 9
+    script = {i: [(big, 0, 50.0 - i)] * 3 for i in range(3)}
+    monkeypatch.setattr(_hip, "run_sampling", _planner(log, script))
+    r = batch.run_batch(trees, streams, 2500, _hip.F_IRRT, 2, window=1000)
+    assert [l["iters"] for l in log] == [1000, 1000, 500]
+    assert [l["each"] for l in log] == [[1000] * 3, [1000] * 3, [500] * 3]
+    assert all(l["flags"] == _hip.F_IRRT for l in log)            # no guidance, no stop-at-first
+    assert r["launches"] == 3 and r["kernel_ms"] == pytest.approx(6.0)
+    assert list(r["iters_done"]) == [2500] * 3 and not r["failed"]
+    for i in range(3):
+        assert r["traces"][i].shape == (2500,) and np.all(r["traces"][i] == 50.0 - i)
+        assert r["stats"][i, _hip.ST_ITERS] == 2500
+        assert r["stats"][i, _hip.ST_T0] == 1000 and r["stats"][i, _hip.ST_T1] == 3007     # first start, last end
+        assert r["stats"][i, _hip.ST_CBEST] == np.float64(50.0 - i).view(np.int64)        # an absolute value, not a sum
+    # every problem's generators went to its tree once, in one call
+    assert dev.set_calls == [(3, True, True)]
+
+
+def test_run_batch_stop_first_retires_solved_trees(dev, monkeypatch):
+    trees = [PlanTree(i) for i in range(2)]
+    streams = [batch.ProblemStreams(i) for i in range(2)]
+    log = []
+    script = {0: [(300, 0, 42.0)], 1: [(10 ** 9, 0, np.inf), (120, 0, 77.0)]}
+    monkeypatch.setattr(_hip, "run_sampling", _planner(log, script))
+    r = batch.run_batch(trees, streams, 5000, _hip.F_IRRT, 2, stop_first=True, window=1000)
+    assert [l["names"] for l in log] == [[0, 1], [1]]
+    assert all(l["flags"] == (_hip.F_IRRT | _hip.F_STOP_FIRST) for l in log)
+    assert list(r["iters_done"]) == [300, 1120]
+    assert r["traces"][0][-1] == 42.0 and r["traces"][1][-1] == 77.0 and np.isinf(r["traces"][1][999])
+
+
+def test_run_batch_refreshes_due_clouds_and_reports_failures(dev, monkeypatch):
+    trees = [PlanTree(i) for i in range(4)]
+    streams = [batch.ProblemStreams(i) for i in range(4)]
+    log = []
+    big = 10 ** 9
+    script = {0: [(400, _hip.E_CLOUD, 90.0), (big, 0, 80.0), (big, 0, 80.0)],   # cloud due after 400 iterations, then runs to the end
+              1: [(big, 0, 70.0), (big, 0, 70.0)],
+              2: [(250, _hip.E_CAPACITY, np.inf)],
+              3: [(10, _hip.E_ARG, np.inf)]}
+    monkeypatch.setattr(_hip, "run_sampling", _planner(log, script))
+    g = FakeGuidance()
+    r = batch.run_batch(trees, streams, 1500, _hip.F_IRRT, 2, problems=[{}] * 4, guidance=g, frames=[None] * 4, window=65536)
+    # guided runs take short launches (a tree whose cloud is due idles until its launch ends)
+    assert log[0]["iters"] == 1024 and log[0]["flags"] == (_hip.F_IRRT | _hip.F_PNG)
+    # init_pc for everybody (c_best = inf), then tree 0 alone with the cost the kernel stopped at
+    assert g.calls[0] == ([0, 1, 2, 3], [np.inf] * 4)
+    assert g.calls[1] == ([0], [90.0])
+    assert len(g.calls) == 2
+    assert log[1]["names"] == [0, 1] and log[1]["each"] == [1024, 476]
+    assert log[2]["names"] == [0] and log[2]["each"] == [76]
+    assert list(r["iters_done"]) == [1500, 1500, 250, 10]
+    assert set(r["failed"]) == {2, 3} and "capacity" in r["failed"][2] and "randint" in r["failed"][3]
+    assert sorted(r["clouds"]) == [0, 1, 2, 3]
