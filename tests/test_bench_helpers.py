@@ -91,3 +91,27 @@ def test_traffic_entry_is_used_only_for_the_exact_configuration(tmp_path, monkey
     assert t == 5e13 and src["collected"] == "2026-09-28" and "FETCH_SIZE" in src["formula"]
     monkeypatch.setattr(sys, "argv", ["bench.py", "--trees", "2048", "--traffic-file", str(f)])
     assert b.measured_traffic(b.parse()) == (None, None)
+
+
+def test_strong_scaling_line_has_a_traffic_key_of_its_own(monkeypatch):
+    b = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--scaling", "strong", "--problems", "1000"])
+    a = b.parse()
+    assert b.config_key(a) == "irrt_2d_b30r16_set1000x50000"      # (not the default line's key: 1000 problems are another launch)
+
+
+def test_every_bench_line_has_its_traffic_entry_in_the_committed_profile(monkeypatch):
+    """the default line and every secondary line look their HBM traffic up in profiles/r04_traffic.json by configuration key:
+    a line added to bench.SECONDARY without its FETCH / WRITE passes would silently report traffic = null"""
+    b = _bench()
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(here, "profiles", "r04_traffic.json")) as fh:
+        entries = json.load(fh)["entries"]
+    lines = [("default", [])] + list(b.SECONDARY)
+    for label, extra in lines:
+        monkeypatch.setattr(sys, "argv", ["bench.py"] + list(extra))
+        a = b.parse()
+        key = b.config_key(a)
+        assert key in entries, (label, key)
+        t, src = b.measured_traffic(a)
+        assert t == entries[key]["traffic_bytes"] and t > 1e12, (label, key)
