@@ -20,8 +20,13 @@ DEPS = SOURCES + [os.path.join(CSRC, "nirrt_device.hpp"), os.path.join(CSRC, "ni
 # -fno-optimize-sibling-calls: keeps LLVM from marking the calls of the loop-body functions `tail`; only then does its
 # inter-procedural register allocation drop the callee-saved saves of those local functions (48 VGPRs = 12.8 KB of
 # scratch written and read back per wave and iteration otherwise - a quarter of the kernel's measured HBM writes).
+# -sink-insts-to-avoid-spills: the persistent loops call the loop's phases with nothing alive in registers (csrc/nirrt_kernels.inc,
+# run_tree_body) - except what machine LICM hoists out of the loop: LDS base addresses, zero constants.  Those were saved to
+# scratch and reloaded around every call (9 dwords per lane and iteration); with this flag they are re-materialised where they
+# are used and the loops of k_run_sample / k_run_pool have no scratch access at all.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fno-optimize-sibling-calls", "-mllvm", "-amdgpu-lower-module-lds-strategy=module"]
+         "-fno-optimize-sibling-calls", "-mllvm", "-amdgpu-lower-module-lds-strategy=module",
+         "-mllvm", "-sink-insts-to-avoid-spills=true"]
 
 
 # Test-only second build with tiny compile-time limits, so that the overflow paths of the loop body (parent chains longer

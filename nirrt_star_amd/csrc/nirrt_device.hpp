@@ -161,12 +161,29 @@ __device__ __forceinline__ double uni(double v)
     int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
+__device__ __forceinline__ long long uni(long long b)
+{
+    int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return ((long long)hi << 32) | (unsigned)lo;
+}
 template <class T>
 __device__ __forceinline__ T *uni(T *v)
 {
     long long b = (long long)v;
     int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
     return (T *)(((long long)hi << 32) | (unsigned)lo);
+}
+
+// Thread index inside the workgroup.  One-wave workgroups (the slim instantiation: most of the library's work) take it from the
+// lane counter - two VALU instructions wherever it is needed - instead of the work-item id register: a value every function of
+// the loop body needs would have to be kept alive (saved and reloaded) across each of the loop's calls, and with no function
+// asking for it the kernels do not even have to pass it down.
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+template <int NT>
+__device__ __forceinline__ int tidx()
+{
+    if (NT == 64) return lane_id();
+    return (int)threadIdx.x;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -328,6 +345,57 @@ struct TreeDev : TreeHotH {
 static_assert(sizeof(TreeHot) % 8 == 0 && sizeof(TreeHot) == sizeof(TreeHotH), "hot_enter / hot_leave copy 8-byte words");
 
 // ------------------------------------------------------------------------------------------------
+// launch arguments of the persistent sampling loops (k_run_sample / k_run_pool)
+// ------------------------------------------------------------------------------------------------
+struct RunSampleDev {
+    unsigned flags;
+    int pad;
+    long long iters;
+    const unsigned *const *np_words;   // nullptr: generator mode - the trees' own MT19937 streams (MtGen) produce the words
+    const long long *n_np;
+    const unsigned *const *py_words;
+    const long long *n_py;
+    long long *np_used;
+    long long *py_used;
+    double *cost_trace;
+    long long *iters_done;
+    int *stop_code;   // per tree: 0 done, NIRRT_E_STREAM, NIRRT_E_CAPACITY
+    const long long *iters_each;   // optional per-tree iteration budgets (<= iters)
+};
+
+// time-sliced launches (k_run_pool): the work queue of a launch group
+struct PoolDev {
+    int n_trees, pad;
+    long long quantum;     // iterations per slice
+    unsigned *ticket;      // next slice to hand out (ticket i = a slice of tree i mod n_trees)
+    int *state;            // per tree: bit 0 = being run, bits 1.. = tickets booked on it while it was being run
+    int *round;            // per tree: slices completed
+    int *fin;              // per tree: run ended early (nothing left for later slices)
+};
+
+// What one run of the sampling loop (run_tree: a whole launch, or one time slice of it) works from.  It lives in LDS: the loop
+// reads a field when it needs it instead of carrying launch arguments in registers across the calls of the loop body - the
+// time-sliced kernel of round 4 kept them in VGPRs that every iteration reloaded from scratch (~30 dwords per lane).
+// the loop's own state: one copy per wave (every wave computes the same values and reads back only what it wrote itself, so no
+// barrier is needed between a write and the reads that follow a call)
+struct RunLoop {
+    long long k, n_it;    // iteration of this slice / iterations this slice runs
+    long long t_begin;
+    double cb;            // best cost on the current tree
+    int have_q, spec, stop, ended;
+};
+struct RunCtx {
+    RunLoop loop[4];      // (LDS_NW_MAX waves)
+    RunSampleDev a;
+    TreeDev *tg;          // the tree's descriptor in HBM
+    int *fin;             // time-sliced launches: fin[b] = the tree's run has ended (nullptr: one launch per tree)
+    long long k0;         // first iteration of this slice
+    long long budget;     // iterations of this slice
+    int b;                // launch position of the tree (row of the per-tree outputs)
+    int sliced;
+};
+
+// ------------------------------------------------------------------------------------------------
 // LDS working set of one workgroup
 // ------------------------------------------------------------------------------------------------
 // Generator state of one tree between draws: stream positions and the 64-word windows (see WordStream in
@@ -387,8 +455,9 @@ struct LdsData {
         long long sp_pos[2];      // persistent loops, thread 0: generator positions before the early draw
         nirrt_step_result *res;
         unsigned flags;
-        int has_next, host_steer, ni, pref_ni, collided, new_idx, n, dup, inserted, dup_parent, dup_ns, dup_ps, dup_fc, k, reparented, n_rewired;
+        int has_next, host_steer, ni, pref_ni, next_ni, collided, new_idx, n, dup, inserted, dup_parent, dup_ns, dup_ps, dup_fc, k, reparented, n_rewired;
     } it;
+    RunCtx run;                   // persistent sampling loops: launch arguments + the slice to run (thread 0 fills it in)
     int n_cand;                   // rewire: members whose stashed margin reaches cost(new) (the stash is compacted to them)
     int cand_listed;              // ... all of them are in the LDS list (else: the spilled part is searched per round)
     long long stat[NSTAT];
@@ -744,7 +813,7 @@ __device__ __forceinline__ bool point_in_obs(const Lds<NT> &s, const double *p, 
 template <int D, int NT>
 __device__ __forceinline__ bool point_in_obs_wave(const Lds<NT> &s, const double *p, double clr)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = lane_id();
     bool hit = false;
     for (int i = lane; i < s.n_round; i += 64) hit = hit || point_in_round<D, NT>(s, i, p, clr);
     for (int i = lane; i < s.n_box; i += 64) hit = hit || point_in_box<D, NT>(s, i, p, clr);
@@ -786,7 +855,7 @@ __device__ __forceinline__ bool point_in_range_lds(const Lds<NT> &s, const doubl
 template <int NT>
 __device__ __forceinline__ void stage_obstacles(Lds<NT> &s, const TreeDev &t)
 {
-    int tid = threadIdx.x;
+    int tid = tidx<NT>();
     if (tid == 0) {
         s.n_round = t.n_round; s.n_box = t.n_box;
         s.stash_off = 4 * t.n_round + 6 * t.n_box;
@@ -810,8 +879,8 @@ __device__ __forceinline__ TreeHot &hot_enter(Lds<NT> &s, TreeDev *tg)
 {
     const long long *src = reinterpret_cast<const long long *>(static_cast<const TreeHotH *>(tg));
     long long *dst = reinterpret_cast<long long *>(&s.hot);
-    for (int i = threadIdx.x; i < (int)(sizeof(TreeHot) / 8); i += NT) dst[i] = src[i];
-    if (threadIdx.x == 0) s.tree_g = tg;
+    for (int i = tidx<NT>(); i < (int)(sizeof(TreeHot) / 8); i += NT) dst[i] = src[i];
+    if (tidx<NT>() == 0) s.tree_g = tg;
     stage_obstacles<NT>(s, *tg);   // ends with a barrier
     return s.hot;
 }
@@ -824,8 +893,8 @@ __device__ __forceinline__ void hot_leave(Lds<NT> &s)
     TreeDev *tg = s.tree_g;
     const long long *src = reinterpret_cast<const long long *>(&s.hot);
     long long *dst = reinterpret_cast<long long *>(static_cast<TreeHotH *>(tg));
-    for (int i = threadIdx.x; i < (int)(sizeof(TreeHot) / 8); i += NT) dst[i] = src[i];
-    if (threadIdx.x == 0)
+    for (int i = tidx<NT>(); i < (int)(sizeof(TreeHot) / 8); i += NT) dst[i] = src[i];
+    if (tidx<NT>() == 0)
         for (int i = 0; i < NSTAT; i++)
             if (i != ST_T0 && i != ST_T1) tg->stat[i] += s.stat[i];
 }
@@ -897,7 +966,7 @@ template <int NT>
 __device__ __forceinline__ void block_argmin(Lds<NT> &s, double &v, int &idx)
 {
     wave_argmin(v, idx);
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int lane = lane_id(), w = tidx<NT>() >> 6;
     __syncthreads();  // protect red_* reuse
     if (lane == 0) { s.red_val[w] = v; s.red_idx[w] = idx; }
     __syncthreads();
@@ -916,7 +985,7 @@ template <int NT>
 __device__ __forceinline__ int block_min_int(Lds<NT> &s, int v)
 {
     v = wave_min(v);
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int lane = lane_id(), w = tidx<NT>() >> 6;
     __syncthreads();
     if (lane == 0) s.red_idx[w] = v;
     __syncthreads();
@@ -930,14 +999,18 @@ __device__ __forceinline__ int block_min_int(Lds<NT> &s, int v)
 // kernel arguments and the workgroup ids in saved scalar registers; a hand-written ballot + LDS version drops those and measures
 // 2.4 % SLOWER on the default bench - 51.0 vs 52.2 M it/s, same box, twice - so the library's version stays)
 template <int NT>
-__device__ __forceinline__ bool block_any(bool p) { return __syncthreads_or(p ? 1 : 0) != 0; }
+__device__ __forceinline__ bool block_any(bool p)
+{
+    if (NT == 64) return __ballot(p) != 0ull;   // one wave: no LDS, no barrier, and no implicit kernel arguments on the call path
+    return __syncthreads_or(p ? 1 : 0) != 0;
+}
 
 // ordered compaction: threads with keep get their output slot (ascending thread order); returns total
 template <int NT>
 __device__ __forceinline__ int block_compact(Lds<NT> &s, bool keep, int &pos)
 {
     unsigned long long m = __ballot(keep);
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int lane = lane_id(), w = tidx<NT>() >> 6;
     int pre = __popcll(m & ((1ull << lane) - 1ull));
     __syncthreads();
     if (lane == 0) s.wave_tot[w] = __popcll(m);
@@ -1027,7 +1100,7 @@ NIRRT_FN __device__ int wg_nearest_exact(int n, double q0, double q1, double q2)
     const TreeHot &t = g_lds.hot;
     double bd = __builtin_inf();
     int bi = 0x7fffffff;
-    for (int sl = threadIdx.x; sl < n; sl += NT) {
+    for (int sl = tidx<NT>(); sl < n; sl += NT) {
         double gx, gy, gz, gc;
         int id;
         slot_load<D>(t, sl, gx, gy, gz, gc, id);
@@ -1046,7 +1119,7 @@ template <int D, int NT>
 __device__ __forceinline__ int wg_nearest_finish(Lds<NT> &s, double m1, int i1, double m2, double *g1_out)
 {
     constexpr int NW = NT / 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = lane_id(), w = tidx<NT>() >> 6;
     double wm = m1;
     int wi = i1;
     wave_argmin(wm, wi);
@@ -1114,7 +1187,7 @@ __device__ __forceinline__ int grid_rows(const int (&c0)[3], const int (&c1)[3])
 template <int NT>
 __device__ __forceinline__ int block_excl_scan(Lds<NT> &s, int v, int &off)
 {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = lane_id(), w = tidx<NT>() >> 6;
     int inc = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1141,7 +1214,7 @@ NIRRT_FN __device__ void wg_grid_rebuild(int n)
 {
     Lds<NT> &s = g_lds;
     TreeHot &t = g_lds.hot;
-    const int tid = threadIdx.x, nc = t.g_ncell, G = t.g_G;
+    const int tid = tidx<NT>(), nc = t.g_ncell, G = t.g_G;
     for (int c = tid; c < nc; c += NT) t.g_cnt[c] = 0;
     __syncthreads();
     auto cell_of = [&](const VRec &v) -> int {
@@ -1213,7 +1286,7 @@ NIRRT_FN __device__ void wg_grid_rebuild2(int n)
 {
     Lds<NT> &s = g_lds;
     TreeHot &t = g_lds.hot;
-    const int tid = threadIdx.x, nc = t.g_ncell2, G = t.g_G2, v0 = t.g_ns, m = n - v0;
+    const int tid = tidx<NT>(), nc = t.g_ncell2, G = t.g_G2, v0 = t.g_ns, m = n - v0;
     for (int c = tid; c < nc; c += NT) t.g_cnt[c] = 0;
     __syncthreads();
     auto cell_of = [&](const VRec &v) -> int {
@@ -1324,7 +1397,7 @@ NIRRT_FN __device__ void wg_query_fn()
 {
     Lds<NT> &s = g_lds;
     const TreeHot &t = g_lds.hot;
-    const int tid = threadIdx.x, lane = tid & 63, G = t.g_G;
+    const int tid = tidx<NT>(), lane = tid & 63, G = t.g_G;
     const unsigned long long lt = (1ull << lane) - 1ull;
     __syncthreads();   // s.qa is in place
     if (tid == 0) { s.ob_n = 0; s.hit_cnt = 0; s.mem_cnt = 0; }
@@ -1686,7 +1759,7 @@ __device__ __forceinline__ void wg_query(Lds<NT> &s, const TreeHot &t, int n, co
                                          const double *q, int *ni, NearResult *nr, int lds_cap,
                                          double floor_m = -__builtin_inf(), bool lazy = false)
 {
-    if (threadIdx.x == 0) {   // the arguments are the same in every thread
+    if (tidx<NT>() == 0) {   // the arguments are the same in every thread
         s.qa.n = n; s.qa.want = (pn ? 1 : 0) | (q ? 2 : 0); s.qa.lazy = lazy ? 1 : 0;
         s.qa.r = r; s.qa.floor_m = floor_m; s.qa.new_idx = new_idx; s.qa.lds_cap = lds_cap;
 #pragma unroll
@@ -1814,7 +1887,7 @@ NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int 
     const int n_src = uni(n_src_in), walk_from = uni(walk_from_in), through = uni(through_in), n_list = uni(n_list_in);
     const int front_off = uni(front_off_in);
     int *fr = front_off >= 0 ? reinterpret_cast<int *>(cand_state(s) + front_off) : nullptr;
-    const int tid = threadIdx.x;
+    const int tid = tidx<NT>();
     const int ns = uni(t.g_ns2);   // vertices below it have their slot in pos[]
 #ifdef NIRRT_PROFILE
     long long rq0_ = wall_clock64();
@@ -1918,7 +1991,7 @@ template <int D, int NT>
 __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v, int through, int n_list = 0)
 {
     __syncthreads();
-    if (threadIdx.x == 0) { t.bfs_q[0] = v; t.g_rank[0] = v; t.bfs_fc[0] = -2; s.bc_i[4] = 1; }
+    if (tidx<NT>() == 0) { t.bfs_q[0] = v; t.g_rank[0] = v; t.bfs_fc[0] = -2; s.bc_i[4] = 1; }
     __syncthreads();
     wg_recost_queue<D, NT>(s, t, 1, 0, through, n_list);
 }
@@ -1928,7 +2001,7 @@ __device__ __forceinline__ void wg_recost_subtree(Lds<NT> &s, TreeHot &t, int v,
 template <int D, int NT>
 __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeHot &t, int new_idx)
 {
-    if (threadIdx.x == 0) {
+    if (tidx<NT>() == 0) {
         double acc = 0.;
         int i = new_idx, len = 0, guard = t.cap + 1, nrec = 0;
         Hop4 h = s.hop_new;
@@ -1988,7 +2061,7 @@ NIRRT_FN __device__ bool wg_collision_fn(double ax, double ay, double az, double
     const double clr = s.k_clr;
     int M = s.n_round + s.n_box;
     bool hit = false;
-    for (int o = threadIdx.x; o < M; o += NT) hit = hit || seg_obstacle<D, NT>(s, o, a, b, clr);
+    for (int o = tidx<NT>(); o < M; o += NT) hit = hit || seg_obstacle<D, NT>(s, o, a, b, clr);
     return block_any<NT>(hit);
 }
 template <int D, int NT>
@@ -2014,7 +2087,7 @@ __device__ __forceinline__ int wg_near_list(Lds<NT> &s, TreeHot &t, int n, const
 template <int D, int NT>
 __device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeHot &t, double &c_best, int &x_best, bool want_x = true)
 {
-    const int tid = threadIdx.x;
+    const int tid = tidx<NT>();
     const int ns = t.n_sol;
     if (ns == 0) { c_best = __builtin_inf(); x_best = -1; return; }
     if (t.sol_dirty) {   // uniform
@@ -2050,7 +2123,7 @@ __device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeHot &t, double 
 template <int D, int NT>
 __device__ __forceinline__ void wg_append_solution(Lds<NT> &s, TreeHot &t, int idx, const double *v)
 {
-    if (threadIdx.x == 0) {
+    if (tidx<NT>() == 0) {
         if (t.n_sol < t.cap_sol) {
             int q = t.n_sol;
             double d[D];
@@ -2076,7 +2149,7 @@ __device__ __forceinline__ void wg_append_solution(Lds<NT> &s, TreeHot &t, int i
 template <int D, int NT>
 __device__ __forceinline__ void wg_goal_parent(Lds<NT> &s, TreeHot &t, int &gp, double &path_len)
 {
-    const int tid = threadIdx.x;
+    const int tid = tidx<NT>();
     const int ng = t.n_gc;
     if (ng == 0) { gp = -1; path_len = __builtin_inf(); return; }
     if (t.gc_dirty) {
@@ -2139,7 +2212,7 @@ __device__ __forceinline__ void wg_goal_candidate(Lds<NT> &s, TreeHot &t, int id
     double h = dist_scan<D>(d);
     if (h <= t.step_len) {  // uniform
         bool col = wg_collision<D, NT>(s, v, t.goal, t.clearance);
-        if (threadIdx.x == 0) {
+        if (tidx<NT>() == 0) {
             int q = t.n_gc;
             t.gc_idx[q] = idx;
             t.gc_dist[q] = h;
@@ -2171,7 +2244,7 @@ NIRRT_FN __device__ void it_extend()
     // left in s.bc_i[6] (else -1) for the caller to pass back as pref_ni.
     Lds<NT> &s = g_lds;
     TreeHot &t = g_lds.hot;
-    const int tid = threadIdx.x;
+    const int tid = tidx<NT>();
     const double clr = t.clearance;
     int n = uni(t.n);
     const bool host_steer = uni(s.it.host_steer) != 0;
@@ -2281,7 +2354,7 @@ NIRRT_FN __device__ void it_connect()
 {
     Lds<NT> &s = g_lds;
     TreeHot &t = g_lds.hot;
-    const int tid = threadIdx.x;
+    const int tid = tidx<NT>();
     const int new_idx = uni(s.it.new_idx), ni = uni(s.it.ni);
     const bool dup = uni(s.it.dup) != 0;
     const double edge_new = uni(s.it.edge_new);
@@ -2786,7 +2859,7 @@ NIRRT_FN __device__ void it_book()
 {
     Lds<NT> &s = g_lds;
     TreeHot &t = g_lds.hot;
-    const int tid = threadIdx.x;
+    const int tid = tidx<NT>();
     const int new_idx = uni(s.it.new_idx);
     const bool inserted = uni(s.it.inserted) != 0;
     const unsigned flags = (unsigned)uni((int)s.it.flags);
@@ -2832,7 +2905,7 @@ NIRRT_FN __device__ void it_book()
 template <int D, int NT>
 __device__ __forceinline__ void wg_iteration_body(Lds<NT> &s, TreeHot &t)
 {
-    const int tid = threadIdx.x;
+    const int tid = tidx<NT>();
     __syncthreads();
     it_extend<D, NT>();
     nirrt_step_result *res = uni(s.it.res);
@@ -2872,11 +2945,60 @@ __device__ __forceinline__ void wg_iteration_body(Lds<NT> &s, TreeHot &t)
     __syncthreads();
 }
 
+// The same iteration for the persistent sampling loops (no result record; the Near set's collision filter deferred), written so
+// that NO value stays in a register across a phase call: a phase clobbers every register - that is what lets it run without
+// saving any - so whatever the caller keeps across the call is stored to scratch before and reloaded after it, per lane and per
+// iteration.  Everything a segment between two calls needs is (re)read from LDS.  Leaves the next sample's nearest vertex in
+// s.it.pref_ni (-1: no query ran).
+template <int D, int NT>
+__device__ __forceinline__ void wg_iteration_flat()
+{
+    Lds<NT> &s = g_lds;
+    __syncthreads();
+    it_extend<D, NT>();
+    if (!uni(s.it.collided) && uni(s.it.new_idx) >= 0) {
+        {
+            // floor of the Near stash: see wg_iteration_body
+            const TreeHot &t = g_lds.hot;
+            double node_new[D], d_root[D];
+#pragma unroll
+            for (int kk = 0; kk < D; kk++) { node_new[kk] = uni(s.it.node_new[kk]); d_root[kk] = node_new[kk] - t.start[kk]; }
+            const double lb_new = __builtin_sqrt(dist2<D>(d_root));
+            const double floor_m = lb_new - (1e-9 + 1e-11 * lb_new);
+            if (tidx<NT>() == 0) {
+                const int n = s.it.n;
+                const bool has_next = s.it.has_next != 0;
+                s.qa.n = n; s.qa.want = 1 | (has_next ? 2 : 0); s.qa.lazy = 1;
+                s.qa.r = s.it.r_query; s.qa.floor_m = floor_m; s.qa.new_idx = s.it.new_idx; s.qa.lds_cap = s.stash_cap;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { s.qa.pn[k] = k < D ? node_new[k] : 0.; s.qa.q[k] = (has_next && k < D) ? s.it.q_next[k] : 0.; }
+                s.it.alg += n;
+            }
+        }
+        wg_query_fn<D, NT>();   // barriers at both ends
+        if (tidx<NT>() == 0) s.it.next_ni = s.qa.ni;
+        it_connect<D, NT>();
+        {
+            // goal bookkeeping only concerns vertices within step_len of the goal (wg_goal_candidate / InGoalRegion test the same
+            // distance again, with the reference's formulas)
+            const TreeHot &t = g_lds.hot;
+            double d_goal[D];
+#pragma unroll
+            for (int kk = 0; kk < D; kk++) d_goal[kk] = t.goal[kk] - uni(s.it.node_new[kk]);
+            if (dist2<D>(d_goal) <= t.step_len * t.step_len * BAND_HI) it_book<D, NT>();
+        }
+    } else if (tidx<NT>() == 0) {
+        s.it.next_ni = -1;
+    }
+    if (tidx<NT>() == 0) { s.stat[ST_ITERS] += 1; s.stat[ST_ALG] += s.it.alg; s.bc_i[6] = s.it.next_ni; s.it.pref_ni = s.it.next_ni; }
+    __syncthreads();
+}
+
 template <int D, int NT>
 __device__ __forceinline__ void wg_iteration(Lds<NT> &s, TreeHot &t, const double *node_in, bool host_steer,
                                              int nearest_in, unsigned flags, nirrt_step_result *res)
 {
-    if (threadIdx.x == 0) {
+    if (tidx<NT>() == 0) {
 #pragma unroll
         for (int k = 0; k < 3; k++) s.it.node_in[k] = k < D ? node_in[k] : 0.;
         s.it.host_steer = host_steer ? 1 : 0; s.it.ni = nearest_in; s.it.pref_ni = -1; s.it.flags = flags; s.it.res = res;

@@ -31,7 +31,7 @@ struct RunDev {
 // order, the neighbours come through ds_bpermute / v_readlane, nothing goes through memory until the block is complete.
 static __device__ __noinline__ void mt_next_block(const GAS unsigned *old_k, GAS unsigned *new_k)
 {
-    const int l = threadIdx.x & 63;
+    const int l = lane_id();
     unsigned o[10], nw[10];
 #pragma unroll
     for (int r = 0; r < 10; r++) o[r] = (64 * r + l) < MT_N ? old_k[64 * r + l] : 0u;
@@ -89,7 +89,7 @@ struct WordStream {
     __device__ __forceinline__ void refill()   // (inline: an out-of-line member would force the stream's state out of registers)
     {
         base = pos;
-        const int lane = threadIdx.x & 63;
+        const int lane = lane_id();
         if (!genmode) {
             const long long i = base + (long long)lane;
             wn = 64;
@@ -126,31 +126,7 @@ struct WordStream {
     __device__ __forceinline__ long long undo_limit() const { return ((pos > 0 ? (pos - 1) / MT_N : 0) + 2) * MT_N; }
 };
 
-struct RunSampleDev {
-    unsigned flags;
-    int pad;
-    long long iters;
-    const unsigned *const *np_words;   // nullptr: generator mode - the trees' own MT19937 streams (MtGen) produce the words
-    const long long *n_np;
-    const unsigned *const *py_words;
-    const long long *n_py;
-    long long *np_used;
-    long long *py_used;
-    double *cost_trace;
-    long long *iters_done;
-    int *stop_code;   // per tree: 0 done, NIRRT_E_STREAM, NIRRT_E_CAPACITY
-    const long long *iters_each;   // optional per-tree iteration budgets (<= iters)
-};
-
-// time-sliced launches (k_run_pool): the work queue of a launch group
-struct PoolDev {
-    int n_trees, pad;
-    long long quantum;     // iterations per slice
-    unsigned *ticket;      // next slice to hand out (ticket i = a slice of tree i mod n_trees)
-    int *state;            // per tree: bit 0 = being run, bits 1.. = tickets booked on it while it was being run
-    int *round;            // per tree: slices completed
-    int *fin;              // per tree: run ended early (nothing left for later slices)
-};
+// (RunSampleDev / PoolDev: nirrt_device.hpp - the run loop keeps its launch arguments in LDS)
 
 // Three instantiations of every kernel; nirrt_run picks by batch size so that the CU's 16 wave slots are busy:
 //   slim   64 threads (one wave per tree, 12 trees per CU = every wave slot at 168 VGPRs): batches of more than 2048 trees;
@@ -193,7 +169,8 @@ namespace slim {
 static_assert(NT_WIDE / 64 <= LDS_NW_MAX && NT_NARROW / 64 <= LDS_NW_MAX, "LdsData reduction slots: raise LDS_NW_MAX");
 static_assert(offsetof(TreeHotH, pc) > offsetof(TreeHotH, CL_C) && offsetof(TreeHotH, g_rec) > offsetof(TreeHotH, c_update),
               "nirrt_set_informed / nirrt_set_cloud patch contiguous field ranges of the descriptor");
-static_assert(sizeof(LdsData) <= 10240, "LdsData must fit 16 times into a CU's 160 KB of LDS (up to 16 one-wave trees per CU)");
+// 12 one-wave trees per CU (3 waves per SIMD at 168 VGPRs): 160 KB / 12 in allocation granules of 1280 bytes = 12800 bytes each
+static_assert(sizeof(LdsData) <= 12800, "LdsData must fit 12 times into a CU's 160 KB of LDS (12 one-wave trees per CU)");
 // nirrt_run: batches larger than the 2048 workgroup slots of the 128-thread kernels run one wave per tree (16 trees per
 // CU with 10 KB of LDS): measured on 4096 problems 12.8 vs 10.9 M it/s (IRRT*), 39.0 vs 26.3 M it/s (RRT*); at 2048
 // problems the 128-thread kernels win (IRRT* 10.9 vs 8.6) or tie (RRT*).  NIRRT_SLIM_MIN_TREES overrides the threshold.
