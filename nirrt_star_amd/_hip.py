@@ -215,6 +215,13 @@ class HipTree:
 
     def close(self):
         if getattr(self, "h", None):
+            # whoever parked generator states in this tree (batch.ProblemStreams) takes them back before the tree goes
+            for hook in list(getattr(self, "_release_hooks", ())):
+                try:
+                    hook()
+                except Exception:
+                    pass
+            self._release_hooks = []
             self.L.nirrt_destroy(self.h)
             self.h = None
 

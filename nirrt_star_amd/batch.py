@@ -48,8 +48,34 @@ class ProblemStreams:
         return self._tree is tree
 
     def bind(self, tree):
-        """(run_batch) the tree takes over; the caller uploads np_state() / py_state() in one batched call"""
+        """(run_batch) the tree takes over; the caller uploads np_state() / py_state() in one batched call.  What a previous
+        owner has drawn is fetched first: a stream that moves from tree A to tree B continues, it does not replay"""
+        if self._tree is not None and self._tree is not tree:
+            self.release()
+        if self._tree is not tree:
+            hooks = getattr(tree, "_release_hooks", None)      # (HipTree.close: the states come home before the tree is destroyed)
+            if hooks is None:
+                hooks = []
+                try:
+                    tree._release_hooks = hooks
+                except AttributeError:
+                    hooks = None
+            if hooks is not None:
+                hooks.append(self.release)
         self._tree = tree
+        self._behind = [False, False]
+        self._touched = [False, False]
+
+    def release(self):
+        """the host objects become current and own the states again (the end of a run: the tree may be closed afterwards)"""
+        if self._tree is not None:
+            if getattr(self._tree, "h", True):          # (a closed tree has nothing left to fetch)
+                self._pull(0)
+                self._pull(1)
+            hooks = getattr(self._tree, "_release_hooks", None)
+            if hooks and self.release in hooks:
+                hooks.remove(self.release)
+            self._tree = None
         self._behind = [False, False]
         self._touched = [False, False]
 
@@ -199,7 +225,8 @@ class Guidance:
     """NIRRT* / NRRT* point-cloud guidance of a batch: policy scalars + the (batched) cloud refresh"""
 
     def __init__(self, wrapper, dim, step_len, pc_n_points=2048, pc_over_sample_scale=5, pc_sample_rate=0.5,
-                 pc_update_cost_ratio=0.9, connect=False, connect_max_trial_attempts=5, informed=True, device_id=0):
+                 pc_update_cost_ratio=0.9, connect=False, connect_max_trial_attempts=5, informed=True, device_id=0,
+                 host_ellipsoid_3d=None):
         self.wrapper = wrapper
         self.dim = dim
         self.radius = step_len              # pc_neighbor_radius = step_len (nirrt_star_png_2d.py:41)
@@ -212,6 +239,10 @@ class Guidance:
         self.device_id = device_id
         self.device_clouds = os.environ.get("NIRRT_HOST_CLOUDS", "0") != "1"   # clouds generated on the device (0: the host path of round 2)
         self.device_input = os.environ.get("NIRRT_HOST_INPUT", "0") != "1"     # network input blocks assembled on the device
+        # parity runs: the 3D ellipsoid candidates (mode 3 of nirrt_guidance_clouds) go through the device's sin / cos and equal the
+        # host's only to a few ulp - a candidate ON an obstacle / range boundary can flip.  NIRRT_HOST_ELLIPSOID3D=1 (or
+        # `host_ellipsoid_3d=True`) draws exactly those clouds with numpy / glibc on the host (bit-reproducible, slower).
+        self.host_ellipsoid_3d = host_ellipsoid_3d if host_ellipsoid_3d is not None else os.environ.get("NIRRT_HOST_ELLIPSOID3D", "0") == "1"
         self.calls = 0                      # PointNet++ forwards (batched ones count once)
         self.clouds_classified = 0
         self.seconds = {"candidates": 0.0, "downsample": 0.0, "classify": 0.0, "set_cloud": 0.0}   # host wall time per refresh stage
@@ -323,7 +354,8 @@ class Guidance:
         t0 = time.perf_counter()
         dev = torch.device("cuda", self.device_id)
         nd = len(due)
-        on_dev = [j for j, i in enumerate(due) if self.device_clouds]
+        on_dev = [j for j, i in enumerate(due)
+                  if self.device_clouds and not (self.host_ellipsoid_3d and self.dim == 3 and c_best[i] < np.inf)]
         on_dev_set = set(on_dev)
         on_host = [j for j in range(nd) if j not in on_dev_set]
         clouds_dev = torch.zeros((nd, self.n_points, 3), dtype=torch.float64, device=dev)

@@ -1307,21 +1307,27 @@ static void report_stats(const nirrt_run_args *a, int i, const long long *after,
 // launches that land on the same queue run one after the other (measured: the 64-lane group started the moment the 256-lane
 // group ended).  Three streams per device, created back to back (consecutive streams get consecutive hardware queues), the
 // first with the highest priority - it carries the widest, longest-running trees.
+// One set per calling THREAD and device: concurrent nirrt_run calls from worker threads (run_batch with NIRRT_BATCH_GROUPS /
+// NIRRT_BATCH_INFLIGHT > 1) must not share streams - their launches would serialize and each call's event timing would contain
+// the other call's kernels.  (The few streams of a worker thread that ends are not destroyed: HIP may already be shutting down.)
 static hipStream_t *group_streams(int device)
 {
-    static std::mutex mu;
-    static hipStream_t st[16][3];
-    static bool made[16] = {false};
-    std::lock_guard<std::mutex> g(mu);
-    const int d = device & 15;
-    if (!made[d]) {
+    struct Set { hipStream_t st[3]; };
+    thread_local std::map<int, Set> sets;
+    auto it = sets.find(device);
+    if (it == sets.end()) {
+        Set s;
         int lo = 0, hi = 0;   // (numerically lower = higher priority)
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
         for (int i = 0; i < 3; i++)
-            if (hipStreamCreateWithPriority(&st[d][i], hipStreamNonBlocking, i == 0 ? hi : lo) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        made[d] = true;
+            if (hipStreamCreateWithPriority(&s.st[i], hipStreamNonBlocking, i == 0 ? hi : lo) != hipSuccess) {
+                (void)hipGetLastError();
+                for (int j = 0; j < i; j++) (void)hipStreamDestroy(s.st[j]);
+                return nullptr;
+            }
+        it = sets.emplace(device, s).first;
     }
-    return st[d];
+    return it->second.st;
 }
 
 // workgroups of the time-sliced loop that are resident at once (occupancy of the kernel x compute units)
@@ -1448,6 +1454,11 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
     HIPCHK_R(dalloc(sizeof(long long) * nt, (void **)&d_done));
     HIPCHK_R(dalloc(sizeof(int) * nt, (void **)&d_stop));
     if (a->cost_trace) HIPCHK_R(dalloc(sizeof(double) * nt * (size_t)a->iters, (void **)&d_trace));
+    // (a tree whose budget is 0 is never run by the time-sliced kernel: its outputs are zeros, not what the scratch pool held)
+    HIPCHK_R(hipMemsetAsync(d_npu, 0, sizeof(long long) * nt, st));
+    HIPCHK_R(hipMemsetAsync(d_pyu, 0, sizeof(long long) * nt, st));
+    HIPCHK_R(hipMemsetAsync(d_done, 0, sizeof(long long) * nt, st));
+    HIPCHK_R(hipMemsetAsync(d_stop, 0, sizeof(int) * nt, st));
     HIPCHK_R(hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(void *) * nt, hipMemcpyHostToDevice, st));
     HIPCHK_R(hipMemcpyAsync(d_npp, npp.data(), sizeof(void *) * nt, hipMemcpyHostToDevice, st));
     HIPCHK_R(hipMemcpyAsync(d_pyp, pyp.data(), sizeof(void *) * nt, hipMemcpyHostToDevice, st));

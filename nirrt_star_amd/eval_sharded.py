@@ -251,7 +251,7 @@ def main():
     ap.add_argument("--pc_sample_rate", type=float, default=0.5)
     ap.add_argument("--pc_update_cost_ratio", type=float, default=0.9)
     ap.add_argument("--connect_max_trial_attempts", type=int, default=5)
-    ap.add_argument("--iter_max", type=int, default=50000)
+    ap.add_argument("--iter_max", type=int, default=None, help="default: 50000 (eval_planning_2d.py:19), 30000 for random_3d (eval_planning_3d.py:19)")
     ap.add_argument("--iter_after_initial", type=int, default=3000)
     ap.add_argument("--step_len", type=float, default=10)
     ap.add_argument("--clearance", type=float, default=None)
@@ -264,6 +264,8 @@ def main():
     args = ap.parse_args()
     if args.clearance is None:
         args.clearance = 2 if args.problem == "random_3d" else 3
+    if args.iter_max is None:      # the reference has one script per dimension, each with its own default
+        args.iter_max = 30000 if args.problem == "random_3d" else 50000
     if args.connect == "bfs" and not args.planner.endswith("_c"):
         args.planner += "_c"
     if args.planner.startswith("n") and args.neural_net == "none":

@@ -31,7 +31,8 @@ def arg_parse():
     p.add_argument('--pc_n_points', type=int, default=2048)
     p.add_argument('--pc_over_sample_scale', type=int, default=5)
     p.add_argument('--pc_sample_rate', type=float, default=0.5)
-    p.add_argument('--pc_update_cost_ratio', type=float, default=0.9)
+    p.add_argument('--pc_update_cost_ratio', type=float, default=None,
+                   help='default: 0.9 for random_2d (demo_planning_2d.py:21), 1.0 for random_3d (demo_planning_3d.py:21)')
     p.add_argument('--connect_max_trial_attempts', type=int, default=5)
     p.add_argument('--problem', default='random_2d', help='random_2d, random_3d')
     p.add_argument('--seed', type=int, default=None)
@@ -43,6 +44,8 @@ def arg_parse():
 def main():
     args = arg_parse()
     dim = "2d" if args.problem == "random_2d" else "3d"
+    if args.pc_update_cost_ratio is None:      # the reference's two demo scripts differ here
+        args.pc_update_cost_ratio = 0.9 if dim == "2d" else 1.0
     name = args.path_planner
     if args.neural_net != 'none':
         assert name in ('nirrt_star', 'nrrt_star')

@@ -282,9 +282,11 @@ def run_planner(name, algo, dim, world_kind, world_seed, pair, iters, seed, trac
     print("   %s: n=%d path_len=%.6f  (%.1fs)" % (name, n, float(arrays["path_len"]), time.time() - t0))
 
 
-def nirrt_fixture(name, dim, connect, world_seed, iters, seed, random_after=None):
+def nirrt_fixture(name, dim, connect, world_seed, iters, seed, random_after=None, ratio=0.9):
     """L3: reference NIRRT*-PNG[(C)] whole run with a deterministic fake wrapper (tests/conftest.py FakePNG)
-    and OUR farthest-point restatement behind the open3d stub: pins update rule + sampling mix + RNG use."""
+    and OUR farthest-point restatement behind the open3d stub: pins update rule + sampling mix + RNG use.
+    ratio = pc_update_cost_ratio: 0.9 is the planner classes' default, 1.0 the default of demo_planning_3d.py:21
+    (a refresh on EVERY improvement of the best cost)."""
     sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
     from conftest import FakePNG
     if dim == 2:
@@ -297,7 +299,7 @@ def nirrt_fixture(name, dim, connect, world_seed, iters, seed, random_after=None
     pr, clearance = make_problem(dim, "b30", world_seed, 0)
     w = FakePNG(pr["x_start"], pr["x_goal"], 25.0 if dim == 2 else 8.0)
     common = [pr["x_start"], pr["x_goal"], STEP_LEN, pr["search_radius"], iters, pr["env_dict"], w]
-    tail = [clearance, 2048, 5, 0.5, 0.9]
+    tail = [clearance, 2048, 5, 0.5, ratio]
     if dim == 2:
         common.append(pr["binary_mask"])
     planner = (PC(*common, *tail, 5) if connect else P(*common, *tail))
@@ -322,7 +324,7 @@ def nirrt_fixture(name, dim, connect, world_seed, iters, seed, random_after=None
     path = np.array(planner.path, dtype=np.float64).reshape(-1, dim) if len(planner.path) else np.zeros((0, dim))
     save(name, env=env_json(pr["env_dict"]), dim=np.array(dim), algo=np.array("nirrt_c" if connect else "nirrt"),
          path_len_list=lst, iter_after_initial=np.array(-1 if random_after is None else random_after),
-         seed=np.array(seed), iter_max=np.array(iters), step_len=np.array(float(STEP_LEN)), clearance=np.array(float(clearance)),
+         pc_update_cost_ratio=np.array(float(ratio)), seed=np.array(seed), iter_max=np.array(iters), step_len=np.array(float(STEP_LEN)), clearance=np.array(float(clearance)),
          search_radius=np.array(float(pr["search_radius"])), x_start=np.array(pr["x_start"], dtype=np.float64),
          x_goal=np.array(pr["x_goal"], dtype=np.float64), n=np.array(n), vertices=planner.vertices[:n].copy(),
          parents=planner.vertex_parents[:n].astype(np.int64), path=path, path_len=np.array(float(planner.get_path_len(planner.path))),
@@ -854,6 +856,10 @@ JOBS = {
     "run_nirrt2d_1500": lambda: nirrt_fixture("run_nirrt2d_1500", 2, False, 9, 1500, 1009),
     "run_nirrtc2d_1500": lambda: nirrt_fixture("run_nirrtc2d_1500", 2, True, 10, 1500, 1010),
     "run_nirrt3d_1500": lambda: nirrt_fixture("run_nirrt3d_1500", 3, False, 4, 1500, 1004),
+    # pc_update_cost_ratio = 1.0, the default of the reference's 3D demo (demo_planning_3d.py:21): a cloud refresh on every
+    # improvement of the best cost (2D twin for the 2D code path)
+    "run_nirrt3d_ratio1_1500": lambda: nirrt_fixture("run_nirrt3d_ratio1_1500", 3, False, 6, 1500, 1026, ratio=1.0),
+    "run_nirrt2d_ratio1_1500": lambda: nirrt_fixture("run_nirrt2d_ratio1_1500", 2, False, 12, 1500, 1027, ratio=1.0),
     "run_nrrt2d_1500": lambda: nrrt_fixture("run_nrrt2d_1500", 2, 12, 1500, 1012),
     "run_nrrt3d_1500": lambda: nrrt_fixture("run_nrrt3d_1500", 3, 6, 1500, 1006),
     "random_irrt3d": lambda: run_planner("random_irrt3d", "irrt", 3, "ref3d", 3, 0, 5000, 1003, mode="random", iter_after_initial=300),

@@ -108,6 +108,41 @@ def test_host_draws_continue_where_the_device_stopped_and_go_back(dev):
     assert s.py.random() == twin_py.random()
 
 
+def test_a_stream_that_moves_to_another_tree_continues_where_the_first_tree_stopped(dev):
+    """bind() to a different tree first fetches what the previous owner drew - the problem must not replay outputs"""
+    a, b, s = FakeTree("a"), FakeTree("b"), batch.ProblemStreams(21)
+    twin_np, twin_py = np.random.RandomState(21), random.Random(21)
+    batch.hand_over([a], [s])
+    dev.draw_on_device(a, 9, 4)
+    twin_np.random_sample(9)
+    [twin_py.random() for _ in range(4)]
+    s.device_drew()
+    batch.hand_over([b], [s])                       # tree b takes the problem over
+    assert s.bound_to(b) and not s.bound_to(a)
+    k, p = _hip.np_state(twin_np)
+    assert b.np_state[1] == p and np.array_equal(b.np_state[0], k)
+    k, p = _hip.py_state(twin_py)
+    assert b.py_state[1] == p and np.array_equal(b.py_state[0], k)
+
+
+def test_closing_the_tree_brings_the_generators_home(dev):
+    """run_batch's promise `streams[i].rs afterwards`: a tree that is closed hands the states back first (HipTree.close runs
+    the release hooks); afterwards the stream is the host's again and asks no dead handle for anything"""
+    t, s = FakeTree(0), batch.ProblemStreams(5)
+    twin = np.random.RandomState(5)
+    batch.hand_over([t], [s])
+    dev.draw_on_device(t, 6, 0)
+    twin.random_sample(6)
+    s.device_drew(py_too=False)
+    assert t._release_hooks == [s.release]
+    _hip.HipTree.close(t_close := type("T", (), {"h": 1, "L": type("L", (), {"nirrt_destroy": staticmethod(lambda h: None)})(),
+                                              "_release_hooks": t._release_hooks})())
+    assert t_close.h is None and not s.bound_to(t)
+    n_get = len(dev.get_calls)
+    assert s.rs.random_sample() == twin.random_sample()
+    assert len(dev.get_calls) == n_get             # nothing fetched after the release: the host object is current
+
+
 def test_device_drew_with_one_stream_only_leaves_the_other_current(dev):
     tree, s = FakeTree(0), batch.ProblemStreams(3)
     batch.hand_over([tree], [s])

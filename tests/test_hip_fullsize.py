@@ -196,3 +196,82 @@ def test_bench_configuration_50k_against_oracle(oracle, monkeypatch, world, pid,
         assert st[5] / iters > 40 and st[6] / iters > 2 and st[19] < 0.5 * st[6]
     t.close()
     o.close()
+
+
+def test_headline_path_time_sliced_own_generators_against_oracle(oracle, monkeypatch):
+    """The EXACT path of bench.py's headline line (VERDICT r4 'weak' 1): more trees than the GPU holds at once (4096 problems of
+    the r in [16, 24] world on 3072 one-wave slots) -> `slim::k_run_pool<2>`, default slice length, every tree drawing from its
+    OWN MT19937 generators (np_words = NULL), slices of a tree running on whatever workgroup / XCD is free.  Five trees are taken
+    out of that launch and handed to the oracle, which is fed the same generators' outputs drawn on the host: vertex count, parents,
+    solution list, best-cost trace, generator outputs consumed and the FINAL GENERATOR STATES must be the reference's
+    (irrt_star_2d.py:42-97).  The five: a problem whose straight start-goal segment is free (the degenerate class), the tree that
+    was busy longest, one of the slowest decile, one dispatched behind the resident set, and problem 1."""
+    from concurrent.futures import ThreadPoolExecutor
+    from types import SimpleNamespace
+    import bench
+    from nirrt_star_amd import _hip, sampling
+    from oracle import oracle as orc
+    monkeypatch.delenv("NIRRT_FORCE_VARIANT", raising=False)
+    monkeypatch.delenv("NIRRT_POOL_RESIDENT", raising=False)
+    B, iters = 4096, 20000
+    a = SimpleNamespace(algo="irrt", dim=2, world="b30r16", iters=iters, trees=B, scaling="weak")
+    cache = {}
+    probs = [bench.make_problem(a, pid, cache) for pid in range(B)]
+    trees = []
+    for pr in probs:
+        t = _hip.HipTree(2, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"])
+        t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
+        trees.append(t)
+    free = [not t.is_collision(pr["x_start"], pr["x_goal"]) for t, pr in zip(trees, probs)]
+    order = sorted(range(B), key=lambda b: (not free[b], b))          # bench.py's dispatch order: free-segment problems first
+    np_st, py_st = bench.problem_generators([probs[b]["pid"] for b in order])
+    launch = [trees[b] for b in order]
+    _hip.set_generators(launch, np_st, py_st)
+    res = _hip.run_sampling(launch, iters, flags=_hip.F_IRRT, want_trace=True)     # slice_iters = 0: the library's own choice
+    assert (res["iters_done"] == iters).all() and not res["status"].any()
+    busy = res["stats"][:, _hip.ST_BUSY].astype(np.float64)
+    # time-sliced for real: a tree's busy time is a fraction of the span between its first and its last slice
+    span = (res["stats"][:, 15] - res["stats"][:, 14]).astype(np.float64)
+    assert np.median(busy / span) < 0.9
+    by_busy = np.argsort(busy)
+    picks = {"free segment": next(j for j, b in enumerate(order) if free[b]), "busiest": int(by_busy[-1]),
+             "slowest decile": int(by_busy[int(0.93 * B)]), "behind the resident set": 3500, "problem 1": order.index(1)}
+    assert free[order[picks["free segment"]]] and len(set(picks.values())) == 5
+    nk, npos, pk, ppos = _hip.get_generators(launch)
+    n_np, n_py = bench.word_budgets(a)
+
+    def check(item):
+        what, j = item
+        pr = probs[order[j]]
+        # the words the oracle is fed: the problem's seeded generators run on the host (the process-global ones are not touched)
+        npw = _hip.mt19937_outputs(np_st[j][0], np_st[j][1], n_np)[0]
+        pyw = _hip.mt19937_outputs(py_st[j][0], py_st[j][1], n_py)[0]
+        frame = sampling.informed_frame(pr["x_start"], pr["x_goal"])
+        o = orc.OracleTree(2, iters, pr["x_start"], pr["x_goal"], 10.0, float(pr["search_radius"]), float(pr["clearance"]), pr["env_dict"])
+        ro = o.run_sampling(iters, npw, pyw, irrt=True, frame=frame, want_trace=True)
+        out = dict(what=what, j=j, ro=ro, parents=o.parents.copy(), vertices=o.vertices.copy(), solutions=np.array(o.solutions), n=o.n)
+        o.close()
+        return out
+
+    with ThreadPoolExecutor(5) as ex:      # (the oracle runs inside ctypes calls: five host cores at once)
+        outs = list(ex.map(check, picks.items()))
+    for out in outs:
+        j, ro, what = out["j"], out["ro"], out["what"]
+        assert ro["iters_done"] == iters, what
+        assert int(res["np_used"][j]) == ro["np_used"] and int(res["py_used"][j]) == ro["py_used"], what
+        v, p = launch[j].download()
+        assert len(v) == out["n"], what
+        assert np.array_equal(p, out["parents"]), what
+        assert np.max(np.abs(v - out["vertices"])) <= 1e-9, what
+        assert np.array_equal(launch[j].solutions, out["solutions"]), what
+        tr, tro = res["cost_trace"][j], ro["cost_trace"]
+        assert np.array_equal(np.isfinite(tr), np.isfinite(tro)), what
+        fin = np.isfinite(tr)
+        assert fin.any() and np.max(np.abs(tr[fin] - tro[fin])) <= 1e-5, what
+        # final generator states = the seeded generators advanced by exactly the outputs the oracle consumed
+        _, k1, p1 = _hip.mt19937_outputs(np_st[j][0], np_st[j][1], ro["np_used"])
+        assert p1 == npos[j] and np.array_equal(k1, nk[j]), what
+        _, k1, p1 = _hip.mt19937_outputs(py_st[j][0], py_st[j][1], ro["py_used"])
+        assert p1 == ppos[j] and np.array_equal(k1, pk[j]), what
+    for t in trees:
+        t.close()

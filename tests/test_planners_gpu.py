@@ -108,16 +108,17 @@ def test_planning_random_lists(name, mode):
     assert n == int(g["n"]) and np.array_equal(p.vertex_parents[:n], g["parents"])
 
 
-@pytest.mark.parametrize("name", ["run_nirrt2d_1500", "run_nirrtc2d_1500", "run_nirrt3d_1500"])
+@pytest.mark.parametrize("name", ["run_nirrt2d_1500", "run_nirrtc2d_1500", "run_nirrt3d_1500", "run_nirrt3d_ratio1_1500", "run_nirrt2d_ratio1_1500"])
 def test_nirrt_control_flow_with_fake_wrapper(name):
     """L3: guidance injected by a deterministic fake wrapper; cloud generation, refresh rule, 50/50 sampling mix
-    and RNG consumption must reproduce the reference run."""
+    and RNG consumption must reproduce the reference run.  The `ratio1` fixtures ran with pc_update_cost_ratio = 1.0, the
+    default of demo_planning_3d.py:21: a refresh on every improvement of the best cost."""
     from nirrt_star_amd import planners
     g = load_golden(name)
     dim = int(g["dim"])
     w = FakePNG(g["x_start"], g["x_goal"], 25.0 if dim == 2 else 8.0)
     common = [tuple(g["x_start"]), tuple(g["x_goal"]), 10, float(g["search_radius"]), int(g["iter_max"]), g["env"], w]
-    tail = [int(g["clearance"]), 2048, 5, 0.5, 0.9]
+    tail = [int(g["clearance"]), 2048, 5, 0.5, float(g["pc_update_cost_ratio"]) if "pc_update_cost_ratio" in g else 0.9]
     connect = str(g["algo"]) == "nirrt_c"
     if dim == 2:
         common.append(g["binary_mask"].astype(np.float64))

@@ -32,7 +32,7 @@ def test_time_sliced_launch_equals_one_workgroup_per_tree(name, irrt, stop_first
     B, iters = 41, 3000
     flags = (_hip.F_IRRT if irrt else 0) | (_hip.F_STOP_FIRST if stop_first else 0)
     each = np.full(B, iters, dtype=np.int64)
-    each[5], each[17], each[40] = 1, 1234, 2999       # per-tree budgets (trees resumed after stopping at different iterations)
+    each[5], each[9], each[17], each[40] = 1, 0, 1234, 2999   # per-tree budgets (trees resumed after stopping at different iterations; 0 = not run at all)
     out = {}
     for mode in ("plain", "sliced"):
         if mode == "sliced":
@@ -94,3 +94,45 @@ def test_scheduled_segments_with_lane_groups_equal_one_launch():
         assert np.array_equal(a, b_)
     assert np.array_equal(d1[0][1], g["parents"])
     assert (r1["seconds"] > 0).all() and np.array_equal(r0["stats"][:, 13], r1["stats"][:, 13])
+
+
+def test_first_solution_on_the_last_iteration_of_a_slice_ends_the_run(monkeypatch):
+    """NIRRT_F_STOP_FIRST with the first solution found on the LAST iteration of a time slice: the run has ended - a
+    further slice would add an iteration (vertex, generator outputs, trace entry) that the launch with one workgroup per tree
+    never runs.  The slice length is set to each of several trees' own first-solution iteration in turn."""
+    from nirrt_star_amd import _hip
+    g = load_golden("run_irrt2d_3000")
+    B, iters = 12, 3000
+    flags = _hip.F_IRRT | _hip.F_STOP_FIRST
+    monkeypatch.delenv("NIRRT_POOL_RESIDENT", raising=False)
+    trees = _batch(g, B, iters, 7000)
+    r0 = _hip.run_sampling(trees, iters, flags=flags, want_trace=True, slice_iters=-1)
+    d0 = [t.download() for t in trees]
+    g0 = _hip.get_generators(trees)
+    for t in trees:
+        t.close()
+    k_first = r0["iters_done"]
+    assert (k_first < iters).sum() >= 3
+    monkeypatch.setenv("NIRRT_POOL_RESIDENT", "5")
+    tested = 0
+    for b in np.argsort(k_first)[:6]:
+        k1 = int(k_first[b])
+        if k1 < 2 or k1 >= iters:
+            continue
+        for q in sorted({k1, k1 // 2 if k1 % 2 == 0 else k1}):      # the solving iteration = last of slice 0 (and of slice 1 when k1 is even)
+            trees = _batch(g, B, iters, 7000)
+            r1 = _hip.run_sampling(trees, iters, flags=flags, want_trace=True, slice_iters=q)
+            assert np.array_equal(r0["iters_done"], r1["iters_done"]), (b, k1, q)
+            assert np.array_equal(r0["np_used"], r1["np_used"]) and np.array_equal(r0["py_used"], r1["py_used"])
+            for j in range(B):
+                v, p = trees[j].download()
+                assert np.array_equal(p, d0[j][1]) and np.array_equal(v, d0[j][0])
+                k = int(r0["iters_done"][j])
+                assert np.array_equal(r0["cost_trace"][j, :k], r1["cost_trace"][j, :k])
+            g1 = _hip.get_generators(trees)
+            for x, y in zip(g0, g1):
+                assert np.array_equal(x, y)
+            for t in trees:
+                t.close()
+            tested += 1
+    assert tested >= 3
