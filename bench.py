@@ -69,6 +69,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline processes (0 = every host core)")
     ap.add_argument("--no-cpu-full", action="store_true", help="skip the ONE full-length single-core oracle run reported beside the sample")
     ap.add_argument("--no-ttfs", action="store_true")
+    ap.add_argument("--ttfs", action="store_true", help="(marks the secondary lines that measure time-to-first-solution; the default line always does)")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-problem-alone latency runs (3 full-length launches)")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="the full per-line records of the secondary runs go here (the JSON line keeps a compact summary of each)")
     ap.add_argument("--pilot", type=int, default=0,
                     help="a step's iterations run as two launches: this many first, then the rest re-scheduled like --segments does; 0 = off")
     ap.add_argument("--segments", type=int, default=1, help="a step's iterations run as this many launches of equal length; between them the "
@@ -82,7 +86,7 @@ def parse(argv=None):
     ap.add_argument("--free-lanes", type=int, default=0, choices=[0, 64, 128, 256],
                     help="workgroup size for the problems with a free start-goal segment (their Near sets grow to thousands of members: the "
                          "visit is arithmetic-bound and scales with the lanes); 0 = like the others")
-    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "r04_traffic.json"),
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "r05_traffic.json"),
                     help="PMC traffic table written by scripts/collect_traffic.py (an entry is used only if its key names this exact configuration)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group / timing protocol only, no GPU work (CPU test of --gpus N)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -242,6 +246,7 @@ def main():
         return bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work)
 
     full_proc = start_cpu_full_run(args) if (rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_cpu_full) else None
+    t_setup = time.perf_counter()
     probs = make_problems(args, rank)
     D, B, iters = args.dim, len(probs), args.iters   # (strong scaling: this rank's share of the fixed set)
     flags = _hip.F_IRRT if args.algo == "irrt" else 0
@@ -270,6 +275,7 @@ def main():
     t_inputs = time.perf_counter()
     np_states, py_states = problem_generators([pr["pid"] for pr in probs])
     input_generation_s = time.perf_counter() - t_inputs   # host: seeding 2 B generators (outside the timed region; the upload is inside)
+    setup_s = time.perf_counter() - t_setup               # this rank: worlds, B x nirrt_create, collision probes, generator seeding
 
     # a step's iterations as `--segments` launches of equal length (or --pilot P: P, then the rest); between launches the host
     # re-schedules from the device's own measurements (nirrt_star_amd.batch.run_scheduled)
@@ -309,6 +315,7 @@ def main():
     st = r["stats"].astype(np.float64)
     tree_s = r["seconds"]                           # per-tree seconds inside the launches of the last step (100 MHz device wall clock)
     elapsed_max, total_iters = reduce_time_and_work(elapsed, sum(done_iters))
+    setup_max, _ = reduce_time_and_work(setup_s, 0)       # (slowest rank's set-up: what an N-GPU run waits for before its first step)
     value = total_iters / elapsed_max
 
     if rank == 0:
@@ -324,7 +331,7 @@ def main():
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "process_group": (dist.get_backend() if grouped else None),
-            "input_generation_s": input_generation_s,
+            "input_generation_s": input_generation_s, "setup_seconds_max_over_ranks": setup_max,
             "end_to_end_value": total_iters / (elapsed_max + input_generation_s),   # incl. seeding every problem's generators on the host
             "config": {"workload": ("%s_star random_2d (%s: %s; clearance 3, step_len 10), %d problems/GPU x %d iters, "
                                     "device-resident batched loop with in-kernel sampling" % (args.algo, args.world, WORLDS[args.world], B, iters))
@@ -357,6 +364,7 @@ def main():
                               "that ran" % (short, B, iters))
         if not args.no_ttfs:
             out["time_to_first_solution"] = time_to_first_solution(args, trees, np_states, py_states, flags)
+        if not args.no_ttfs and not args.no_single:
             out["single_tree"] = single_tree_latency(args, trees, np_states, py_states, flags)
         if not args.no_cpu_baseline and world == 1:      # (the host-core baseline belongs to the N = 1 line)
             out["cpu_baseline"] = cpu_baseline(args, full_proc)
@@ -367,7 +375,16 @@ def main():
             trees = []
             torch.cuda.empty_cache()
             _hip.pool_trim()
-            out["secondary"] = secondary_runs(args)
+            detail = secondary_runs(args)
+            detail["eval_set protocol (config 5 as the reference runs it)"] = eval_protocol_run(args)
+            try:
+                os.makedirs(os.path.dirname(args.detail_file), exist_ok=True)
+                with open(args.detail_file, "w") as f:
+                    json.dump({"headline": out, "secondary": detail}, f, indent=1)
+            except OSError:
+                pass
+            # LAST key of the line, compact: the driver keeps the line's tail
+            out["secondary"] = {k: compact(v) for k, v in detail.items()}
         print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()
@@ -447,14 +464,18 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
         dist.destroy_process_group()
 
 
+TTFS = ["--ttfs"]   # these lines also measure time-to-first-solution - the metric's second half (the others run --no-ttfs)
 SECONDARY = [   # (label, bench arguments): each runs `--steps 1 --warmup 0` in a process of its own
-    ("rrt_2d", ["--algo", "rrt", "--world", "b30"]),
-    ("rrt_3d", ["--algo", "rrt", "--dim", "3"]),
+    ("rrt_2d", ["--algo", "rrt", "--world", "b30"] + TTFS),
+    ("rrt_3d", ["--algo", "rrt", "--dim", "3"] + TTFS),
     # (trees whose visits cover thousands of index slots per iteration - the degenerate, near-straight-line class - move to 256 / 128 lanes)
-    ("irrt_3d", ["--algo", "irrt", "--dim", "3", "--trees", "4096", "--segments", "3", "--wide-visits", "6000", "--narrow-visits", "2000"]),
+    ("irrt_3d", ["--algo", "irrt", "--dim", "3", "--trees", "4096", "--segments", "3", "--wide-visits", "6000", "--narrow-visits", "2000"] + TTFS),
     ("irrt_2d_b30 (r in [8, 12])", ["--algo", "irrt", "--world", "b30"]),
-    ("nirrt_2d", ["--algo", "nirrt", "--trees", "4096", "--world", "b30"]),
-    ("nirrt_c_2d (config 3)", ["--algo", "nirrt_c", "--trees", "2048", "--world", "b30"]),
+    # the reference's own random_2d obstacle distribution: 8-12 rectangles + 8-12 circles (env_configs/random_2d.yml:5-6)
+    ("irrt_2d_ref2d (rectangles + circles)", ["--algo", "irrt", "--world", "ref2d"] + TTFS),
+    # (the guided 2D lines run on the primary world b30r16 since round 5, like the headline)
+    ("nirrt_2d", ["--algo", "nirrt", "--trees", "4096"]),
+    ("nirrt_c_2d (config 3)", ["--algo", "nirrt_c", "--trees", "2048"]),
     ("nirrt_3d (config 4)", ["--algo", "nirrt", "--dim", "3", "--trees", "2048"]),
     # BASELINE config 5 as written, on ONE GPU: the fixed 1000-problem evaluation set (the anchor of the strong-scaling curve)
     ("irrt_2d eval set (config 5, N = 1)", ["--algo", "irrt", "--scaling", "strong", "--problems", "1000"]),
@@ -466,8 +487,9 @@ def secondary_runs(args):
     3 and 4): one step each, no warm-up, same iteration count; the fields a reader needs to judge them."""
     out = {}
     for label, extra in SECONDARY:
+        ttfs = "--ttfs" in extra
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--iters", str(args.iters),
-               "--no-cpu-baseline", "--no-ttfs", "--no-secondary"] + extra
+               "--no-cpu-baseline", "--no-secondary", "--no-single"] + ([] if ttfs else ["--no-ttfs"]) + list(extra)
         t0 = time.perf_counter()
         try:
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
@@ -482,11 +504,77 @@ def secondary_runs(args):
                           "trees_per_gpu": cfg.get("trees_per_gpu"), "trees_stopped_early": cfg.get("trees_stopped_early", cfg.get("failed")),
                           "per_tree_seconds": cfg.get("per_tree_seconds"), "host_seconds": cfg.get("host_seconds_last_step"),
                           "launches_per_step": cfg.get("launches_per_step"), "trees_on_256_lanes": cfg.get("trees_on_256_lanes"),
-                          "problem_set": cfg.get("problem_set"),
+                          "problem_set": cfg.get("problem_set"), "wasted_traffic_ratio": rf.get("wasted_traffic_ratio"),
+                          "kernel_share_of_step": rf.get("kernel_share_of_step"), "time_to_first_solution": d.get("time_to_first_solution"),
+                          "workload": cfg.get("workload"),
                           "warning": d.get("warning"), "wall_s": time.perf_counter() - t0}
         except subprocess.TimeoutExpired:
             out[label] = {"error": "timed out after 900 s"}
     return out
+
+
+def compact(v):
+    """one secondary record as the few numbers the line itself carries: M it/s, roofline fraction, HBM traffic / algorithmic
+    bytes, share of the step spent in the kernel, time-to-first-solution medians (ms; one problem alone / in a 256-problem launch)"""
+    if "error" in v:
+        return {"error": v["error"][:80]}
+    c = {"Mits": round(v["value"] / 1e6, 2)}
+    if v.get("roofline_frac") is not None:
+        c["frac"] = round(v["roofline_frac"], 3)
+    if v.get("wasted_traffic_ratio") is not None:
+        c["waste"] = round(v["wasted_traffic_ratio"], 2)
+    if v.get("kernel_share_of_step") is not None:
+        c["kshare"] = round(v["kernel_share_of_step"], 2)
+    t = v.get("time_to_first_solution")
+    if t and t["single"]["median_seconds"] is not None and t["batch"]["median_seconds"] is not None:
+        c["ttfs_ms"] = [round(t["single"]["median_seconds"] * 1e3, 2), round(t["batch"]["median_seconds"] * 1e3, 2)]
+    for k in ("resumed_s", "problems"):
+        if k in v:
+            c[k] = v[k]
+    if v.get("trees_stopped_early"):
+        c["short"] = v["trees_stopped_early"]
+    return c
+
+
+def eval_protocol_run(args):
+    """BASELINE config 5 the way the reference runs it (eval_planning_2d.py:83-136): planning_random(3000) - plan until the first
+    solution, then 3000 more iterations - over the 1000-problem evaluation set, results in the reference's pickle; then the same
+    command again on a result file cut back to its first 900 problems (the reference's resume: eval_planning_2d.py:99-110).
+    value = iterations planned / wall seconds of the harness process's planning loop (its own summary)."""
+    import pickle
+    import shutil
+    import tempfile
+    work = tempfile.mkdtemp(prefix="nirrt_eval_")
+    cmd = [sys.executable, "-m", "nirrt_star_amd.eval_sharded", "--problem", "random_2d", "--planner", "irrt_star", "--iter_after_initial", "3000",
+           "--out", os.path.join(work, "summary.json")]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    try:
+        runs = []
+        for k in range(2):
+            t0 = time.perf_counter()
+            p = subprocess.run(cmd, cwd=work, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not line:
+                return {"error": "rc %d: %s" % (p.returncode, p.stderr.strip().splitlines()[-1] if p.stderr.strip() else "no output")}
+            d = json.loads(line[-1])
+            d["wall_s"] = time.perf_counter() - t0
+            runs.append(d)
+            if k == 0:      # cut the result file back to its first 900 problems: the second run resumes from there
+                pk = os.path.join(work, "results", "evaluation", "2d", "random_2d-irrt_star-none-%d.pickle" % d["problems"])
+                with open(pk, "rb") as f:
+                    lst = pickle.load(f)
+                with open(pk, "wb") as f:
+                    pickle.dump(lst[: int(0.9 * len(lst))], f)
+        full, res = runs
+        return {"value": full["iterations_planned"] / full["seconds"], "unit": "iterations/s", "problems": full["problems"], "solved": full["solved"],
+                "seconds": full["seconds"], "process_wall_s": full["wall_s"], "iterations_planned": full["iterations_planned"],
+                "median_first_solution_iter": full["median_first_solution_iter"],
+                "resumed_from": res["resumed_from"], "resumed_planned": res["planned"], "resumed_s": round(res["seconds"], 2),
+                "workload": "eval_sharded --problem random_2d --planner irrt_star --iter_after_initial 3000 (planning_random over the 1000-problem set, N = 1)"}
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after 900 s"}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def single_tree_latency(args, trees, np_states, py_states, flags):
@@ -615,6 +703,9 @@ def cpu_baseline(args, full_proc=None):
             "values_of_repetitions": [r["value"] for r in reps],
             "single_core_median": m["single_core_median"], "single_core_min": m["single_core_min"], "single_core_max": m["single_core_max"],
             "full_run": full,
+            # (the same numbers once more as plain scalars: a record parser that keeps only flat fields still sees them)
+            "full_run_iterations_per_second": (full or {}).get("iterations_per_second"), "full_run_seconds": (full or {}).get("seconds"),
+            "full_run_iterations": (full or {}).get("iterations"),
             "sample": "median of %d repetitions of: %d processes (one per host core) x first %d of %d iterations of problems 0..%d of the batch "
                       "(oracle loop only, %.1f s for the slowest process of the median repetition, %.1f s for everything incl. start-up); the "
                       "per-iteration cost grows with the tree, so the truncated sample flatters the CPU - full_run is one problem at full length"

@@ -227,11 +227,20 @@ struct __attribute__((aligned(32))) VRec {
 };
 
 // one slot of the grid index (see "uniform-grid index"): what a query needs about a vertex, in one 32-byte record
+#ifdef NIRRT_SLOT_PAD   // A/B experiment only: a 64-byte slot stride (twice the bytes per visited slot, same work) - how bandwidth-bound is the visit?
+struct __attribute__((aligned(64))) GSlot {
+    double x, y;
+    double cost;
+    double w;
+    double pad_[4];
+};
+#else
 struct __attribute__((aligned(32))) GSlot {
     double x, y;
     double cost;   // exact cost(v), kept in step with vrec[v].cost
     double w;      // 2D: the vertex index (integer bit pattern in the low word); 3D: z (the index is in g_idx[slot])
 };
+#endif
 
 // The part of a tree descriptor the loop body touches: copied into LDS when a kernel starts (hot_enter) and written back when
 // it ends (hot_leave), so that a pointer or a counter of the tree costs an LDS read instead of a dependent scalar load from HBM

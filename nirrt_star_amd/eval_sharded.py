@@ -22,8 +22,40 @@ CHECKPOINTS = list(range(0, 3001, 250))   # cost recorded at +0, +250, ... +3000
 RECORD_LEN = 4 + len(CHECKPOINTS)         # problem_id, first_solution_iter, n_vertices, total_iters, costs...
 
 
-def shard_indices(n_problems, rank, world_size):
-    return list(range(rank, n_problems, world_size))
+def shard_indices(n_problems, rank, world_size, heavy=None, first=0):
+    """problem ids [first, n_problems) of rank `rank`.  Without a predictor: round-robin `i -> i mod world_size`.  With `heavy`
+    (one bool per problem id, the same on every rank - e.g. straight_segment_free): the heavy problems are dealt round-robin
+    first, then the light ones continue the deal where the heavy ones stopped, so that every rank gets the same number of each
+    (+- 1) and the same number in total (+- 1).  Every rank computes the same partition from the same inputs; no collective."""
+    ids = list(range(int(first), int(n_problems)))
+    if heavy is None:
+        return ids[rank::world_size]
+    deal = [i for i in ids if heavy[i]] + [i for i in ids if not heavy[i]]
+    return sorted(deal[rank::world_size])
+
+
+def straight_segment_free(env_dict, clearance, x_start=None, x_goal=None, spacing=0.5):
+    """Host-side PREDICTOR of a slow problem (scheduling only - no planning result depends on it): is the straight start-goal
+    segment free of the clearance-inflated obstacles?  Such problems end up with an informed set collapsed onto the segment and
+    Near sets of thousands of members (2-3x the median run time in 2D, 5x+ in 3D).  Sampled every `spacing` units against
+    circles / rectangles (2D) or balls / boxes (3D)."""
+    a = np.asarray(x_start if x_start is not None else env_dict["start"][0], dtype=np.float64)
+    b = np.asarray(x_goal if x_goal is not None else env_dict["goal"][0], dtype=np.float64)
+    n = max(2, int(np.ceil(np.linalg.norm(b - a) / spacing)) + 1)
+    pts = a[None, :] + np.linspace(0.0, 1.0, n)[:, None] * (b - a)[None, :]
+    d = pts.shape[1]
+    round_obs = env_dict.get("circle_obstacles" if d == 2 else "ball_obstacles", [])
+    box_obs = env_dict.get("rectangle_obstacles" if d == 2 else "box_obstacles", [])
+    for o in round_obs:
+        c, r = np.asarray(o[:d], dtype=np.float64), float(o[d])
+        if (np.sum((pts - c) ** 2, axis=1) <= (r + clearance) ** 2).any():
+            return False
+    for o in box_obs:
+        lo = np.asarray(o[:d], dtype=np.float64) - clearance
+        hi = np.asarray(o[:d], dtype=np.float64) + np.asarray(o[d:2 * d], dtype=np.float64) + clearance
+        if np.all((pts >= lo) & (pts <= hi), axis=1).any():
+            return False
+    return True
 
 
 def gather_records(local, world_size, rank, device="cpu"):
@@ -174,6 +206,16 @@ def gather_results(local, world_size, rank):
     return sorted(x for part in out for x in part)
 
 
+def gather_rank_seconds(seconds, n_problems, world_size, rank):
+    """(seconds spent planning, problems planned) of every rank -> rank 0 (how even the partition was)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [(seconds, n_problems)]
+    out = [None] * world_size if rank == 0 else None
+    dist.gather_object((float(seconds), int(n_problems)), out, dst=0)
+    return out if rank == 0 else [(seconds, n_problems)]
+
+
 def write_reference_pickle(path, env_configs, results):
     """eval_planning_2d.py:100-136 wire format: a pickled list of copies of the env config dicts, each with the
     planner's path_len_list under 'result' - what result_analysis_*.py reads."""
@@ -256,7 +298,9 @@ def main():
     ap.add_argument("--step_len", type=float, default=10)
     ap.add_argument("--clearance", type=float, default=None)
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--max_problems", type=int, default=None)
+    ap.add_argument("--max_problems", "--num_problems", dest="max_problems", type=int, default=None)
+    ap.add_argument("--no_resume", action="store_true", help="plan every problem even if the result pickle already holds a prefix of them")
+    ap.add_argument("--no_balance", action="store_true", help="plain round-robin sharding (no free-segment predictor)")
     ap.add_argument("--out", default="results/evaluation/sharded_result.json")
     ap.add_argument("--pickle_out", default="auto",
                     help="reference-format result pickle (list of env configs + 'result'); 'auto' = the reference's "
@@ -295,7 +339,23 @@ def main():
         get = P.get_random_3d_problem_input
     if args.max_problems:
         cfgs = cfgs[: args.max_problems]
-    mine = shard_indices(len(cfgs), rank, world)
+    pickle_path = args.pickle_out
+    if pickle_path == "auto":
+        pickle_path = os.path.join("results", "evaluation", "3d" if args.problem == "random_3d" else "2d",
+                                   "%s-%s%s-%s-%d.pickle" % (args.problem, args.planner[:-2] if args.planner.endswith("_c") else args.planner,
+                                                             "-c-bfs" if args.planner.endswith("_c") else "", args.neural_net, len(cfgs)))
+    # resume like the reference (eval_planning_2d.py:99-110): an existing result file holds the first K problems' lists; they are
+    # kept as they are and only problems K.. are planned (every rank reads the same file: same K everywhere)
+    loaded = []
+    if pickle_path != "none" and not args.no_resume and os.path.exists(pickle_path):
+        import pickle
+        with open(pickle_path, "rb") as f:
+            loaded = pickle.load(f)[: len(cfgs)]
+    # heavy problems (free straight start-goal segment) are dealt across the ranks first, then the rest (shard_indices)
+    heavy = None
+    if world > 1 and args.problem in ("random_2d", "random_3d") and not args.no_balance:
+        heavy = [straight_segment_free(c["env_dict"], args.clearance) for c in cfgs]
+    mine = shard_indices(len(cfgs), rank, world, heavy, first=len(loaded))
     wrapper = make_wrapper(args, 3 if args.problem == "random_3d" else 2, "cuda:%d" % local_rank) if args.neural_net == "pointnet2" else None
     t0 = time.time()
     recs, results = [], []
@@ -317,21 +377,25 @@ def main():
             r, traces = plan_batch(probs, ids, args, local_rank, wrapper)
         recs += r
         results += list(zip(ids, result_lists(args.problem, traces, thr)))
+    plan_s = time.time() - t0
+    # the loaded problems' records (rank 0 only: they need no planning) from their lists, like a freshly planned one's
+    if rank == 0 and args.problem in ("random_2d", "random_3d"):
+        recs = [make_record(i, np.asarray(d["result"], dtype=np.float64), -1) for i, d in enumerate(loaded)] + recs
     allr = gather_records(np.array(recs).reshape(-1, RECORD_LEN), world, rank, device="cuda")
     all_results = gather_results(results, world, rank) if args.pickle_out != "none" else None
+    rank_seconds = gather_rank_seconds(plan_s, len(mine), world, rank)
     if rank == 0 and all_results is not None:
-        path = args.pickle_out
-        if path == "auto":
-            path = os.path.join("results", "evaluation", "3d" if args.problem == "random_3d" else "2d",
-                                "%s-%s%s-%s-%d.pickle" % (args.problem, args.planner[:-2] if args.planner.endswith("_c") else args.planner,
-                                                          "-c-bfs" if args.planner.endswith("_c") else "", args.neural_net, len(cfgs)))
-        write_reference_pickle(path, cfgs, all_results)
+        all_results = [(i, d["result"]) for i, d in enumerate(loaded)] + list(all_results)
+        write_reference_pickle(pickle_path, cfgs, all_results)
     if rank == 0:
         solved = allr[allr[:, 1] > 0]
         summary = {"problems": int(len(allr)), "solved": int(len(solved)), "world_size": world,
+                   "resumed_from": len(loaded), "planned": int(len(cfgs) - len(loaded)),
+                   "rank_problems": [int(v[1]) for v in rank_seconds], "rank_seconds": [round(float(v[0]), 3) for v in rank_seconds],
                    "median_first_solution_iter": float(np.median(solved[:, 1])) if len(solved) else None,
                    "mean_cost_at": {str(c): float(np.mean(solved[:, 4 + j][np.isfinite(solved[:, 4 + j])]))
                                     for j, c in enumerate(CHECKPOINTS) if len(solved) and np.isfinite(solved[:, 4 + j]).any()},
+                   "iterations_planned": int(allr[len(loaded):, 3].sum()) if args.problem in ("random_2d", "random_3d") else int(allr[:, 3].sum()),
                    "seconds": time.time() - t0}
         os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
         with open(args.out, "w") as f:

@@ -17,7 +17,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("NIRRT_ROUND", "r04")   # prefix of the files written under profiles/
+ROUND = os.environ.get("NIRRT_ROUND", "r05")   # prefix of the files written under profiles/
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 

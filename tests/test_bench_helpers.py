@@ -53,16 +53,17 @@ def test_primary_world_of_the_survey_has_large_circles_and_connected_start_goal(
         assert all(16 <= c[2] <= 24 for c in p["env_dict"]["circle_obstacles"])
 
 
-def test_gpus_flag_spawns_that_many_ranks_and_prints_one_line():
-    """`python bench.py --gpus 2` with no launcher around it must become two ranks (gloo here: no GPU) and print ONE
-    JSON line with n_gpus = 2; the work of both ranks is in it."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--trees", "10",
-                        "--iters", "100"], capture_output=True, text=True, cwd=ROOT, timeout=300)
+@pytest.mark.parametrize("n", [2, 8])
+def test_gpus_flag_spawns_that_many_ranks_and_prints_one_line(n):
+    """`python bench.py --gpus N` with no launcher around it must become N ranks (gloo here: no GPU) and print ONE
+    JSON line with n_gpus = N; the work of all ranks is in it (N = 8: the node the driver's scaling run uses)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-run", "--steps", "3", "--trees", "10",
+                        "--iters", "100"], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["work_all_ranks"] == 2 * 10 * 100 * 3
+    assert d["n_gpus"] == n and d["dry_run"] is True and d["work_all_ranks"] == n * 10 * 100 * 3
 
 
 def test_launcher_world_size_mismatch_is_an_error():
@@ -101,11 +102,11 @@ def test_strong_scaling_line_has_a_traffic_key_of_its_own(monkeypatch):
 
 
 def test_every_bench_line_has_its_traffic_entry_in_the_committed_profile(monkeypatch):
-    """the default line and every secondary line look their HBM traffic up in profiles/r04_traffic.json by configuration key:
+    """the default line and every secondary line look their HBM traffic up in profiles/r05_traffic.json by configuration key:
     a line added to bench.SECONDARY without its FETCH / WRITE passes would silently report traffic = null"""
     b = _bench()
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(here, "profiles", "r04_traffic.json")) as fh:
+    with open(os.path.join(here, "profiles", "r05_traffic.json")) as fh:
         entries = json.load(fh)["entries"]
     lines = [("default", [])] + list(b.SECONDARY)
     for label, extra in lines:

@@ -71,3 +71,53 @@ def test_bench_timing_protocol_under_a_one_rank_rccl_group(tmp_path):
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["process_group"] == "nccl"
     assert d["config"]["trees_stopped_early"] == 0
+
+
+def test_eval_sharded_resumes_from_an_existing_result_file(tmp_path):
+    """The reference's resume (eval_planning_2d.py:99-110): an existing result pickle holds the first K problems; they are kept
+    as they are and only problems K.. are planned.  A run over 12 problems, its pickle cut back to 5 entries, the same command
+    again: 7 problems planned, the final file equal to the uninterrupted one (seeded per problem: deterministic)."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    pk = tmp_path / "results" / "evaluation" / "2d" / "random_2d-irrt_star-none-12.pickle"
+    cmd = [sys.executable, "-m", "nirrt_star_amd.eval_sharded", "--problem", "random_2d", "-p", "irrt_star", "--num_problems", "12",
+           "--iter_max", "3000", "--iter_after_initial", "500", "--out", str(tmp_path / "res.json")]       # --pickle_out auto: the reference's file name
+
+    def run():
+        p = subprocess.run(cmd, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        with open(pk, "rb") as f:
+            return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1]), pickle.load(f)
+
+    s1, full = run()
+    assert s1["problems"] == 12 and s1["resumed_from"] == 0 and s1["planned"] == 12 and len(full) == 12
+    with open(pk, "wb") as f:
+        pickle.dump(full[:5], f)
+    s2, again = run()
+    assert s2["resumed_from"] == 5 and s2["planned"] == 7 and s2["problems"] == 12 and s2["solved"] == s1["solved"]
+    assert len(again) == 12
+    for a, b in zip(full, again):
+        assert a["img_idx"] == b["img_idx"] and a["start_goal_idx"] == b["start_goal_idx"]
+        assert np.array_equal(np.asarray(a["result"]), np.asarray(b["result"]))
+    assert s2["mean_cost_at"] == s1["mean_cost_at"] and s2["median_first_solution_iter"] == s1["median_first_solution_iter"]
+    # a complete file: nothing left to plan
+    s3, third = run()
+    assert s3["resumed_from"] == 12 and s3["planned"] == 0 and len(third) == 12
+
+
+def test_free_segment_predictor_agrees_with_the_device_collision_test():
+    """eval_sharded.straight_segment_free (host, sampled; used only to deal the slow problems evenly across ranks) against the
+    device's exact segment test on the first 200 problems of the 2D set and 100 of the 3D set: it may err on grazing segments,
+    nothing else"""
+    from nirrt_star_amd import _hip, eval_sharded as es, problems as P
+    for dim, cfgs, get, clr in ((2, P.get_random_2d_env_configs()[:200], P.get_random_2d_problem_input, 3),
+                                (3, P.get_random_3d_env_configs()[:100], P.get_random_3d_problem_input, 2)):
+        agree = 0
+        for i, c in enumerate(cfgs):
+            if dim == 3:
+                np.random.seed(i)
+            pr = get(c)
+            t = _hip.HipTree(dim, 8, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], clr, pr["env"])
+            free_dev = not t.is_collision(pr["x_start"], pr["x_goal"])
+            agree += int(free_dev == es.straight_segment_free(c["env_dict"], clr))
+            t.close()
+        assert agree >= 0.97 * len(cfgs), (dim, agree, len(cfgs))

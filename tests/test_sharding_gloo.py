@@ -81,3 +81,76 @@ def test_shard_indices_partition():
             parts = [es.shard_indices(n, r, w) for r in range(w)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_heavy_problems_are_dealt_across_the_ranks_first():
+    """with the free-segment predictor every rank gets the same number of heavy problems (+- 1) and the same
+    number in total (+- 1); a resumed run shards only the problems the loaded file does not hold"""
+    from nirrt_star_amd import eval_sharded as es
+    rng = np.random.default_rng(0)
+    for n, w, first in ((1000, 8, 0), (1000, 8, 123), (37, 4, 0), (5, 8, 0), (0, 2, 0)):
+        heavy = list(rng.random(n) < 0.12)
+        parts = [es.shard_indices(n, r, w, heavy, first=first) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(first, n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+        hv = [sum(heavy[i] for i in p) for p in parts]
+        assert max(hv) - min(hv) <= 1
+        assert all(p == sorted(p) for p in parts)
+
+
+def test_free_segment_predictor_on_known_worlds():
+    from nirrt_star_amd import eval_sharded as es
+    ed = {"env_dims": (224, 224), "circle_obstacles": [[100, 100, 10]], "rectangle_obstacles": [[150, 20, 20, 30]],
+          "start": [[20, 100]], "goal": [[200, 100]]}
+    assert not es.straight_segment_free(ed, 3)                                     # straight through the circle
+    assert es.straight_segment_free(ed, 3, x_start=(20, 120), x_goal=(200, 120))   # passes 20 above its centre (r + clearance = 13)
+    assert not es.straight_segment_free(ed, 3, x_start=(20, 112), x_goal=(200, 112))
+    assert not es.straight_segment_free(ed, 3, x_start=(140, 35), x_goal=(200, 35))   # through the rectangle
+    assert es.straight_segment_free(ed, 3, x_start=(140, 60), x_goal=(200, 60))
+    ed3 = {"env_dims": [50, 50, 50], "ball_obstacles": [[25, 25, 25, 5]], "box_obstacles": [[5, 5, 5, 10, 10, 10]],
+           "start": [[2, 25, 25]], "goal": [[48, 25, 25]]}
+    assert not es.straight_segment_free(ed3, 2)
+    assert es.straight_segment_free(ed3, 2, x_start=(2, 40, 40), x_goal=(48, 40, 40))
+    assert not es.straight_segment_free(ed3, 2, x_start=(2, 10, 10), x_goal=(48, 10, 10))
+
+
+def _worker8(rank, world, port, n_problems, first, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from nirrt_star_amd import eval_sharded as es
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    heavy = [(i * 7) % 11 == 0 for i in range(n_problems)]
+    mine = es.shard_indices(n_problems, rank, world, heavy, first=first)
+    recs = [es.make_record(pid, np.full(30, 100.0 - pid), 50 + pid) for pid in mine]
+    out = es.gather_records(np.array(recs).reshape(-1, es.RECORD_LEN), world, rank, device="cpu")
+    res = es.gather_results([(pid, [float(pid)]) for pid in mine], world, rank)
+    secs = es.gather_rank_seconds(0.5 + rank, len(mine), world, rank)
+    if rank == 0:
+        q.put((out, res, secs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_problems,first", [(21, 0), (21, 18), (1000, 997)])
+def test_world_8_gather_with_uneven_and_empty_shards(n_problems, first):
+    """eight gloo ranks (the node the path is meant for): balanced shards, ranks with one problem fewer than others and ranks
+    with NO problem at all (a resumed run with 3 problems left) all take part in the one gather"""
+    from nirrt_star_amd import eval_sharded as es
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000) + n_problems % 97 + first % 13
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, n_problems, first, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, res, secs = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ids = np.arange(first, n_problems)
+    assert out.shape == (len(ids), es.RECORD_LEN) and np.array_equal(out[:, 0], ids)
+    assert np.allclose(out[:, 4], 100.0 - ids)
+    assert res == [(int(pid), [float(pid)]) for pid in ids]
+    assert [round(s[0] - 0.5) for s in secs] == list(range(8)) and sum(s[1] for s in secs) == len(ids)

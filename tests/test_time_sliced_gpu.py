@@ -62,7 +62,7 @@ def test_time_sliced_launch_equals_one_workgroup_per_tree(name, irrt, stop_first
         assert (r1["iters_done"] <= each).all() and (r1["iters_done"] < iters).any()
     # the counters add up over the slices; busy time is reported per tree
     assert np.array_equal(r0["stats"][:, 13], r1["stats"][:, 13]) and np.array_equal(r0["stats"][:, 9], r1["stats"][:, 9])
-    assert (r1["stats"][:, _hip.ST_BUSY] > 0).all()
+    assert (r1["stats"][each > 0, _hip.ST_BUSY] > 0).all() and r1["iters_done"][9] == 0 == r0["iters_done"][9]
 
 
 def test_scheduled_segments_with_lane_groups_equal_one_launch():
