@@ -2036,7 +2036,48 @@ __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeHot &t, 
     return c;
 }
 
-// steer (new_state).  2D: rrt_star_2d.py:67-78, device atan2/cos/sin; 3D: rrt_star_3d.py:67-78, IEEE only.
+// glibc 2.35's sin / cos / atan2 (the x86-64 FMA variants: what math.sin / math.cos / math.atan2 of the reference's interpreter
+// call on an FMA + AVX2 host), restated instruction by instruction - see csrc/glibc235_libm.inc.  With them the 2D steer is
+// bit-identical to the reference's (rounds 1-4 used the device's own libm: vertices within 1e-9, and on degenerate trees - free
+// straight start-goal segment, hundreds of near-ties per rewiring pass - an ulp was enough to flip a parent now and then).
+namespace glibc235 {
+static __device__ __forceinline__ uint64_t ld64(int64_t a);
+#define LIBM_CONST(name, val) static constexpr uint64_t name = val;
+#define LIBM_TABLE(name, n) __device__ const uint64_t name[n]
+#define LIBM_FN static __device__ __noinline__
+#define D(u) __longlong_as_double((long long)(u))
+#define B(d) ((uint64_t)__double_as_longlong(d))
+#define DB(u) D(u)
+#define UNSUPPORTED(msg) return __builtin_nan("")
+#define S64(off) stk[(off) / 8]
+#define W64(off, v) (stk[(off) / 8] = (v))
+#define S32(off) ((uint32_t)(stk[(off) / 8] >> (((off) & 4) * 8)))
+#define W32(off, v) (stk[(off) / 8] = (stk[(off) / 8] & ~(0xffffffffull << (((off) & 4) * 8))) | ((uint64_t)(uint32_t)(v) << (((off) & 4) * 8)))
+#define LD64(a) glibc235::ld64(a)
+#define LD32(a) ((uint32_t)glibc235::ld64(a))
+#include "glibc235_libm.inc"
+static __device__ __forceinline__ uint64_t ld64(int64_t a)
+{
+    if (a >= LIBM_T_SINCOS_BASE && a < LIBM_T_SINCOS_BASE + 8 * 440) return T_sincos[(a - LIBM_T_SINCOS_BASE) / 8];
+    if (a >= LIBM_T_ATAN_BASE && a < LIBM_T_ATAN_BASE + 8 * 241 * 7) return T_atan[(a - LIBM_T_ATAN_BASE) / 8];
+    return 0;
+}
+#undef LIBM_CONST
+#undef LIBM_TABLE
+#undef LIBM_FN
+#undef D
+#undef B
+#undef DB
+#undef UNSUPPORTED
+#undef S64
+#undef W64
+#undef S32
+#undef W32
+#undef LD64
+#undef LD32
+}   // namespace glibc235
+
+// steer (new_state).  2D: rrt_star_2d.py:67-78 with the reference's own libm functions (above); 3D: rrt_star_3d.py:67-78, IEEE only.
 template <int D>
 __device__ __forceinline__ void steer(const TreeHot &t, const double *from, const double *to, double *out)
 {
@@ -2046,9 +2087,9 @@ __device__ __forceinline__ void steer(const TreeHot &t, const double *from, cons
     double dist = hypot_py<D>(d);
     double m = dist < t.step_len ? dist : t.step_len;
     if (D == 2) {
-        double theta = atan2(d[1], d[0]);
-        out[0] = from[0] + m * cos(theta);
-        out[1] = from[1] + m * sin(theta);
+        const double theta = glibc235::glibc_atan2(d[1], d[0]);
+        out[0] = from[0] + m * glibc235::glibc_cos(theta, 0.);
+        out[1] = from[1] + m * glibc235::glibc_sin(theta, 0.);
     } else {
         double dir[3] = {0., 0., 0.};
         if (dist != 0) {

@@ -15,7 +15,8 @@ _SO = os.path.join(_HERE, "libnirrt_oracle.so")
 
 def build(force=False):
     src = os.path.join(_HERE, "nirrt_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    mk = os.path.join(_HERE, "Makefile")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(mk)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
