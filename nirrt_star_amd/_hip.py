@@ -72,13 +72,14 @@ STAT_NAMES = ["visited", "visit_bytes", "members", "spilled", "hop_records", "re
 def useful_bytes(stats, dim):
     """Bytes the IMPLEMENTED algorithm has to move for what a launch did (per tree or summed), from the kernel's own
     counters (include/nirrt_hip.h, nirrt_run_args.stats): visited slot records (32 B, + 4 B of index in 3D - already in
-    bytes), 64 B per tree record walked (four hops each), one 32-byte vertex record + one 64-byte tree record per rewire
-    candidate examined, 16 B written per re-costed vertex (its record's and its slot's cost), 12 B + one 32-byte record per
-    re-evaluated list entry, 136 B (+ 4 in 3D) written per inserted vertex (vertex record 32, tree record 64, slot record 32,
-    two link words), 32 B read + 32 + 4 (+ 4 in 3D) + 8 B written per vertex of an index rebuild."""
+    bytes), 96 B per tree record walked (the hop part: eight hops each since round 5; 64 B / four hops before), one 32-byte
+    vertex record + 20 B of its tree record (links, parent) per rewire candidate examined, 16 B written per re-costed vertex
+    (its record's and its slot's cost), 12 B + one 32-byte record per re-evaluated list entry, 184 B (+ 4 in 3D) written per
+    inserted vertex (vertex record 32, tree record 112, slot record 32, two link words), 32 B read + 32 + 4 (+ 4 in 3D) + 8 B
+    written per vertex of an index rebuild."""
     st = np.asarray(stats, dtype=np.float64).reshape(-1, N_STATS).sum(axis=0)
     d3 = 4 if dim == 3 else 0
-    return float(st[1] + 64 * st[4] + 96 * st[5] + 16 * st[7] + 44 * st[8] + (136 + d3) * st[9] + (32 + 32 + 4 + d3 + 8) * st[10])
+    return float(st[1] + 96 * st[4] + 52 * st[5] + 16 * st[7] + 44 * st[8] + (184 + d3) * st[9] + (32 + 32 + 4 + d3 + 8) * st[10])
 
 
 _lib = None

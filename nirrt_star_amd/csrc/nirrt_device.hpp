@@ -88,7 +88,7 @@ struct Topo;
 #endif
 #define OB_POOL NIRRT_OBSTACLE_POOL   // slots the obstacle tables may take (the rest, >= 256 entries, is the stash)
 #define SCAN_PAD 256     // extra elements allocated behind every per-vertex array (vector loads may overrun n)
-#define WALK_R 4         // parent chains chased concurrently per lane
+#define WALK_R (NHOP == 8 ? 2 : 4)   // parent chains chased concurrently per lane (their records live in registers)
 #ifndef CHAIN_MAX
 #define CHAIN_MAX 96     // LDS slots for the new->root edge-length sequence (deeper chains continue in HBM, t.chain_g)
 #endif
@@ -189,35 +189,53 @@ __device__ __forceinline__ int tidx()
 // ------------------------------------------------------------------------------------------------
 // per-tree state in HBM
 // ------------------------------------------------------------------------------------------------
-// four hops of the parent chain in one 48-byte record: a cost() walk needs one memory round trip per FOUR edges.
+// NHOP hops of the parent chain in one record: a cost() walk needs one memory round trip per NHOP edges.
 // e[j] / a[j] = length / upper end of the j-th edge above the vertex; beyond the root the entries are (0, 0), and
 // adding 0.0 to the (non-negative) running sum leaves it bit-identical, so a walk may run over the end of the chain.
+// Round 5: 8 hops (96 bytes) instead of 4 - cost(new), the one long dependent pointer chase of an iteration (~40 edges at
+// 50 000 vertices), is 5 round trips instead of 10.
+#ifndef NHOP
+#define NHOP 8
+#endif
 struct __attribute__((aligned(16))) Hop4 {
-    double e[4];
-    int a[4];
+    double e[NHOP];
+    int a[NHOP];
 };
 
-// the hop part (first 48 bytes) of a vertex's record
+// the hop part (first 12 * NHOP bytes) of a vertex's record
 __device__ __forceinline__ Hop4 ld_hop(const GAS Topo *p) { return ldg(reinterpret_cast<const GAS Hop4 *>(p)); }
 __device__ __forceinline__ void st_hop(GAS Topo *p, const Hop4 &h) { stg(reinterpret_cast<GAS Hop4 *>(p), h); }
 
 __device__ __forceinline__ Hop4 hop_shift(const Hop4 &p, double e0, int a0)
 {
     Hop4 r;
-    r.e[0] = e0; r.e[1] = p.e[0]; r.e[2] = p.e[1]; r.e[3] = p.e[2];
-    r.a[0] = a0; r.a[1] = p.a[0]; r.a[2] = p.a[1]; r.a[3] = p.a[2];
+    r.e[0] = e0; r.a[0] = a0;
+#pragma unroll
+    for (int j = 1; j < NHOP; j++) { r.e[j] = p.e[j - 1]; r.a[j] = p.a[j - 1]; }
     return r;
 }
 
-// Everything about a vertex's place in the tree in ONE 64-byte record (one sector): the four hops above it (a[0] = its
+// Everything about a vertex's place in the tree in ONE record (one 128-byte line with NHOP = 8): the hops above it (a[0] = its
 // parent, e[0] = math.hypot(v - v_parent), the term cost() adds for this vertex; 0 for the root), its child-list links and
 // its list-membership flags.  A cost walk, a re-parenting and a subtree traversal each touch one record per vertex.
-struct __attribute__((aligned(64))) Topo {
-    double e[4];
-    int a[4];
+struct __attribute__((aligned(NHOP == 8 ? 128 : 64))) Topo {
+    double e[NHOP];
+    int a[NHOP];
     int fc, ns, ps;   // first child, next / previous sibling (-1 = none); the root is nobody's child
     int flags;        // bit 0 = in sol[], bit 1 = in gc_idx[] (a re-costed listed vertex invalidates the cached best)
 };
+// the links + flags of a vertex (the 16 bytes behind the hop part) in one load
+struct __attribute__((aligned(16))) TopoLinks { int fc, ns, ps, flags; };
+__device__ __forceinline__ TopoLinks ld_links(const GAS Topo *p)
+{
+    return ldg(reinterpret_cast<const GAS TopoLinks *>(reinterpret_cast<const GAS char *>(p) + sizeof(Hop4)));
+}
+__device__ __forceinline__ void st_links(GAS Topo *p, const TopoLinks &l)
+{
+    stg(reinterpret_cast<GAS TopoLinks *>(reinterpret_cast<GAS char *>(p) + sizeof(Hop4)), l);
+}
+// a whole record without its padding: hop part + links
+__device__ __forceinline__ void ld_topo(const GAS Topo *p, Hop4 &h, TopoLinks &l) { h = ld_hop(p); l = ld_links(p); }
 
 // random-access twin of a vertex: one 32-byte record (half a 64-byte sector) holds everything the O(k) phases
 // need about a Near candidate - coordinates and the exact cost(v) - so a candidate costs ONE sector read
@@ -1814,7 +1832,7 @@ __device__ __forceinline__ int walk_chains(const TreeHot &t, int (&idx)[WALK_R],
         for (int r = 0; r < WALK_R; r++) {
             if (idx[r] > 0 && idx[r] != stop_at) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < NHOP; j++) {
                     if (idx[r] > 0 && idx[r] != stop_at) {
                         acc[r] += h[r].e[j];
                         idx[r] = h[r].a[j];
@@ -1909,9 +1927,9 @@ NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int 
             if (in_lds) { const int *f = fr + cur * 3 * BFS_FRONT; u = f[i - head]; c = f[BFS_FRONT + i - head]; su = f[2 * BFS_FRONT + i - head]; }
             else { u = t.bfs_q[i]; su = t.g_rank[i]; c = t.bfs_fc[i]; }
             if (c == -2) c = t.topo[u].fc;
-            // the records of the three levels below a re-parented vertex mention its edge too
+            // the records of the NHOP - 1 levels below a re-parented vertex mention its edge too
             Hop4 hu;
-            if (level < 3 && c >= 0) hu = ld_hop(&t.topo[u]);
+            if (level < NHOP - 1 && c >= 0) hu = ld_hop(&t.topo[u]);
             while (c >= 0) {
                 GAS Topo &hc = t.topo[c];
                 const int c_ns = hc.ns, c_fc = hc.fc;   // one record: the sibling link now, the child link for the next level
@@ -1921,9 +1939,9 @@ NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int 
                 t.bfs_fc[pos] = c_fc;
                 const int lp = pos - tail;
                 if (fr && lp < BFS_FRONT) { int *f = fr + (cur ^ 1) * 3 * BFS_FRONT; f[lp] = c; f[BFS_FRONT + lp] = c_fc; f[2 * BFS_FRONT + lp] = su; }
-                if (level < 3) {   // entry 0 of the child's record (its own edge) is unchanged
-                    hc.e[1] = hu.e[0]; hc.e[2] = hu.e[1]; hc.e[3] = hu.e[2];
-                    hc.a[1] = hu.a[0]; hc.a[2] = hu.a[1]; hc.a[3] = hu.a[2];
+                if (level < NHOP - 1) {   // entry 0 of the child's record (its own edge) is unchanged
+#pragma unroll
+                    for (int j = 1; j < NHOP; j++) { hc.e[j] = hu.e[j - 1]; hc.a[j] = hu.a[j - 1]; }
                 }
                 c = c_ns;
             }
@@ -2018,7 +2036,7 @@ __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeHot &t, 
             if (nrec > 0) h = ld_hop(&t.topo[i]);
             nrec++;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < NHOP; j++) {
                 if (i > 0) {
                     acc += h.e[j];
                     if (len < CHAIN_MAX) s.chainE[len] = h.e[j]; else t.chain_g[len] = h.e[j];
@@ -2323,7 +2341,9 @@ NIRRT_FN __device__ void it_extend()
     // (tree size unchanged for a "same point", + 1 otherwise) ride along in the same round trip
     // ... and so does the vertex's tree record (parent chain + head of its child list: what an insertion under it needs)
     const VRec vnear = ldg(&t.vrec[ni]);
-    const Topo tnear = ldg(&t.topo[ni]);
+    Hop4 hnear;
+    TopoLinks tnear;
+    ld_topo(&t.topo[ni], hnear, tnear);
     const double r_same = t.near_r[n], r_grown = t.near_r[n + 1 <= t.cap ? n + 1 : n];
     nearest[0] = vnear.x; nearest[1] = vnear.y;
     if (D == 3) nearest[D - 1] = vnear.z;
@@ -2347,7 +2367,7 @@ NIRRT_FN __device__ void it_extend()
         bool inserted = false;
         if (dup) {
             new_idx = ni;
-            if (tid == 0) s.hop_new = *reinterpret_cast<const Hop4 *>(&tnear);   // only thread 0 reads it back
+            if (tid == 0) s.hop_new = hnear;   // only thread 0 reads it back
 #pragma unroll
             for (int k = 0; k < D; k++) node_new[k] = nearest[k];
         } else if (n >= t.cap) {
@@ -2357,15 +2377,14 @@ NIRRT_FN __device__ void it_extend()
             new_idx = n;
             if (tid == 0) {
                 // (the nearest vertex's record arrived with its coordinates: stores only)
-                const Hop4 hp = *reinterpret_cast<const Hop4 *>(&tnear);
                 const int fc_ni = tnear.fc;
-                s.hop_new = hop_shift(hp, edge_new, ni);
-                Topo tn;
-#pragma unroll
-                for (int j = 0; j < 4; j++) { tn.e[j] = s.hop_new.e[j]; tn.a[j] = s.hop_new.a[j]; }
+                const Hop4 hn = hop_shift(hnear, edge_new, ni);
+                s.hop_new = hn;
                 // link_child(new_idx, ni) with the head read above; new's own links are remembered for a re-parenting
-                tn.fc = -1; tn.ns = fc_ni; tn.ps = -1; tn.flags = 0;
-                stg(&t.topo[new_idx], tn);
+                TopoLinks ln;
+                ln.fc = -1; ln.ns = fc_ni; ln.ps = -1; ln.flags = 0;
+                st_hop(&t.topo[new_idx], hn);
+                st_links(&t.topo[new_idx], ln);
                 VRec vr;
                 vr.x = node_new[0]; vr.y = node_new[1]; vr.z = D == 3 ? node_new[D - 1] : 0.; vr.cost = 0.;
                 stg(&t.vrec[new_idx], vr);
@@ -2393,7 +2412,7 @@ NIRRT_FN __device__ void it_extend()
             for (int k = 0; k < D; k++) s.it.node_new[k] = node_new[k];
             s.it.dup = dup_ ? 1 : 0; s.it.inserted = inserted_ ? 1 : 0; s.it.edge_new = edge_new_; s.it.cost_ni = vnear.cost;
             s.it.r_query = inserted_ ? r_grown : r_same;
-            s.it.dup_parent = tnear.a[0]; s.it.dup_ns = tnear.ns; s.it.dup_ps = tnear.ps; s.it.dup_fc = tnear.fc;
+            s.it.dup_parent = hnear.a[0]; s.it.dup_ns = tnear.ns; s.it.dup_ps = tnear.ps; s.it.dup_fc = tnear.fc;
         }
     }
     __syncthreads();
@@ -2453,9 +2472,8 @@ NIRRT_FN __device__ void it_connect()
                 if (tid == 0) {
                     // loads first (one round trip), then the stores
                     const VRec vb = ldg(&t.vrec[best_parent]);
-                    const Topo tb = ldg(&t.topo[best_parent]);
-                    const Hop4 hp = *reinterpret_cast<const Hop4 *>(&tb);
-                    const int fc_bp = tb.fc;
+                    const Hop4 hp = ld_hop(&t.topo[best_parent]);
+                    const int fc_bp = t.topo[best_parent].fc;
                     int old_p, nx, pv;
                     if (dup) { old_p = tnear.a[0]; nx = tnear.ns; pv = tnear.ps; }   // new_idx == ni: its record is at hand
                     else { old_p = ni; nx = s.new_next; pv = -1; }   // just inserted at the head of ni's children
@@ -2696,7 +2714,8 @@ NIRRT_FN __device__ void it_connect()
                     const double bound = new_cost - (1e-9 + 1e-11 * new_cost);   // an ancestor that passes costs more than cost(new)
                     const int clen = s.chain_len;
                     VRec vr;
-                    Topo tp;
+                    TopoLinks tp;      // (single: the candidate's links + parent stay in registers; its hops are read when phase B needs them)
+                    int tp_a0 = 0;
                     int slot = 0;
                     for (;;) {
                         __syncthreads();
@@ -2712,7 +2731,7 @@ NIRRT_FN __device__ void it_connect()
                                 if (st & CAND_DIRTY) {
                                     const int id = ids[a];
                                     vr = ldg(&t.vrec[id]);
-                                    if (single) { tp = ldg(&t.topo[id]); slot = id < ns_ ? t.pos[id] : id; }
+                                    if (single) { tp = ld_links(&t.topo[id]); tp_a0 = t.topo[id].a[0]; slot = id < ns_ ? t.pos[id] : id; }
                                     const double dx = vr.x - node_new[0], dy = vr.y - node_new[1], dz = D == 3 ? vr.z - node_new[D - 1] : 0.;
                                     st = vr.cost > new_cost + dist_scan_cold<D>(dx, dy, dz) ? CAND_PASS : 0u;
                                     state[a] = (unsigned char)st;
@@ -2733,14 +2752,12 @@ NIRRT_FN __device__ void it_connect()
                             const int a = base + tid;
                             if (a < n_list && state[a] == CAND_PASS) {
                                 const int id = ids[a];
-                                Hop4 h;
-                                double cst;
-                                if (single) { h = *reinterpret_cast<const Hop4 *>(&tp); cst = vr.cost; }
-                                else { h = ld_hop(&t.topo[id]); cst = t.vrec[id].cost; }
+                                Hop4 h = ld_hop(&t.topo[id]);
+                                double cst = single ? vr.cost : t.vrec[id].cost;
                                 bool blocked = false, stop = false;
                                 for (int guard = 0; guard <= t.cap && !stop; guard++) {
 #pragma unroll
-                                    for (int j = 0; j < 4; j++) {
+                                    for (int j = 0; j < NHOP; j++) {
                                         if (!stop) {
                                             const int anc = h.a[j];
                                             cst -= h.e[j];   // ~ cost(anc)
@@ -2756,7 +2773,7 @@ NIRRT_FN __device__ void it_connect()
                                             }
                                         }
                                     }
-                                    if (!stop) h = ld_hop(&t.topo[h.a[3]]);
+                                    if (!stop) h = ld_hop(&t.topo[h.a[NHOP - 1]]);
                                 }
                                 if (blocked) state[a] = (unsigned char)(CAND_PASS | CAND_BLOCKED);
                             }
@@ -2794,8 +2811,8 @@ NIRRT_FN __device__ void it_connect()
                             int v = -1, pv = -1, nx = -1, old_p = -1, fc = -1, flg = 0;
                             if (mine) {
                                 v = ids[a];
-                                if (!single) { vr = ldg(&t.vrec[v]); tp = ldg(&t.topo[v]); slot = v < ns_ ? t.pos[v] : v; }
-                                pv = tp.ps; nx = tp.ns; old_p = tp.a[0]; fc = tp.fc; flg = tp.flags;
+                                if (!single) { vr = ldg(&t.vrec[v]); tp = ld_links(&t.topo[v]); tp_a0 = t.topo[v].a[0]; slot = v < ns_ ? t.pos[v] : v; }
+                                pv = tp.ps; nx = tp.ns; old_p = tp_a0; fc = tp.fc; flg = tp.flags;
                             }
                             if (tid < 64) { ch_v[tid] = v; ch_pv[tid] = pv; ch_nx[tid] = nx; }
                             __syncthreads();

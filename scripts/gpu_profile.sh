@@ -1,8 +1,8 @@
 #!/bin/bash
 # A round's evidence, collected on the GPU box in ONE gpurun call (everything lands under gpurun_out/<round>/; copy what is wanted
-# into profiles/):   NIRRT_ROUND=r04 gpurun --timeout 3600 -- scripts/gpu_profile.sh [stage ...]     stages: calib traffic stats sq pn2
+# into profiles/):   NIRRT_ROUND=r05 gpurun --timeout 3600 -- scripts/gpu_profile.sh [stage ...]     stages: calib traffic stats sq pn2
 R=$(cd "$(dirname "$0")/.." && pwd)
-RD=${NIRRT_ROUND:-r04}
+RD=${NIRRT_ROUND:-r05}
 export NIRRT_ROUND=$RD
 out=$R/gpurun_out/$RD
 mkdir -p $out $R/profiles
@@ -30,9 +30,19 @@ print("factors", f_fetch, f_write)
 PY
   cp $R/profiles/r03_traffic_calibration.json $out/ ;;
 traffic)
-  for cfg in "" "--algo rrt --world b30" "--algo irrt --dim 3 --trees 4096 --segments 3 --wide-visits 6000 --narrow-visits 2000" "--algo irrt --world b30" "--algo nirrt --trees 4096 --world b30" "--algo rrt --dim 3" "--algo nirrt --dim 3 --trees 2048" "--algo nirrt_c --trees 2048 --world b30"; do
+  # FETCH / WRITE passes of the default line and of every secondary line of bench.py (one configuration key each)
+  python3 - "$R" > $out/traffic_configs.txt <<'PY'
+import sys
+sys.path.insert(0, sys.argv[1])
+import bench
+print("")
+for label, extra in bench.SECONDARY:
+    print(" ".join(e for e in extra if e != "--ttfs"))
+PY
+  while IFS= read -r cfg; do
     python $R/scripts/collect_traffic.py $cfg > $out/traffic_$(echo $cfg | tr -d ' -').txt 2>&1
-  done
+    tail -1 $out/traffic_$(echo $cfg | tr -d ' -').txt | cut -c1-200
+  done < $out/traffic_configs.txt
   cp $R/profiles/${RD}_traffic.json $R/profiles/${RD}_pmc_*.csv $out/ 2>/dev/null ;;
 stats)
   for cfg in "" "--algo irrt --dim 3 --trees 4096 --segments 3 --wide-visits 6000 --narrow-visits 2000"; do
