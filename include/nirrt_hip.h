@@ -15,8 +15,8 @@
  *   - one tree = one opaque handle = one HIP stream; a handle is not thread-safe.
  *   - vertices cross the boundary as (n, dim) row-major float64 (the reference's
  *     `self.vertices[:n]`), parents as int64 (`self.vertex_parents[:n]`).  In HBM a tree is ONE device range (its arena)
- *     holding records, not coordinate columns: a 32-byte vertex record {x, y, z, cost(v)} and a 64-byte
- *     tree record {four hops of the parent chain with their edge lengths, child-list links, flags} per vertex, a 32-byte slot
+ *     holding records, not coordinate columns: a 32-byte vertex record {x, y, z, cost(v)} and a 128-byte
+ *     tree record {eight hops of the parent chain with their edge lengths, child-list links, flags} per vertex, a 32-byte slot
  *     record per vertex of the two-level uniform-grid index (cell-ordered part, coarse level over the recent insertions,
  *     unsorted rest), the solution / goal-candidate lists, the Near-radius table, the guidance cloud and the tree's two
  *     MT19937 generators.  Everything is float64 / int32 on the device; there are no float32 copies.
@@ -233,7 +233,7 @@ typedef struct nirrt_run_args {
                             (B_iter = 2*n*D*8) */
     int64_t *stats;      /* optional (n_trees, NIRRT_N_STATS): what this launch did per tree -
                             [0] slots visited by the fused nearest / Near passes, [1] bytes those visits read (32 B per slot
-                            record, + 4 in 3D), [2] Near members, [3] members spilled out of LDS, [4] tree records (64 B, four
+                            record, + 4 in 3D), [2] Near members, [3] members spilled out of LDS, [4] tree records (96 B of hops, eight
                             hops each) read by cost walks,
                             [5] rewire candidates examined, [6] vertices rewired, [7] vertices re-costed,
                             [8] solution / goal-candidate list entries re-evaluated, [9] vertices inserted,

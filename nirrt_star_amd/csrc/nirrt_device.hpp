@@ -2061,8 +2061,8 @@ __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeHot &t, 
 namespace glibc235 {
 static __device__ __forceinline__ uint64_t ld64(int64_t a);
 #define LIBM_CONST(name, val) static constexpr uint64_t name = val;
-#define LIBM_TABLE(name, n) __device__ const uint64_t name[n]
-#define LIBM_FN static __device__ __noinline__
+#define LIBM_TABLE(name, n) __constant__ uint64_t name[n]   // (constant address space + a wave-uniform index: scalar loads, see ld64)
+#define LIBM_FN static __device__ __forceinline__
 #define D(u) __longlong_as_double((long long)(u))
 #define B(d) ((uint64_t)__double_as_longlong(d))
 #define DB(u) D(u)
@@ -2074,10 +2074,14 @@ static __device__ __forceinline__ uint64_t ld64(int64_t a);
 #define LD64(a) glibc235::ld64(a)
 #define LD32(a) ((uint32_t)glibc235::ld64(a))
 #include "glibc235_libm.inc"
+// a table entry.  Every lane of the workgroup steers the same point, so the address is the same in all of them: it is moved to
+// a scalar register and the entry comes through the scalar cache (s_load_dwordx2) instead of a 64-lane vector load of one word -
+// three dependent table look-ups per steer (atan2, cos, sin) cost ~2.5 us per iteration as vector loads.
 static __device__ __forceinline__ uint64_t ld64(int64_t a)
 {
-    if (a >= LIBM_T_SINCOS_BASE && a < LIBM_T_SINCOS_BASE + 8 * 440) return T_sincos[(a - LIBM_T_SINCOS_BASE) / 8];
-    if (a >= LIBM_T_ATAN_BASE && a < LIBM_T_ATAN_BASE + 8 * 241 * 7) return T_atan[(a - LIBM_T_ATAN_BASE) / 8];
+    const int off = __builtin_amdgcn_readfirstlane((int)a);
+    if (off >= LIBM_T_SINCOS_BASE && off < LIBM_T_SINCOS_BASE + 8 * 440) return T_sincos[(off - LIBM_T_SINCOS_BASE) >> 3];
+    if (off >= LIBM_T_ATAN_BASE && off < LIBM_T_ATAN_BASE + 8 * 241 * 7) return T_atan[(off - LIBM_T_ATAN_BASE) >> 3];
     return 0;
 }
 #undef LIBM_CONST
@@ -2093,6 +2097,17 @@ static __device__ __forceinline__ uint64_t ld64(int64_t a)
 #undef W32
 #undef LD64
 #undef LD32
+// theta = atan2(dy, dx); (cos(theta), sin(theta)): ONE out-of-line function with the three restated routines inlined - their table
+// look-ups (scalar loads) and range tests are scheduled together instead of call after call
+typedef double v2d __attribute__((ext_vector_type(2)));
+static __device__ __noinline__ v2d cos_sin_atan2(double dy, double dx)
+{
+    const double theta = glibc_atan2(dy, dx);
+    v2d cs;
+    cs.x = glibc_cos(theta, 0.);
+    cs.y = glibc_sin(theta, 0.);
+    return cs;
+}
 }   // namespace glibc235
 
 // steer (new_state).  2D: rrt_star_2d.py:67-78 with the reference's own libm functions (above); 3D: rrt_star_3d.py:67-78, IEEE only.
@@ -2105,9 +2120,9 @@ __device__ __forceinline__ void steer(const TreeHot &t, const double *from, cons
     double dist = hypot_py<D>(d);
     double m = dist < t.step_len ? dist : t.step_len;
     if (D == 2) {
-        const double theta = glibc235::glibc_atan2(d[1], d[0]);
-        out[0] = from[0] + m * glibc235::glibc_cos(theta, 0.);
-        out[1] = from[1] + m * glibc235::glibc_sin(theta, 0.);
+        const glibc235::v2d cs = glibc235::cos_sin_atan2(d[1], d[0]);
+        out[0] = from[0] + m * cs.x;
+        out[1] = from[1] + m * cs.y;
     } else {
         double dir[3] = {0., 0., 0.};
         if (dist != 0) {
