@@ -259,6 +259,12 @@ typedef struct nirrt_run_args {
                             is still running when its next turn comes simply keeps its workgroup - nobody waits).  0 = the library
                             chooses (iters / 48, at least 128; env NIRRT_SLICE overrides, 0 there = off), < 0 = off (one workgroup
                             per tree for the whole launch).  Results never depend on it. */
+    const int32_t *run_ahead; /* optional (n_trees,), time-sliced launches: run_ahead[i] != 0 = tree i never waits for its turn - the
+                            workgroup that runs it carries straight on with its next slice.  For trees KNOWN to be long (a free
+                            straight start-goal segment: their iterations get slower as the tree grows): taking turns while their
+                            slices are still short costs them time they cannot make up once the slices are long, and the launch
+                            ends with the last of them (round 5: one such tree, 6.9 s of work spread over 9.5 s of a launch whose
+                            other 8191 trees were done after 7.5 s).  Results never depend on it. */
 } nirrt_run_args;
 int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *args);
 

@@ -60,7 +60,7 @@ class RunArgs(C.Structure):
                 ("status", C.POINTER(C.c_int32)), ("kernel_ms", C.POINTER(C.c_double)),
                 ("scan_elems", C.POINTER(C.c_int64)), ("alg_elems", C.POINTER(C.c_int64)),
                 ("stats", C.POINTER(C.c_int64)), ("iters_each", C.POINTER(C.c_int64)), ("lanes_hint", C.POINTER(C.c_int32)),
-                ("slice_iters", C.c_int64)]
+                ("slice_iters", C.c_int64), ("run_ahead", C.POINTER(C.c_int32))]
 
 N_STATS = 24
 ST_ITERS, ST_T0, ST_T1, ST_CBEST, ST_BUSY = 13, 14, 15, 17, 20   # slots 14 / 15 / 17 are absolute values of a launch, the rest are deltas
@@ -499,7 +499,7 @@ def run_replay(trees, samples, flags=0, want_trace=False, device_ptr=None, iters
 
 
 def run_sampling(trees, iters, np_words=None, py_words=None, flags=0, want_trace=False, on_device=False, iters_each=None, lanes_hint=None,
-                 slice_iters=0):
+                 slice_iters=0, run_ahead=None):
     """Device-resident loop with in-kernel sampling.  np_words = None (the normal case): every tree draws from its own
     generators resident in HBM (set_generators / get_generators).  Otherwise np_words / py_words: per-tree uint32 arrays of
     raw MT19937 outputs (numpy legacy global stream / python `random`); with on_device=True they are
@@ -538,6 +538,11 @@ def run_sampling(trees, iters, np_words=None, py_words=None, flags=0, want_trace
         assert len(hint) == nt
         keep.append(hint)
         a.lanes_hint = hint.ctypes.data_as(C.POINTER(C.c_int32))
+    if run_ahead is not None:      # per-tree flag: a tree known to be long never waits for its turn in a time-sliced launch
+        ahead = np.ascontiguousarray(run_ahead, dtype=np.int32)
+        assert len(ahead) == nt
+        keep.append(ahead)
+        a.run_ahead = ahead.ctypes.data_as(C.POINTER(C.c_int32))
     a.samples = None
     a.slice_iters = int(slice_iters)     # 0: the library decides whether / how to time-slice a batch larger than the GPU; < 0: never
     if np_words is not None:      # None: the trees' own generators (set_generators) produce the words on the device

@@ -171,7 +171,7 @@ def fetch_np(trees, streams, idx):
             streams[i].absorb(np_st=(nk[k], npos[k]))
 
 
-def run_scheduled(trees, seg_len, flags, order=None, hint=None, wide_visits=0.0, narrow_visits=0.0, reorder=True):
+def run_scheduled(trees, seg_len, flags, order=None, hint=None, wide_visits=0.0, narrow_visits=0.0, reorder=True, ahead=None):
     """RRT* / IRRT* on a batch whose trees draw from their own generators, as len(seg_len) persistent launches of seg_len[k]
     iterations each.  Between two launches the HOST re-schedules the independent problems from what the device measured in the
     launch before (problems, generators and results are untouched: a tree resumes exactly where it stopped):
@@ -180,7 +180,9 @@ def run_scheduled(trees, seg_len, flags, order=None, hint=None, wide_visits=0.0,
       * a tree whose fused nearest / Near visits covered >= wide_visits slots per iteration moves to a 256-lane workgroup
         (>= narrow_visits: 128 lanes): its visit is the whole iteration and scales with the lanes (a 3D tree with 14 000 visited
         slots per iteration: 450 us per iteration on one wave, 190 us on four).  Lane groups run at the same time.
-    `order` / `hint`: dispatch order / lane hints (by position in `order`) of the FIRST launch.
+    `order` / `hint`: dispatch order / lane hints (by position in `order`) of the FIRST launch.  `ahead`: per TREE (index into
+    `trees`) flag - a tree known to be long (free straight start-goal segment) never waits for its turn in a time-sliced launch
+    (nirrt_run_args.run_ahead).
     Returns the sums over the segments: kernel_ms, stats (B, N_STATS), alg_elems, iters_done, seconds, status, words; wide /
     narrow = trees on 256 / 128 lanes in the last launch."""
     B = len(trees)
@@ -197,7 +199,8 @@ def run_scheduled(trees, seg_len, flags, order=None, hint=None, wide_visits=0.0,
             keep = {b: (hint[j] if hint is not None else 0) for j, b in enumerate(order)}
             order = live
             hint = np.array([keep[b] for b in order], dtype=np.int32) if hint is not None else None
-        r = _hip.run_sampling([trees[b] for b in order], int(n_it), flags=flags, lanes_hint=hint)
+        r = _hip.run_sampling([trees[b] for b in order], int(n_it), flags=flags, lanes_hint=hint,
+                              run_ahead=None if ahead is None else [1 if ahead[b] else 0 for b in order])
         idx = np.asarray(order)
         secs = r["stats"][:, _hip.ST_BUSY] / 1e8      # (device time inside the loop; a time-sliced launch idles a tree between its slices)
         tot["kernel_ms"] += r["kernel_ms"]

@@ -398,6 +398,7 @@ struct PoolDev {
     int *state;            // per tree: bit 0 = being run, bits 1.. = tickets booked on it while it was being run
     int *round;            // per tree: slices completed
     int *fin;              // per tree: run ended early (nothing left for later slices)
+    const int *ahead;      // per tree (optional): never waits for its turn (nirrt_run_args.run_ahead)
 };
 
 // What one run of the sampling loop (run_tree: a whole launch, or one time slice of it) works from.  It lives in LDS: the loop
@@ -1558,7 +1559,10 @@ NIRRT_FN __device__ void wg_query_fn()
     // Written with selects instead of nested branches (the common path is straight-line code; only the rare long paths -
     // guard-band re-decision, obstacle tests, near-ties of the running minimum - sit behind branches).
     auto process = [&](const SlotRegs &p, double &sm) -> bool {
-        {
+        // (round 5) the loop is bound by instruction issue as much as by latency: a trip slot whose 64 lanes all sit in rows listed
+        // for ONE of the two questions skips the other question's arithmetic altogether (wave-uniform branches: rows are listed
+        // Near rows first, nearest rows after them, so most trip slots are pure)
+        if (__ballot((p.fl & GRID_Q) != 0) != 0ull) {
             const bool isQ = (p.fl & GRID_Q) != 0;
             const double dx = qx - p.x, dy = qy - p.y;
             double wv = dx * dx + dy * dy;
@@ -1569,6 +1573,7 @@ NIRRT_FN __device__ void wg_query_fn()
             m1 = lt1 ? wv : m1;
             i1 = lt1 ? p.id : i1;
         }
+        if (__ballot((p.fl & GRID_N) != 0) == 0ull) { sm = 0.; return false; }   // nobody here answers the Near question
         const double dx = pnx - p.x, dy = pny - p.y, dz = D == 3 ? pnz - p.z : 0.;
         double v = dx * dx + dy * dy;
         if (D == 3) v = v + dz * dz;
@@ -1680,7 +1685,7 @@ NIRRT_FN __device__ void wg_query_fn()
                     if (f0 + u * NT < total) {   // uniform
                         double sm = 0.;
                         const bool member = cur[u].fl ? process(cur[u], sm) : false;
-                        if (wantN) stash(member, cur[u].id, sm);
+                        if (wantN && __ballot(member) != 0ull) stash(member, cur[u].id, sm);
                     }
                 }
 #pragma unroll

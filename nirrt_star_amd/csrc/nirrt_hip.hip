@@ -1476,6 +1476,14 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         HIPCHK_R(dalloc(sizeof(long long) * nt, (void **)&d_each));
         HIPCHK_R(hipMemcpyAsync(d_each, each.data(), sizeof(long long) * nt, hipMemcpyHostToDevice, st));
     }
+    int *d_ahead = nullptr;
+    if (a->run_ahead) {
+        std::vector<int> ah(nt);
+        for (int j = 0; j < n_trees; j++) ah[(size_t)j] = a->run_ahead[perm[(size_t)j]] != 0;
+        HIPCHK_R(dalloc(sizeof(int) * nt, (void **)&d_ahead));
+        HIPCHK_R(hipMemcpyAsync(d_ahead, ah.data(), sizeof(int) * nt, hipMemcpyHostToDevice, st));
+        HIPCHK_R(hipStreamSynchronize(st));   // (the vector goes out of scope)
+    }
     long long *d_col = nullptr;   // k_collect rows before / after the launch
     HIPCHK_R(dalloc(sizeof(long long) * 2 * nt * COLLECT_W, (void **)&d_col));
     hipLaunchKernelGGL(k_collect, dim3((n_trees + 255) / 256), dim3(256), 0, st, (TreeDev *const *)d_ptrs, n_trees, d_col);
@@ -1507,6 +1515,7 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
             PoolDev pd;
             pd.n_trees = n_g; pd.pad = 0; pd.quantum = slice; pd.ticket = (unsigned *)d_pool;
             pd.state = d_pool + 64; pd.round = d_pool + 64 + n_g; pd.fin = d_pool + 64 + 2 * n_g;
+            pd.ahead = d_ahead ? d_ahead + o : nullptr;
             HIPCHK_R(hipEventRecord(g.e0, g.st));
             LAUNCH_V(g.v, D, k_run_pool, resident, g.st, (TreeDev *const *)(d_ptrs + o), rd, pd);
         } else {

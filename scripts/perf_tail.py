@@ -1,40 +1,41 @@
-"""The slowest trees of the default bench batch, alone: per-tree seconds, counters per iteration and (profile build) phase shares.
-    NIRRT_HIP_SO=nirrt_star_amd/libnirrt_hip_prof.so NIRRT_FORCE_VARIANT=slim python scripts/perf_tail.py 1626,5727,1363,3362,2760 [world]"""
-import os, sys
-from types import SimpleNamespace
-sys.path.insert(0, '.')
-import numpy as np
-import bench
-from nirrt_star_amd import _hip, sampling
+#!/usr/bin/env python3
+"""Which trees end a time-sliced launch: busy time vs wall span of the slowest trees of one bench step (python scripts/perf_tail.py [bench args])"""
+import os
+import sys
 
-# "find:B" = the whole batch of B problems, slowest 8 printed; TAIL_DIM=3 for the 3D worlds
-find = sys.argv[1].startswith("find:")
-pids = list(range(int(sys.argv[1][5:]))) if find else [int(x) for x in sys.argv[1].split(",")]
-world = sys.argv[2] if len(sys.argv) > 2 else "b30"
-iters = int(os.environ.get("TAIL_ITERS", "50000"))
-DIM = int(os.environ.get("TAIL_DIM", "2"))
-a = SimpleNamespace(algo="irrt", dim=DIM, world=world, iters=iters, trees=0)
-cache, trees = {}, []
-for pid in pids:
-    pr = bench.make_problem(a, pid, cache)
-    t = _hip.HipTree(DIM, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"])
-    t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
-    trees.append(t)
-np_st, py_st = bench.problem_generators(pids)
-_hip.set_generators(trees, np_st, py_st)
-res = _hip.run_sampling(trees, iters, flags=_hip.F_IRRT)
-st = res["stats"].astype(float)
-secs = (st[:, 15] - st[:, 14]) / 1e8
-names = _hip.STAT_NAMES
-show = list(np.argsort(-secs)[:8]) if find else range(len(pids))
-if find:
-    print("kernel %.0f ms; per-tree s: mean %.2f median %.2f p99 %.2f max %.2f; slowest: %s" % (res["kernel_ms"], secs.mean(), np.median(secs), np.percentile(secs, 99), secs.max(), ",".join(str(pids[i]) for i in show)))
-for i in show:
-    pid = pids[i]
-    print("pid %d: %.2f s n=%d | " % (pid, secs[i], trees[i].n) + ", ".join("%s %.1f" % (names[j], st[i, j] / iters) for j in list(range(13)) + [18, 19]))
-pr_ = np.array([t.debug_prof() for t in trees]).astype(float)
-pn = ["nearest", "steer+edge", "query", "choose", "cost(new)", "rewire", "goal/ingoal", "report", "(R.collect)", "(R.relink C)", "(R.recost)", "(R.recost.bfs)", "rebuild", "(Q.visit)", "(Q.nearest)", "(Q.finish)", "L.draw", "L.iteration", "L.report", "L.other", "(Q.setup)", "(R.test A)", "(R.block B)", "#bfs_levels"]
-for row in pr_[:0] if find else pr_:
-    tot = row[16:20].sum()
-    if tot > 0:
-        print("phase share: " + ", ".join("%s %.1f%%" % (n, 100 * v / tot) for n, v in zip(pn, row) if v > 0), "| us/iter %.1f" % (tot / iters / 100.0))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    args = bench.parse(sys.argv[1:])
+    from nirrt_star_amd import _hip, sampling
+    probs = bench.make_problems(args, 0)
+    D, iters = args.dim, args.iters
+    flags = _hip.F_IRRT if args.algo == "irrt" else 0
+    trees = []
+    for pr in probs:
+        t = _hip.HipTree(D, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"])
+        t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
+        trees.append(t)
+    free = [not t.is_collision(pr["x_start"], pr["x_goal"]) for t, pr in zip(trees, probs)]
+    order = sorted(range(len(trees)), key=lambda b: (not free[b], b)) if args.algo == "irrt" else list(range(len(trees)))
+    np_st, py_st = bench.problem_generators([probs[b]["pid"] for b in order])
+    launch = [trees[b] for b in order]
+    _hip.set_generators(launch, np_st, py_st)
+    ahead = [1 if free[b] else 0 for b in order] if os.environ.get("RUN_AHEAD", "1") == "1" else None
+    r = _hip.run_sampling(launch, iters, flags=flags, run_ahead=ahead)
+    st = r["stats"].astype(np.float64)
+    busy = st[:, _hip.ST_BUSY] / 1e8
+    t0, t1 = st[:, 14] / 1e8, st[:, 15] / 1e8
+    base = t0.min()
+    print("kernel %.0f ms; busy mean %.3f max %.3f; last tree ends %.3f s after the first starts" % (r["kernel_ms"], busy.mean(), busy.max(), t1.max() - base))
+    for j in np.argsort(-t1)[:12]:
+        print("  launch pos %5d pid %5d free %d: starts %.3f ends %.3f busy %.3f  visited/it %.0f members/it %.0f rewire cand/it %.1f one-by-one %.2f"
+              % (j, probs[order[j]]["pid"], free[order[j]], t0[j] - base, t1[j] - base, busy[j], st[j, 0] / iters, st[j, 2] / iters, st[j, 5] / iters, st[j, 19] / iters))
+
+
+if __name__ == "__main__":
+    main()

@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_hip.StepResult) == 8 + 16 + 16 + 8 + 24 + 8 + 8 + 8 + 8
     assert _hip.StepResult.c_best.offset == 72
     assert C.sizeof(_hip.Config) == 8 + 8 + 24 + 24 + 24 + 24 + 24 + 8 + 8 + 8 + 8
-    assert C.sizeof(_hip.RunArgs) == 8 + 8 + 8 * 17
+    assert C.sizeof(_hip.RunArgs) == 8 + 8 + 8 * 18
 
 
 def test_no_silent_cpu_fallback_without_device():

@@ -40,7 +40,9 @@ def test_time_sliced_launch_equals_one_workgroup_per_tree(name, irrt, stop_first
         else:
             monkeypatch.delenv("NIRRT_POOL_RESIDENT", raising=False)
         trees = _batch(g, B, iters, 7000)
-        r = _hip.run_sampling(trees, iters, flags=flags, want_trace=True, iters_each=each, slice_iters=(-1 if mode == "plain" else 137))
+        ahead = None if mode == "plain" else [1 if b % 5 == 0 else 0 for b in range(B)]     # (every fifth tree never waits for its turn)
+        r = _hip.run_sampling(trees, iters, flags=flags, want_trace=True, iters_each=each, slice_iters=(-1 if mode == "plain" else 137),
+                              run_ahead=ahead)
         st = _hip.get_generators(trees)
         out[mode] = (r, [t.download() for t in trees], [t.solutions for t in trees], st)
         for t in trees:
