@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libnirrt_hip.so")
 SOURCES = [os.path.join(CSRC, "nirrt_hip.hip"), os.path.join(CSRC, "pointops.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "nirrt_device.hpp"), os.path.join(CSRC, "nirrt_kernels.inc"), os.path.join(CSRC, "glibc235_libm.inc"),
+DEPS = SOURCES + [os.path.join(CSRC, "nirrt_device.hpp"), os.path.join(CSRC, "nirrt_kernels.inc"), os.path.join(CSRC, "glibc235_libm.inc"), os.path.join(CSRC, "glibc235_device.inc"),
                   os.path.join(os.path.dirname(HERE), "include", "nirrt_hip.h")]
 # one module-wide LDS object at the same address in every kernel: the non-inlined loop-body functions then address it
 # with constant offsets instead of a per-kernel offset-table lookup (see LdsData in csrc/nirrt_device.hpp)

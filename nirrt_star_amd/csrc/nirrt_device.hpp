@@ -2063,57 +2063,11 @@ __device__ __forceinline__ double wg_chain_of_new(Lds<NT> &s, const TreeHot &t, 
 // call on an FMA + AVX2 host), restated instruction by instruction - see csrc/glibc235_libm.inc.  With them the 2D steer is
 // bit-identical to the reference's (rounds 1-4 used the device's own libm: vertices within 1e-9, and on degenerate trees - free
 // straight start-goal segment, hundreds of near-ties per rewiring pass - an ulp was enough to flip a parent now and then).
-namespace glibc235 {
-static __device__ __forceinline__ uint64_t ld64(int64_t a);
-#define LIBM_CONST(name, val) static constexpr uint64_t name = val;
-#define LIBM_TABLE(name, n) __constant__ uint64_t name[n]   // (constant address space + a wave-uniform index: scalar loads, see ld64)
-#define LIBM_FN static __device__ __forceinline__
-#define D(u) __longlong_as_double((long long)(u))
-#define B(d) ((uint64_t)__double_as_longlong(d))
-#define DB(u) D(u)
-#define UNSUPPORTED(msg) return __builtin_nan("")
-#define S64(off) stk[(off) / 8]
-#define W64(off, v) (stk[(off) / 8] = (v))
-#define S32(off) ((uint32_t)(stk[(off) / 8] >> (((off) & 4) * 8)))
-#define W32(off, v) (stk[(off) / 8] = (stk[(off) / 8] & ~(0xffffffffull << (((off) & 4) * 8))) | ((uint64_t)(uint32_t)(v) << (((off) & 4) * 8)))
-#define LD64(a) glibc235::ld64(a)
-#define LD32(a) ((uint32_t)glibc235::ld64(a))
-#include "glibc235_libm.inc"
-// a table entry.  Every lane of the workgroup steers the same point, so the address is the same in all of them: it is moved to
-// a scalar register and the entry comes through the scalar cache (s_load_dwordx2) instead of a 64-lane vector load of one word -
-// three dependent table look-ups per steer (atan2, cos, sin) cost ~2.5 us per iteration as vector loads.
-static __device__ __forceinline__ uint64_t ld64(int64_t a)
-{
-    const int off = __builtin_amdgcn_readfirstlane((int)a);
-    if (off >= LIBM_T_SINCOS_BASE && off < LIBM_T_SINCOS_BASE + 8 * 440) return T_sincos[(off - LIBM_T_SINCOS_BASE) >> 3];
-    if (off >= LIBM_T_ATAN_BASE && off < LIBM_T_ATAN_BASE + 8 * 241 * 7) return T_atan[(off - LIBM_T_ATAN_BASE) >> 3];
-    return 0;
-}
-#undef LIBM_CONST
-#undef LIBM_TABLE
-#undef LIBM_FN
-#undef D
-#undef B
-#undef DB
-#undef UNSUPPORTED
-#undef S64
-#undef W64
-#undef S32
-#undef W32
-#undef LD64
-#undef LD32
-// theta = atan2(dy, dx); (cos(theta), sin(theta)): ONE out-of-line function with the three restated routines inlined - their table
-// look-ups (scalar loads) and range tests are scheduled together instead of call after call
-typedef double v2d __attribute__((ext_vector_type(2)));
-static __device__ __noinline__ v2d cos_sin_atan2(double dy, double dx)
-{
-    const double theta = glibc_atan2(dy, dx);
-    v2d cs;
-    cs.x = glibc_cos(theta, 0.);
-    cs.y = glibc_sin(theta, 0.);
-    return cs;
-}
-}   // namespace glibc235
+#define GLIBC_NS glibc235
+#define GLIBC_UNIFORM 1
+#include "glibc235_device.inc"
+#undef GLIBC_NS
+#undef GLIBC_UNIFORM
 
 // steer (new_state).  2D: rrt_star_2d.py:67-78 with the reference's own libm functions (above); 3D: rrt_star_3d.py:67-78, IEEE only.
 template <int D>

@@ -9,6 +9,13 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+// glibc 2.35's sin / cos (restated; every lane its own argument): the 3D ellipsoid candidates of the guidance clouds
+#define GLIBC_NS glibc235v
+#define GLIBC_UNIFORM 0
+#include "glibc235_device.inc"
+#undef GLIBC_NS
+#undef GLIBC_UNIFORM
+
 #define FPS_NT 1024
 #define FPS_MAX_PER_THREAD 8   // N <= 8192
 
@@ -466,7 +473,9 @@ __global__ __launch_bounds__(CAND_NT) void k_cloud_candidates(const nirrt_cloud_
                     const double rr = 0.0 + (1.0 - 0.0) * mt_double(jb.words, (long long)i);
                     const double th = 0.0 + (PI - 0.0) * mt_double(jb.words, (long long)n_raw + i);
                     const double ph = 0.0 + (2 * PI - 0.0) * mt_double(jb.words, 2ll * n_raw + i);
-                    const double st = sin(th), ct = cos(th), sp = sin(ph), cp = cos(ph);
+                    // (np.sin / np.cos of numpy 2.2 are libm's for float64: the restated glibc functions, one argument per lane)
+                    const double st = glibc235v::sin_fn(th), ct = glibc235v::cos_fn(th);
+                    const double sp = glibc235v::sin_fn(ph), cp = glibc235v::cos_fn(ph);
                     const double s0 = rr * st * cp, s1 = rr * st * sp, s2 = rr * ct;
                     x = __builtin_fma(jb.a[2], s2, __builtin_fma(jb.a[1], s1, jb.a[0] * s0)) + jb.a[9];
                     y = __builtin_fma(jb.a[5], s2, __builtin_fma(jb.a[4], s1, jb.a[3] * s0)) + jb.a[10];
