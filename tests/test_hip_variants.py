@@ -71,7 +71,7 @@ def test_variant_in_kernel_sampling_irrt(forced_variant, name):
 
 
 def test_variant_in_kernel_sampling_irrt3d_and_resume(forced_variant):
-    S.test_irrt3d_in_kernel_sampling_tolerance()
+    S.test_irrt3d_in_kernel_sampling_bit_equal()
     S.test_stream_exhaustion_stops_cleanly_and_resumes()
 
 
