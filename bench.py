@@ -129,8 +129,9 @@ def make_problem(args, pid, cache=None):
         w = pid % 250
         if w not in cache:
             kind, rr = {"b30": ("b30", None), "b30r16": ("b30", (16, 24)), "ref2d": ("ref2d", None)}[args.world]
-            cache[w] = worlds.random_world_2d(w, kind, circle_radius_range=rr)
-        pr = worlds.problem_2d(cache[w], (pid // 250) % 4)
+            ed = worlds.random_world_2d(w, kind, circle_radius_range=rr)
+            cache[w] = (ed, worlds.rasterize_mask_2d(ed["env_dims"], ed["rectangle_obstacles"], ed["circle_obstacles"]))
+        pr = worlds.problem_2d(cache[w][0], (pid // 250) % 4, mask=cache[w][1])      # (one rasterisation per world, not per problem)
         pr["clearance"] = 3
     else:
         np.random.seed(pid)

@@ -692,8 +692,7 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     if (t->arena && t->arena_pooled) g_pool.give(t->device, t->arena_bytes, t->arena);
     else if (t->arena) (void)hipFree(t->arena);
     if (t->scratch) (void)hipHostFree(t->scratch);
-    if (t->stream) (void)hipStreamDestroy(t->stream);
-    delete t;
+    delete t;      // (the stream belongs to the device's pool)
     return NIRRT_OK;
 }
 
@@ -736,8 +735,70 @@ extern "C" int nirrt_reset_batch(nirrt_tree *const *trees, int32_t n_trees)
     return rc;
 }
 
+static hipStream_t tree_stream(int device)
+{
+    static std::mutex mu;
+    static std::map<int, std::vector<hipStream_t>> pools;
+    static std::map<int, size_t> next;
+    std::lock_guard<std::mutex> g(mu);
+    std::vector<hipStream_t> &p = pools[device];
+    if (p.empty()) {   // all of a device's streams at its first tree: one-time runtime allocations, like the code objects
+        for (int i = 0; i < 32; i++) {
+            hipStream_t st = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+            p.push_back(st);
+        }
+        if (p.empty()) return nullptr;
+    }
+    return p[next[device]++ % p.size()];
+}
+
+// the Near radius r(n) = min(gamma * f(n), step_len) with f(n) = sqrt(log n / n) (2D) / (log n / n)^(1/3) (3D), host libm
+// (rrt_star_2d.py:133, rrt_star_3d.py:134): f depends on the dimension only - tabulated once per capacity, not per tree
+static const std::vector<double> &near_factor(int D, int cap)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, std::vector<double>> tabs;
+    std::lock_guard<std::mutex> g(mu);
+    std::vector<double> &f = tabs[{D, cap}];
+    if (f.empty()) {
+        f.assign((size_t)cap + 1, 0.0);
+        for (int n = 1; n <= cap; n++) {
+            const double x = std::log((double)n) / (double)n;
+            f[(size_t)n] = D == 2 ? std::sqrt(x) : std::pow(x, 1 / 3.);
+        }
+    }
+    return f;
+}
+
+// NIRRT_CREATE_PROFILE=1: host seconds per stage of nirrt_create, printed every 1024 trees (set-up of a large batch is outside the
+// benchmark's timed step but it is what a user waits for first)
+#include <chrono>
+static double g_create_s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static long g_create_n = 0;
+struct CreateTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    CreateTimer() : on(std::getenv("NIRRT_CREATE_PROFILE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void lap(int slot)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        g_create_s[slot] += std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+    }
+    void done()
+    {
+        if (!on) return;
+        if (++g_create_n % 1024 == 0)
+            fprintf(stderr, "nirrt_create x %ld: stream %.3f arena %.3f memset %.3f pinned %.3f near_r %.3f desc+reset %.3f s\n", g_create_n,
+                    g_create_s[0], g_create_s[1], g_create_s[2], g_create_s[3], g_create_s[4], g_create_s[5]);
+    }
+};
+
 extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
 {
+    CreateTimer tm;
     if (!cfg || !out) { g_err = "null argument"; return NIRRT_E_ARG; }
     *out = nullptr;
     if (cfg->dim != 2 && cfg->dim != 3) { g_err = "dim must be 2 or 3"; return NIRRT_E_ARG; }
@@ -780,7 +841,11 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         }                                                                                     \
     } while (0)
     HIPCHK_T(hipSetDevice(t->device));
-    HIPCHK_T(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    // A tree's calls are ordered on its stream.  Thousands of trees do not get a stream each (0.44 ms per hipStreamCreate, and a
+    // handful of hardware queues behind them anyway): the trees of a device share a pool of 32, dealt round-robin.
+    t->stream = tree_stream(t->device);
+    if (!t->stream) return fail(NIRRT_E_HIP);
+    tm.lap(0);
     TreeDev &h = t->host;
     const size_t np = (size_t)t->cap + SCAN_PAD;   // padded element count of every per-vertex array
     // uniform-grid index: 256^2 / 32^3 cells over the range box (2D, measured at the bench configuration: 256^2 visits
@@ -827,6 +892,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         size_t off = 0;
         for (const Piece &pc : pieces) { *pc.dst = (char *)t->arena + off; off += (pc.bytes + A - 1) / A * A; }
     }
+    tm.lap(1);
     HIPCHK_T(hipMemset(h.vrec, 0, sizeof(VRec) * np));
     HIPCHK_T(hipMemset(h.tie_stamp, 0, sizeof(int) * np));   // (a pooled arena carries an earlier tree's stamps)
     HIPCHK_T(hipMemset(t->mt, 0, sizeof(MtGen)));   // (generator 5489-less: all-zero state until nirrt_set_generators)
@@ -853,20 +919,23 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         h.g_margin2[k] = ext / (double)h.g_G2 / 256.0;
     }
     HIPCHK_T(hipMemcpy(t->self_dev, &t->dev, sizeof(TreeDev *), hipMemcpyHostToDevice));
+    tm.lap(2);
     HIPCHK_T(hipHostMalloc((void **)&t->scratch, sizeof(Scratch), hipHostMallocMapped));
     HIPCHK_T(hipHostGetDevicePointer((void **)&t->scratch_dev, t->scratch, 0));
+    tm.lap(3);
     // Near radius table with the host libm (the reference's math.sqrt/math.log/float pow):
     // rrt_star_2d.py:133  r = min(gamma*sqrt(log(n)/n), step_len);  rrt_star_3d.py:134 cube root
     {
+        const std::vector<double> &f = near_factor(D, t->cap);
         std::vector<double> r((size_t)t->cap + 1, 0.0);
         for (int n = 1; n <= t->cap; n++) {
-            double x = std::log((double)n) / (double)n;
-            double v = D == 2 ? cfg->search_radius * std::sqrt(x) : cfg->search_radius * std::pow(x, 1 / 3.);
+            const double v = cfg->search_radius * f[(size_t)n];
             r[(size_t)n] = v < cfg->step_len ? v : cfg->step_len;
         }
         HIPCHK_T(hipMemcpy(t->near_r, r.data(), sizeof(double) * r.size(), hipMemcpyHostToDevice));
     }
     h.near_r = t->near_r;
+    tm.lap(4);
     for (int k = 0; k < 3; k++) {
         h.start[k] = k < D ? cfg->x_start[k] : 0.;
         h.goal[k] = k < D ? cfg->x_goal[k] : 0.;
@@ -893,6 +962,8 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     int rc = push_desc(t);
     if (!rc) rc = nirrt_reset(t);
     if (rc) return fail(rc);
+    tm.lap(5);
+    tm.done();
     *out = t;
     return NIRRT_OK;
 #undef HIPCHK_T

@@ -196,12 +196,15 @@ def random_world_3d(seed):
 # ----------------------------------------------------------------------------
 # problem dicts (reference schema)
 # ----------------------------------------------------------------------------
-def problem_2d(env_dict, pair=0):
-    """= get_random_2d_problem_input (planning_problem_utils_2d.py:145-162) minus the png read."""
+def problem_2d(env_dict, pair=0, mask=None):
+    """= get_random_2d_problem_input (planning_problem_utils_2d.py:145-162) minus the png read.  `mask`: the world's free-space
+    mask if the caller already has it (it does not depend on the start / goal pair: batches of thousands of problems over a few
+    hundred worlds rasterise each world once)."""
     ed = dict(env_dict)
     ed["start"] = [list(env_dict["start"][pair])]
     ed["goal"] = [list(env_dict["goal"][pair])]
-    mask = rasterize_mask_2d(ed["env_dims"], ed["rectangle_obstacles"], ed["circle_obstacles"])
+    if mask is None:
+        mask = rasterize_mask_2d(ed["env_dims"], ed["rectangle_obstacles"], ed["circle_obstacles"])
     return {
         "x_start": tuple(ed["start"][0]),
         "x_goal": tuple(ed["goal"][0]),
