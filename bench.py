@@ -64,6 +64,9 @@ def parse(argv=None):
     ap.add_argument("--world", default="b30r16", choices=sorted(WORLDS),
                     help="b30r16 = SURVEY.md 8(d)'s primary world (30 circles r in [16, 24], start / goal in one free component); b30 = its "
                          "lighter fallback (r in [8, 12])")
+    ap.add_argument("--pc-update-cost-ratio", type=float, default=0.9,
+                    help="guided lines: refresh the cloud when the best cost drops below this fraction of the cost at the last refresh "
+                         "(0.9 = the planner classes' and eval scripts' default; demo_planning_3d.py:21 passes 1.0: every improvement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=6000, help="iterations each CPU-baseline process runs (per repetition)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline processes (0 = every host core)")
@@ -412,7 +415,7 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):   # the wrapper announces itself like the reference's does; stdout carries ONE JSON line
         wrapper = eval_sharded.make_wrapper(NS(root_dir=os.path.join(ROOT, "gpurun_out", "bench_ck")), D, "cuda:%d" % local_rank)
-    guidance = batch.Guidance(wrapper, D, 10, connect=args.algo == "nirrt_c", device_id=local_rank)
+    guidance = batch.Guidance(wrapper, D, 10, pc_update_cost_ratio=args.pc_update_cost_ratio, connect=args.algo == "nirrt_c", device_id=local_rank)
     trees, frames = [], []
     for pr in probs:
         t = _hip.HipTree(D, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"], device_id=local_rank)

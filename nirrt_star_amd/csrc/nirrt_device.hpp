@@ -99,6 +99,11 @@ struct Topo;
 #ifndef NEAR_STASH
 #define NEAR_STASH LDS_POOL      // upper limit of Near members whose (index, bound) pair stays in LDS (the pool slots the
 #endif                           // obstacle tables leave free); the rest spills to nr_idx / nr_m.  Test builds set it to 8.
+#ifndef GRID_U_WIDE
+#define GRID_U_WIDE 2            // ... of the 256-lane kernels (one or a few heavy trees).  Round 5: 3 and 4 spill inside the visit and lose
+                                 // everywhere the 256-lane kernels run (1000-problem set 18.2 / 16.6 / 15.4 M it/s, one tree alone
+                                 // 1.66 / 1.73 / 1.82 s, 3D IRRT* 11.0 / 10.9 / 10.3)
+#endif
 #ifndef GRID_U
 #define GRID_U 2                 // slots per lane and trip of a grid visit (measured: 2 beats 4 by 12 %, 8 spills).  Round 4: TWO trips
                                  // requested ahead of the one being evaluated (three register sets taking turns, loop unrolled by
@@ -1673,15 +1678,18 @@ NIRRT_FN __device__ void wg_query_fn()
                 slot_load<D>(t, sl, o.x, o.y, o.z, o.c, o.id);
                 o.fl = live ? r_flag : 0u;
             };
-            SlotRegs cur[GRID_U], nxt[GRID_U];
+            // slots per lane and trip: GRID_U on the one- / two-wave workgroups (many trees share the memory system), GRID_U_WIDE on
+            // the 256-lane ones (one or a few heavy trees: fewer, larger trips - a trip is a dependent round trip)
+            constexpr int GU = NT >= 256 ? GRID_U_WIDE : GRID_U;
+            SlotRegs cur[GU], nxt[GU];
 #pragma unroll
-            for (int u = 0; u < GRID_U; u++) fetch(u * NT + tid, cur[u]);
+            for (int u = 0; u < GU; u++) fetch(u * NT + tid, cur[u]);
 #pragma nounroll
-            for (int f0 = 0; f0 < total; f0 += NT * GRID_U) {
+            for (int f0 = 0; f0 < total; f0 += NT * GU) {
 #pragma unroll
-                for (int u = 0; u < GRID_U; u++) fetch(f0 + NT * GRID_U + u * NT + tid, nxt[u]);   // (past the end: dummy loads)
+                for (int u = 0; u < GU; u++) fetch(f0 + NT * GU + u * NT + tid, nxt[u]);   // (past the end: dummy loads)
 #pragma unroll
-                for (int u = 0; u < GRID_U; u++) {
+                for (int u = 0; u < GU; u++) {
                     if (f0 + u * NT < total) {   // uniform
                         double sm = 0.;
                         const bool member = cur[u].fl ? process(cur[u], sm) : false;
@@ -1689,7 +1697,7 @@ NIRRT_FN __device__ void wg_query_fn()
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < GRID_U; u++) cur[u] = nxt[u];
+                for (int u = 0; u < GU; u++) cur[u] = nxt[u];
             }
         }
         if (stage == 0) {
