@@ -487,11 +487,25 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
 
     import time
     prof = {"generators": 0.0, "wait_launch": 0.0, "book": 0.0, "refresh": 0.0}
+    pace = np.zeros(B)      # device ticks per iteration of every tree in its last launch (0: not run yet)
+    paced = png and os.environ.get("NIRRT_BATCH_PACE", "1") == "1"
+    pace_ref = float(os.environ.get("NIRRT_BATCH_PACE_REF", "1.25"))      # trees slower than this x the median get shorter windows
 
     def launch(act):
         """the arguments of one persistent launch over the trees `act` (each draws from its own generators, in HBM); host
         generators that were handed out since the last launch (host-side cloud candidates) go back to their trees first"""
         rem = np.minimum(remaining[act], window)
+        if paced and len(act) > 1:
+            # A launch lasts as long as its slowest tree.  A tree whose iterations cost more than the typical one (measured: its
+            # device time per iteration in its last launch) gets proportionally fewer of them this time, so that everybody is
+            # done at about the same moment; it catches up over more launches while the others refresh their clouds.  Trees are
+            # independent and launch boundaries never change a result.
+            p_act = pace[act]
+            known = p_act[p_act > 0]
+            if len(known):
+                ref = pace_ref * float(np.median(known))
+                scale = np.where(p_act > ref, ref / np.maximum(p_act, 1e-12), 1.0)
+                rem = np.minimum(rem, np.maximum(window // 8, (window * scale).astype(np.int64)))
         t_w = time.perf_counter()
         hand_over([trees[i] for i in act], [streams[i] for i in act], only_touched=True)
         for i in act:
@@ -513,6 +527,8 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
                 traces[i].append(tr.copy())
                 c_best[i] = tr[-1]
             remaining[i] -= d
+            if d > 0:
+                pace[i] = float(r["stats"][j, _hip.ST_BUSY]) / d
             # delta slots add up; T0 / T1 (device clocks) and the best-cost bit pattern are absolute values of the launch:
             # first T0, last T1, last best cost
             first_launch = stats[i, _hip.ST_ITERS] == 0 and stats[i, _hip.ST_T0] == 0
