@@ -356,3 +356,44 @@ def test_run_batch_refreshes_due_clouds_and_reports_failures(dev, monkeypatch):
     assert list(r["iters_done"]) == [1500, 1500, 250, 10]
     assert set(r["failed"]) == {2, 3} and "capacity" in r["failed"][2] and "randint" in r["failed"][3]
     assert sorted(r["clouds"]) == [0, 1, 2, 3]
+
+
+def test_guided_windows_are_paced_by_each_trees_own_speed(dev, monkeypatch):
+    """Paced windows (round 5): in a guided batch a tree whose iterations took longer than 1.25 x the median in its last launch
+    gets proportionally fewer iterations in the next one (never fewer than an eighth of the window), the others keep the full
+    window; every tree still runs exactly its budget, and NIRRT_BATCH_PACE=0 restores equal windows."""
+    ticks_per_iter = {0: 100, 1: 110, 2: 90, 3: 400, 4: 5000}       # trees 3 and 4 are slow (4 x / 50 x the typical tree)
+
+    def fake(log):
+        def run_sampling(trees, iters, flags=0, want_trace=False, iters_each=None, **kw):
+            n = len(trees)
+            log.append({"names": [t.name for t in trees], "each": [int(v) for v in iters_each]})
+            done = np.array([int(v) for v in iters_each], dtype=np.int64)
+            stats = np.zeros((n, _hip.N_STATS), dtype=np.int64)
+            for j, t in enumerate(trees):
+                stats[j, _hip.ST_ITERS] = done[j]
+                stats[j, _hip.ST_BUSY] = ticks_per_iter[t.name] * done[j]
+                stats[j, 17] = np.float64(60.0).view(np.int64)
+                stats[j, _hip.ST_CBEST] = stats[j, 17]
+            return {"kernel_ms": 1.0, "iters_done": done, "cost_trace": np.full((n, iters), 60.0), "stats": stats,
+                    "status": np.zeros(n, dtype=np.int32)}
+        return run_sampling
+
+    for paced in (True, False):
+        monkeypatch.setenv("NIRRT_BATCH_PACE", "1" if paced else "0")
+        trees = [PlanTree(i) for i in range(5)]
+        streams = [batch.ProblemStreams(i) for i in range(5)]
+        log = []
+        monkeypatch.setattr(_hip, "run_sampling", fake(log))
+        r = batch.run_batch(trees, streams, 3000, _hip.F_IRRT, 2, problems=[{}] * 5, guidance=FakeGuidance(), frames=[None] * 5, window=1024)
+        assert list(r["iters_done"]) == [3000] * 5 and not r["failed"]
+        assert log[0]["each"] == [1024] * 5                       # nothing is known before the first launch
+        if not paced:
+            assert all(e in (1024, 3000 - 2048) for l in log for e in l["each"])
+            continue
+        second = dict(zip(log[1]["names"], log[1]["each"]))
+        assert second[0] == second[1] == second[2] == 1024         # within 1.25 x the median (110 ticks)
+        assert second[3] == int(1024 * (1.25 * 110) / 400)         # proportionally fewer
+        assert second[4] == 1024 // 8                              # ... but never fewer than an eighth of the window
+        assert len(log) > 3                                        # the slow trees catch up over more launches
+        assert log[-1]["names"] == [4]
