@@ -853,6 +853,9 @@ JOBS = {
     "random_irrt2d": lambda: run_planner("random_irrt2d", "irrt", 2, "ref2d", 4, 0, 5000, 1004, mode="random", iter_after_initial=300),
     "random_rrt3d": lambda: run_planner("random_rrt3d", "rrt", 3, "ref3d", 3, 0, 5000, 1003, mode="random", iter_after_initial=300),
     "pointnet2_ref": pointnet2_fixture,
+    # a DEGENERATE problem (free straight start-goal segment: the informed set collapses onto the segment, every rewiring pass sees
+    # dozens of members within rounding of the threshold) - the class on which an ulp in the steer used to flip parents (round 5)
+    "run_irrt2d_free_5000": lambda: run_planner("run_irrt2d_free_5000", "irrt", 2, "b30", 6, 2, 5000, 1031),
     "run_nirrt2d_1500": lambda: nirrt_fixture("run_nirrt2d_1500", 2, False, 9, 1500, 1009),
     "run_nirrtc2d_1500": lambda: nirrt_fixture("run_nirrtc2d_1500", 2, True, 10, 1500, 1010),
     "run_nirrt3d_1500": lambda: nirrt_fixture("run_nirrt3d_1500", 3, False, 4, 1500, 1004),

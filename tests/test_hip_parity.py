@@ -94,7 +94,7 @@ def test_primitives_on_frozen_tree(oracle, name):
     o.close()
 
 
-RUNS = ["run_rrt2d_500", "run_rrt2d_3000", "run_rrt2d_b30_2000", "run_irrt2d_800", "run_irrt2d_3000",
+RUNS = ["run_rrt2d_500", "run_rrt2d_3000", "run_rrt2d_b30_2000", "run_irrt2d_800", "run_irrt2d_3000", "run_irrt2d_free_5000",
         "run_rrt3d_500", "run_rrt3d_3000", "run_irrt3d_3000"]
 
 

@@ -52,7 +52,7 @@ def test_rrt_in_kernel_sample_free(name):
     t.close()
 
 
-@pytest.mark.parametrize("name", ["run_irrt2d_800", "run_irrt2d_3000"])
+@pytest.mark.parametrize("name", ["run_irrt2d_800", "run_irrt2d_3000", "run_irrt2d_free_5000"])
 def test_irrt2d_in_kernel_informed_sampling(name):
     from nirrt_star_amd import _hip
     g = load_golden(name)

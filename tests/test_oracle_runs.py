@@ -5,7 +5,7 @@ import pytest
 
 from conftest import load_golden, make_oracle_tree
 
-RUNS = ["run_rrt2d_500", "run_rrt2d_3000", "run_rrt2d_b30_2000", "run_irrt2d_800", "run_irrt2d_3000",
+RUNS = ["run_rrt2d_500", "run_rrt2d_3000", "run_rrt2d_b30_2000", "run_irrt2d_800", "run_irrt2d_3000", "run_irrt2d_free_5000",
         "run_rrt3d_500", "run_rrt3d_3000", "run_irrt3d_3000"]
 
 
