@@ -362,7 +362,7 @@ def main():
                          "useful_bytes_per_launch": useful_b, "visited_index_bytes_per_launch": float(np.mean(visit_b)),
                          "per_iteration": {"visited_slots": per_it[0], "visit_bytes": per_it[1], "near_members": per_it[2],
                                            "members_spilled": per_it[3], "chain_records": per_it[4], "rewire_candidates": per_it[5],
-                                           "rewired": per_it[6], "recosted": per_it[7], "list_entries": per_it[8],
+                                           "rewired": per_it[6], "recosted": per_it[7], "list_entries": per_it[8] + per_it[21],
                                            "inserted": per_it[9], "rebuilt": per_it[10], "nearest_revisits": per_it[11],
                                            "whole_tree_visits": per_it[12],
                                            "useful_bytes": useful_b / max(1.0, float(np.mean(done_iters)))},

@@ -12,7 +12,10 @@
  *   - every function returns 0 on success or a negative NIRRT_E_* code; nothing throws.
  *   - the caller owns all host buffers (C-contiguous float64 / int64 / uint8, like the numpy
  *     arrays the reference passes around); the library owns device memory until nirrt_destroy.
- *   - one tree = one opaque handle = one HIP stream; a handle is not thread-safe.
+ *   - one tree = one opaque handle; a handle is not thread-safe.  The trees of a device share a pool of 32 HIP streams (a
+ *     tree's own calls are ordered on its stream; two trees may share one); nirrt_run launches and times its kernels on streams
+ *     that belong to the CALLING THREAD, so concurrent nirrt_run calls from different threads neither serialize nor see each
+ *     other's kernels in kernel_ms.
  *   - vertices cross the boundary as (n, dim) row-major float64 (the reference's
  *     `self.vertices[:n]`), parents as int64 (`self.vertex_parents[:n]`).  In HBM a tree is ONE device range (its arena)
  *     holding records, not coordinate columns: a 32-byte vertex record {x, y, z, cost(v)} and a 128-byte
@@ -44,6 +47,15 @@ extern "C" {
 #define NIRRT_E_NODEVICE (-4) /* no gfx950 device visible                              */
 #define NIRRT_E_STREAM (-5)   /* random-word stream exhausted inside nirrt_run         */
 #define NIRRT_E_CLOUD (-6)    /* nirrt_run + NIRRT_F_PNG: guidance cloud refresh due (not an error) */
+#define NIRRT_E_LIBM (-7)     /* the restated libm routines left their supported domain (a NaN steer result): the iteration was
+                                 dropped and the run stopped instead of inserting a NaN vertex */
+#define NIRRT_E_PARK (-8)     /* nirrt_run with park_limit: the launch ended early because enough trees were waiting for a
+                                 guidance-cloud refresh (not an error: resume with the remaining budget) */
+
+/* Version of this header's structs and entry points.  nirrt_abi_version() returns the value the LIBRARY was built with: a caller
+ * compiled against another header must not pass it structs (nirrt_run_args grew in rounds 4, 5 and 6).  nirrt_run_args also
+ * carries its own size in its first member and nirrt_run refuses a struct of another size with NIRRT_E_ARG. */
+#define NIRRT_ABI_VERSION 6
 
 #define NIRRT_MAX_OBSTACLES 64 /* per kind (round / box) */
 #define NIRRT_OBSTACLE_POOL 640 /* = 4 * 64 + 6 * 64: the tables live in LDS, 4 * n_round + 6 * n_box doubles of them */
@@ -101,6 +113,7 @@ typedef struct nirrt_step_result {
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 const char *nirrt_last_error(void);
+int nirrt_abi_version(void);
 int nirrt_device_count(int *count);
 /* RRTBase2D/3D.__init__ (rrt_base_2d.py:8-37, rrt_base_3d.py:8-38): allocate the tree in HBM,
  * vertex 0 = x_start, parent[0] = 0, num_vertices = 1. */
@@ -182,10 +195,11 @@ int nirrt_set_cloud(nirrt_tree *t, int64_t n, const double *pts, double sample_r
 /* ---- one whole iteration --------------------------------------------------------------------- */
 /* Loop body of RRTStar2D.planning (rrt_star_2d.py:37-55) / IRRTStar2D.planning
  * (irrt_star_2d.py:54-73) given node_rand: nearest -> steer -> edge collision -> insert -> Near ->
- * choose_parent -> rewire [-> InGoalRegion].  Steer runs on the device (2D: device libm
- * atan2/cos/sin, not bit-identical to glibc; 3D: IEEE ops only, bit-identical). */
+ * choose_parent -> rewire [-> InGoalRegion].  Steer runs on the device: 2D with glibc 2.35's atan2 / cos / sin restated
+ * (csrc/glibc235_libm.inc: bit-identical to the reference on an x86-64 FMA host with that libm - nirrt_libm_probe lets a caller
+ * check its own host), 3D with IEEE operations only; a NaN result ends the call with NIRRT_E_LIBM. */
 int nirrt_step(nirrt_tree *t, const double *node_rand, uint32_t flags, nirrt_step_result *res);
-/* Same body with the steer done by the caller (bit-exact 2D vertices): nearest_idx from
+/* Same body with the steer done by the caller (for hosts whose libm is not the restated one): nearest_idx from
  * nirrt_nearest, node_new = new_state(node_nearest, node_rand) computed on the host. */
 int nirrt_extend(nirrt_tree *t, int64_t nearest_idx, const double *node_new, uint32_t flags, nirrt_step_result *res);
 
@@ -211,9 +225,16 @@ int nirrt_extend(nirrt_tree *t, int64_t nearest_idx, const double *node_new, uin
  *   F_GOAL_SCAN: get_path_len(extract_path(search_goal_parent())) (rrt_star_2d.py:223-229).
  * iters_done[i] < iters only if a word stream ran dry or a capacity was hit (status[i] != 0). */
 typedef struct nirrt_run_args {
+    uint32_t struct_size;     /* = sizeof(nirrt_run_args) of the caller's header (anything else: NIRRT_E_ARG) */
     uint32_t flags;
     int32_t inputs_on_device; /* != 0: samples / np_words[i] / py_words[i] are DEVICE pointers already resident
                                  in HBM (e.g. torch.cuda tensors); 0: host pointers, copied in by nirrt_run */
+    int32_t park_limit;    /* sampling mode + NIRRT_F_PNG: > 0 = end the launch as soon as this many trees have stopped for a cloud
+                            refresh (NIRRT_E_CLOUD): the others leave their loops at the next iteration boundary with status
+                            NIRRT_E_PARK and their remaining budget.  A guided launch otherwise lasts as long as its slowest tree
+                            while the trees whose cloud is due idle in their slots - with the 3D demo's pc_update_cost_ratio = 1.0
+                            (demo_planning_3d.py:21: a refresh on EVERY improvement) most of a launch's slots were idle most of
+                            the time.  0 = off.  Results never depend on it (launch boundaries never do). */
     int64_t iters;
     const double *samples;
     const uint32_t *const *np_words;
@@ -236,7 +257,7 @@ typedef struct nirrt_run_args {
                             record, + 4 in 3D), [2] Near members, [3] members spilled out of LDS, [4] tree records (96 B of hops, eight
                             hops each) read by cost walks,
                             [5] rewire candidates examined, [6] vertices rewired, [7] vertices re-costed,
-                            [8] solution / goal-candidate list entries re-evaluated, [9] vertices inserted,
+                            [8] goal-candidate list entries re-evaluated (12 B + one 32-byte record each), [9] vertices inserted,
                             [10] vertices passed through index rebuilds, [11] widened nearest visits,
                             [12] whole-tree visits, [13] iterations, [14] / [15] device wall clock (100 MHz ticks)
                             when the tree's loop started / ended, [16] = alg_elems, [17] sampling mode: bit pattern (IEEE double) of
@@ -245,7 +266,8 @@ typedef struct nirrt_run_args {
                             [18] rewire rounds that re-parented something, [19] vertices re-parented one at a time
                             (candidate list larger than its LDS room), [20] device ticks the tree's loop was running (the launch may
                             share its workgroups among the trees in time slices: then [14] / [15] span the idle time in between),
-                            [21..23] reserved */
+                            [21] solution list entries re-evaluated (8 B each: the cached cost + Line(v, goal) that every re-costing keeps current),
+                            [22..23] reserved */
     const int64_t *iters_each; /* optional (n_trees,), sampling mode: tree i runs at most iters_each[i] <= iters iterations
                             (trees of one batch resumed after stopping at different iterations, e.g. NIRRT_E_CLOUD);
                             cost_trace rows stay `iters` long */

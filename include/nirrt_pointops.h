@@ -121,6 +121,14 @@ int nirrt_connect_round(const nirrt_connect_job *jobs, int n_jobs, double radius
                         int device_id);
 int nirrt_connect_masks(const nirrt_connect_job *jobs, int n_jobs, double radius, const int32_t *seed_idx, int device_id);
 
+/* The library's restatement of glibc 2.35's atan2 / sin / cos (csrc/glibc235_libm.inc: what math.atan2 / math.cos / math.sin of
+ * the reference's new_state, rrt_star_2d.py:67-78, and np.sin / np.cos of irrt_star_3d.py:146-158 resolve to on an x86-64 FMA host
+ * with that libm) evaluated ON THE DEVICE for the caller's arguments: fn 0 = atan2(a[i], b[i]), 1 = sin(a[i]), 2 = cos(a[i]);
+ * a, b, out HOST f64 (n,).  A caller compares `out` with its own libm bit for bit before trusting the device-side steer / samplers
+ * on this host (nirrt_star_amd/_hip.libm_check does, once per process); arguments whose restated path the translator could not
+ * express (|x| > 1e8, Inf) return NaN. */
+int nirrt_libm_probe(int32_t fn, int64_t n, const double *a, const double *b, double *out, int device_id);
+
 #ifdef __cplusplus
 }
 #endif

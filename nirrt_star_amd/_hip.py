@@ -17,7 +17,8 @@ F_GOAL_SCAN = 2
 F_STOP_FIRST = 4
 F_PNG = 8
 
-E_ARG, E_HIP, E_CAPACITY, E_NODEVICE, E_STREAM, E_CLOUD = -1, -2, -3, -4, -5, -6
+E_ARG, E_HIP, E_CAPACITY, E_NODEVICE, E_STREAM, E_CLOUD, E_LIBM, E_PARK = -1, -2, -3, -4, -5, -6, -7, -8
+ABI_VERSION = 6   # include/nirrt_hip.h NIRRT_ABI_VERSION: the structs below mirror THAT header
 MAX_OBSTACLES = 64
 
 EXPORTS = [
@@ -25,7 +26,7 @@ EXPORTS = [
     "nirrt_download", "nirrt_num_vertices", "nirrt_nearest", "nirrt_collision_batch", "nirrt_points_in_obs",
     "nirrt_near", "nirrt_cost", "nirrt_search_goal_parent", "nirrt_best_solution", "nirrt_solutions",
     "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed", "nirrt_debug_prof", "nirrt_set_cloud", "nirrt_reset_batch", "nirrt_pool_trim", "nirrt_set_cloud_batch",
-    "nirrt_mt19937_fill", "nirrt_set_generators", "nirrt_get_generators", "nirrt_generator_words",
+    "nirrt_mt19937_fill", "nirrt_set_generators", "nirrt_get_generators", "nirrt_generator_words", "nirrt_abi_version",
 ]
 
 
@@ -51,7 +52,7 @@ class StepResult(C.Structure):
 
 
 class RunArgs(C.Structure):
-    _fields_ = [("flags", C.c_uint32), ("inputs_on_device", C.c_int32), ("iters", C.c_int64),
+    _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("inputs_on_device", C.c_int32), ("park_limit", C.c_int32), ("iters", C.c_int64),
                 ("samples", C.POINTER(C.c_double)),
                 ("np_words", C.POINTER(C.POINTER(C.c_uint32))), ("n_np", C.POINTER(C.c_int64)),
                 ("py_words", C.POINTER(C.POINTER(C.c_uint32))), ("n_py", C.POINTER(C.c_int64)),
@@ -66,7 +67,7 @@ N_STATS = 24
 ST_ITERS, ST_T0, ST_T1, ST_CBEST, ST_BUSY = 13, 14, 15, 17, 20   # slots 14 / 15 / 17 are absolute values of a launch, the rest are deltas
 STAT_NAMES = ["visited", "visit_bytes", "members", "spilled", "hop_records", "rewire_candidates", "rewired", "recosted",
               "list_entries", "inserted", "rebuilt", "revisits", "whole_tree_visits", "iterations", "t0_ticks", "t1_ticks",
-              "alg_elems", "c_best_bits", "rewire_rounds", "rewired_one_by_one", "busy_ticks", "r21", "r22", "r23"]
+              "alg_elems", "c_best_bits", "rewire_rounds", "rewired_one_by_one", "busy_ticks", "solution_entries", "r22", "r23"]
 
 
 def useful_bytes(stats, dim):
@@ -74,12 +75,13 @@ def useful_bytes(stats, dim):
     counters (include/nirrt_hip.h, nirrt_run_args.stats): visited slot records (32 B, + 4 B of index in 3D - already in
     bytes), 96 B per tree record walked (the hop part: eight hops each since round 5; 64 B / four hops before), one 32-byte
     vertex record + 20 B of its tree record (links, parent) per rewire candidate examined, 16 B written per re-costed vertex
-    (its record's and its slot's cost), 12 B + one 32-byte record per re-evaluated list entry, 184 B (+ 4 in 3D) written per
+    (its record's and its slot's cost), 12 B + one 32-byte record per re-evaluated goal-candidate list entry, 8 B per re-evaluated
+    solution list entry (its cached cost + Line(v, goal): round 6; 44 B before), 184 B (+ 4 in 3D) written per
     inserted vertex (vertex record 32, tree record 112, slot record 32, two link words), 32 B read + 32 + 4 (+ 4 in 3D) + 8 B
     written per vertex of an index rebuild."""
     st = np.asarray(stats, dtype=np.float64).reshape(-1, N_STATS).sum(axis=0)
     d3 = 4 if dim == 3 else 0
-    return float(st[1] + 96 * st[4] + 52 * st[5] + 16 * st[7] + 44 * st[8] + (184 + d3) * st[9] + (32 + 32 + 4 + d3 + 8) * st[10])
+    return float(st[1] + 96 * st[4] + 52 * st[5] + 16 * st[7] + 44 * st[8] + 8 * st[21] + (184 + d3) * st[9] + (32 + 32 + 4 + d3 + 8) * st[10])
 
 
 _lib = None
@@ -134,11 +136,72 @@ def load():
     L.nirrt_set_informed.argtypes = [vp, C.c_double, dp, dp]
     L.nirrt_debug_prof.argtypes = [vp, ip]
     L.nirrt_set_cloud.argtypes = [vp, C.c_int64, dp, C.c_double, C.c_double, C.c_double]
+    L.nirrt_abi_version.argtypes = []
+    L.nirrt_libm_probe.argtypes = [C.c_int32, C.c_int64, dp, dp, dp, C.c_int]   # (include/nirrt_pointops.h)
+    L.nirrt_libm_probe.restype = C.c_int
     for name in EXPORTS:
         if name != "nirrt_last_error":
             getattr(L, name).restype = C.c_int
+    if L.nirrt_abi_version() != ABI_VERSION:
+        raise NirrtError("%s was built from another include/nirrt_hip.h (NIRRT_ABI_VERSION %d, this binding mirrors %d): rebuild it with "
+                         "`python -m nirrt_star_amd.build --force`" % (SO_PATH, L.nirrt_abi_version(), ABI_VERSION))
     _lib = L
     return L
+
+
+def _run_args():
+    a = RunArgs()   # (zero-initialised)
+    a.struct_size = C.sizeof(RunArgs)
+    return a
+
+
+# ---- does this host's libm compute what the device's restatement computes? ----------------------------------------------------
+# The reference steers with math.atan2 / math.cos / math.sin (rrt_star_2d.py:67-78) and samples the 3D unit ball with np.sin /
+# np.cos (irrt_star_3d.py:146-158): whatever libm its host has.  The device evaluates glibc 2.35's x86-64 FMA variants, restated
+# (csrc/glibc235_libm.inc).  On a host with another libm / CPU the REFERENCE computes other last bits, and the device-resident
+# loop would no longer be bit-identical to it: the planner classes then default to mode="exact" (steer / sampling with the host's
+# libm between two launches).  Checked once per process, the first time a planner asks (needs a GPU).
+_libm_ok = None
+
+
+def libm_check(device_id=0, n=4096, force=False):
+    """True if the device-side atan2 / sin / cos equal this host's math.atan2 / math.sin / math.cos bit for bit on n random steer
+    arguments each (+ the quadrant boundaries); False (with ONE RuntimeWarning) otherwise.  NIRRT_LIBM_CHECK=0 skips the probe
+    (returns True); the result is cached."""
+    global _libm_ok
+    if _libm_ok is not None and not force:
+        return _libm_ok
+    if os.environ.get("NIRRT_LIBM_CHECK", "1") == "0":
+        _libm_ok = True
+        return True
+    import math
+    import warnings
+    L = load()
+    rng = np.random.RandomState(20260930)
+    dy, dx = rng.uniform(-224.0, 224.0, n), rng.uniform(-224.0, 224.0, n)
+    dy[:8] = [0.0, 0.0, 1.0, -1.0, 5.0, -5.0, 1e-300, -0.0]
+    dx[:8] = [1.0, -1.0, 0.0, 0.0, 5.0, -5.0, 1.0, -1.0]
+    ang = np.concatenate([rng.uniform(-math.pi, math.pi, n - 64), rng.uniform(0.0, 2 * math.pi, 32), rng.uniform(-1e-6, 1e-6, 32)])
+    bad = []
+    for fn, name, a, b, host in ((0, "atan2", dy, dx, lambda i: math.atan2(dy[i], dx[i])),
+                                 (1, "sin", ang, ang, lambda i: math.sin(ang[i])),
+                                 (2, "cos", ang, ang, lambda i: math.cos(ang[i]))):
+        out = np.zeros(n, dtype=np.float64)
+        a_, b_ = _f64(a), _f64(b)
+        rc = L.nirrt_libm_probe(fn, n, _dp(a_), _dp(b_), _dp(out), int(device_id))
+        if rc != 0:
+            raise NirrtError("nirrt_libm_probe failed (%d)" % rc)
+        ref = np.array([host(i) for i in range(n)], dtype=np.float64)
+        diff = int(np.count_nonzero(out.view(np.uint64) != ref.view(np.uint64)))
+        if diff:
+            bad.append("%s: %d of %d" % (name, diff, n))
+    _libm_ok = not bad
+    if bad:
+        warnings.warn("nirrt_star_amd: this host's libm differs from the one the device code restates (glibc 2.35, x86-64, FMA) - "
+                      + "; ".join(bad) + " arguments give other bits.  The reference itself computes this host's values, so the "
+                      "planner classes now default to mode='exact' (steer and sampling on the host, bit-identical, slower); "
+                      "scripts/libm_port/make_inc.sh regenerates the restatement from another libm.", RuntimeWarning, stacklevel=2)
+    return _libm_ok
 
 
 def device_count():
@@ -473,7 +536,7 @@ def run_replay(trees, samples, flags=0, want_trace=False, device_ptr=None, iters
     status = np.zeros(nt, dtype=np.int32)
     ms = C.c_double(0)
     trace = np.zeros((nt, iters), dtype=np.float64) if want_trace else None
-    a = RunArgs()
+    a = _run_args()
     a.flags = int(flags)
     a.iters = iters
     if device_ptr is None:
@@ -499,7 +562,7 @@ def run_replay(trees, samples, flags=0, want_trace=False, device_ptr=None, iters
 
 
 def run_sampling(trees, iters, np_words=None, py_words=None, flags=0, want_trace=False, on_device=False, iters_each=None, lanes_hint=None,
-                 slice_iters=0, run_ahead=None):
+                 slice_iters=0, run_ahead=None, park_limit=0):
     """Device-resident loop with in-kernel sampling.  np_words = None (the normal case): every tree draws from its own
     generators resident in HBM (set_generators / get_generators).  Otherwise np_words / py_words: per-tree uint32 arrays of
     raw MT19937 outputs (numpy legacy global stream / python `random`); with on_device=True they are
@@ -524,7 +587,7 @@ def run_sampling(trees, iters, np_words=None, py_words=None, flags=0, want_trace
         keep.append((ptrs, cnt))
         return C.cast(ptrs, C.POINTER(u32p)), _ip(cnt)
 
-    a = RunArgs()
+    a = _run_args()
     a.flags = int(flags)
     a.inputs_on_device = 1 if on_device else 0
     a.iters = int(iters)
@@ -544,6 +607,7 @@ def run_sampling(trees, iters, np_words=None, py_words=None, flags=0, want_trace
         keep.append(ahead)
         a.run_ahead = ahead.ctypes.data_as(C.POINTER(C.c_int32))
     a.samples = None
+    a.park_limit = int(park_limit)       # guided runs: the launch ends once this many trees wait for a cloud refresh (status E_PARK for the others)
     a.slice_iters = int(slice_iters)     # 0: the library decides whether / how to time-slice a batch larger than the GPU; < 0: never
     if np_words is not None:      # None: the trees' own generators (set_generators) produce the words on the device
         a.np_words, a.n_np = table(np_words)

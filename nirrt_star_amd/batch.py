@@ -490,6 +490,8 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
     pace = np.zeros(B)      # device ticks per iteration of every tree in its last launch (0: not run yet)
     paced = png and os.environ.get("NIRRT_BATCH_PACE", "1") == "1"
     pace_ref = float(os.environ.get("NIRRT_BATCH_PACE_REF", "1.25"))      # trees slower than this x the median get shorter windows
+    park_frac = float(os.environ.get("NIRRT_BATCH_PARK", "0.25"))        # a guided launch ends when this share of its trees waits for a refresh (0 = off)
+    park_min = int(os.environ.get("NIRRT_BATCH_PARK_MIN", "16"))
 
     def launch(act):
         """the arguments of one persistent launch over the trees `act` (each draws from its own generators, in HBM); host
@@ -511,7 +513,13 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
         for i in act:
             streams[i].device_drew(py_too=need_py)
         prof["generators"] += time.perf_counter() - t_w
-        return lambda: _hip.run_sampling([trees[i] for i in act], int(rem.max()), flags=run_flags, want_trace=want_trace, iters_each=rem)
+        # A tree whose cloud is due idles in its slot until the launch ends.  With park_frac > 0 the launch itself ends as soon as
+        # that share of its trees is waiting (nirrt_run_args.park_limit): the others come back with status E_PARK and their
+        # remaining budget.  What decides is how often clouds fall due: at pc_update_cost_ratio = 1.0 (demo_planning_3d.py:21, a
+        # refresh on EVERY improvement) most trees of a window-long launch were parked most of the time.
+        park = max(park_min, int(park_frac * len(act))) if (png and park_frac > 0 and len(act) > 1) else 0
+        return lambda: _hip.run_sampling([trees[i] for i in act], int(rem.max()), flags=run_flags, want_trace=want_trace, iters_each=rem,
+                                         park_limit=park)
 
     def absorb(act, r):
         """book a finished launch, refresh the clouds that are due; returns the trees of `act` that go on"""
@@ -552,7 +560,7 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
             elif st == _hip.E_ARG:
                 failed[i] = "empty predicted cloud (np.random.randint(0, 0) in the reference)"
                 finished[i] = True
-            elif st == 0:
+            elif st == 0 or st == _hip.E_PARK:   # (E_PARK: the launch ended early for the others' cloud refreshes; the tree goes on)
                 if remaining[i] <= 0 or (stop_first and d > 0 and np.isfinite(c_best[i])) or (stop_first and not want_trace):
                     finished[i] = True
             else:

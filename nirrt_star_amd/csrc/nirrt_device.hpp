@@ -127,7 +127,8 @@ struct Topo;
 #define ST_ROUNDS 5      // rewire candidates examined (one 32-byte record each)
 #define ST_REWIRED 6     // vertices re-parented by rewire
 #define ST_RECOST 7      // vertices re-costed below re-parented vertices
-#define ST_LISTSCAN 8    // solution / goal-candidate list entries re-evaluated (12 B + one 32-byte record each)
+#define ST_LISTSCAN 8    // goal-candidate list entries re-evaluated (12 B + one 32-byte record each)
+#define ST_SOLSCAN 21    // solution list entries re-evaluated (8 B each: the cached cost + Line(v, goal) of round 6)
 #define ST_INSERTED 9    // vertices appended
 #define ST_REBUILT 10    // vertices passed through index rebuilds (32 B read + 28 / 36 B + 4 B written each)
 #define ST_REVISITS 11   // additional visits of a widened nearest box
@@ -228,7 +229,13 @@ struct __attribute__((aligned(NHOP == 8 ? 128 : 64))) Topo {
     int a[NHOP];
     int fc, ns, ps;   // first child, next / previous sibling (-1 = none); the root is nobody's child
     int flags;        // bit 0 = in sol[], bit 1 = in gc_idx[] (a re-costed listed vertex invalidates the cached best)
+    // (round 6) what used to be looked up in arrays of their own - a 4-byte read that cost a 128-byte line of HBM traffic each -
+    // rides in the record's last 16 bytes, which every reader of the record has fetched anyway:
+    int slot;         // slot of the vertex in the grid index (valid for vertices below g_ns2; slot = index above)
+    int sol_q;        // first position of the vertex in sol[] (valid if flags & 1): where its cached cost + Line(v, goal) lives
+    int pad_[2];
 };
+static_assert(sizeof(Topo) == (NHOP == 8 ? 128 : 64) || NHOP != 8, "the tree record is one 128-byte line");
 // the links + flags of a vertex (the 16 bytes behind the hop part) in one load
 struct __attribute__((aligned(16))) TopoLinks { int fc, ns, ps, flags; };
 __device__ __forceinline__ TopoLinks ld_links(const GAS Topo *p)
@@ -289,6 +296,10 @@ struct TreeHotT {
     // IRRT*: path_solutions (goal-parent indices, duplicates allowed) + cached costs
     typename P<int>::type sol;
     typename P<double>::type sol_line;   // Line(v, goal) of each solution vertex (static)
+    // cost(sol[q]) + sol_line[q] as of the vertex's last re-costing (+inf at the later positions of a vertex listed twice: the
+    // first one has the same value and the lower position, so it is the one np.argmin finds).  find_best_path_solution's scan reads
+    // this array front to back instead of gathering the vertices' records - one 128-byte line of HBM traffic per list entry before
+    typename P<double>::type sol_val;
     int n_sol;
     int cap_sol;
     int sol_dirty;   // some parent changed since sol_best was computed
@@ -325,7 +336,6 @@ struct TreeHotT {
     // [0, g_ns) ordered by cell, slots [g_ns, n) the vertices appended since (slot i = vertex i): a query streams slot ranges only
     typename P<GSlot>::type g_rec;            // coordinates + exact cost(v) (kept in step with vrec[v].cost) + index (2D) / z (3D)
     typename P<int>::type g_idx;              // 3D: vertex index by slot
-    typename P<int>::type pos;                // slot of vertex i (valid for i < g_ns; slot i otherwise)
     typename P<int>::type g_start;            // g_start[c] .. g_start[c+1]: slots of cell c inside [0, g_ns); g_ncell + 1 entries
     typename P<int>::type g_cnt;              // rebuild scratch: per-cell counters
     typename P<int>::type g_rank;             // rebuild scratch: rank of vertex i inside its cell
@@ -348,6 +358,7 @@ struct TreeHotT {
     int g_every2;
     double g_inv_h2[3];
     double g_margin2[3];
+    double g_h[3], g_h2[3];   // cell sizes of both levels (1 / g_inv_h: the host's division is the device's, both correctly rounded)
 };
 using TreeHotH = TreeHotT<gp_plain>;    // as stored in HBM and as the host fills it in
 using TreeHot = TreeHotT<gp_global>;    // the device code's view (same layout)
@@ -393,6 +404,8 @@ struct RunSampleDev {
     long long *iters_done;
     int *stop_code;   // per tree: 0 done, NIRRT_E_STREAM, NIRRT_E_CAPACITY
     const long long *iters_each;   // optional per-tree iteration budgets (<= iters)
+    int *park;                     // optional (nirrt_run_args.park_limit): trees of this call that stopped for a cloud refresh so far
+    int park_limit, pad2;
 };
 
 // time-sliced launches (k_run_pool): the work queue of a launch group
@@ -1088,10 +1101,18 @@ template <int D>
 __device__ __forceinline__ void slot_load(const TreeHot &t, int sl, double &x, double &y, double &z, double &c, int &id)
 {
     const GAS char *p = (const GAS char *)(t.g_rec + sl);
+#ifdef NIRRT_SLOT_NT   // A/B: the visit's stream marked non-temporal (does it leave more of the L2 to the records the chases re-read?)
+    const nirrt_v2d xy = __builtin_nontemporal_load((const GAS nirrt_v2d *)p);
+#else
     const nirrt_v2d xy = *(const GAS nirrt_v2d *)p;
+#endif
     x = xy.x; y = xy.y;
     if (D == 2) {
+#ifdef NIRRT_SLOT_NT
+        const nirrt_v3u b = __builtin_nontemporal_load((const GAS nirrt_v3u *)(p + 16));
+#else
         const nirrt_v3u b = *(const GAS nirrt_v3u *)(p + 16);
+#endif
         c = __longlong_as_double(((long long)b.y << 32) | (long long)b.x);
         id = (int)b.z;
         z = 0.;
@@ -1109,13 +1130,6 @@ __device__ __forceinline__ double dist_scan_cold(double dx, double dy, double dz
 {
     if (D == 2) return hypot_np_cold(dx, dy);
     return __builtin_sqrt(dx * dx + dy * dy + dz * dz);
-}
-// cost(j) + d(j, p) with the reference's distance, from vertex j's record (the same doubles its slot record holds)
-template <int D>
-NIRRT_FN __device__ double near_exact_cold(int j, double px, double py, double pz)
-{
-    const VRec v = ldg(&g_lds.hot.vrec[j]);
-    return v.cost + dist_scan_cold<D>(px - v.x, py - v.y, D == 3 ? pz - v.z : 0.);
 }
 // exact segment test against obstacle #o of the LDS tables
 template <int D>
@@ -1305,7 +1319,7 @@ NIRRT_FN __device__ void wg_grid_rebuild(int n)
                 const double xyz[3] = {v[u].x, v[u].y, v[u].z};
                 stg(&t.g_rec[sl], slot_make<D>(xyz, v[u].cost, i));
                 if (D == 3) t.g_idx[sl] = i;
-                t.pos[i] = sl;
+                t.topo[i].slot = sl;
             }
         }
     }
@@ -1378,7 +1392,7 @@ NIRRT_FN __device__ void wg_grid_rebuild2(int n)
                 const double xyz[3] = {v[u].x, v[u].y, v[u].z};
                 stg(&t.g_rec[sl], slot_make<D>(xyz, v[u].cost, i));
                 if (D == 3) t.g_idx[sl] = i;
-                t.pos[i] = sl;
+                t.topo[i].slot = sl;
             }
         }
     }
@@ -1477,7 +1491,7 @@ NIRRT_FN __device__ void wg_query_fn()
 #pragma unroll
             for (int k = 1; k < D; k++) {
                 const int ck = k == 1 ? cy : cz;
-                const double h = 1.0 / (L == 0 ? t.g_inv_h[k] : t.g_inv_h2[k]);
+                const double h = L == 0 ? t.g_h[k] : t.g_h2[k];
                 const double a = ck == 0 ? -__builtin_inf() : t.lo[k] + ck * h;
                 const double b = ck == GL - 1 ? __builtin_inf() : t.lo[k] + (ck + 1) * h;
                 double dk = fmax(fmax(a - ball[k], ball[k] - b), 0.0) - (L == 0 ? t.g_margin[k] : t.g_margin2[k]);
@@ -1554,6 +1568,10 @@ NIRRT_FN __device__ void wg_query_fn()
     double ba = __builtin_inf();
     bool b_exact = false;
     int cj = 0x7fffffff;
+    // 2D: offset to and cost of that member (its slot record's own doubles): the exact value is computed from registers -
+    // re-reading the record for it cost a scattered 32-byte load per lane and query (64 cache lines of HBM traffic and a dependent
+    // round trip at the end of every visit)
+    double bdx = 0., bdy = 0., bcost = 0.;
     int n_mem = 0;                                        // members seen by this wave
     __syncthreads();
     const int n_ob = wantN ? uni(s.ob_n) : 0;
@@ -1622,8 +1640,9 @@ NIRRT_FN __device__ void wg_query_fn()
         ba = better ? c : ba;
         cj = better ? p.id : cj;
         b_exact = better ? exact : b_exact;
+        if (D == 2) { bdx = better ? dx : bdx; bdy = better ? dy : bdy; bcost = better ? p.c : bcost; }
         if (close) {
-            if (!b_exact) { ba = near_exact_cold<D>(cj, pnx, pny, pnz); b_exact = true; }
+            if (!b_exact) { ba = bcost + hypot_np_cold(bdx, bdy); b_exact = true; }
             const double ce = exact ? c : p.c + dist_scan_cold<D>(dx, dy, dz);
             if (ce < ba || (ce == ba && p.id < cj)) { ba = ce; cj = p.id; }
         }
@@ -1726,7 +1745,7 @@ NIRRT_FN __device__ void wg_query_fn()
         if (g1 == __builtin_inf()) {
             double h = 0.;
 #pragma unroll
-            for (int k = 0; k < D; k++) h = fmax(h, 1.0 / t.g_inv_h[k]);
+            for (int k = 0; k < D; k++) h = fmax(h, t.g_h[k]);
             ring += h;
             grid_box<D>(t, qv, ring, eb0, eb1);
         } else {
@@ -1777,7 +1796,7 @@ NIRRT_FN __device__ void wg_query_fn()
     double cand = ba;
     if (wantN) {
         if (lane == 0 && n_mem) atomicAdd(&s.mem_cnt, n_mem);
-        if (D == 2 && cj != 0x7fffffff && !b_exact) cand = near_exact_cold<D>(cj, pnx, pny, pnz);   // every lane's best with the reference's distance
+        if (D == 2 && cj != 0x7fffffff && !b_exact) cand = bcost + hypot_np(bdx, bdy);   // every lane's best with the reference's distance
         block_argmin<NT>(s, cand, cj);   // lexicographic (value, index): np.argmin's first minimum of the ascending list (barriers inside)
     }
     if (tid == 0) {
@@ -1983,7 +2002,7 @@ NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int 
             acc[r] = 0.;
         }
 #pragma unroll
-        for (int r = 0; r < WALK_R; r++) slot[r] = (who[r] >= 0 && who[r] < ns) ? t.pos[who[r]] : who[r];   // appended vertices: slot = index
+        for (int r = 0; r < WALK_R; r++) slot[r] = (who[r] >= 0 && who[r] < ns) ? t.topo[who[r]].slot : who[r];   // appended vertices: slot = index
         const int clen = s.chain_len;
         nrec += walk_chains<D>(t, idx, acc, through);
 #pragma unroll
@@ -1997,7 +2016,7 @@ NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int 
                 t.g_rec[slot[r]].cost = acc[r];
                 const int li = t.topo[who[r]].flags;
                 const int ts = stamp ? t.tie_stamp[who[r]] : 0;
-                if (li & 1) t.sol_dirty = 1;
+                if (li & 1) { const int q = t.topo[who[r]].sol_q; t.sol_val[q] = acc[r] + t.sol_line[q]; t.sol_dirty = 1; }
                 if (li & 2) t.gc_dirty = 1;
                 if (n_list > 0 && src[r] < who[r]) {
                     int *ids = stash_ids(s);
@@ -2144,25 +2163,16 @@ __device__ __forceinline__ void wg_best_solution(Lds<NT> &s, TreeHot &t, double 
         double bv = __builtin_inf();
         int bs = 0x7fffffff;
         for (int q0 = tid; q0 < ns; q0 += NT * LIST_U) {   // LIST_U entries per lane and trip, loads issued back to back
-            int vi[LIST_U];
-            double li[LIST_U], co[LIST_U];
+            double c[LIST_U];                               // (cost(sol[q]) + Line(sol[q], goal), kept current by every re-costing)
 #pragma unroll
-            for (int u = 0; u < LIST_U; u++) {
-                const int q = q0 + u * NT;
-                vi[u] = 0; li[u] = __builtin_inf();
-                if (q < ns) { vi[u] = t.sol[q]; li[u] = t.sol_line[q]; }
-            }
+            for (int u = 0; u < LIST_U; u++) c[u] = q0 + u * NT < ns ? t.sol_val[q0 + u * NT] : __builtin_inf();
 #pragma unroll
-            for (int u = 0; u < LIST_U; u++) co[u] = q0 + u * NT < ns ? t.vrec[vi[u]].cost : 0.;
-#pragma unroll
-            for (int u = 0; u < LIST_U; u++) {
-                const double c = co[u] + li[u];
-                if (q0 + u * NT < ns && c < bv) { bv = c; bs = q0 + u * NT; }
-            }
+            for (int u = 0; u < LIST_U; u++)
+                if (q0 + u * NT < ns && c[u] < bv) { bv = c[u]; bs = q0 + u * NT; }
         }
         block_argmin<NT>(s, bv, bs);
         if (bs == 0x7fffffff) bs = 0;
-        if (tid == 0) { t.sol_dirty = 0; t.sol_best = bs; t.sol_best_cost = bv; s.stat[ST_LISTSCAN] += ns; }
+        if (tid == 0) { t.sol_dirty = 0; t.sol_best = bs; t.sol_best_cost = bv; s.stat[ST_SOLSCAN] += ns; }
         __syncthreads();
     }
     c_best = t.sol_best_cost;
@@ -2182,9 +2192,12 @@ __device__ __forceinline__ void wg_append_solution(Lds<NT> &s, TreeHot &t, int i
             double line = hypot_py<D>(d);
             t.sol[q] = idx;
             t.sol_line[q] = line;
-            t.topo[idx].flags |= 1;
+            const int fl = t.topo[idx].flags;
+            const double c = t.vrec[idx].cost + line;
+            // a vertex listed before ("same point" iterations append it again): its first position keeps the value
+            t.sol_val[q] = (fl & 1) ? __builtin_inf() : c;
+            if (!(fl & 1)) { t.topo[idx].flags = fl | 1; t.topo[idx].sol_q = q; }
             if (!t.sol_dirty) {
-                double c = t.vrec[idx].cost + line;
                 if (q == 0 || c < t.sol_best_cost) { t.sol_best = q; t.sol_best_cost = c; }
             }
             t.n_sol = q + 1;
@@ -2330,12 +2343,17 @@ NIRRT_FN __device__ void it_extend()
     nearest[0] = vnear.x; nearest[1] = vnear.y;
     if (D == 3) nearest[D - 1] = vnear.z;
     if (!host_steer) steer<D>(t, nearest, node_in, node_new);
+    // the restated libm routines return NaN on the paths their translation does not cover (|theta| > 1e8, Inf: unreachable for
+    // atan2's results, but nothing else would notice): no NaN vertex enters the tree - the iteration is dropped and the run ends
+    bool bad_steer = false;
+    if (D == 2 && !host_steer) bad_steer = node_new[0] != node_new[0] || node_new[1] != node_new[1];
     if (res && tid == 0) {
         res->collided = 0; res->inserted = 0; res->nearest_idx = ni; res->new_idx = -1; res->n_near = 0;
         res->reparented = 0; res->n_rewired = 0; res->in_goal = 0; res->status = 0; res->reserved = 0;
         res->node_new[0] = node_new[0]; res->node_new[1] = node_new[1]; res->node_new[2] = D == 3 ? node_new[D - 1] : 0.;
     }
-    bool collided = wg_collision<D, NT>(s, nearest, node_new, clr);
+    bool collided = bad_steer || wg_collision<D, NT>(s, nearest, node_new, clr);
+    if (bad_steer && tid == 0) t.status = NIRRT_E_LIBM;
     PROF(1);
     int new_idx = -1;
     bool dup_ = false, inserted_ = false;
@@ -2632,7 +2650,7 @@ NIRRT_FN __device__ void it_connect()
                         const bool leaf = t.topo[vj].fc < 0;
                         const int old_p = t.topo[vj].a[0], nx = t.topo[vj].ns, pv = t.topo[vj].ps;
                         const int li = t.topo[vj].flags;
-                        const int slot = vj < t.g_ns2 ? t.pos[vj] : vj;
+                        const int slot = vj < t.g_ns2 ? t.topo[vj].slot : vj;
                         const int fc_new = s.new_fc;   // head of new's child list: kept in LDS during the pass
                         const double el = hypot_py<D>(d);
                         if (pv >= 0) t.topo[pv].ns = nx; else t.topo[old_p].fc = nx;
@@ -2654,7 +2672,7 @@ NIRRT_FN __device__ void it_connect()
                             acc = chain_finish(s, t, acc, clen);
                             t.vrec[vj].cost = acc;
                             t.g_rec[slot].cost = acc;
-                            if (li & 1) t.sol_dirty = 1;
+                            if (li & 1) { const int q = t.topo[vj].sol_q; t.sol_val[q] = acc + t.sol_line[q]; t.sol_dirty = 1; }
                             if (li & 2) t.gc_dirty = 1;
                             fast = 1;
                         }
@@ -2713,7 +2731,7 @@ NIRRT_FN __device__ void it_connect()
                                 if (st & CAND_DIRTY) {
                                     const int id = ids[a];
                                     vr = ldg(&t.vrec[id]);
-                                    if (single) { tp = ld_links(&t.topo[id]); tp_a0 = t.topo[id].a[0]; slot = id < ns_ ? t.pos[id] : id; }
+                                    if (single) { tp = ld_links(&t.topo[id]); tp_a0 = t.topo[id].a[0]; slot = id < ns_ ? t.topo[id].slot : id; }
                                     const double dx = vr.x - node_new[0], dy = vr.y - node_new[1], dz = D == 3 ? vr.z - node_new[D - 1] : 0.;
                                     st = vr.cost > new_cost + dist_scan_cold<D>(dx, dy, dz) ? CAND_PASS : 0u;
                                     state[a] = (unsigned char)st;
@@ -2793,7 +2811,7 @@ NIRRT_FN __device__ void it_connect()
                             int v = -1, pv = -1, nx = -1, old_p = -1, fc = -1, flg = 0;
                             if (mine) {
                                 v = ids[a];
-                                if (!single) { vr = ldg(&t.vrec[v]); tp = ld_links(&t.topo[v]); tp_a0 = t.topo[v].a[0]; slot = v < ns_ ? t.pos[v] : v; }
+                                if (!single) { vr = ldg(&t.vrec[v]); tp = ld_links(&t.topo[v]); tp_a0 = t.topo[v].a[0]; slot = v < ns_ ? t.topo[v].slot : v; }
                                 pv = tp.ps; nx = tp.ns; old_p = tp_a0; fc = tp.fc; flg = tp.flags;
                             }
                             if (tid < 64) { ch_v[tid] = v; ch_pv[tid] = pv; ch_nx[tid] = nx; }
@@ -2827,7 +2845,7 @@ NIRRT_FN __device__ void it_connect()
                                 acc = chain_finish(s, t, acc, clen);
                                 t.vrec[v].cost = acc;
                                 t.g_rec[slot].cost = acc;
-                                if (flg & 1) t.sol_dirty = 1;
+                                if (flg & 1) { const int q = t.topo[v].sol_q; t.sol_val[q] = acc + t.sol_line[q]; t.sol_dirty = 1; }
                                 if (flg & 2) t.gc_dirty = 1;
                                 state[a] = (unsigned char)CAND_DONE;
                             }

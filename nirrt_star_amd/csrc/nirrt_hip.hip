@@ -274,6 +274,7 @@ struct nirrt_tree {
 };
 
 extern "C" const char *nirrt_last_error(void) { return g_err.c_str(); }
+extern "C" int nirrt_abi_version(void) { return NIRRT_ABI_VERSION; }
 
 extern "C" int nirrt_device_count(int *count)
 {
@@ -873,10 +874,10 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         want(&t->mt, 1);
         want(&h.vrec, np);
         want(&h.topo, np);
-        want(&h.g_rec, np); want(&h.g_idx, np); want(&h.pos, np);
+        want(&h.g_rec, np); want(&h.g_idx, np);
         want(&h.g_start, (size_t)h.g_ncell + 1);
         want(&h.g_start2, (size_t)h.g_ncell2 + 1);
-        want(&h.sol, np); want(&h.sol_line, np);
+        want(&h.sol, np); want(&h.sol_line, np); want(&h.sol_val, np);
         want(&h.gc_idx, np); want(&h.gc_dist, np); want(&h.gc_col, np);
         want(&h.nr_idx, np); want(&h.nr_m, np);
         want(&h.bfs_q, np); want(&h.bfs_fc, np); want(&h.chain_g, np);
@@ -917,6 +918,8 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         h.g_margin[k] = ext / (double)h.g_G / 256.0;
         h.g_inv_h2[k] = (double)h.g_G2 / ext;
         h.g_margin2[k] = ext / (double)h.g_G2 / 256.0;
+        h.g_h[k] = 1.0 / h.g_inv_h[k];
+        h.g_h2[k] = 1.0 / h.g_inv_h2[k];
     }
     HIPCHK_T(hipMemcpy(t->self_dev, &t->dev, sizeof(TreeDev *), hipMemcpyHostToDevice));
     tm.lap(2);
@@ -1191,7 +1194,11 @@ static int do_step(nirrt_tree *t, const double *p, int host_steer, int64_t neare
     if (rc) return rc;
     *res = t->scratch->step;
     t->last_n = res->n;
-    if (res->status) { g_err = "capacity exceeded inside step"; return res->status; }
+    if (res->status) {
+        g_err = res->status == NIRRT_E_LIBM ? "the restated libm routines returned NaN for this steer (argument outside their supported domain)"
+                                            : "capacity exceeded inside step";
+        return res->status;
+    }
     return NIRRT_OK;
 }
 
@@ -1477,10 +1484,11 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
             if (want[(size_t)i] == v) perm.push_back(i);
         if ((int)perm.size() > b0) groups.push_back(Group{v, b0, (int)perm.size(), trees[perm[(size_t)b0]]->stream, nullptr, nullptr});
     }
-    if (groups.size() > 1) {
-        if (hipStream_t *gs = group_streams(t0->device))
-            for (size_t gi = 0; gi < groups.size(); gi++) groups[gi].st = gs[gi];
-    }
+    // The kernels are launched and timed on streams that belong to the calling thread (one group: the first of its set).  The
+    // trees' own streams come from a pool of 32 per device: two nirrt_run calls from two threads could land on the same one -
+    // their launches would serialize and each call's kernel_ms would contain the other's kernels.
+    if (hipStream_t *gs = group_streams(t0->device))
+        for (size_t gi = 0; gi < groups.size(); gi++) groups[gi].st = gs[groups.size() > 1 ? gi : 2];   // (one group: a normal-priority stream)
     bool identity = true;
     for (int j = 0; j < n_trees; j++) identity = identity && perm[(size_t)j] == j;
     std::vector<TreeDev *> ptrs((size_t)n_trees);
@@ -1555,6 +1563,11 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         HIPCHK_R(hipMemcpyAsync(d_ahead, ah.data(), sizeof(int) * nt, hipMemcpyHostToDevice, st));
         HIPCHK_R(hipStreamSynchronize(st));   // (the vector goes out of scope)
     }
+    int *d_park = nullptr;
+    if (a->park_limit > 0 && (a->flags & NIRRT_F_PNG)) {
+        HIPCHK_R(dalloc(256, (void **)&d_park));
+        HIPCHK_R(hipMemsetAsync(d_park, 0, 256, st));
+    }
     long long *d_col = nullptr;   // k_collect rows before / after the launch
     HIPCHK_R(dalloc(sizeof(long long) * 2 * nt * COLLECT_W, (void **)&d_col));
     hipLaunchKernelGGL(k_collect, dim3((n_trees + 255) / 256), dim3(256), 0, st, (TreeDev *const *)d_ptrs, n_trees, d_col);
@@ -1567,6 +1580,7 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
         rd.np_words = gen_mode ? nullptr : d_npp + o; rd.n_np = d_nnp + o; rd.py_words = a->py_words ? d_pyp + o : nullptr; rd.n_py = d_npy + o;
         rd.np_used = d_npu + o; rd.py_used = d_pyu + o; rd.cost_trace = d_trace ? d_trace + (size_t)o * (size_t)a->iters : nullptr;
         rd.iters_done = d_done + o; rd.stop_code = d_stop + o;
+        rd.park = d_park; rd.park_limit = a->park_limit; rd.pad2 = 0;
         HIPCHK_R(hipEventCreate(&g.e0));
         HIPCHK_R(hipEventCreate(&g.e1));
         // more trees than the GPU holds at once: a resident set of workgroups shares them in time slices (k_run_pool)
@@ -1660,6 +1674,11 @@ extern "C" int nirrt_debug_prof(nirrt_tree *t, int64_t *out24)
 extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_run_args *a)
 {
     if (!trees || n_trees <= 0 || !a || a->iters < 0) return NIRRT_E_ARG;
+    if (a->struct_size != sizeof(nirrt_run_args)) {
+        g_err = "nirrt_run: nirrt_run_args.struct_size does not match this library (NIRRT_ABI_VERSION " + std::to_string(NIRRT_ABI_VERSION) +
+                ", sizeof " + std::to_string(sizeof(nirrt_run_args)) + "): recompile the caller against include/nirrt_hip.h";
+        return NIRRT_E_ARG;
+    }
     nirrt_tree *t0 = trees[0];
     for (int i = 0; i < n_trees; i++) {
         if (!trees[i] || trees[i]->device != t0->device || trees[i]->dim != t0->dim) {
@@ -1671,8 +1690,10 @@ extern "C" int nirrt_run(nirrt_tree *const *trees, int32_t n_trees, const nirrt_
     for (int i = 1; i < n_trees; i++) HIPCHK(hipStreamSynchronize(trees[i]->stream));
     if (!a->samples) return run_sampling(trees, n_trees, a);
     const int D = t0->dim;
-    hipStream_t st = t0->stream;
-    for (int i = 1; i < n_trees; i++) HIPCHK(hipStreamSynchronize(trees[i]->stream));
+    // (launched and timed on a stream of the calling thread, see run_sampling)
+    HIPCHK(hipStreamSynchronize(t0->stream));
+    hipStream_t *gs_ = group_streams(t0->device);
+    hipStream_t st = gs_ ? gs_[2] : t0->stream;
     std::vector<TreeDev *> ptrs((size_t)n_trees);
     for (int i = 0; i < n_trees; i++) ptrs[(size_t)i] = trees[i]->dev;
     TreeDev **d_ptrs = nullptr;

@@ -408,6 +408,56 @@ extern "C" int nirrt_fps_f64_batch(const double *pts, int n_clouds, const int *c
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// nirrt_libm_probe: the restated glibc routines (csrc/glibc235_libm.inc) evaluated on the device for arguments the CALLER chooses -
+// the Python binding compares them with the host's own math.atan2 / math.sin / math.cos before it trusts the device-side steer
+// (a host whose libm is not glibc 2.35 / x86-64 / FMA computes other last bits in the REFERENCE: nirrt_star_amd/_hip.libm_check)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_libm_probe(int fn, long long n, const double *a, const double *b, double *out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double r;
+    if (fn == 0) r = glibc235v::glibc_atan2(a[i], b[i]);
+    else if (fn == 1) r = glibc235v::sin_fn(a[i]);
+    else r = glibc235v::cos_fn(a[i]);
+    out[i] = r;
+}
+
+extern "C" int nirrt_libm_probe(int32_t fn, int64_t n, const double *a, const double *b, double *out, int device_id)
+{
+    if (fn < 0 || fn > 2 || n < 0 || (n > 0 && (!a || !out || (fn == 0 && !b)))) return -1;
+    if (n == 0) return 0;
+    if (hipSetDevice(device_id) != hipSuccess) { (void)hipGetLastError(); return -4; }
+    double *d = nullptr;
+    if (hipMalloc(&d, sizeof(double) * 3 * (size_t)n) != hipSuccess) { (void)hipGetLastError(); return -2; }
+    int rc = 0;
+    // test hook (tests/test_libm_check_gpu.py): NIRRT_LIBM_PROBE_FLIP=1 flips the lowest bit of one word of the sin / cos table for
+    // the duration of the probe - what a table that does not belong to the host's libm looks like to the caller
+    const char *flip = getenv("NIRRT_LIBM_PROBE_FLIP");
+    const bool do_flip = flip && *flip && *flip != '0';
+    uint64_t saved[440];
+    if (do_flip) {
+        if (hipMemcpyFromSymbol(saved, HIP_SYMBOL(glibc235v::T_sincos), sizeof(saved)) != hipSuccess) rc = -2;
+        if (!rc) {
+            uint64_t bad[440];
+            for (int i = 0; i < 440; i++) bad[i] = saved[i] ^ ((i % 4 == 0) ? 1ull : 0ull);   // the leading word of every entry
+            if (hipMemcpyToSymbol(HIP_SYMBOL(glibc235v::T_sincos), bad, sizeof(bad)) != hipSuccess) rc = -2;
+        }
+    }
+    if (!rc && hipMemcpy(d, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) rc = -2;
+    if (!rc && fn == 0 && hipMemcpy(d + n, b, sizeof(double) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) rc = -2;
+    if (!rc) {
+        hipLaunchKernelGGL(k_libm_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (int)fn, (long long)n, (const double *)d,
+                           (const double *)(d + n), d + 2 * n);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out, d + 2 * n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = -2;
+    }
+    if (do_flip && hipMemcpyToSymbol(HIP_SYMBOL(glibc235v::T_sincos), saved, sizeof(saved)) != hipSuccess) rc = -2;
+    (void)hipFree(d);
+    if (rc == -2) (void)hipGetLastError();
+    return rc;
+}
+
 // one cloud: pts (N,3) row-major f64, sel (N,) bytes (1 = kept)
 extern "C" int nirrt_fps_f64(const double *pts, int N, int num_samples, unsigned char *sel, int device_id)
 {

@@ -56,10 +56,14 @@ class _HipPlanner:
         if D == 3:
             self.z_range = env.z_range
         self.path_planner_name = name
-        self.mode = mode or self.default_mode
         self.device_id = device_id
         self.tree = _hip.HipTree(D, iter_max, self.x_start, self.x_goal, step_len, search_radius, clearance, env,
                                  device_id=device_id)
+        # The device-resident loop evaluates glibc 2.35's atan2 / cos / sin (2D steer, 3D informed sampling); on a host with another
+        # libm the reference computes other last bits, and only steer / sampling on THIS host reproduce it: mode "exact".
+        # (3D RRT* needs IEEE operations only.)
+        uses_libm = D == 2 or isinstance(self, _IRRTStar)
+        self.mode = mode or (self.default_mode if (not uses_libm or _hip.libm_check(device_id)) else "exact")
         self.utils = _Utils(self)
         self.last_kernel_ms = 0.0
 

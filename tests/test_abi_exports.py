@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), "missing export %s" % s
     assert set(_hip.EXPORTS) == set(syms)
     pn = _declared_symbols("nirrt_pointops.h")
-    assert len(pn) == 13
+    assert len(pn) == 14
     for s in pn:
         assert hasattr(L, s), "missing export %s" % s
 
@@ -36,7 +36,26 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_hip.StepResult) == 8 + 16 + 16 + 8 + 24 + 8 + 8 + 8 + 8
     assert _hip.StepResult.c_best.offset == 72
     assert C.sizeof(_hip.Config) == 8 + 8 + 24 + 24 + 24 + 24 + 24 + 8 + 8 + 8 + 8
-    assert C.sizeof(_hip.RunArgs) == 8 + 8 + 8 * 18
+    assert C.sizeof(_hip.RunArgs) == 16 + 8 + 8 * 18
+    assert _hip.RunArgs.struct_size.offset == 0 and _hip.RunArgs.iters.offset == 16
+
+
+def test_run_args_size_and_version_match_the_c_header(tmp_path):
+    """the ctypes mirror against the header itself: a C compiler's sizeof / offsetof of nirrt_run_args and NIRRT_ABI_VERSION, and the
+    version the built library reports (nirrt_run refuses a struct of another size; _hip.load() a library of another version)"""
+    import ctypes as C
+    import subprocess
+    from nirrt_star_amd import _hip
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nirrt_hip.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %d\\n", sizeof(nirrt_run_args), offsetof(nirrt_run_args, iters), '
+                   'offsetof(nirrt_run_args, run_ahead), sizeof(nirrt_step_result), NIRRT_ABI_VERSION); return 0; }\n')
+    exe = str(tmp_path / "abi")
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    size, off_iters, off_ahead, step, ver = (int(x) for x in subprocess.check_output([exe], text=True).split())
+    assert size == C.sizeof(_hip.RunArgs) and off_iters == _hip.RunArgs.iters.offset and off_ahead == _hip.RunArgs.run_ahead.offset
+    assert step == C.sizeof(_hip.StepResult)
+    assert ver == _hip.ABI_VERSION == _hip.load().nirrt_abi_version()
 
 
 def test_no_silent_cpu_fallback_without_device():

@@ -180,6 +180,6 @@ def test_nirrt_c_planner_with_a_running_connect_loop_equals_the_reference(name):
     n = p.num_vertices
     assert len(calls) == int(g["n_classifications"])
     assert n == int(g["n"]) and np.array_equal(p.vertex_parents[:n], g["parents"])
-    assert np.max(np.abs(p.vertices[:n] - g["vertices"])) <= 1e-9
+    assert np.array_equal(p.vertices[:n], g["vertices"])
     assert np.array_equal(np.array(p.path_solutions), g["path_solutions"])
     assert abs(p.get_path_len(p.path) - float(g["path_len"])) <= 1e-5

@@ -159,7 +159,7 @@ def test_bench_configuration_50k_against_oracle(oracle, monkeypatch, world, pid,
     """The benchmarked configuration itself at full size: 2D IRRT*, 30 circles, 50 000 iterations,
     in-kernel sampling from the problem's own seeded generators, the one-wave-per-tree kernels (`slim`) - one problem of
     bench.py's batch (and one of the r in [16, 24] world) against orc_run_sampling fed with the same words: vertex count,
-    parents, solution list, generator words consumed identical; vertices <= 1e-9; best path cost <= 1e-5
+    parents, solution list, generator words consumed identical; vertices bit-equal; best path cost <= 1e-5
     (irrt_star_2d.py:42-97).  The oracle needs 2 - 4 minutes for the 50 000-iteration problem (its cost walks are the
     reference's, un-cached), so the r in [16, 24] problem stops at 20 000.  Problem 5727 of the b30 batch is DEGENERATE (free
     straight start-goal segment: hundreds of near-tie rewire candidates per iteration, ~10 re-parentings per rewiring pass): it

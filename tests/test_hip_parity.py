@@ -2,7 +2,7 @@
 
 Bars: integer bookkeeping (n, parents, Near sets, solution lists, booleans)
 bit-exact; float64 values that involve only IEEE ops (cost walks, 3D vertices, host-steered 2D
-vertices) bit-exact; 2D vertices steered with the device libm <= 1e-9 absolute; path cost <= 1e-5.
+vertices) bit-exact, in 2D too (the steer evaluates glibc's atan2 / cos / sin, restated); path cost <= 1e-5.
 """
 import numpy as np
 import pytest
@@ -103,10 +103,7 @@ def _check_final(t, g, irrt, exact_vertices):
     v, p = t.download()
     assert len(v) == int(g["n"])
     assert np.array_equal(p, g["parents"])
-    if True:      # (round 5: the 2D steer and the 3D informed sampler evaluate the reference's own libm functions, restated: bit-equal)
-        assert np.array_equal(v, g["vertices"])
-    else:
-        assert np.max(np.abs(v - g["vertices"])) <= 1e-9
+    assert np.array_equal(v, g["vertices"])   # (since round 5 the 2D steer and the 3D informed sampler evaluate the reference's own libm functions)
     if irrt:
         assert np.array_equal(t.solutions, g["path_solutions"])
         if len(g["path_solutions"]):
@@ -116,7 +113,7 @@ def _check_final(t, g, irrt, exact_vertices):
         gp, ln = t.search_goal_parent()
         if np.isfinite(float(g["path_len"])):
             assert abs(ln - float(g["path_len"])) <= 1e-5
-            assert np.max(np.abs(v[gp] - g["path"][-2])) <= 1e-9
+            assert np.array_equal(v[gp], g["path"][-2])
 
 
 @pytest.mark.parametrize("name", RUNS)

@@ -38,10 +38,7 @@ def test_rrt_in_kernel_sample_free(name):
     assert res["iters_done"][0] == int(g["iter_max"]) and res["status"][0] == 0
     v, p = t.download()
     assert len(v) == int(g["n"]) and np.array_equal(p, g["parents"])
-    if dim == 3:
-        assert np.array_equal(v, g["vertices"])
-    else:
-        assert np.max(np.abs(v - g["vertices"])) <= 1e-9
+    assert np.array_equal(v, g["vertices"])
     # words consumed = 2*dim per SampleFree attempt; the last accepted attempt produced the last sample
     used = int(res["np_used"][0])
     assert used % (2 * dim) == 0

@@ -136,7 +136,7 @@ def test_more_than_2048_trees_in_one_launch_against_the_oracle(oracle, irrt):
         assert int(res["np_used"][b]) == ro["np_used"] and int(res["py_used"][b]) == ro["py_used"]
         v, p = trees[b].download()
         assert len(v) == o.n and np.array_equal(p, o.parents)
-        assert np.max(np.abs(v - o.vertices)) <= 1e-9
+        assert np.array_equal(v, o.vertices)
         if irrt:
             assert np.array_equal(trees[b].solutions, o.solutions)
         o.close()

@@ -33,10 +33,7 @@ def _check_tree(p, g, exact):
     n = p.num_vertices
     assert n == int(g["n"])
     assert np.array_equal(p.vertex_parents[:n], g["parents"])
-    if True:      # (round 5: the device's 2D steer and 3D informed sampler evaluate the reference's own libm functions - bit-equal vertices)
-        assert np.array_equal(p.vertices[:n], g["vertices"])
-    else:
-        assert np.max(np.abs(p.vertices[:n] - g["vertices"])) <= 1e-9
+    assert np.array_equal(p.vertices[:n], g["vertices"])   # (the device's 2D steer and 3D informed sampler evaluate the reference's own libm functions)
     if np.isfinite(float(g["path_len"])):
         assert abs(p.get_path_len(p.path) - float(g["path_len"])) <= 1e-5
         assert p.check_success(p.path)
@@ -278,7 +275,7 @@ def test_planning_block_gap_against_reference_run(name):
         assert np.max(np.abs(lst[m] - exp[m])) <= 1e-5
     n = p.num_vertices
     assert n == int(g["n"]) and np.array_equal(p.vertex_parents[:n], g["parents"])
-    assert np.max(np.abs(p.vertices[:n] - g["vertices"])) <= 1e-9
+    assert np.array_equal(p.vertices[:n], g["vertices"])
 
 
 def test_block_gap_batch_evaluation_is_segment_independent():
