@@ -92,7 +92,7 @@ def parse(argv=None):
     ap.add_argument("--free-lanes", type=int, default=0, choices=[0, 64, 128, 256],
                     help="workgroup size for the problems with a free start-goal segment (their Near sets grow to thousands of members: the "
                          "visit is arithmetic-bound and scales with the lanes); 0 = like the others")
-    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "r05_traffic.json"),
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "r06_traffic.json"),
                     help="PMC traffic table written by scripts/collect_traffic.py (an entry is used only if its key names this exact configuration)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group / timing protocol only, no GPU work (CPU test of --gpus N)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -100,7 +100,11 @@ def parse(argv=None):
                          "the 1000-problem evaluation set) is sharded round-robin over the ranks (problem i -> rank i mod N)")
     ap.add_argument("--problems", type=int, default=1000, help="size of the fixed problem set of --scaling strong")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other BASELINE configurations (N = 1 only)")
-    ap.add_argument("--cpu-reps", type=int, default=2, help="repetitions of the CPU-baseline sample (the median is reported)")
+    ap.add_argument("--cpu-reps", type=int, default=1, help="repetitions of the truncated CPU-baseline sample (the median is reported)")
+    ap.add_argument("--cpu-full-deadline", type=float, default=240.0,
+                    help="cpu_baseline.value: every host core plans ONE problem of the batch for the FULL iteration count (the identical loop, SURVEY.md "
+                         "8(d)(i)); a process still running after this many seconds stops and reports the iterations it did (0 = skip, the truncated "
+                         "sample alone is reported)")
     return ap.parse_args(argv)
 
 
@@ -257,12 +261,11 @@ def main():
     probs = make_problems(args, rank)
     D, B, iters = args.dim, len(probs), args.iters   # (strong scaling: this rank's share of the fixed set)
     flags = _hip.F_IRRT if args.algo == "irrt" else 0
-    trees = []
-    for pr in probs:
-        t = _hip.HipTree(D, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"],
-                         device_id=local_rank)
-        t.set_informed(*sampling.informed_frame(pr["x_start"], pr["x_goal"]))
-        trees.append(t)
+    # every tree of the rank in ONE creation call (nirrt_create_batch: host work per tree, one device pass), the informed-sampling
+    # frames in one launch
+    trees = _hip.create_trees(D, iters, [(pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"]) for pr in probs],
+                              device_id=local_rank)
+    _hip.set_informed_batch(trees, [sampling.informed_frame(pr["x_start"], pr["x_goal"]) for pr in probs])
     # Scheduling of the independent problems (host side; problems, seeds and results are untouched).  Per-tree run times are
     # heavy-tailed - a problem whose straight start-goal segment is free ends up with an informed set collapsed onto that segment,
     # Near sets of thousands of members, and takes 2-3x the median - and a persistent launch lasts as long as its slowest tree.
@@ -273,7 +276,8 @@ def main():
     first_hint = None
     free_line = None
     if args.algo == "irrt" and B > 1 and (args.free_first or args.free_lanes):
-        free_line = [not t.is_collision(pr["x_start"], pr["x_goal"]) for t, pr in zip(trees, probs)]
+        free_line = [bool(f) for f in ~_hip.collision_each(trees, [np.stack([np.asarray(pr["x_start"], dtype=np.float64),
+                                                                             np.asarray(pr["x_goal"], dtype=np.float64)]) for pr in probs])]
         if args.free_first:
             first_order = sorted(range(B), key=lambda b: (not free_line[b], b))
         if args.free_lanes:
@@ -372,8 +376,14 @@ def main():
         if short:
             out["warning"] = ("%d of %d trees stopped before iteration %d (a draw rejected 2^22 generator outputs, or a tree ran out of capacity): `value` counts only the iterations "
                               "that ran" % (short, B, iters))
+        detail_head = {}
         if not args.no_ttfs:
-            out["time_to_first_solution"] = time_to_first_solution(args, trees, np_states, py_states, flags)
+            t_full = time_to_first_solution(args, trees, np_states, py_states, flags)
+            detail_head["time_to_first_solution"] = t_full
+            # (the line keeps the medians; the full record goes to the detail file)
+            out["time_to_first_solution"] = {"single": {k: t_full["single"][k] for k in ("problems", "solved", "median_seconds", "median_iterations")},
+                                             "batch": {k: t_full["batch"][k] for k in ("problems", "solved", "median_seconds", "median_iterations")},
+                                             "iteration_cap": t_full["iteration_cap"]}
         if not args.no_ttfs and not args.no_single:
             out["single_tree"] = single_tree_latency(args, trees, np_states, py_states, flags)
         if not args.no_cpu_baseline and world == 1:      # (the host-core baseline belongs to the N = 1 line)
@@ -390,7 +400,7 @@ def main():
             try:
                 os.makedirs(os.path.dirname(args.detail_file), exist_ok=True)
                 with open(args.detail_file, "w") as f:
-                    json.dump({"headline": out, "secondary": detail}, f, indent=1)
+                    json.dump({"headline": dict(out, **detail_head), "secondary": detail}, f, indent=1)
             except OSError:
                 pass
             # LAST key of the line, compact: the driver keeps the line's tail
@@ -416,12 +426,10 @@ def bench_nirrt(args, rank, world, local_rank, barrier, reduce_time_and_work):
     with contextlib.redirect_stdout(sys.stderr):   # the wrapper announces itself like the reference's does; stdout carries ONE JSON line
         wrapper = eval_sharded.make_wrapper(NS(root_dir=os.path.join(ROOT, "gpurun_out", "bench_ck")), D, "cuda:%d" % local_rank)
     guidance = batch.Guidance(wrapper, D, 10, pc_update_cost_ratio=args.pc_update_cost_ratio, connect=args.algo == "nirrt_c", device_id=local_rank)
-    trees, frames = [], []
-    for pr in probs:
-        t = _hip.HipTree(D, iters, pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"], device_id=local_rank)
-        frames.append(sampling.informed_frame(pr["x_start"], pr["x_goal"]))
-        t.set_informed(*frames[-1])
-        trees.append(t)
+    trees = _hip.create_trees(D, iters, [(pr["x_start"], pr["x_goal"], 10, pr["search_radius"], pr["clearance"], pr["env"]) for pr in probs],
+                              device_id=local_rank)
+    frames = [sampling.informed_frame(pr["x_start"], pr["x_goal"]) for pr in probs]
+    _hip.set_informed_batch(trees, frames)
 
     # inputs: every step starts from freshly seeded generators (np.random.seed(s); random.seed(s); torch.manual_seed(s) per
     # problem); run_batch hands their states to the trees inside the timed step, every output is produced on the device
@@ -647,8 +655,12 @@ def measured_traffic(args):
         with open(args.traffic_file) as f:
             tab = json.load(f)
         e = tab["entries"][config_key(args)]
-        return float(e["traffic_bytes"]), {"file": os.path.relpath(args.traffic_file, ROOT), "collected": e.get("collected"),
-                                           "kernel": e.get("kernel"), "formula": tab.get("formula")}
+        # (a flat string: the driver's record keeps scalars of the roofline object and drops nested ones)
+        return float(e["traffic_bytes"]), ("%s, entry %s, collected %s by scripts/collect_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / "
+                                           "WRITE_SIZE passes of this exact configuration (%.3f x FETCH_SIZE + %.3f x WRITE_SIZE, factors from %s); "
+                                           "a constant replayed into the line, not a counter read in this run"
+                                           % (os.path.relpath(args.traffic_file, ROOT), config_key(args), e.get("collected"), e.get("f_fetch", 2.0),
+                                              e.get("f_write", 1.0), e.get("calibration")))
     except Exception:
         return None, None
 
@@ -710,10 +722,42 @@ def cpu_baseline(args, full_proc=None):
         return None
     reps.sort(key=lambda r: r["value"])
     m = reps[len(reps) // 2]
-    return {"value": m["value"], "unit": "iterations/s", "cores": m["cores"], "host_cores": os.cpu_count(), "cpu_model": cpu_model(),
+    # The SAME work as a GPU tree: every host core plans one problem of the batch for the full iteration count (the oracle's
+    # per-iteration cost grows with the tree, so the truncated sample above flatters the CPU).  value = iterations of all processes /
+    # wall time of the slowest; a process that is not done at the deadline stops there and counts with what it did.
+    same = None
+    if args.cpu_full_deadline > 0:
+        t_f = time.perf_counter()
+        cmd_f = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--algo", args.algo, "--dim", str(args.dim), "--world", args.world,
+                 "--iters", str(args.iters), "--cap", str(args.iters), "--deadline-s", str(args.cpu_full_deadline)]
+        ps = [subprocess.Popen(cmd_f + ["--pid", str(i)], stdout=subprocess.PIPE, text=True) for i in range(procs)]
+        res = []
+        for p in ps:
+            try:
+                outp = p.communicate(timeout=args.cpu_full_deadline + 300)[0]
+            except subprocess.TimeoutExpired:
+                p.kill()
+                continue
+            if p.returncode == 0:
+                res.append(json.loads(outp.strip().splitlines()[-1]))
+        if res:
+            loop_s = max(r["seconds"] for r in res)
+            rates = sorted(r["iters"] / r["seconds"] for r in res)
+            same = {"value": sum(r["iters"] for r in res) / loop_s, "cores": len(res), "loop_s": loop_s, "iterations_each": args.iters,
+                    "complete": int(sum(1 for r in res if r.get("complete"))), "deadline_s": args.cpu_full_deadline,
+                    "iterations_done": int(sum(r["iters"] for r in res)),
+                    "single_core_median": rates[len(rates) // 2], "single_core_min": rates[0], "single_core_max": rates[-1],
+                    "wall_s": time.perf_counter() - t_f}
+    head = same if same else m
+    return {"value": head["value"], "unit": "iterations/s", "cores": head["cores"], "host_cores": os.cpu_count(), "cpu_model": cpu_model(),
             "kind": "port", "repetitions": len(reps),
+            "value_is": ("%d processes (one per host core) x ALL %d iterations of problems 0..%d of the batch: %d finished within the %.0f s "
+                         "deadline, the others count with the iterations they did; %d iterations in %.1f s (slowest process)"
+                         % (same["cores"], args.iters, same["cores"] - 1, same["complete"], same["deadline_s"], same["iterations_done"], same["loop_s"]))
+                        if same else "the truncated sample (see `sample`)",
+            "same_work": same, "truncated_sample_value": m["value"],
             "values_of_repetitions": [r["value"] for r in reps],
-            "single_core_median": m["single_core_median"], "single_core_min": m["single_core_min"], "single_core_max": m["single_core_max"],
+            "single_core_median": head["single_core_median"], "single_core_min": head["single_core_min"], "single_core_max": head["single_core_max"],
             "full_run": full,
             # (the same numbers once more as plain scalars: a record parser that keeps only flat fields still sees them)
             "full_run_iterations_per_second": (full or {}).get("iterations_per_second"), "full_run_seconds": (full or {}).get("seconds"),

@@ -19,8 +19,8 @@
  *   - vertices cross the boundary as (n, dim) row-major float64 (the reference's
  *     `self.vertices[:n]`), parents as int64 (`self.vertex_parents[:n]`).  In HBM a tree is ONE device range (its arena)
  *     holding records, not coordinate columns: a 32-byte vertex record {x, y, z, cost(v)} and a 128-byte
- *     tree record {eight hops of the parent chain with their edge lengths, child-list links, flags} per vertex, a 32-byte slot
- *     record per vertex of the two-level uniform-grid index (cell-ordered part, coarse level over the recent insertions,
+ *     tree record {eight hops of the parent chain with their edge lengths, child-list links, flags, slot number} per vertex, a packed
+ *     28- / 36-byte slot record {coordinates, cost(v), vertex index} per vertex of the two-level uniform-grid index (cell-ordered part, coarse level over the recent insertions,
  *     unsorted rest), the solution / goal-candidate lists, the Near-radius table, the guidance cloud and the tree's two
  *     MT19937 generators.  Everything is float64 / int32 on the device; there are no float32 copies.
  *   - nearest_neighbor / find_near_neighbors answers come from the grid index on large trees and from whole scans on small
@@ -118,6 +118,10 @@ int nirrt_device_count(int *count);
 /* RRTBase2D/3D.__init__ (rrt_base_2d.py:8-37, rrt_base_3d.py:8-38): allocate the tree in HBM,
  * vertex 0 = x_start, parent[0] = 0, num_vertices = 1. */
 int nirrt_create(const nirrt_config *cfg, nirrt_tree **out);
+/* the same for n problems at once (the planner objects of an evaluation set, eval_planning_2d.py:83-136): per tree only host work
+ * (its arena comes out of the pool, its descriptor is filled in and copied asynchronously), then ONE device pass over the batch.
+ * out[0 .. n) are ordinary handles (nirrt_destroy each); on failure nothing is left allocated and every out[i] is NULL. */
+int nirrt_create_batch(const nirrt_config *cfgs, int32_t n, nirrt_tree **out);
 int nirrt_destroy(nirrt_tree *t);
 int nirrt_reset(nirrt_tree *t);
 /* Trees of at least 1 MB are carved out of multi-GB device chunks (NIRRT_POOL_CHUNK_MB, default 4096, 0 = one allocation per
@@ -165,6 +169,9 @@ int nirrt_nearest(nirrt_tree *t, const double *q, int64_t *idx);
  * (collision_check_utils.py:158-218); 3D rrt_utils_3d.py:22-36 -> check_collision_line_balls_boxes
  * (collision_check_utils_3d.py:151-216).  seg = (n_seg, 2, dim) f64; out[i] = 0/1. */
 int nirrt_collision_batch(nirrt_tree *t, int64_t n_seg, const double *seg, uint8_t *out);
+/* the same test for ONE segment per tree, each against its own tree's obstacles, in one launch (a batch's "is the straight
+ * start-goal segment free?" probes): seg = (n_trees, 2, dim) f64, out[i] = 0/1; trees of one device and dimension */
+int nirrt_collision_each(nirrt_tree *const *trees, int32_t n_trees, const double *seg, uint8_t *out);
 /* Utils.is_inside_obs / Utils.is_valid (rrt_utils_2d.py:35-79, rrt_utils_3d.py:39-86);
  * pts = (n, dim); either output may be NULL. */
 int nirrt_points_in_obs(nirrt_tree *t, int64_t n, const double *pts, uint8_t *inside, uint8_t *valid);
@@ -185,6 +192,8 @@ int nirrt_solutions(nirrt_tree *t, int64_t *n_sol, int64_t *out, int64_t cap);
  * the caller exactly like the reference (math.hypot, numpy SVD): c_min, x_center (dim), C (3x3 row-major).
  * Only needed before nirrt_run with in-kernel IRRT* sampling. */
 int nirrt_set_informed(nirrt_tree *t, double c_min, const double *x_center, const double *C);
+/* ... for a batch (same device): c_min (n,), x_center (n, 3), C (n, 9) - one copy, one launch */
+int nirrt_set_informed_batch(nirrt_tree *const *trees, int32_t n_trees, const double *c_min, const double *x_center, const double *C);
 
 /* NIRRT* guidance state for nirrt_run + NIRRT_F_PNG: the predicted path points `self.path_point_cloud_pred`
  * ((n, dim) f64), pc_sample_rate, pc_update_cost_ratio and c_update (nirrt_star_png_2d.py:56-63,99-130).  The
@@ -253,8 +262,8 @@ typedef struct nirrt_run_args {
                             nearest_neighbor + n per find_near_neighbors - i.e. algorithmic bytes = alg_elems * dim * 8
                             (B_iter = 2*n*D*8) */
     int64_t *stats;      /* optional (n_trees, NIRRT_N_STATS): what this launch did per tree -
-                            [0] slots visited by the fused nearest / Near passes, [1] bytes those visits read (32 B per slot
-                            record, + 4 in 3D), [2] Near members, [3] members spilled out of LDS, [4] tree records (96 B of hops, eight
+                            [0] slots visited by the fused nearest / Near passes, [1] bytes those visits read (28 B per slot
+                            record in 2D, 36 B in 3D: packed records with the vertex index inside), [2] Near members, [3] members spilled out of LDS, [4] tree records (96 B of hops, eight
                             hops each) read by cost walks,
                             [5] rewire candidates examined, [6] vertices rewired, [7] vertices re-costed,
                             [8] goal-candidate list entries re-evaluated (12 B + one 32-byte record each), [9] vertices inserted,

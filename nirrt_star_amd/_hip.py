@@ -27,6 +27,7 @@ EXPORTS = [
     "nirrt_near", "nirrt_cost", "nirrt_search_goal_parent", "nirrt_best_solution", "nirrt_solutions",
     "nirrt_step", "nirrt_extend", "nirrt_run", "nirrt_set_informed", "nirrt_debug_prof", "nirrt_set_cloud", "nirrt_reset_batch", "nirrt_pool_trim", "nirrt_set_cloud_batch",
     "nirrt_mt19937_fill", "nirrt_set_generators", "nirrt_get_generators", "nirrt_generator_words", "nirrt_abi_version",
+    "nirrt_create_batch", "nirrt_set_informed_batch", "nirrt_collision_each",
 ]
 
 
@@ -72,16 +73,16 @@ STAT_NAMES = ["visited", "visit_bytes", "members", "spilled", "hop_records", "re
 
 def useful_bytes(stats, dim):
     """Bytes the IMPLEMENTED algorithm has to move for what a launch did (per tree or summed), from the kernel's own
-    counters (include/nirrt_hip.h, nirrt_run_args.stats): visited slot records (32 B, + 4 B of index in 3D - already in
-    bytes), 96 B per tree record walked (the hop part: eight hops each since round 5; 64 B / four hops before), one 32-byte
-    vertex record + 20 B of its tree record (links, parent) per rewire candidate examined, 16 B written per re-costed vertex
+    counters (include/nirrt_hip.h, nirrt_run_args.stats): visited slot records (28 B in 2D, 36 B in 3D since round 6 - packed
+    records with the vertex index inside; already in bytes), 96 B per tree record walked (the hop part: eight hops each), one
+    32-byte vertex record + 20 B of its tree record (links, parent) per rewire candidate examined, 16 B written per re-costed vertex
     (its record's and its slot's cost), 12 B + one 32-byte record per re-evaluated goal-candidate list entry, 8 B per re-evaluated
-    solution list entry (its cached cost + Line(v, goal): round 6; 44 B before), 184 B (+ 4 in 3D) written per
-    inserted vertex (vertex record 32, tree record 112, slot record 32, two link words), 32 B read + 32 + 4 (+ 4 in 3D) + 8 B
-    written per vertex of an index rebuild."""
+    solution list entry (its cached cost + Line(v, goal): round 6; 44 B before), per inserted vertex the vertex record (32), the tree
+    record (112), the slot record and two link words (8) written, per vertex of an index rebuild 32 B read + the slot record + 4
+    (its slot number) + 8 (rank) written."""
     st = np.asarray(stats, dtype=np.float64).reshape(-1, N_STATS).sum(axis=0)
-    d3 = 4 if dim == 3 else 0
-    return float(st[1] + 96 * st[4] + 52 * st[5] + 16 * st[7] + 44 * st[8] + 8 * st[21] + (184 + d3) * st[9] + (32 + 32 + 4 + d3 + 8) * st[10])
+    slot = 36 if dim == 3 else 28
+    return float(st[1] + 96 * st[4] + 52 * st[5] + 16 * st[7] + 44 * st[8] + 8 * st[21] + (32 + 112 + slot + 8) * st[9] + (32 + slot + 4 + 8) * st[10])
 
 
 _lib = None
@@ -137,6 +138,9 @@ def load():
     L.nirrt_debug_prof.argtypes = [vp, ip]
     L.nirrt_set_cloud.argtypes = [vp, C.c_int64, dp, C.c_double, C.c_double, C.c_double]
     L.nirrt_abi_version.argtypes = []
+    L.nirrt_create_batch.argtypes = [C.POINTER(Config), C.c_int32, C.POINTER(vp)]
+    L.nirrt_set_informed_batch.argtypes = [C.POINTER(vp), C.c_int32, dp, dp, dp]
+    L.nirrt_collision_each.argtypes = [C.POINTER(vp), C.c_int32, dp, up]
     L.nirrt_libm_probe.argtypes = [C.c_int32, C.c_int64, dp, dp, dp, C.c_int]   # (include/nirrt_pointops.h)
     L.nirrt_libm_probe.restype = C.c_int
     for name in EXPORTS:
@@ -244,45 +248,102 @@ def obstacle_tables(env, dim):
     return np.ascontiguousarray(rnd), np.ascontiguousarray(box), lo, hi
 
 
+def _fill_config(cfg, dim, iter_max, x_start, x_goal, step_len, search_radius, clearance, env, device_id):
+    """nirrt_config of one problem; returns the arrays its pointers refer to (to be kept alive until the create call returns)"""
+    rnd, box, lo, hi = obstacle_tables(env, dim)
+    cfg.dim = int(dim)
+    cfg.device_id = int(device_id)
+    cfg.iter_max = int(iter_max)
+    xs, xg = _f64(x_start), _f64(x_goal)
+    for k in range(dim):
+        cfg.x_start[k] = xs[k]
+        cfg.x_goal[k] = xg[k]
+        cfg.range_lo[k] = lo[k]
+        cfg.range_hi[k] = hi[k]
+    cfg.step_len = float(step_len)
+    cfg.search_radius = float(search_radius)
+    cfg.clearance = float(clearance)
+    cfg.n_round = len(rnd)
+    cfg.round_obs = _dp(rnd) if len(rnd) else None
+    cfg.n_box = len(box)
+    cfg.box_obs = _dp(box) if len(box) else None
+    return rnd, box
+
+
+def create_trees(dim, iter_max, specs, device_id=0):
+    """One tree per problem of `specs` = [(x_start, x_goal, step_len, search_radius, clearance, env), ...] through nirrt_create_batch:
+    host work per tree, ONE device pass for the batch (8192 trees: ~1 s instead of the 5 s of 8192 nirrt_create calls)."""
+    L = load()
+    n = len(specs)
+    if n == 0:
+        return []
+    cfgs = (Config * n)()
+    keep = []
+    for i, (xs, xg, step_len, radius, clearance, env) in enumerate(specs):
+        keep.append(_fill_config(cfgs[i], int(dim), int(iter_max), xs, xg, step_len, radius, clearance, env, device_id))
+    handles = (C.c_void_p * n)()
+    _check(L.nirrt_create_batch(cfgs, n, handles))
+    return [HipTree(dim, iter_max, None, None, None, None, None, None, device_id=device_id, _handle=C.c_void_p(handles[i])) for i in range(n)]
+
+
+def set_informed_batch(trees, frames):
+    """IRRTStar.init for a batch: frames[i] = (c_min, x_center, C) of sampling.informed_frame - one copy, one launch"""
+    nt = len(trees)
+    if nt == 0:
+        return
+    cm = np.zeros(nt)
+    xc = np.zeros((nt, 3))
+    Cm = np.zeros((nt, 9))
+    for i, (c_min, x_center, Cmat) in enumerate(frames):
+        cm[i] = float(c_min)
+        v = np.asarray(x_center, dtype=np.float64).ravel()
+        xc[i, : trees[i].dim] = v[: trees[i].dim]
+        Cm[i] = np.asarray(Cmat, dtype=np.float64).reshape(9)
+    handles = (C.c_void_p * nt)(*[t.h for t in trees])
+    _check(load().nirrt_set_informed_batch(handles, nt, _dp(cm), _dp(xc), _dp(Cm)))
+
+
+def collision_each(trees, segs):
+    """Utils.is_collision of ONE segment per tree (segs: (n_trees, 2, dim)), each against its own tree's obstacles, in one launch:
+    the "is the straight start-goal segment free?" probes of a batch"""
+    nt = len(trees)
+    if nt == 0:
+        return np.zeros(0, dtype=bool)
+    seg = _f64(segs).reshape(nt, 2, trees[0].dim)
+    out = np.zeros(nt, dtype=np.uint8)
+    handles = (C.c_void_p * nt)(*[t.h for t in trees])
+    _check(load().nirrt_collision_each(handles, nt, _dp(seg), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return out.astype(bool)
+
+
 class HipTree:
     """One planning tree resident in HBM (opaque nirrt_tree handle)."""
 
-    def __init__(self, dim, iter_max, x_start, x_goal, step_len, search_radius, clearance, env, device_id=0):
+    def __init__(self, dim, iter_max, x_start, x_goal, step_len, search_radius, clearance, env, device_id=0, _handle=None):
         L = load()
         self.L = L
         self.dim = int(dim)
         self.iter_max = int(iter_max)
         self.device_id = int(device_id)
-        rnd, box, lo, hi = obstacle_tables(env, self.dim)
-        self._keep = (rnd, box)
+        self._res = StepResult()
+        if _handle is not None:     # (create_trees: the handle comes out of nirrt_create_batch)
+            self.h = _handle
+            return
         cfg = Config()
-        cfg.dim = self.dim
-        cfg.device_id = int(device_id)
-        cfg.iter_max = self.iter_max
-        xs, xg = _f64(x_start), _f64(x_goal)
-        for k in range(self.dim):
-            cfg.x_start[k] = xs[k]
-            cfg.x_goal[k] = xg[k]
-            cfg.range_lo[k] = lo[k]
-            cfg.range_hi[k] = hi[k]
-        cfg.step_len = float(step_len)
-        cfg.search_radius = float(search_radius)
-        cfg.clearance = float(clearance)
-        cfg.n_round = len(rnd)
-        cfg.round_obs = _dp(rnd) if len(rnd) else None
-        cfg.n_box = len(box)
-        cfg.box_obs = _dp(box) if len(box) else None
+        self._keep = _fill_config(cfg, self.dim, self.iter_max, x_start, x_goal, step_len, search_radius, clearance, env, device_id)
         h = C.c_void_p()
         _check(L.nirrt_create(C.byref(cfg), C.byref(h)))
         self.h = h
-        self._res = StepResult()
 
     def close(self):
         if getattr(self, "h", None):
             # whoever parked generator states in this tree (batch.ProblemStreams) takes them back before the tree goes
             for hook in list(getattr(self, "_release_hooks", ())):
                 try:
-                    hook()
+                    import weakref
+                    fn = hook() if isinstance(hook, weakref.WeakMethod) else hook   # (batch.ProblemStreams registers weak references)
+                    if fn is not None:
+                        fn()
                 except Exception:
                     pass
             self._release_hooks = []

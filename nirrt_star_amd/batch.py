@@ -16,6 +16,7 @@ Reference loop being batched: eval_planning_2d.py:83-136 calling planning_random
 """
 import os
 import random
+import weakref
 
 import numpy as np
 
@@ -61,7 +62,9 @@ class ProblemStreams:
                 except AttributeError:
                     hooks = None
             if hooks is not None:
-                hooks.append(self.release)
+                # (a weak reference: the tree keeps no stream alive and no tree <-> stream cycle keeps a closed-over arena from
+                #  being freed by reference counting)
+                hooks.append(weakref.WeakMethod(self.release))
         self._tree = tree
         self._behind = [False, False]
         self._touched = [False, False]
@@ -72,12 +75,15 @@ class ProblemStreams:
             if getattr(self._tree, "h", True):          # (a closed tree has nothing left to fetch)
                 self._pull(0)
                 self._pull(1)
-            hooks = getattr(self._tree, "_release_hooks", None)
-            if hooks and self.release in hooks:
-                hooks.remove(self.release)
+            self._unhook()
             self._tree = None
         self._behind = [False, False]
         self._touched = [False, False]
+
+    def _unhook(self):
+        hooks = getattr(self._tree, "_release_hooks", None)
+        if hooks:
+            hooks[:] = [h for h in hooks if (h() if isinstance(h, weakref.WeakMethod) else h) not in (None, self.release)]
 
     def np_state(self):
         return _hip.np_state(self._rs)
@@ -160,6 +166,22 @@ def hand_over(trees, streams, only_touched=False):
         _hip.set_generators([trees[i] for i in only_np], [streams[i].np_state() for i in only_np], None)
     if only_py:
         _hip.set_generators([trees[i] for i in only_py], None, [streams[i].py_state() for i in only_py])
+
+
+def release_all(trees, streams):
+    """the end of a batch: every problem's generators come home in ONE call per stream kind (HipTree.close would fetch them tree by
+    tree - thousands of small synchronous copies for a large batch), after which the trees can be closed"""
+    for which in (0, 1):
+        idx = [i for i, s in enumerate(streams) if s._tree is trees[i] and s._behind[which] and getattr(trees[i], "h", None)]
+        if idx:
+            nk, npos, pk, ppos = _hip.get_generators([trees[i] for i in idx], want_np=which == 0, want_py=which == 1)
+            for k, i in enumerate(idx):
+                if which == 0:
+                    streams[i].absorb(np_st=(nk[k], npos[k]))
+                else:
+                    streams[i].absorb(py_st=(pk[k], ppos[k]))
+    for s in streams:
+        s.release()      # (nothing left to fetch: bookkeeping only)
 
 
 def fetch_np(trees, streams, idx):
@@ -550,6 +572,11 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
                 # the cost the stopped kernel compared with ratio * c_update (find_best_path_solution), handed back with the
                 # launch's counters: no extra launch per stopped tree
                 c_best[i] = float(r["stats"][j, 17:18].view(np.float64)[0])
+                if frames is not None and frames[i] is not None and not (c_best[i] >= float(frames[i][0]) * (1.0 - 1e-9)):
+                    # (a solution cannot be shorter than the straight start-goal distance: the device handed back something else)
+                    raise RuntimeError("tree %d stopped for a cloud refresh with best cost %r < |goal - start| = %r (launch %d, %d iterations in it, "
+                                       "budget %d, counters %s)" % (i, c_best[i], float(frames[i][0]), launches, d, int(remaining[i]) + d,
+                                                                    r["stats"][j].tolist()))
                 due.append(i)
             elif st == _hip.E_STREAM:   # one draw rejected 2^22 generator outputs in a row
                 failed[i] = "sampling cannot make progress (free space empty?)"

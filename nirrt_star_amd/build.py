@@ -25,8 +25,10 @@ DEPS = SOURCES + [os.path.join(CSRC, "nirrt_device.hpp"), os.path.join(CSRC, "ni
 # scratch and reloaded around every call (9 dwords per lane and iteration); with this flag they are re-materialised where they
 # are used and the loops of k_run_sample / k_run_pool have no scratch access at all.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fno-optimize-sibling-calls", "-mllvm", "-amdgpu-lower-module-lds-strategy=module",
-         "-mllvm", "-sink-insts-to-avoid-spills=true"]
+         "-fno-optimize-sibling-calls", "-mllvm", "-amdgpu-lower-module-lds-strategy=module"]
+# (an -mllvm option the compiler does not know is a hard error: probed once per build, dropped with a note if this ROCm lacks it -
+#  the library is then correct but its persistent loops reload a few hoisted constants from scratch every iteration)
+OPTIONAL_MLLVM = ["-sink-insts-to-avoid-spills=true"]
 
 
 # Test-only second build with tiny compile-time limits, so that the overflow paths of the loop body (parent chains longer
@@ -43,9 +45,32 @@ def needs_build(so=SO):
     return any(os.path.getmtime(p) > so_m for p in DEPS + [os.path.abspath(__file__)])
 
 
+_optional = None
+
+
+def optional_flags(hipcc):
+    """the -mllvm options of OPTIONAL_MLLVM this compiler accepts (device-only compile of an empty kernel, a second per option)"""
+    global _optional
+    if _optional is None:
+        import tempfile
+        _optional = []
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "probe.hip")
+            with open(src, "w") as f:
+                f.write("__global__ void k() {}\n")
+            for opt in OPTIONAL_MLLVM:
+                r = subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-c", "-mllvm", opt, "-o", os.path.join(d, "probe.o"), src],
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                if r.returncode == 0:
+                    _optional += ["-mllvm", opt]
+                else:
+                    print("nirrt_star_amd.build: this hipcc does not know -mllvm %s: built without it" % opt, file=sys.stderr)
+    return _optional
+
+
 def _compile(so, extra, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + extra + ["-o", so] + SOURCES
+    cmd = [hipcc] + FLAGS + optional_flags(hipcc) + extra + ["-o", so] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -93,7 +93,9 @@ struct Topo;
 #define CHAIN_MAX 96     // LDS slots for the new->root edge-length sequence (deeper chains continue in HBM, t.chain_g)
 #endif
 #define GRID_MIN_VERTICES 2048   // smaller trees are visited whole (everything is "tail")
-#define GRID_REBUILD_EVERY 1024  // vertices appended behind the cell-ordered part before it is rebuilt
+#define GRID_REBUILD_EVERY 2048  // vertices appended behind the cell-ordered part before it is rebuilt (round 6: 2048, coarse level every
+                                 // 128 - a full rebuild re-sorts the whole tree, and with the other traffic of an iteration cut it showed:
+                                 // 1024 / 2048 / 4096: 58.3 / 59.3 / 57.0 M it/s on the default line, RRT* 2D 77.5 / 80.4 at 1024 / 2048)
 #define GRID_RG_MAX 64           // rows of cells per query (<= the smallest workgroup: one row per thread); larger boxes fall
                                  // back to visiting the whole tree
 #ifndef NEAR_STASH
@@ -115,6 +117,8 @@ struct Topo;
 #ifndef LIST_U
 #define LIST_U 8                 // solution / goal-candidate list entries per lane and trip
 #endif
+#define RG_BITS 11264            // flat offsets of a range list that the start-bit map covers (1408 B of LDS: what 12 trees per CU leave -
+                                 // the module's LDS, this struct + 256 B of other kernels' variables, must stay within 12800 B)
 #define GRID_N 1u                // range serves the Near query
 #define GRID_Q 2u                // range serves the nearest query
 
@@ -256,21 +260,13 @@ struct __attribute__((aligned(32))) VRec {
     double cost;   // exact cost(v) of the CURRENT tree (see walk_chains / wg_recost_subtree)
 };
 
-// one slot of the grid index (see "uniform-grid index"): what a query needs about a vertex, in one 32-byte record
-#ifdef NIRRT_SLOT_PAD   // A/B experiment only: a 64-byte slot stride (twice the bytes per visited slot, same work) - how bandwidth-bound is the visit?
-struct __attribute__((aligned(64))) GSlot {
-    double x, y;
-    double cost;
-    double w;
-    double pad_[4];
-};
-#else
-struct __attribute__((aligned(32))) GSlot {
-    double x, y;
-    double cost;   // exact cost(v), kept in step with vrec[v].cost
-    double w;      // 2D: the vertex index (integer bit pattern in the low word); 3D: z (the index is in g_idx[slot])
-};
-#endif
+// One slot of the grid index (see "uniform-grid index"): what a query needs about a vertex - coordinates, exact cost(v) (kept in
+// step with vrec[v].cost) and the vertex index - PACKED (round 6): 28 bytes in 2D {x, y, cost, id}, 36 in 3D {x, y, cost, z, id}.
+// The visit streams rows of these records and its bytes are what an iteration's memory traffic mostly is: rounds 3 - 5 kept a
+// 32-byte record (4 bytes of padding in 2D) and, in 3D, the index in an array of its own - a second stream with a 128-byte line of
+// its own for every row of a handful of slots.  Records are only 4-byte aligned; the loads below say so.
+template <int D> struct SlotBytes { static constexpr int value = D == 2 ? 28 : 36; };
+#define SLOT_COST_OFF 16   // cost sits at the same place in both layouts
 
 // The part of a tree descriptor the loop body touches: copied into LDS when a kernel starts (hot_enter) and written back when
 // it ends (hot_leave), so that a pointer or a counter of the tree costs an LDS read instead of a dependent scalar load from HBM
@@ -334,8 +330,7 @@ struct TreeHotT {
     double c_update;         // best cost at the last cloud refresh (inf before the first solution)
     // uniform-grid index (see "uniform-grid index" below): one 32-byte record per SLOT - slots [0, g_ns) hold vertices
     // [0, g_ns) ordered by cell, slots [g_ns, n) the vertices appended since (slot i = vertex i): a query streams slot ranges only
-    typename P<GSlot>::type g_rec;            // coordinates + exact cost(v) (kept in step with vrec[v].cost) + index (2D) / z (3D)
-    typename P<int>::type g_idx;              // 3D: vertex index by slot
+    typename P<char>::type g_rec;             // packed slot records (SlotBytes<D> each): coordinates, exact cost(v), vertex index
     typename P<int>::type g_start;            // g_start[c] .. g_start[c+1]: slots of cell c inside [0, g_ns); g_ncell + 1 entries
     typename P<int>::type g_cnt;              // rebuild scratch: per-cell counters
     typename P<int>::type g_rank;             // rebuild scratch: rank of vertex i inside its cell
@@ -359,6 +354,10 @@ struct TreeHotT {
     double g_inv_h2[3];
     double g_margin2[3];
     double g_h[3], g_h2[3];   // cell sizes of both levels (1 / g_inv_h: the host's division is the device's, both correctly rounded)
+    // g_start is stored TILED when g_G is a power of two >= 8 (g_lgG = its log2, else 0 = plain row-major): the words of 4 rows x 8
+    // columns of cells share one 128-byte line.  A query asks for two words per row of its box (first cell / cell behind the last);
+    // row-major, the ~10 rows of a Near box touched 10 - 20 lines of HBM for 20 words, tiled they touch 5 - 6 (grid_word below)
+    int g_lgG, pad3;
 };
 using TreeHotH = TreeHotT<gp_plain>;    // as stored in HBM and as the host fills it in
 using TreeHot = TreeHotT<gp_global>;    // the device code's view (same layout)
@@ -384,6 +383,10 @@ struct TreeDev : TreeHotH {
     double box[MAX_OBS][6];  // x, y, z, w, h, d
     long long prof[24];      // NIRRT_PROFILE: wall_clock64 ticks (100 MHz) per phase
     MtGen *mt;               // the tree's generators (inside its arena)
+    // creation (k_init mode 2): the Near radii are tabulated on the device from f(n) (host libm, one table per capacity) and gamma
+    const double *near_f;
+    double gamma;
+    TreeDev **self_slot;     // one-element device array that is to hold the descriptor's own address
 };
 static_assert(sizeof(TreeHot) % 8 == 0 && sizeof(TreeHot) == sizeof(TreeHotH), "hot_enter / hot_leave copy 8-byte words");
 
@@ -490,6 +493,13 @@ struct LdsData {
     unsigned char ob_list[2 * MAX_OBS];
     int rg_beg[GRID_RG_MAX + 1], rg_len[GRID_RG_MAX + 1];   // + 1: the appended vertices [g_ns, n)
     unsigned char rg_flag[GRID_RG_MAX + 4];
+    // (round 6) where a lane's flat offset falls in the range list, without walking the list: bit f of rg_bits is set iff a range
+    // starts at flat offset f; the range of offset f is (number of set bits at or below f) - 1 = one popcount per lane on the word
+    // of its wave's 64-offset window (a wave-uniform LDS read) + the starts before the window, which the wave carries along.
+    // rg_cb[r] = (start offset of range r | its flag << 16, first slot).  Lists of more than RG_BITS slots keep the walk.
+    unsigned long long rg_bits[RG_BITS / 64];
+    int rg_cb[GRID_RG_MAX + 1][2] __attribute__((aligned(8)));
+    int rg_total, rg_fast;
     struct {                      // arguments / results of wg_query_fn
         double pn[3], q[3], r, floor_m, cand;
         int lazy;                 // collision filter of the Near members deferred to the members that can matter (wg_query_fn)
@@ -1082,44 +1092,60 @@ __device__ __forceinline__ void load_vertex(const TreeHot &t, int i, double *v)
     for (int k = 0; k < D; k++) v[k] = k == 0 ? t.vrec[i].x : (k == 1 ? t.vrec[i].y : t.vrec[i].z);
 }
 
-// slot record helpers (GSlot: x, y, cost, w; w = the vertex index in 2D, z in 3D - there the index sits in g_idx[])
-template <int D>
-__device__ __forceinline__ GSlot slot_make(const double *v, double cost, int id)
-{
-    GSlot g;
-    g.x = v[0]; g.y = v[1];
-    g.cost = cost;
-    g.w = D == 3 ? v[D - 1] : __longlong_as_double((long long)id);
-    return g;
-}
+// slot record helpers
 typedef double nirrt_v2d __attribute__((ext_vector_type(2)));
 typedef unsigned nirrt_v3u __attribute__((ext_vector_type(3)));
+typedef nirrt_v2d nirrt_v2d_a4 __attribute__((aligned(4)));   // (the same vectors at the 4-byte alignment packed records have)
+typedef nirrt_v3u nirrt_v3u_a4 __attribute__((aligned(4)));
+typedef double nirrt_f64_a4 __attribute__((aligned(4)));
+template <int D>
+__device__ __forceinline__ GAS char *slot_ptr(const TreeHot &t, int sl)
+{
+    return (GAS char *)t.g_rec + (long long)sl * SlotBytes<D>::value;
+}
+template <int D>
+__device__ __forceinline__ void slot_store(const TreeHot &t, int sl, const double *v, double cost, int id)
+{
+    GAS char *p = slot_ptr<D>(t, sl);
+    nirrt_v2d xy;
+    xy.x = v[0]; xy.y = v[1];
+    *(GAS nirrt_v2d_a4 *)p = xy;
+    const unsigned long long cb = (unsigned long long)__double_as_longlong(cost);
+    if (D == 2) {
+        nirrt_v3u b;
+        b.x = (unsigned)cb; b.y = (unsigned)(cb >> 32); b.z = (unsigned)id;
+        *(GAS nirrt_v3u_a4 *)(p + 16) = b;
+    } else {
+        nirrt_v2d cz;
+        cz.x = cost; cz.y = v[D - 1];
+        *(GAS nirrt_v2d_a4 *)(p + 16) = cz;
+        *(GAS int *)(p + 32) = id;
+    }
+}
+// the cost of the vertex in slot sl changed (every re-costing writes the vertex record and this)
+template <int D>
+__device__ __forceinline__ void slot_set_cost(const TreeHot &t, int sl, double cost)
+{
+    *(GAS nirrt_f64_a4 *)(slot_ptr<D>(t, sl) + SLOT_COST_OFF) = cost;
+}
 // the fields of slot sl, fetched with loads whose every register is used (x, y: 16 bytes; 2D: cost + index 12 bytes;
 // 3D: cost + z 16 bytes and the index word) - a wider load with a dead lane would let the register allocator recycle that
 // lane and wait for the load right after issuing it
 template <int D>
 __device__ __forceinline__ void slot_load(const TreeHot &t, int sl, double &x, double &y, double &z, double &c, int &id)
 {
-    const GAS char *p = (const GAS char *)(t.g_rec + sl);
-#ifdef NIRRT_SLOT_NT   // A/B: the visit's stream marked non-temporal (does it leave more of the L2 to the records the chases re-read?)
-    const nirrt_v2d xy = __builtin_nontemporal_load((const GAS nirrt_v2d *)p);
-#else
-    const nirrt_v2d xy = *(const GAS nirrt_v2d *)p;
-#endif
+    const GAS char *p = slot_ptr<D>(t, sl);
+    const nirrt_v2d xy = *(const GAS nirrt_v2d_a4 *)p;
     x = xy.x; y = xy.y;
     if (D == 2) {
-#ifdef NIRRT_SLOT_NT
-        const nirrt_v3u b = __builtin_nontemporal_load((const GAS nirrt_v3u *)(p + 16));
-#else
-        const nirrt_v3u b = *(const GAS nirrt_v3u *)(p + 16);
-#endif
+        const nirrt_v3u b = *(const GAS nirrt_v3u_a4 *)(p + 16);
         c = __longlong_as_double(((long long)b.y << 32) | (long long)b.x);
         id = (int)b.z;
         z = 0.;
     } else {
-        const nirrt_v2d cz = *(const GAS nirrt_v2d *)(p + 16);
+        const nirrt_v2d cz = *(const GAS nirrt_v2d_a4 *)(p + 16);
         c = cz.x; z = cz.y;
-        id = t.g_idx[sl];
+        id = *(const GAS int *)(p + 32);
     }
 }
 
@@ -1205,6 +1231,15 @@ __device__ __forceinline__ int wg_nearest_finish(Lds<NT> &s, double m1, int i1, 
 // fall into border cells, which extend to infinity.  The order inside a cell is whatever the atomics produce; no result
 // depends on it (minima are reduced as (value, index) pairs, rewire selects by index).
 // ------------------------------------------------------------------------------------------------
+// position of cell c's word in g_start (c = row-major cell number, or g_ncell for the end word): see TreeHot::g_lgG
+__device__ __forceinline__ int grid_word(const TreeHot &t, int c)
+{
+    const int lg = t.g_lgG;
+    if (lg == 0 || c >= t.g_ncell) return c;
+    const int G = 1 << lg, x = c & (G - 1), y = (c >> lg) & (G - 1), slab = c >> (2 * lg);
+    return (slab << (2 * lg)) + ((((y >> 2) << (lg - 3)) + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7);
+}
+
 template <int L = 0>   // L = 0: the G^D grid of the cell-ordered part; L = 1: the coarse grid of the second level
 __device__ __forceinline__ int grid_cell_axis(const TreeHot &t, int k, double x)
 {
@@ -1294,7 +1329,7 @@ NIRRT_FN __device__ void wg_grid_rebuild(int n)
     for (int j = 0; j < per; j++) {
         if (b + j < nc) {
             int c = t.g_cnt[b + j];
-            t.g_start[b + j] = run;
+            t.g_start[grid_word(t, b + j)] = run;
             run += c;
         }
     }
@@ -1310,15 +1345,14 @@ NIRRT_FN __device__ void wg_grid_rebuild(int n)
             if (i < n) { v[u] = ldg(&t.vrec[i]); rk[u] = t.g_rank[i]; }
         }
 #pragma unroll
-        for (int u = 0; u < REBUILD_U; u++) st[u] = i0 + u * NT < n ? t.g_start[cell_of(v[u])] : 0;
+        for (int u = 0; u < REBUILD_U; u++) st[u] = i0 + u * NT < n ? t.g_start[grid_word(t, cell_of(v[u]))] : 0;
 #pragma unroll
         for (int u = 0; u < REBUILD_U; u++) {
             const int i = i0 + u * NT;
             if (i < n) {
                 const int sl = st[u] + rk[u];
                 const double xyz[3] = {v[u].x, v[u].y, v[u].z};
-                stg(&t.g_rec[sl], slot_make<D>(xyz, v[u].cost, i));
-                if (D == 3) t.g_idx[sl] = i;
+                slot_store<D>(t, sl, xyz, v[u].cost, i);
                 t.topo[i].slot = sl;
             }
         }
@@ -1390,13 +1424,53 @@ NIRRT_FN __device__ void wg_grid_rebuild2(int n)
             if (j < m) {
                 const int i = v0 + j, sl = st[u] + rk[u];
                 const double xyz[3] = {v[u].x, v[u].y, v[u].z};
-                stg(&t.g_rec[sl], slot_make<D>(xyz, v[u].cost, i));
-                if (D == 3) t.g_idx[sl] = i;
+                slot_store<D>(t, sl, xyz, v[u].cost, i);
                 t.topo[i].slot = sl;
             }
         }
     }
     if (tid == 0) { t.g_ns2 = n; s.stat[ST_REBUILT] += m; }
+    __syncthreads();
+}
+
+// A range list goes to LDS through rg_publish: thread i contributes range i (mine), thread 0 may add one more behind them; empty
+// ranges are dropped, the kept ones get their start offsets (exclusive scan) and - for lists within RG_BITS slots - their start
+// bits.  Barriers inside; every thread calls it.  (Out of line: four call sites, two of them on rare paths.)
+#ifndef NIRRT_RG_FAST
+#define NIRRT_RG_FAST 1   // 0: A/B build that always walks the list
+#endif
+template <int NT>
+NIRRT_FN __device__ void rg_publish(bool mine, int my_beg, int my_len, unsigned my_flag, int extra_beg, int extra_len, unsigned extra_flag)
+{
+    Lds<NT> &s = g_lds;
+    const int tid = tidx<NT>();
+    const bool keep = mine && my_len > 0;
+    int pos = 0, cs = 0;
+    int R = block_compact<NT>(s, keep, pos);
+    int total = block_excl_scan<NT>(s, keep ? my_len : 0, cs);
+    const bool has_extra = extra_len > 0;     // (uniform: every thread passes the same extra range)
+    const int R_all = R + (has_extra ? 1 : 0), total_all = total + (has_extra ? extra_len : 0);
+    const bool fast = NIRRT_RG_FAST && R_all >= 1 && total_all <= RG_BITS;
+    if (fast)
+        for (int w = tid; w < (total_all + 63) / 64; w += NT) s.rg_bits[w] = 0ull;
+    __syncthreads();
+    if (keep) {
+        s.rg_beg[pos] = my_beg; s.rg_len[pos] = my_len; s.rg_flag[pos] = (unsigned char)my_flag;
+        if (fast) {
+            s.rg_cb[pos][0] = cs | (int)(my_flag << 16); s.rg_cb[pos][1] = my_beg;
+            atomicOr(&s.rg_bits[cs >> 6], 1ull << (cs & 63));
+        }
+    }
+    if (tid == 0) {
+        if (has_extra) {
+            s.rg_beg[R] = extra_beg; s.rg_len[R] = extra_len; s.rg_flag[R] = (unsigned char)extra_flag;
+            if (fast) {
+                s.rg_cb[R][0] = total | (int)(extra_flag << 16); s.rg_cb[R][1] = extra_beg;
+                atomicOr(&s.rg_bits[total >> 6], 1ull << (total & 63));
+            }
+        }
+        s.rg_n = R_all; s.rg_total = total_all; s.rg_fast = fast ? 1 : 0;
+    }
     __syncthreads();
 }
 
@@ -1508,7 +1582,7 @@ NIRRT_FN __device__ void wg_query_fn()
         const int base = (cz * GL + cy) * GL;
         int b = 0, e = 0;
         if (!empty) {
-            if (L == 0) { b = t.g_start[base + x0]; e = t.g_start[base + x1 + 1]; }
+            if (L == 0) { b = t.g_start[grid_word(t, base + x0)]; e = t.g_start[grid_word(t, base + x1 + 1)]; }
             else { b = t.g_start2[base + x0]; e = t.g_start2[base + x1 + 1]; }
         }
         rb = b; rl = e;     // first slot / end slot: nothing is computed from the two loads here, so they stay in flight
@@ -1557,11 +1631,9 @@ NIRRT_FN __device__ void wg_query_fn()
         else if (tid < rows1 + rows2N) row_range(LV1, cb0, cb1, tid - rows1, pnv, r, rb, rl);
         else if (tid < rowsAll) row_range(LV1, db0, db1, tid - rows1 - rows2N, nullptr, 0., rb, rl);
     }
-    if (tid == 0) {
-        // first pass: the vertices no level covers yet (and the coarse level whole if its rows found no room in the list)
-        const int beg = brute ? 0 : (coarse_whole || !lvl2 ? ns : ns2);
-        s.rg_beg[0] = beg; s.rg_len[0] = n - beg; s.rg_flag[0] = (unsigned char)fl_all; s.rg_n = 1;
-    }
+    auto publish = [&](bool mine, int my_beg, int my_len, unsigned my_flag, int extra_beg, int extra_len, unsigned extra_flag) {
+        rg_publish<NT>(mine, my_beg, my_len, my_flag, extra_beg, extra_len, extra_flag);
+    };
     double m1 = __builtin_inf(), m2 = __builtin_inf();   // nearest: smallest / second-smallest squared distance of this lane
     int i1 = 0x7fffffff;
     // Near: this lane's best cost + dist (ba: by sqrt(v) until b_exact, then the reference's value) and its index
@@ -1670,64 +1742,101 @@ NIRRT_FN __device__ void wg_query_fn()
     int pass = 0;
     double ring = 0.;
     int result_ni = -1;
+    {
+        // first pass: the vertices no level covers yet (and the coarse level whole if its rows found no room in the list)
+        const int beg = brute ? 0 : (coarse_whole || !lvl2 ? ns : ns2);
+        publish(tid == 0, beg, n - beg, fl_all, 0, 0, 0u);
+    }
+    // slots per lane and trip: GRID_U on the one- / two-wave workgroups (many trees share the memory system), GRID_U_WIDE on
+    // the 256-lane ones (one or a few heavy trees: fewer, larger trips - a trip is a dependent round trip)
+    constexpr int GU = NT >= 256 ? GRID_U_WIDE : GRID_U;
+    constexpr int NW = NT / 64;
+    const int wv = NT == 64 ? 0 : (tid >> 6);
+    const unsigned long long le_mask = (2ull << lane) - 1ull;   // (lane 63: all ones)
+    // one trip loop for both ways of finding a lane's slot: `fetch(Fbase, o)` loads the record of flat offset Fbase + tid
+    // (Fbase = the workgroup's window, uniform and a multiple of NT).  The loads are issued unconditionally (lanes past the end
+    // read slot 0 and get flag 0): a load behind a branch would make the number of loads in flight unknown to the wait-count
+    // insertion, which then waits for all of them
+    auto run_trips = [&](int total, auto &fetch) {
+        SlotRegs cur[GU], nxt[GU];
+#pragma unroll
+        for (int u = 0; u < GU; u++) fetch(u * NT, cur[u]);
+#pragma nounroll
+        for (int f0 = 0; f0 < total; f0 += NT * GU) {
+#pragma unroll
+            for (int u = 0; u < GU; u++) fetch(f0 + NT * GU + u * NT, nxt[u]);   // (past the end: dummy loads)
+#pragma unroll
+            for (int u = 0; u < GU; u++) {
+                if (f0 + u * NT < total) {   // uniform
+                    double sm = 0.;
+                    const bool member = cur[u].fl ? process(cur[u], sm) : false;
+                    if (wantN && __ballot(member) != 0ull) stash(member, cur[u].id, sm);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GU; u++) cur[u] = nxt[u];
+        }
+    };
 #pragma nounroll
     for (;;) {
         // ---------------- visit the ranges listed in s.rg_* ----------------
         {
-            const int R = uni(s.rg_n);
-            int total = 0;
-            for (int i = 0; i < R; i++) total += s.rg_len[i];
-            total = uni(total);
+            const int total = uni(s.rg_total);
             visited += total;
-            // a lane's flat offsets only grow (with u and with the trip), so its position in the range list is carried along
-            int rr = 0, r_lo = 0, r_hi = s.rg_len[0], r_beg = s.rg_beg[0];
-            unsigned r_flag = (unsigned)s.rg_flag[0];
-            // the loads are issued unconditionally (lanes past the end read slot 0 and get flag 0): a load behind a branch would
-            // make the number of loads in flight unknown to the wait-count insertion, which then waits for all of them
-            auto fetch = [&](int off, SlotRegs &o) {
-                const bool live = off < total;
-                if (live) {
-                    while (off >= r_hi) {
-                        rr++;
-                        r_lo = r_hi;
-                        r_hi += s.rg_len[rr]; r_beg = s.rg_beg[rr]; r_flag = (unsigned)s.rg_flag[rr];
+            if (__builtin_expect(uni(s.rg_fast) != 0, 1)) {
+                // range of a flat offset = (range starts at or below it) - 1: the wave's 64-offset window is one word of the start-bit
+                // map (a uniform LDS read), the starts before the window are carried along (windows are fetched in ascending order)
+                const int n_words = (total + 63) >> 6;
+                int rbase = 0;   // range starts before the workgroup's current window row
+                auto fetch = [&](int Fbase, SlotRegs &o) {
+                    const int off = Fbase + tid, w0 = Fbase >> 6;
+                    unsigned long long M = 0ull;
+                    int before = rbase, row = 0;
+#pragma unroll
+                    for (int k = 0; k < NW; k++) {
+                        const unsigned long long m = w0 + k < n_words ? uni((long long)s.rg_bits[w0 + k]) : 0ull;
+                        const int c = __popcll(m);
+                        if (k < wv) before += c;
+                        if (k == wv) M = m;
+                        row += c;
                     }
-                }
-                const int sl = live ? r_beg + (off - r_lo) : 0;
-                slot_load<D>(t, sl, o.x, o.y, o.z, o.c, o.id);
-                o.fl = live ? r_flag : 0u;
-            };
-            // slots per lane and trip: GRID_U on the one- / two-wave workgroups (many trees share the memory system), GRID_U_WIDE on
-            // the 256-lane ones (one or a few heavy trees: fewer, larger trips - a trip is a dependent round trip)
-            constexpr int GU = NT >= 256 ? GRID_U_WIDE : GRID_U;
-            SlotRegs cur[GU], nxt[GU];
-#pragma unroll
-            for (int u = 0; u < GU; u++) fetch(u * NT + tid, cur[u]);
-#pragma nounroll
-            for (int f0 = 0; f0 < total; f0 += NT * GU) {
-#pragma unroll
-                for (int u = 0; u < GU; u++) fetch(f0 + NT * GU + u * NT + tid, nxt[u]);   // (past the end: dummy loads)
-#pragma unroll
-                for (int u = 0; u < GU; u++) {
-                    if (f0 + u * NT < total) {   // uniform
-                        double sm = 0.;
-                        const bool member = cur[u].fl ? process(cur[u], sm) : false;
-                        if (wantN && __ballot(member) != 0ull) stash(member, cur[u].id, sm);
+                    rbase += row;
+                    const bool live = off < total;
+                    int r = before + __popcll(M & le_mask) - 1;
+                    r = live ? r : 0;
+                    const long long cb = *reinterpret_cast<const long long *>(&s.rg_cb[r][0]);   // (one 8-byte LDS read, unconditional)
+                    const int c0 = (int)cb, b0 = (int)(cb >> 32);
+                    const int sl = live ? b0 + (off - (c0 & 0xffff)) : 0;
+                    slot_load<D>(t, sl, o.x, o.y, o.z, o.c, o.id);
+                    o.fl = live ? (unsigned)c0 >> 16 : 0u;
+                };
+                run_trips(total, fetch);
+            } else {
+                // one range (the whole tree, the appended vertices) or more slots than the start-bit map covers: a lane's flat offsets
+                // only grow (with u and with the trip), so its position in the range list is carried along
+                int rr = 0, r_lo = 0, r_hi = s.rg_len[0], r_beg = s.rg_beg[0];
+                unsigned r_flag = (unsigned)s.rg_flag[0];
+                auto fetch = [&](int Fbase, SlotRegs &o) {
+                    const int off = Fbase + tid;
+                    const bool live = off < total;
+                    if (live) {
+                        while (off >= r_hi) {
+                            rr++;
+                            r_lo = r_hi;
+                            r_hi += s.rg_len[rr]; r_beg = s.rg_beg[rr]; r_flag = (unsigned)s.rg_flag[rr];
+                        }
                     }
-                }
-#pragma unroll
-                for (int u = 0; u < GU; u++) cur[u] = nxt[u];
+                    const int sl = live ? r_beg + (off - r_lo) : 0;
+                    slot_load<D>(t, sl, o.x, o.y, o.z, o.c, o.id);
+                    o.fl = live ? r_flag : 0u;
+                };
+                run_trips(total, fetch);
             }
         }
         if (stage == 0) {
             // the rows of cells: the range list goes to LDS now (their g_start words have had the first pass to arrive)
-            __syncthreads();
-            if (tid < rowsAll) {
-                s.rg_beg[tid] = rb; s.rg_len[tid] = rl - rb;
-                s.rg_flag[tid] = (tid < rowsN || (tid >= rows1 && tid < rows1 + rows2N)) ? GRID_N : GRID_Q;
-            }
-            if (tid == 0) s.rg_n = rowsAll;
-            __syncthreads();
+            const unsigned my_flag = (tid < rowsN || (tid >= rows1 && tid < rows1 + rows2N)) ? GRID_N : GRID_Q;
+            publish(tid < rowsAll, rb, rl - rb, my_flag, 0, 0, 0u);
             stage = 1;
             PROF(13);
             if (rowsAll > 0) continue;
@@ -1773,22 +1882,19 @@ NIRRT_FN __device__ void wg_query_fn()
         const int rowsE = grid_rows(eb0, eb1);
         // another visit, nearest only, with a fresh reduction (a vertex seen twice would look like its own runner-up)
         m1 = __builtin_inf(); m2 = __builtin_inf(); i1 = 0x7fffffff;
-        __syncthreads();
         if (rowsE > GRID_RG_MAX || pass >= 3 || (g1 == __builtin_inf() && pass >= 2)) {
             brute = true;
             brutes++;
-            if (tid == 0) { s.rg_beg[0] = 0; s.rg_len[0] = n; s.rg_flag[0] = GRID_Q; s.rg_n = 1; }
+            publish(tid == 0, 0, n, GRID_Q, 0, 0, 0u);
         } else {
             revisits++;
             int eb = 0, el = 0;
             if (tid < rowsE) row_range(LV0, eb0, eb1, tid, nullptr, 0., eb, el);
-            if (tid < rowsE) { s.rg_beg[tid] = eb; s.rg_len[tid] = el - eb; s.rg_flag[tid] = GRID_Q; }
-            if (tid == 0) { s.rg_beg[rowsE] = ns; s.rg_len[rowsE] = n - ns; s.rg_flag[rowsE] = GRID_Q; s.rg_n = rowsE + 1; }
+            publish(tid < rowsE, eb, el - eb, GRID_Q, ns, n - ns, GRID_Q);   // + everything behind the cell-ordered part
 #pragma unroll
             for (int k = 0; k < 3; k++) { qb0[k] = eb0[k]; qb1[k] = eb1[k]; }
             coarse_whole = true;   // (everything behind the cell-ordered part has been visited whole from here on)
         }
-        __syncthreads();
         stage = 2;
         pass++;
     }
@@ -1802,7 +1908,7 @@ NIRRT_FN __device__ void wg_query_fn()
     if (tid == 0) {
         s.qa.ni = result_ni;
         s.qa.cand = cand; s.qa.cj = cj;
-        s.stat[ST_VISITED] += visited; s.stat[ST_VISIT_B] += visited * (D == 3 ? 36 : 32); s.stat[ST_REVISITS] += revisits; s.stat[ST_BRUTE] += brutes;
+        s.stat[ST_VISITED] += visited; s.stat[ST_VISIT_B] += visited * SlotBytes<D>::value; s.stat[ST_REVISITS] += revisits; s.stat[ST_BRUTE] += brutes;
         if (wantN) {
             const int ks = s.hit_cnt;
             s.stat[ST_MEMBERS] += s.mem_cnt;
@@ -2013,7 +2119,7 @@ NIRRT_FN __device__ void wg_recost_queue_fn(int n_src_in, int walk_from_in, int 
         for (int r = 0; r < WALK_R; r++) {
             if (who[r] >= 0) {
                 t.vrec[who[r]].cost = acc[r];
-                t.g_rec[slot[r]].cost = acc[r];
+                slot_set_cost<D>(t, slot[r], acc[r]);
                 const int li = t.topo[who[r]].flags;
                 const int ts = stamp ? t.tie_stamp[who[r]] : 0;
                 if (li & 1) { const int q = t.topo[who[r]].sol_q; t.sol_val[q] = acc[r] + t.sol_line[q]; t.sol_dirty = 1; }
@@ -2343,17 +2449,18 @@ NIRRT_FN __device__ void it_extend()
     nearest[0] = vnear.x; nearest[1] = vnear.y;
     if (D == 3) nearest[D - 1] = vnear.z;
     if (!host_steer) steer<D>(t, nearest, node_in, node_new);
-    // the restated libm routines return NaN on the paths their translation does not cover (|theta| > 1e8, Inf: unreachable for
-    // atan2's results, but nothing else would notice): no NaN vertex enters the tree - the iteration is dropped and the run ends
-    bool bad_steer = false;
-    if (D == 2 && !host_steer) bad_steer = node_new[0] != node_new[0] || node_new[1] != node_new[1];
     if (res && tid == 0) {
         res->collided = 0; res->inserted = 0; res->nearest_idx = ni; res->new_idx = -1; res->n_near = 0;
         res->reparented = 0; res->n_rewired = 0; res->in_goal = 0; res->status = 0; res->reserved = 0;
         res->node_new[0] = node_new[0]; res->node_new[1] = node_new[1]; res->node_new[2] = D == 3 ? node_new[D - 1] : 0.;
     }
-    bool collided = bad_steer || wg_collision<D, NT>(s, nearest, node_new, clr);
-    if (bad_steer && tid == 0) t.status = NIRRT_E_LIBM;
+    bool collided = wg_collision<D, NT>(s, nearest, node_new, clr);
+    // the restated libm routines return NaN on the paths their translation does not cover (|theta| > 1e8, Inf: unreachable for
+    // atan2's results, but nothing else would notice): no NaN vertex enters the tree - the iteration is dropped and the run ends
+    if (D == 2 && !host_steer && (node_new[0] != node_new[0] || node_new[1] != node_new[1])) {   // (a NaN end point collides with nothing)
+        collided = true;
+        if (tid == 0) t.status = NIRRT_E_LIBM;
+    }
     PROF(1);
     int new_idx = -1;
     bool dup_ = false, inserted_ = false;
@@ -2388,8 +2495,7 @@ NIRRT_FN __device__ void it_extend()
                 VRec vr;
                 vr.x = node_new[0]; vr.y = node_new[1]; vr.z = D == 3 ? node_new[D - 1] : 0.; vr.cost = 0.;
                 stg(&t.vrec[new_idx], vr);
-                stg(&t.g_rec[new_idx], slot_make<D>(node_new, 0., new_idx));   // its slot (appended vertices: slot = index)
-                if (D == 3) t.g_idx[new_idx] = new_idx;
+                slot_store<D>(t, new_idx, node_new, 0., new_idx);   // its slot (appended vertices: slot = index)
                 if (fc_ni >= 0) t.topo[fc_ni].ps = new_idx;
                 t.topo[ni].fc = new_idx;
                 s.new_next = fc_ni;
@@ -2505,7 +2611,7 @@ NIRRT_FN __device__ void it_connect()
                 if (dup) {
                     if (reparented) wg_recost_subtree<D, NT>(s, t, new_idx, new_idx);
                 } else {
-                    if (tid == 0) { t.vrec[new_idx].cost = new_cost; t.g_rec[new_idx].cost = new_cost; }
+                    if (tid == 0) { t.vrec[new_idx].cost = new_cost; slot_set_cost<D>(t, new_idx, new_cost); }
                 }
             }
             PROF(4);
@@ -2671,7 +2777,7 @@ NIRRT_FN __device__ void it_connect()
                             acc += el;
                             acc = chain_finish(s, t, acc, clen);
                             t.vrec[vj].cost = acc;
-                            t.g_rec[slot].cost = acc;
+                            slot_set_cost<D>(t, slot, acc);
                             if (li & 1) { const int q = t.topo[vj].sol_q; t.sol_val[q] = acc + t.sol_line[q]; t.sol_dirty = 1; }
                             if (li & 2) t.gc_dirty = 1;
                             fast = 1;
@@ -2844,7 +2950,7 @@ NIRRT_FN __device__ void it_connect()
                                 acc += el;
                                 acc = chain_finish(s, t, acc, clen);
                                 t.vrec[v].cost = acc;
-                                t.g_rec[slot].cost = acc;
+                                slot_set_cost<D>(t, slot, acc);
                                 if (flg & 1) { const int q = t.topo[v].sol_q; t.sol_val[q] = acc + t.sol_line[q]; t.sol_dirty = 1; }
                                 if (flg & 2) t.gc_dirty = 1;
                                 state[a] = (unsigned char)CAND_DONE;

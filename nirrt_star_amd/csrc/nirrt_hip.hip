@@ -11,6 +11,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <tuple>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------
@@ -170,7 +171,7 @@ static_assert(NT_WIDE / 64 <= LDS_NW_MAX && NT_NARROW / 64 <= LDS_NW_MAX, "LdsDa
 static_assert(offsetof(TreeHotH, pc) > offsetof(TreeHotH, CL_C) && offsetof(TreeHotH, g_rec) > offsetof(TreeHotH, c_update),
               "nirrt_set_informed / nirrt_set_cloud patch contiguous field ranges of the descriptor");
 // 12 one-wave trees per CU (3 waves per SIMD at 168 VGPRs): 160 KB / 12 in allocation granules of 1280 bytes = 12800 bytes each
-static_assert(sizeof(LdsData) <= 12800, "LdsData must fit 12 times into a CU's 160 KB of LDS (12 one-wave trees per CU)");
+static_assert(sizeof(LdsData) + 256 <= 12800, "LdsData (+ the 256 B of LDS the module's other kernels declare: one module-wide allocation) must fit 12 times into a CU's 160 KB of LDS");
 // nirrt_run: batches larger than the 2048 workgroup slots of the 128-thread kernels run one wave per tree (16 trees per
 // CU with 10 KB of LDS): measured on 4096 problems 12.8 vs 10.9 M it/s (IRRT*), 39.0 vs 26.3 M it/s (RRT*); at 2048
 // problems the 128-thread kernels win (IRRT* 10.9 vs 8.6) or tie (RRT*).  NIRRT_SLIM_MIN_TREES overrides the threshold.
@@ -251,6 +252,8 @@ struct Scratch {  // pinned, device-visible result slots
     double d[4];
 };
 
+#include <atomic>
+struct ScratchBlock { void *base; std::atomic<int> refs; };
 #define PC_OWN_POINTS 4096   // guidance-cloud points that fit the per-tree arena (pc_n_points is 2048 in the reference's configs)
 struct nirrt_tree {
     nirrt_config cfg;
@@ -265,8 +268,9 @@ struct nirrt_tree {
     size_t arena_bytes;
     bool arena_pooled;   // carved out of a pool chunk (see ArenaPool) / an allocation of its own
     double *near_r;  // device table (inside the arena)
-    Scratch *scratch;      // pinned host memory
+    Scratch *scratch;      // pinned host memory (a slot of sblk)
     Scratch *scratch_dev;  // device alias of the same memory
+    struct ScratchBlock *sblk;   // the pinned block the slot lives in, shared by the trees of one nirrt_create_batch call
     double *pc_dev;        // guidance cloud (nirrt_set_cloud): pc_own (inside the arena, PC_OWN_POINTS points) or an allocation of its own
     double *pc_own;
     MtGen *mt;             // the tree's generators (inside the arena)
@@ -692,7 +696,10 @@ extern "C" int nirrt_destroy(nirrt_tree *t)
     if (t->pc_dev && t->pc_dev != t->pc_own) (void)hipFree(t->pc_dev);
     if (t->arena && t->arena_pooled) g_pool.give(t->device, t->arena_bytes, t->arena);
     else if (t->arena) (void)hipFree(t->arena);
-    if (t->scratch) (void)hipHostFree(t->scratch);
+    if (t->sblk && --t->sblk->refs == 0) {
+        if (t->sblk->base) (void)hipHostFree(t->sblk->base);
+        delete t->sblk;
+    }
     delete t;      // (the stream belongs to the device's pool)
     return NIRRT_OK;
 }
@@ -797,11 +804,15 @@ struct CreateTimer {
     }
 };
 
-extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
+// ---- creation: host-side preparation per tree, ONE device pass per batch ---------------------------------------------------------
+// nirrt_create is the batch of one.  Per tree nothing waits for the device: the arena is carved out of a pool chunk, the descriptor
+// is filled in on the host and copied asynchronously; one k_init launch (mode 2) over the batch clears what must be clear in a
+// (possibly recycled) arena - the rewire stamps and the generators -, tabulates the Near radii and builds the one-vertex trees.
+// Round 5 did per tree: four hipMemsets (8 MB of vertex / tree records that the loop overwrites before it reads them), a pinned
+// allocation, a 400 KB synchronous copy of the Near-radius table, a synchronous copy of the descriptor's address and a k_init launch
+// with its own synchronisation - 5.4 s for the 8192 trees of the bench.
+static int validate_config(const nirrt_config *cfg)
 {
-    CreateTimer tm;
-    if (!cfg || !out) { g_err = "null argument"; return NIRRT_E_ARG; }
-    *out = nullptr;
     if (cfg->dim != 2 && cfg->dim != 3) { g_err = "dim must be 2 or 3"; return NIRRT_E_ARG; }
     if (cfg->iter_max < 0 || cfg->iter_max + 1 > (1ll << 30)) { g_err = "iter_max out of range"; return NIRRT_E_ARG; }
     if (cfg->n_round < 0 || cfg->n_round > MAX_OBS || cfg->n_box < 0 || cfg->n_box > MAX_OBS) {
@@ -813,14 +824,27 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         g_err = "obstacle tables exceed the LDS pool (4 * n_round + 6 * n_box <= NIRRT_OBSTACLE_POOL)";
         return NIRRT_E_CAPACITY;
     }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        (void)hipGetLastError();
-        g_err = "no HIP device visible";
-        return NIRRT_E_NODEVICE;
-    }
-    if (cfg->device_id < 0 || cfg->device_id >= ndev) { g_err = "device_id out of range"; return NIRRT_E_ARG; }
+    return NIRRT_OK;
+}
 
+// f(n) of the Near radius (near_factor) resident on the device, once per (device, dimension, capacity)
+static const double *near_factor_dev(int device, int D, int cap)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int>, double *> tabs;
+    const std::vector<double> &f = near_factor(D, cap);
+    std::lock_guard<std::mutex> g(mu);
+    double *&d = tabs[std::make_tuple(device, D, cap)];
+    if (!d) {
+        if (hipMalloc(&d, sizeof(double) * f.size()) != hipSuccess) { (void)hipGetLastError(); d = nullptr; return nullptr; }
+        if (hipMemcpy(d, f.data(), sizeof(double) * f.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); d = nullptr; return nullptr; }
+    }
+    return d;
+}
+
+// everything of a tree that needs no answer from the device
+static int prepare_tree(const nirrt_config *cfg, nirrt_tree **out, CreateTimer &tm)
+{
     nirrt_tree *t = new nirrt_tree();
     std::memset(&t->host, 0, sizeof(TreeDev));
     t->cfg = *cfg;
@@ -831,6 +855,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     t->device = cfg->device_id;
     t->stream = nullptr;
     t->arena = nullptr; t->arena_bytes = 0; t->arena_pooled = false; t->pc_own = nullptr; t->mt = nullptr; t->dev = nullptr; t->self_dev = nullptr; t->near_r = nullptr; t->scratch = nullptr; t->scratch_dev = nullptr; t->pc_dev = nullptr;
+    t->sblk = nullptr;
     const int D = t->dim;
     auto fail = [&](int rc) { nirrt_destroy(t); return rc; };
 #define HIPCHK_T(expr)                                                                        \
@@ -853,8 +878,11 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     // 12 % fewer slots than 128^2 and is 5 % faster; 3D IRRT*, 4096 trees, round 5: 32^3 visits 2490 slots per iteration where
     // 16^3 visited 3600 - 11.3 vs 10.7 M it/s; 24^3: 9.9, 40^3: 10.7 with twice the whole-tree fallbacks)
     h.g_G = D == 2 ? 256 : 32;
-    if (const char *e = std::getenv("NIRRT_GRID_G")) h.g_G = std::min(D == 2 ? 256 : 40, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("NIRRT_GRID_G")) h.g_G = std::min(D == 2 ? 1024 : 64, std::max(1, std::atoi(e)));
     h.g_ncell = D == 2 ? h.g_G * h.g_G : h.g_G * h.g_G * h.g_G;
+    h.g_lgG = 0;   // tiled g_start (nirrt_device.hpp, grid_word) for power-of-two grids; NIRRT_GRID_TILE=0 keeps it row-major (A/B, tests)
+    if (h.g_G >= 8 && (h.g_G & (h.g_G - 1)) == 0 && env_int("NIRRT_GRID_TILE", 1) != 0)
+        for (int g = h.g_G; g > 1; g >>= 1) h.g_lgG++;
     // second level over the vertices appended since the last full rebuild: 32^2 / 8^3 coarse cells, re-sorted every 64 insertions
     h.g_G2 = D == 2 ? 32 : 8;
     if (const char *e = std::getenv("NIRRT_GRID_G2")) h.g_G2 = std::min(D == 2 ? 64 : 16, std::max(1, std::atoi(e)));
@@ -874,7 +902,7 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         want(&t->mt, 1);
         want(&h.vrec, np);
         want(&h.topo, np);
-        want(&h.g_rec, np); want(&h.g_idx, np);
+        want(&h.g_rec, np * (size_t)(D == 2 ? SlotBytes<2>::value : SlotBytes<3>::value));   // (char elements: packed slot records)
         want(&h.g_start, (size_t)h.g_ncell + 1);
         want(&h.g_start2, (size_t)h.g_ncell2 + 1);
         want(&h.sol, np); want(&h.sol_line, np); want(&h.sol_val, np);
@@ -894,11 +922,8 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         for (const Piece &pc : pieces) { *pc.dst = (char *)t->arena + off; off += (pc.bytes + A - 1) / A * A; }
     }
     tm.lap(1);
-    HIPCHK_T(hipMemset(h.vrec, 0, sizeof(VRec) * np));
-    HIPCHK_T(hipMemset(h.tie_stamp, 0, sizeof(int) * np));   // (a pooled arena carries an earlier tree's stamps)
-    HIPCHK_T(hipMemset(t->mt, 0, sizeof(MtGen)));   // (generator 5489-less: all-zero state until nirrt_set_generators)
+    // (no memsets: the loop writes a vertex's records before anything reads them; k_init clears the rewire stamps and the generators)
     h.mt = t->mt;
-    HIPCHK_T(hipMemset(h.topo, 0, sizeof(Topo) * np));
     h.cap = t->cap;
     h.dim = D;
     h.cap_sol = t->cap;
@@ -921,22 +946,14 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
         h.g_h[k] = 1.0 / h.g_inv_h[k];
         h.g_h2[k] = 1.0 / h.g_inv_h2[k];
     }
-    HIPCHK_T(hipMemcpy(t->self_dev, &t->dev, sizeof(TreeDev *), hipMemcpyHostToDevice));
     tm.lap(2);
-    HIPCHK_T(hipHostMalloc((void **)&t->scratch, sizeof(Scratch), hipHostMallocMapped));
-    HIPCHK_T(hipHostGetDevicePointer((void **)&t->scratch_dev, t->scratch, 0));
-    tm.lap(3);
-    // Near radius table with the host libm (the reference's math.sqrt/math.log/float pow):
-    // rrt_star_2d.py:133  r = min(gamma*sqrt(log(n)/n), step_len);  rrt_star_3d.py:134 cube root
-    {
-        const std::vector<double> &f = near_factor(D, t->cap);
-        std::vector<double> r((size_t)t->cap + 1, 0.0);
-        for (int n = 1; n <= t->cap; n++) {
-            const double v = cfg->search_radius * f[(size_t)n];
-            r[(size_t)n] = v < cfg->step_len ? v : cfg->step_len;
-        }
-        HIPCHK_T(hipMemcpy(t->near_r, r.data(), sizeof(double) * r.size(), hipMemcpyHostToDevice));
-    }
+    // Near radius r(n) = min(gamma * f(n), step_len) (rrt_star_2d.py:133, rrt_star_3d.py:134): f(n) with the host's libm once per
+    // capacity (near_factor), resident on the device; k_init multiplies by the tree's gamma - the same IEEE product and comparison
+    // the host made per tree in round 5 (400 KB copied per tree)
+    h.near_f = near_factor_dev(t->device, D, t->cap);
+    if (!h.near_f) { g_err = "Near-radius table: device allocation failed"; return fail(NIRRT_E_HIP); }
+    h.gamma = cfg->search_radius;
+    h.self_slot = t->self_dev;
     h.near_r = t->near_r;
     tm.lap(4);
     for (int k = 0; k < 3; k++) {
@@ -962,14 +979,101 @@ extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
     for (int k = 0; k < 9; k++) h.CL_C[k] = (k % 4 == 0) ? 1. : 0.;
     h.pc = nullptr; h.pc_n = 0; h.pad2 = 0; h.pc_rate = 0.; h.pc_ratio = 0.; h.c_update = std::numeric_limits<double>::infinity();
     h.n = 1;
-    int rc = push_desc(t);
-    if (!rc) rc = nirrt_reset(t);
-    if (rc) return fail(rc);
-    tm.lap(5);
-    tm.done();
+    host_mirror_reset(t);
     *out = t;
     return NIRRT_OK;
 #undef HIPCHK_T
+}
+
+// the device pass for prepared trees of ONE device and dimension (ts[0 .. n)): pinned result slots (one block for all of them),
+// descriptors, one k_init launch
+static int finish_trees(nirrt_tree **ts, int n, CreateTimer &tm)
+{
+    nirrt_tree *t0 = ts[0];
+    HIPCHK(hipSetDevice(t0->device));
+    ScratchBlock *blk = new ScratchBlock();
+    blk->base = nullptr;
+    blk->refs = 0;
+    if (hipHostMalloc(&blk->base, sizeof(Scratch) * (size_t)n, hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        delete blk;
+        g_err = "hipHostMalloc of the result slots failed";
+        return NIRRT_E_HIP;
+    }
+    Scratch *dev_alias = nullptr;
+    hipError_t e = hipHostGetDevicePointer((void **)&dev_alias, blk->base, 0);
+    for (int i = 0; i < n; i++) {   // (every tree holds a reference from here on: nirrt_destroy releases the block with the last one)
+        ts[i]->sblk = blk;
+        blk->refs++;
+        ts[i]->scratch = (Scratch *)blk->base + i;
+        ts[i]->scratch_dev = dev_alias ? dev_alias + i : nullptr;
+    }
+    if (e != hipSuccess) { g_err = std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e); return NIRRT_E_HIP; }
+    tm.lap(3);
+    hipStream_t st = t0->stream;
+    std::vector<TreeDev *> ptrs((size_t)n);
+    for (int i = 0; i < n; i++) {
+        ptrs[(size_t)i] = ts[i]->dev;
+        HIPCHK(hipMemcpyAsync(ts[i]->dev, &ts[i]->host, sizeof(TreeDev), hipMemcpyHostToDevice, st));
+    }
+    TreeDev **d_ptrs = nullptr;
+    size_t got = 0;
+    HIPCHK(g_scratch.take(t0->device, sizeof(TreeDev *) * (size_t)n, (void **)&d_ptrs, &got));
+    e = hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(TreeDev *) * (size_t)n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        const Variant fv = forced_variant();
+        LAUNCH_V(fv == V_AUTO ? V_WIDE : fv, t0->dim, k_init, n, st, (TreeDev *const *)d_ptrs, 2);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    g_scratch.give(t0->device, got, d_ptrs);
+    if (e != hipSuccess) { g_err = std::string("nirrt_create: ") + hipGetErrorString(e); return NIRRT_E_HIP; }
+    tm.lap(5);
+    return NIRRT_OK;
+}
+
+extern "C" int nirrt_create_batch(const nirrt_config *cfgs, int32_t n, nirrt_tree **out)
+{
+    CreateTimer tm;
+    if (!cfgs || !out || n <= 0) { g_err = "null argument"; return NIRRT_E_ARG; }
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        g_err = "no HIP device visible";
+        return NIRRT_E_NODEVICE;
+    }
+    for (int i = 0; i < n; i++) {
+        int rc = validate_config(&cfgs[i]);
+        if (rc) return rc;
+        if (cfgs[i].device_id < 0 || cfgs[i].device_id >= ndev) { g_err = "device_id out of range"; return NIRRT_E_ARG; }
+    }
+    auto undo = [&](int rc) {
+        for (int i = 0; i < n; i++) { if (out[i]) nirrt_destroy(out[i]); out[i] = nullptr; }
+        return rc;
+    };
+    for (int i = 0; i < n; i++) {
+        int rc = prepare_tree(&cfgs[i], &out[i], tm);
+        if (rc) return undo(rc);
+    }
+    // one device pass per (device, dimension) group, in the caller's order within a group
+    std::vector<char> done((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        if (done[(size_t)i]) continue;
+        std::vector<nirrt_tree *> grp;
+        for (int j = i; j < n; j++)
+            if (!done[(size_t)j] && out[j]->device == out[i]->device && out[j]->dim == out[i]->dim) { grp.push_back(out[j]); done[(size_t)j] = 1; }
+        int rc = finish_trees(grp.data(), (int)grp.size(), tm);
+        if (rc) return undo(rc);
+    }
+    for (int i = 0; i < n; i++) tm.done();
+    return NIRRT_OK;
+}
+
+extern "C" int nirrt_create(const nirrt_config *cfg, nirrt_tree **out)
+{
+    if (!cfg || !out) { g_err = "null argument"; return NIRRT_E_ARG; }
+    return nirrt_create_batch(cfg, 1, out);
 }
 
 extern "C" int nirrt_num_vertices(nirrt_tree *t, int64_t *n)
@@ -1224,6 +1328,96 @@ extern "C" int nirrt_set_informed(nirrt_tree *t, double c_min, const double *x_c
     const size_t off = offsetof(TreeHotH, c_min), end = offsetof(TreeHotH, pc);   // c_min, x_center, CL_C
     HIPCHK(hipMemcpyAsync((char *)t->dev + off, (char *)&t->host + off, end - off, hipMemcpyHostToDevice, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
+    return NIRRT_OK;
+}
+
+// IRRTStar.init for a whole batch: tree i gets (c_min[i], x_center[3 i ..], C[9 i ..]) - one copy and one launch instead of a copy
+// and a synchronisation per tree
+__global__ void k_set_informed(TreeDev *const *trees, int n, const double *vals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    TreeDev *t = trees[i];
+    const double *v = vals + (size_t)i * 13;
+    t->c_min = v[0];
+    for (int k = 0; k < 3; k++) t->x_center[k] = v[1 + k];
+    for (int k = 0; k < 9; k++) t->CL_C[k] = v[4 + k];
+}
+
+extern "C" int nirrt_set_informed_batch(nirrt_tree *const *trees, int32_t n_trees, const double *c_min, const double *x_center, const double *C)
+{
+    if (!c_min || !x_center || !C) return NIRRT_E_ARG;
+    TreeList tl;
+    int rc = tree_list(trees, n_trees, "nirrt_set_informed_batch", tl);
+    if (rc) return rc;
+    std::vector<double> vals((size_t)n_trees * 13);
+    for (int i = 0; i < n_trees; i++) {
+        nirrt_tree *t = trees[i];
+        double *v = &vals[(size_t)i * 13];
+        v[0] = c_min[i];
+        for (int k = 0; k < 3; k++) v[1 + k] = k < t->dim ? x_center[(size_t)i * 3 + k] : 0.;
+        for (int k = 0; k < 9; k++) v[4 + k] = C[(size_t)i * 9 + k];
+        t->host.c_min = v[0];
+        for (int k = 0; k < 3; k++) t->host.x_center[k] = v[1 + k];
+        for (int k = 0; k < 9; k++) t->host.CL_C[k] = v[4 + k];
+    }
+    hipStream_t st = trees[0]->stream;
+    double *d = nullptr;
+    size_t got = 0;
+    HIPCHK(g_scratch.take(tl.device, sizeof(double) * vals.size(), (void **)&d, &got));
+    hipError_t e = hipMemcpyAsync(d, vals.data(), sizeof(double) * vals.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_set_informed, dim3((n_trees + 255) / 256), dim3(256), 0, st, (TreeDev *const *)tl.d, (int)n_trees, (const double *)d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    g_scratch.give(tl.device, got, d);
+    if (e != hipSuccess) { g_err = std::string("nirrt_set_informed_batch: ") + hipGetErrorString(e); return NIRRT_E_HIP; }
+    return NIRRT_OK;
+}
+
+// Utils.is_collision for ONE segment per tree, each against its own tree's obstacles (the free-segment probe of a batch of
+// problems: is the straight start-goal segment free?): one thread per tree, the tables read from the descriptors
+template <int D>
+__global__ void k_collision_each(TreeDev *const *trees, int n, const double *seg, unsigned char *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const TreeDev *t = trees[i];
+    double a[D], b[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) { a[k] = seg[(size_t)i * 2 * D + k]; b[k] = seg[(size_t)i * 2 * D + D + k]; }
+    const double clr = t->clearance;
+    bool hit = false;
+    for (int o = 0; o < t->n_round && !hit; o++) hit = D == 2 ? seg_round_2d(a, b, t->rnd[o], clr) : seg_round_3d(a, b, t->rnd[o], clr);
+    for (int o = 0; o < t->n_box && !hit; o++) hit = D == 2 ? seg_box_2d(a, b, t->box[o], clr) : seg_box_3d(a, b, t->box[o], clr);
+    out[i] = hit ? 1 : 0;
+}
+
+extern "C" int nirrt_collision_each(nirrt_tree *const *trees, int32_t n_trees, const double *seg, uint8_t *out)
+{
+    if (!seg || !out) return NIRRT_E_ARG;
+    TreeList tl;
+    int rc = tree_list(trees, n_trees, "nirrt_collision_each", tl);
+    if (rc) return rc;
+    const int D = trees[0]->dim;
+    for (int i = 0; i < n_trees; i++)
+        if (trees[i]->dim != D) { g_err = "nirrt_collision_each: all trees must share dim"; return NIRRT_E_ARG; }
+    hipStream_t st = trees[0]->stream;
+    const size_t sb = sizeof(double) * (size_t)n_trees * 2 * D;
+    char *d = nullptr;
+    size_t got = 0;
+    HIPCHK(g_scratch.take(tl.device, sb + (size_t)n_trees + 256, (void **)&d, &got));
+    hipError_t e = hipMemcpyAsync(d, seg, sb, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        if (D == 2) hipLaunchKernelGGL(k_collision_each<2>, dim3((n_trees + 63) / 64), dim3(64), 0, st, (TreeDev *const *)tl.d, (int)n_trees, (const double *)d, (unsigned char *)(d + sb));
+        else hipLaunchKernelGGL(k_collision_each<3>, dim3((n_trees + 63) / 64), dim3(64), 0, st, (TreeDev *const *)tl.d, (int)n_trees, (const double *)d, (unsigned char *)(d + sb));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d + sb, (size_t)n_trees, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    g_scratch.give(tl.device, got, d);
+    if (e != hipSuccess) { g_err = std::string("nirrt_collision_each: ") + hipGetErrorString(e); return NIRRT_E_HIP; }
     return NIRRT_OK;
 }
 

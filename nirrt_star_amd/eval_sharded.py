@@ -121,18 +121,17 @@ def _batch_setup(problems, pids, args, device_id, cap, wrapper):
     planner = args.planner
     informed = planner in ("irrt_star", "nirrt_star", "nirrt_star_c")
     flags = _hip.F_IRRT if informed else _hip.F_GOAL_SCAN
-    trees, streams, frames = [], [], []
-    for pr, pid in zip(problems, pids):
-        t = _hip.HipTree(dim, cap, pr["x_start"], pr["x_goal"], args.step_len, pr["search_radius"], args.clearance, pr["env"],
-                         device_id=device_id)
-        frames.append(sampling.informed_frame(pr["x_start"], pr["x_goal"]))
-        t.set_informed(*frames[-1])
-        trees.append(t)
-        streams.append(batch.ProblemStreams(1000 + pid))
+    # the whole batch in one creation call (one device pass), one launch for the informed-sampling frames, one for the probes
+    trees = _hip.create_trees(dim, cap, [(pr["x_start"], pr["x_goal"], args.step_len, pr["search_radius"], args.clearance, pr["env"])
+                                         for pr in problems], device_id=device_id)
+    frames = [sampling.informed_frame(pr["x_start"], pr["x_goal"]) for pr in problems]
+    _hip.set_informed_batch(trees, frames)
+    streams = [batch.ProblemStreams(1000 + pid) for pid in pids]
     # dispatch order inside the persistent launches = longest first by the one predictor that is known before planning: a free
     # straight start-goal segment (informed set collapsed onto it, Near sets of thousands of members: 2-3x the median run time)
     if informed and len(trees) > 1:
-        free = [not t.is_collision(pr["x_start"], pr["x_goal"]) for t, pr in zip(trees, problems)]
+        free = ~_hip.collision_each(trees, [np.stack([np.asarray(pr["x_start"], dtype=np.float64), np.asarray(pr["x_goal"], dtype=np.float64)])
+                                            for pr in problems])
         order = sorted(range(len(trees)), key=lambda i: (not free[i], i))
         trees, streams, frames = [trees[i] for i in order], [streams[i] for i in order], [frames[i] for i in order]
     else:
@@ -161,7 +160,10 @@ def plan_batch(problems, pids, args, device_id, wrapper=None):
     cap = args.iter_max + args.iter_after_initial
     dim, flags, trees, streams, frames, guidance, order = _batch_setup(problems, pids, args, device_id, cap, wrapper)
     problems, pids = [problems[i] for i in order], [pids[i] for i in order]      # dispatch order from here on; undone at the end
-    r1 = batch.run_batch(trees, streams, args.iter_max, flags, dim, problems, guidance, frames, want_trace=True, stop_first=True)
+    # phase 1 (until the first solution) in launches of 4096 iterations: the typical problem is solved within a few hundred, and a
+    # launch's cost traces are (trees x launch length) doubles on both sides of the bus - 400 MB for 1000 problems at iter_max 50000
+    r1 = batch.run_batch(trees, streams, args.iter_max, flags, dim, problems, guidance, frames, want_trace=True, stop_first=True,
+                         window=int(os.environ.get("NIRRT_EVAL_FIRST_WINDOW", "4096")))
     _raise_failures(r1, pids)
     traces = list(r1["traces"])
     solved = [i for i in range(len(trees)) if len(traces[i]) and np.isfinite(traces[i][-1])]
@@ -172,6 +174,7 @@ def plan_batch(problems, pids, args, device_id, wrapper=None):
         for j, i in enumerate(solved):
             traces[i] = np.concatenate([traces[i], r2["traces"][j]])
     recs = [make_record(pid, tr, t.n) for pid, tr, t in zip(pids, traces, trees)]
+    batch.release_all(trees, streams)      # (the generators come home in one call, not tree by tree inside close())
     for t in trees:
         t.close()
     back = np.argsort(order)      # results in the caller's order
@@ -232,6 +235,52 @@ def write_reference_pickle(path, env_configs, results):
     return lst
 
 
+FINGERPRINT_KEYS = ("problem", "planner", "neural_net", "iter_max", "iter_after_initial", "step_len", "clearance", "pc_n_points",
+                    "pc_over_sample_scale", "pc_sample_rate", "pc_update_cost_ratio", "connect_max_trial_attempts",
+                    "path_len_threshold_percentage")
+
+
+def run_fingerprint(args, n_problems, wrapper_id=None):
+    """what a result list depends on besides the problem itself: a result file is only resumed by a run with the same values (the
+    reference's file name holds problem / planner / network / count only - a rerun with another iter_max or clearance would silently
+    mix two experiments)"""
+    fp = {k: getattr(args, k, None) for k in FINGERPRINT_KEYS}
+    fp["n_problems"] = int(n_problems)
+    fp["weights"] = wrapper_id
+    return fp
+
+
+def meta_path(pickle_path):
+    return pickle_path + ".meta.json"
+
+
+def load_resumable(pickle_path, fingerprint, n_problems):
+    """the result dicts of an earlier run of THIS experiment (eval_planning_2d.py:99-110), or [] with the reason printed: no
+    fingerprint beside the file (not written by this harness / an older version) or another fingerprint -> nothing is reused"""
+    import pickle
+    if not os.path.exists(pickle_path):
+        return []
+    try:
+        with open(meta_path(pickle_path)) as f:
+            old = json.load(f)
+    except (OSError, ValueError):
+        print("eval_sharded: %s has no fingerprint file beside it (%s): not resumed, every problem is planned" % (pickle_path, meta_path(pickle_path)))
+        return []
+    diff = sorted(k for k in set(old) | set(fingerprint) if old.get(k) != fingerprint.get(k))
+    if diff:
+        print("eval_sharded: %s was written with other settings (%s): not resumed, every problem is planned"
+              % (pickle_path, ", ".join("%s %r -> %r" % (k, old.get(k), fingerprint.get(k)) for k in diff)))
+        return []
+    with open(pickle_path, "rb") as f:
+        return pickle.load(f)[:n_problems]
+
+
+def write_meta(pickle_path, fingerprint):
+    os.makedirs(os.path.dirname(pickle_path) or ".", exist_ok=True)
+    with open(meta_path(pickle_path), "w") as f:
+        json.dump(fingerprint, f)
+
+
 def first_below(trace, threshold):
     """planning_block_gap's stopping rule (rrt_star_2d.py:159-196): number of iterations until the best path length is
     below the threshold (the list the reference returns has exactly that many entries), or -1."""
@@ -272,6 +321,7 @@ def plan_batch_block_gap(problems, pids, thresholds, args, device_id, wrapper=No
         active = still
         done_iters += seg
     recs = [make_block_gap_record(pid, tr, thr, t.n) for pid, tr, thr, t in zip(pids, traces, thresholds, trees)]
+    batch.release_all(trees, streams)
     for t in trees:
         t.close()
     back = np.argsort(order)      # results in the caller's order
@@ -345,20 +395,35 @@ def main():
                                    "%s-%s%s-%s-%d.pickle" % (args.problem, args.planner[:-2] if args.planner.endswith("_c") else args.planner,
                                                              "-c-bfs" if args.planner.endswith("_c") else "", args.neural_net, len(cfgs)))
     # resume like the reference (eval_planning_2d.py:99-110): an existing result file holds the first K problems' lists; they are
-    # kept as they are and only problems K.. are planned (every rank reads the same file: same K everywhere)
+    # kept as they are and only problems K.. are planned.  Only a file of the SAME experiment counts (run_fingerprint beside the
+    # pickle), and rank 0 decides for everybody: ranks without a shared file system would otherwise read different K and shard
+    # inconsistently.
+    wrapper = make_wrapper(args, 3 if args.problem == "random_3d" else 2, "cuda:%d" % local_rank) if args.neural_net == "pointnet2" else None
+    weights_id = None
+    if wrapper is not None:
+        from . import png_wrapper as W
+        ck = W.checkpoint_path(args.root_dir, 3 if args.problem == "random_3d" else 2)
+        weights_id = "%s:%d" % (os.path.basename(ck), os.path.getsize(ck)) if os.path.exists(ck) else None
+    fingerprint = run_fingerprint(args, len(cfgs), weights_id)
     loaded = []
-    if pickle_path != "none" and not args.no_resume and os.path.exists(pickle_path):
-        import pickle
-        with open(pickle_path, "rb") as f:
-            loaded = pickle.load(f)[: len(cfgs)]
+    if pickle_path != "none" and not args.no_resume and rank == 0:
+        loaded = load_resumable(pickle_path, fingerprint, len(cfgs))
+    if dist.is_initialized() and world > 1:
+        box = [loaded]
+        dist.broadcast_object_list(box, src=0)
+        loaded = box[0]
     # heavy problems (free straight start-goal segment) are dealt across the ranks first, then the rest (shard_indices)
     heavy = None
     if world > 1 and args.problem in ("random_2d", "random_3d") and not args.no_balance:
         heavy = [straight_segment_free(c["env_dict"], args.clearance) for c in cfgs]
     mine = shard_indices(len(cfgs), rank, world, heavy, first=len(loaded))
-    wrapper = make_wrapper(args, 3 if args.problem == "random_3d" else 2, "cuda:%d" % local_rank) if args.neural_net == "pointnet2" else None
     t0 = time.time()
     recs, results = [], []
+    # one rank plans problems K, K + 1, ... in order: the result file is rewritten after every batch (the reference writes after
+    # every problem), so a crash leaves a resumable prefix.  With several ranks the lists meet on rank 0 at the end only.
+    incremental = world == 1 and pickle_path != "none"
+    if incremental:
+        write_meta(pickle_path, fingerprint)
     for b0 in range(0, len(mine), args.batch):
         ids = mine[b0:b0 + args.batch]
         probs = []
@@ -377,16 +442,28 @@ def main():
             r, traces = plan_batch(probs, ids, args, local_rank, wrapper)
         recs += r
         results += list(zip(ids, result_lists(args.problem, traces, thr)))
+        if incremental:
+            write_reference_pickle(pickle_path, cfgs, [(i, d["result"]) for i, d in enumerate(loaded)] + sorted(results))
     plan_s = time.time() - t0
-    # the loaded problems' records (rank 0 only: they need no planning) from their lists, like a freshly planned one's
-    if rank == 0 and args.problem in ("random_2d", "random_3d"):
-        recs = [make_record(i, np.asarray(d["result"], dtype=np.float64), -1) for i, d in enumerate(loaded)] + recs
+    # the loaded problems' records (rank 0 only: they need no planning) from their lists, like a freshly planned one's (n_vertices
+    # is not in the file: -1).  block / gap: the list IS the trace cut at the first entry below the threshold
+    if rank == 0 and loaded:
+        if args.problem in ("random_2d", "random_3d"):
+            recs = [make_record(i, np.asarray(d["result"], dtype=np.float64), -1) for i, d in enumerate(loaded)] + recs
+        else:
+            old = []
+            for i, d in enumerate(loaded):
+                pr = get(cfgs[i])
+                thr_i = pr["best_path_len"] * (1 + args.path_len_threshold_percentage) if args.problem == "block" else pr["flank_path_len"]
+                old.append(make_block_gap_record(i, np.asarray(d["result"], dtype=np.float64), thr_i, -1))
+            recs = old + recs
     allr = gather_records(np.array(recs).reshape(-1, RECORD_LEN), world, rank, device="cuda")
     all_results = gather_results(results, world, rank) if args.pickle_out != "none" else None
     rank_seconds = gather_rank_seconds(plan_s, len(mine), world, rank)
     if rank == 0 and all_results is not None:
         all_results = [(i, d["result"]) for i, d in enumerate(loaded)] + list(all_results)
         write_reference_pickle(pickle_path, cfgs, all_results)
+        write_meta(pickle_path, fingerprint)
     if rank == 0:
         solved = allr[allr[:, 1] > 0]
         summary = {"problems": int(len(allr)), "solved": int(len(solved)), "world_size": world,
@@ -395,7 +472,7 @@ def main():
                    "median_first_solution_iter": float(np.median(solved[:, 1])) if len(solved) else None,
                    "mean_cost_at": {str(c): float(np.mean(solved[:, 4 + j][np.isfinite(solved[:, 4 + j])]))
                                     for j, c in enumerate(CHECKPOINTS) if len(solved) and np.isfinite(solved[:, 4 + j]).any()},
-                   "iterations_planned": int(allr[len(loaded):, 3].sum()) if args.problem in ("random_2d", "random_3d") else int(allr[:, 3].sum()),
+                   "iterations_planned": int(np.maximum(allr[len(loaded):, 3], 0).sum()),
                    "seconds": time.time() - t0}
         os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
         with open(args.out, "w") as f:

@@ -17,6 +17,10 @@ try:
     pi = r.get("per_iteration", {})
     print("%-28s %7.2f M it/s  kernel %7.0f ms  frac %.3f  per-tree %s" % (sys.argv[2], d["value"] / 1e6, r["kernel_ms"], r["frac"],
           {k: round(v, 2) for k, v in d["config"].get("per_tree_seconds", {}).items()}), flush=True)
+    c = d["config"]
+    if "forwards_per_step" in c:
+        print("      launches %.0f forwards %.0f clouds %.0f kernel share %.2f host %s" % (c["launches_per_step"], c["forwards_per_step"], c["clouds_per_step"],
+              r.get("kernel_share_of_step", 0), c.get("host_seconds_last_step")), flush=True)
     if pi:
         print("      visited %.0f members %.0f chain %.1f cand %.2f rewired %.2f recost %.1f list %.1f rebuilt %.1f" % (
             pi["visited_slots"], pi["near_members"], pi["chain_records"], pi["rewire_candidates"], pi["rewired"], pi["recosted"], pi["list_entries"], pi["rebuilt"]), flush=True)

@@ -89,7 +89,7 @@ def test_traffic_entry_is_used_only_for_the_exact_configuration(tmp_path, monkey
     f.write_text(json.dumps(tab))
     monkeypatch.setattr(sys, "argv", ["bench.py", "--trees", "4096", "--traffic-file", str(f)])   # the entry's configuration
     t, src = b.measured_traffic(b.parse())
-    assert t == 5e13 and src["collected"] == "2026-09-28" and "FETCH_SIZE" in src["formula"]
+    assert t == 5e13 and isinstance(src, str) and "2026-09-28" in src and "FETCH_SIZE" in src and "irrt_2d_b30r16_4096x50000" in src
     monkeypatch.setattr(sys, "argv", ["bench.py", "--trees", "2048", "--traffic-file", str(f)])
     assert b.measured_traffic(b.parse()) == (None, None)
 
@@ -102,11 +102,12 @@ def test_strong_scaling_line_has_a_traffic_key_of_its_own(monkeypatch):
 
 
 def test_every_bench_line_has_its_traffic_entry_in_the_committed_profile(monkeypatch):
-    """the default line and every secondary line look their HBM traffic up in profiles/r05_traffic.json by configuration key:
-    a line added to bench.SECONDARY without its FETCH / WRITE passes would silently report traffic = null"""
+    """the default line and every secondary line look their HBM traffic up in the round's traffic table (bench.py --traffic-file,
+    default profiles/r06_traffic.json) by configuration key: a line added to bench.SECONDARY without its FETCH / WRITE passes would
+    silently report traffic = null"""
     b = _bench()
-    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(here, "profiles", "r05_traffic.json")) as fh:
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    with open(b.parse().traffic_file) as fh:
         entries = json.load(fh)["entries"]
     lines = [("default", [])] + list(b.SECONDARY)
     for label, extra in lines:
@@ -116,3 +117,23 @@ def test_every_bench_line_has_its_traffic_entry_in_the_committed_profile(monkeyp
         assert key in entries, (label, key)
         t, src = b.measured_traffic(a)
         assert t == entries[key]["traffic_bytes"] and t > 1e12, (label, key)
+
+
+def test_scale_script_dry_run_collects_and_checks_every_line(tmp_path):
+    """scripts/scale_1248.sh --dry-run: the launcher / process-group / timing protocol of every N (gloo ranks on the CPU) for the weak
+    and the strong line, then scripts/scale_check.py over what it collected; a doctored line (wrong rank count) fails the check"""
+    env = dict(os.environ, SCALE_NS="1 2 8", SCALE_STEPS="1", SCALE_WARMUP="0")
+    r = subprocess.run([os.path.join(ROOT, "scripts", "scale_1248.sh"), "--dry-run", "--trees", "10", "--iters", "100"], capture_output=True,
+                       text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    for mode in ("weak", "strong"):
+        for n in (1, 2, 8):
+            assert "%-6s N=%d  dry run: %d ranks" % (mode, n, n) in r.stdout, r.stdout
+    out = os.path.join(ROOT, "gpurun_out", "scale")
+    d = json.loads(open(os.path.join(out, "weak_2.json")).read().strip().splitlines()[-1])
+    d["n_gpus"] = 3
+    bad = tmp_path / "scale"
+    bad.mkdir()
+    (bad / "weak_2.json").write_text(json.dumps(d))
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "scale_check.py"), str(bad)], capture_output=True, text=True)
+    assert r2.returncode == 1 and "3 ranks answered" in r2.stdout

@@ -102,6 +102,16 @@ def test_eval_sharded_resumes_from_an_existing_result_file(tmp_path):
     # a complete file: nothing left to plan
     s3, third = run()
     assert s3["resumed_from"] == 12 and s3["planned"] == 0 and len(third) == 12
+    # the same file name, another experiment (the reference's name holds problem / planner / network / count only): the fingerprint
+    # beside the pickle does not match -> nothing is reused, every problem is planned again
+    cmd[cmd.index("--iter_after_initial") + 1] = "400"
+    s4, fourth = run()
+    assert s4["resumed_from"] == 0 and s4["planned"] == 12 and len(fourth) == 12
+    assert all(len(a["result"]) == len(b["result"]) - 100 for a, b in zip(fourth, full) if np.isfinite(np.asarray(b["result"])).any())
+    # ... and a result file without a fingerprint (written by something else) is not trusted either
+    os.remove(str(pk) + ".meta.json")
+    s5, _ = run()
+    assert s5["resumed_from"] == 0 and s5["planned"] == 12
 
 
 def test_free_segment_predictor_agrees_with_the_device_collision_test():

@@ -219,3 +219,34 @@ def test_launch_groups_change_no_result(monkeypatch):
         out[mode] = es.plan_batch(probs, list(range(7)), _args("nirrt_star", 2, 3000, 400), 0, wrapper=DiagonalFake(2))
     for a, b in zip(out["one"][1], out["split"][1]):
         assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ratio", [0.9, 1.0])
+def test_parked_launches_change_no_result(monkeypatch, ratio):
+    """a guided batch whose launches end as soon as a share of the trees waits for a cloud refresh (nirrt_run_args.park_limit:
+    the others come back with NIRRT_E_PARK, their early draw taken back, and resume) against launches that always run their
+    window: identical traces - also at the 3D demo's pc_update_cost_ratio = 1.0 (demo_planning_3d.py:21), where every improvement
+    of the best cost parks a tree"""
+    from nirrt_star_amd import eval_sharded as es, worlds
+
+    class EveryOtherPoint(DiagonalFake):
+        """labels that depend on nothing but the point's place in the cloud - never an empty prediction (an empty one ends a
+        planner like it ends the reference: np.random.randint(0, 0)), the same for every batch composition"""
+
+        def classify_path_points(self, pc, start_mask, goal_mask):
+            pred = (np.arange(len(pc)) % 2 == 0).astype(np.int64)
+            return pred, pred.astype(np.float32)
+
+    out = {}
+    for mode, env in (("off", {"NIRRT_BATCH_PARK": "0"}), ("on", {"NIRRT_BATCH_PARK": "0.3", "NIRRT_BATCH_PARK_MIN": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        probs = [worlds.problem_2d(worlds.random_world_2d(80 + i, "b30"), 0) for i in range(9)]
+        a = _args("nirrt_star", 2, 3000, 600)
+        a.pc_update_cost_ratio = ratio
+        out[mode] = es.plan_batch(probs, list(range(9)), a, 0, wrapper=EveryOtherPoint(2))
+        monkeypatch.delenv("NIRRT_BATCH_PARK_MIN", raising=False)
+    for a, b in zip(out["off"][1], out["on"][1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    assert [r[1] for r in out["off"][0]] == [r[1] for r in out["on"][0]]
