@@ -265,7 +265,11 @@ struct __attribute__((aligned(32))) VRec {
 // The visit streams rows of these records and its bytes are what an iteration's memory traffic mostly is: rounds 3 - 5 kept a
 // 32-byte record (4 bytes of padding in 2D) and, in 3D, the index in an array of its own - a second stream with a 128-byte line of
 // its own for every row of a handful of slots.  Records are only 4-byte aligned; the loads below say so.
+#ifdef NIRRT_SLOT_PAD   // A/B builds only: the record stride of rounds 3 - 5 (32 bytes in 2D) / a 40-byte 3D record
+template <int D> struct SlotBytes { static constexpr int value = D == 2 ? 32 : 40; };
+#else
 template <int D> struct SlotBytes { static constexpr int value = D == 2 ? 28 : 36; };
+#endif
 #define SLOT_COST_OFF 16   // cost sits at the same place in both layouts
 
 // The part of a tree descriptor the loop body touches: copied into LDS when a kernel starts (hot_enter) and written back when

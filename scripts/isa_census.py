@@ -11,6 +11,7 @@ import re
 import subprocess
 import sys
 
+MIN_LOOP = 8
 CLASSES = ["valu", "valu_f64", "valu_trans", "lane", "salu", "lds", "vmem", "smem", "branch", "wait", "call"]
 
 
@@ -62,7 +63,12 @@ def main():
         if s.startswith(".Lfunc_end"):
             cur = None
             continue
-        if not s or s.startswith(";"):
+        if not s:
+            continue
+        if s.startswith(";"):
+            # the loop comments of a label continue on the lines after it ("Parent Loop ...", "=> This Inner Loop Header: Depth=3")
+            if body and body[-1][0] == "label":
+                body[-1] = ("label", body[-1][1], body[-1][2] + line)
             continue
         if s.startswith(".L") and ":" in s:
             body.append(("label", s.split(":")[0], line))
@@ -85,7 +91,7 @@ def main():
         labels = {b[1]: i for i, b in enumerate(body) if b[0] == "label"}
         for lab, i0 in labels.items():
             raw = body[i0][2]
-            m = re.search(r"Loop Header: Depth=(\d+)", raw + "".join(b[2] for b in body[i0 + 1:i0 + 4] if b[0] != "ins"))
+            m = re.search(r"This (?:Inner )?Loop Header: Depth=(\d+)", raw)
             if not m:
                 continue
             last = None
@@ -95,7 +101,7 @@ def main():
             if last is None:
                 continue
             li = [b[1] for b in body[i0:last + 1] if b[0] == "ins"]
-            if len(li) < 40:
+            if len(li) < MIN_LOOP:
                 continue
             lc = census(li)
             print("%-74s %6d " % ("    loop %s (depth %s)" % (lab, m.group(1)), len(li)) + " ".join("%8d" % lc[k] for k in CLASSES))
