@@ -133,9 +133,20 @@ class ProblemStreams:
         """the reference's `torch.randint(0, N, (B,))` of one forward over ONE cloud (pointnet2_utils.py:77), from this
         problem's own torch generator"""
         import torch
+        return torch.from_numpy(self.fps_starts((n_points,)))
+
+    def fps_starts(self, sizes):
+        """the start indices of one forward's farthest-point samplings (`torch.randint(0, N, (1,))` per set-abstraction level, N in
+        `sizes`) as an int64 array.  torch's CPU generator is MT19937 seeded by init_genrand(seed), and randint over a range below
+        2^32 is `next 32-bit output % N`; the same outputs come from a numpy MT19937 with the same seeding, a call of which costs
+        a tenth of four torch.randint calls (at pc_update_cost_ratio = 1.0 a batch makes > 100 000 forwards' worth of them per
+        step).  tests/test_batch_host_logic.py compares the two generators draw by draw."""
         if self._torch is None:
-            self._torch = torch.Generator().manual_seed(self.seed)
-        return torch.randint(0, int(n_points), (1,), generator=self._torch, dtype=torch.long)
+            if not 0 <= self.seed < 2 ** 32:
+                raise ValueError("ProblemStreams: seeds of the torch generator twin must fit 32 bits")
+            self._torch = np.random.RandomState(self.seed)
+        raw = self._torch.randint(0, 2 ** 32, size=len(sizes), dtype=np.uint32).astype(np.int64)
+        return raw % np.asarray(sizes, dtype=np.int64)
 
 
 def hand_over(trees, streams, only_touched=False):
@@ -311,54 +322,75 @@ class Guidance:
         return n_raw, 2 * (2 if self.dim == 2 else 3) * n_raw
 
     def _device_jobs(self, idx, problems, word_addr, c_best, frames, dev):
-        """nirrt_cloud_job of every problem in idx (2D: whole image / ellipse; 3D: whole box / ellipsoid); word_addr[k] = device
-        address of the generator outputs job k reads (nirrt_generator_words of the problem's tree)"""
+        """nirrt_cloud_job of every problem in idx (2D: whole image / ellipse; 3D: whole box / ellipsoid) as one job table
+        (pointops.cloud_job_table); word_addr[k] = device address of the generator outputs job k reads (nirrt_generator_words of
+        the problem's tree).  What depends on the problem alone (device copies of its obstacle tables, the rotation C of its
+        start-goal frame, its range) is made once per problem and kept in the problem's dict; the per-refresh part of a batch is
+        filled column by column."""
         import torch
         from . import pointops
         n_raw, n_words = self.cloud_words()
-        jobs = []
-        for k, i in enumerate(idx):
-            pr = problems[i]
-            j = pointops.CloudJob()
-            j.words = int(word_addr[k])
-            if self.dim == 2:
+        n = len(idx)
+        jobs = pointops.cloud_job_table(n)
+        jobs["words"] = np.asarray(word_addr, dtype=np.uint64)
+        cb = np.array([c_best[i] for i in idx], dtype=np.float64)
+        finite = cb < np.inf
+        if self.dim == 2:
+            for k, i in enumerate(idx):
+                pr = problems[i]
                 if "_free_tab_dev" not in pr:
                     pr["_free_tab_dev"] = torch.from_numpy(pcu.free_block_table(pr["binary_mask"])).to(dev)
                 h, w = pr["binary_mask"].shape
-                j.free_tab, j.w, j.h = pr["_free_tab_dev"].data_ptr(), int(w), int(h)
-                if c_best[i] < np.inf:
+                j = jobs[k]
+                j["free_tab"], j["w"], j["h"] = pr["_free_tab_dev"].data_ptr(), int(w), int(h)
+                if finite[k]:
                     xs, xg = np.asarray(pr["x_start"], dtype=np.float64), np.asarray(pr["x_goal"], dtype=np.float64)
-                    j.mode = 1
+                    j["mode"] = 1
                     if "_ellipse_frame" not in pr:
                         pr["_ellipse_frame"] = pcu.ellipse_frame_2d(xs, xg)      # (the SVD behind C is the same for every refresh)
-                    for k, v in enumerate(pcu.ellipse_transform_2d(xs, xg, c_best[i] / frames[i][0], pr["_ellipse_frame"])):
-                        j.a[k] = v
+                    j["a"][:6] = pcu.ellipse_transform_2d(xs, xg, c_best[i] / frames[i][0], pr["_ellipse_frame"])
                 else:
-                    j.mode = 0
-                    j.a[0], j.a[1] = float(w), float(h)
-            else:
-                env = pr["env"]
-                if "_obs_dev" not in pr:
-                    pr["_obs_dev"] = (torch.from_numpy(np.ascontiguousarray(np.asarray(env.obs_ball, dtype=np.float64).reshape(-1, 4))).to(dev),
-                                      torch.from_numpy(np.ascontiguousarray(np.asarray(env.obs_box, dtype=np.float64).reshape(-1, 6))).to(dev))
-                balls, boxes = pr["_obs_dev"]
-                j.mode, j.balls, j.boxes, j.n_ball, j.n_box = 2, balls.data_ptr(), boxes.data_ptr(), int(balls.shape[0]), int(boxes.shape[0])
-                lo = np.array([env.x_range[0] + 0, env.y_range[0] + 0, env.z_range[0] + 0], dtype=np.float64)
-                hi = np.array([env.x_range[1] - 0, env.y_range[1] - 0, env.z_range[1] - 0], dtype=np.float64)
-                if c_best[i] < np.inf:      # ellipsoid-restricted cloud (point_cloud_mask_utils_3d.py:132-200)
+                    j["mode"] = 0
+                    j["a"][0], j["a"][1] = float(w), float(h)
+        else:
+            consts = []
+            for i in idx:
+                pr = problems[i]
+                c = pr.get("_cloud_const_3d")
+                if c is None:
+                    env = pr["env"]
+                    balls = torch.from_numpy(np.ascontiguousarray(np.asarray(env.obs_ball, dtype=np.float64).reshape(-1, 4))).to(dev)
+                    boxes = torch.from_numpy(np.ascontiguousarray(np.asarray(env.obs_box, dtype=np.float64).reshape(-1, 6))).to(dev)
+                    pr["_obs_dev"] = (balls, boxes)
+                    lo = np.array([env.x_range[0] + 0, env.y_range[0] + 0, env.z_range[0] + 0], dtype=np.float64)
+                    hi = np.array([env.x_range[1] - 0, env.y_range[1] - 0, env.z_range[1] - 0], dtype=np.float64)
                     xs, xg = np.asarray(pr["x_start"], dtype=np.float64), np.asarray(pr["x_goal"], dtype=np.float64)
-                    CL, xc = pcu.ellipsoid_transform_3d(xs, xg, c_best[i] / frames[i][0])
-                    j.mode = 3
-                    for k in range(9):
-                        j.a[k] = float(CL[k // 3, k % 3])
-                    for k in range(3):
-                        j.a[9 + k], j.a[12 + k], j.a[15 + k] = float(xc[k]), float(lo[k]), float(hi[k])
-                else:
-                    diff = hi - lo
-                    for k in range(3):
-                        j.a[k], j.a[3 + k] = float(lo[k]), float(diff[k])
-                j.clearance = 0.0
-            jobs.append(j)
+                    c_min, C, xc = pcu.ellipsoid_frame_3d(xs, xg)      # (point_cloud_mask_utils_3d.py:137-141: the same for every refresh)
+                    c = pr["_cloud_const_3d"] = {"balls": balls.data_ptr(), "boxes": boxes.data_ptr(), "n_ball": int(balls.shape[0]),
+                                                 "n_box": int(boxes.shape[0]), "lo": lo, "hi": hi, "diff": hi - lo, "c_min": float(c_min),
+                                                 "C": np.ascontiguousarray(C, dtype=np.float64), "xc": np.asarray(xc, dtype=np.float64)}
+                consts.append(c)
+            jobs["balls"] = np.array([c["balls"] for c in consts], dtype=np.uint64)
+            jobs["boxes"] = np.array([c["boxes"] for c in consts], dtype=np.uint64)
+            jobs["n_ball"] = [c["n_ball"] for c in consts]
+            jobs["n_box"] = [c["n_box"] for c in consts]
+            jobs["mode"] = np.where(finite, 3, 2)
+            A = jobs["a"]
+            lo = np.stack([c["lo"] for c in consts])
+            hi = np.stack([c["hi"] for c in consts])
+            whole = ~finite
+            if whole.any():      # whole box: lo, hi - lo
+                A[whole, 0:3] = lo[whole]
+                A[whole, 3:6] = np.stack([c["diff"] for c in consts])[whole]
+            if finite.any():     # ellipsoid-restricted cloud (point_cloud_mask_utils_3d.py:132-200): C.L, x_center, range
+                f = np.nonzero(finite)[0]
+                ratio = np.array([c_best[idx[k]] / frames[idx[k]][0] for k in f], dtype=np.float64)
+                CL = pcu.ellipsoid_transforms_3d(np.array([consts[k]["c_min"] for k in f]), np.stack([consts[k]["C"] for k in f]), ratio)
+                A[f, 0:9] = CL.reshape(len(f), 9)
+                A[f, 9:12] = np.stack([consts[k]["xc"] for k in f])
+                A[f, 12:15] = lo[f]
+                A[f, 15:18] = hi[f]
+            jobs["clearance"] = 0.0
         return jobs, n_raw, n_words
 
     def refresh(self, due, problems, trees, streams, c_best, frames):
@@ -421,7 +453,8 @@ class Guidance:
 
         def fps_starts_for(group):   # group: positions inside `due`
             sizes = (int(n_out[group[0]]), 1024, 256, 64)
-            return [torch.cat([streams[due[j]].fps_start(n) for j in group]) for n in sizes]
+            st = np.stack([streams[due[j]].fps_starts(sizes) for j in group])      # (len(group), 4): every problem draws from its own generator
+            return [torch.from_numpy(np.ascontiguousarray(st[:, k])) for k in range(len(sizes))]
 
         preds = [None] * nd
         pred_dev = None
@@ -543,8 +576,9 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
         return lambda: _hip.run_sampling([trees[i] for i in act], int(rem.max()), flags=run_flags, want_trace=want_trace, iters_each=rem,
                                          park_limit=park)
 
-    def absorb(act, r):
-        """book a finished launch, refresh the clouds that are due; returns the trees of `act` that go on"""
+    def absorb(act, r, defer_refresh=False):
+        """book a finished launch, refresh the clouds that are due; returns the trees of `act` that go on (defer_refresh: the
+        trees that go on WITHOUT the due ones, and the due ones - their refresh is the caller's)"""
         nonlocal kernel_ms, launches
         kernel_ms += r["kernel_ms"]
         launches += 1
@@ -595,6 +629,9 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
                 finished[i] = True
         t_r = time.perf_counter()
         prof["book"] += t_r - t_b
+        if defer_refresh:      # (overlapped mode: the caller refreshes `due` while the others are already running again)
+            due_set = set(due)
+            return [i for i in act if not finished[i] and remaining[i] > 0 and i not in due_set], due
         if due:
             clouds.update(guidance.refresh(due, problems, trees, streams, c_best, frames))
         prof["refresh"] += time.perf_counter() - t_r
@@ -617,6 +654,42 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
     window = int(os.environ.get("NIRRT_BATCH_WINDOW", window))
     n_groups = max(1, int(os.environ.get("NIRRT_BATCH_GROUPS", "1"))) if (png and B >= 2 * overlap_min) else 1
     in_flight = max(1, min(max(1, n_groups - 1), int(os.environ.get("NIRRT_BATCH_INFLIGHT", "1"))))   # launches on the device at once
+    # Overlapped refresh (round 6, one group): the trees whose cloud is due sit a launch out - the others are launched again at
+    # once, and the due trees' clouds (candidates, down-sampling, PointNet++ forward: device work on other streams + host
+    # bookkeeping) are made WHILE that launch runs; they join the launch after.  Nobody's results depend on launch boundaries.
+    # What it buys depends on how often clouds fall due: at pc_update_cost_ratio = 1.0 (demo_planning_3d.py:21) the refreshes were
+    # 40 % of a step that alternated strictly between launch and refresh.
+    overlap = png and n_groups == 1 and B > 1 and os.environ.get("NIRRT_BATCH_OVERLAP", "1") == "1"
+    if overlap:
+        active = list(range(B))
+        if init_clouds:
+            t_r = time.perf_counter()
+            clouds.update(guidance.refresh(active, problems, trees, streams, c_best, frames))
+            prof["refresh"] += time.perf_counter() - t_r
+        pending = []
+        prof["refresh_hidden"] = 0.0
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            while active or pending:
+                fut = pool.submit(launch(active)) if active else None
+                refreshed = []
+                if pending:
+                    t_r = time.perf_counter()
+                    clouds.update(guidance.refresh(pending, problems, trees, streams, c_best, frames))
+                    dt = time.perf_counter() - t_r
+                    prof["refresh"] += dt
+                    if fut is not None:
+                        prof["refresh_hidden"] += dt
+                    refreshed, pending = pending, []
+                cont = []
+                if fut is not None:
+                    t_w = time.perf_counter()
+                    r = fut.result()
+                    prof["wait_launch"] += time.perf_counter() - t_w
+                    cont, pending = absorb(active, r, defer_refresh=True)
+                active = cont + [i for i in refreshed if not finished[i] and remaining[i] > 0]
+        return {"traces": [np.concatenate(t) if t else np.zeros(0) for t in traces], "iters_done": int(iters) - remaining,
+                "kernel_ms": kernel_ms, "launches": launches, "stats": stats, "failed": failed, "clouds": clouds,
+                "host_seconds": dict(prof, **(guidance.seconds if png else {}))}
     groups = [list(range(g, B, n_groups)) for g in range(n_groups)]
     futures = [None] * n_groups
     with ThreadPoolExecutor(max_workers=in_flight) as pool:

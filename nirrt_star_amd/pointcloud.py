@@ -192,12 +192,39 @@ def _rotation_to_world_3d(x_start, x_goal, L):
     return U @ np.diag([1, 1, np.linalg.det(U) * np.linalg.det(V)]) @ V.T
 
 
-def ellipsoid_transform_3d(start_point, goal_point, max_min_ratio):
-    """the constants of ellipsoid_candidates_3d's transform, formed like the reference forms them (point_cloud_mask_utils_3d.py:
-    137-150): (C.L (3, 3), x_center (3,)) - what the device-side candidate generation takes"""
+def ellipsoid_frame_3d(start_point, goal_point):
+    """what ellipsoid_candidates_3d derives from the problem alone: (c_min, C, x_center) (point_cloud_mask_utils_3d.py:137-141) -
+    the SVD behind C is the same for every refresh of a problem's cloud"""
     c_min = np.linalg.norm(goal_point - start_point)
     C = _rotation_to_world_3d(start_point, goal_point, c_min)
     x_center = (start_point + goal_point) / 2.
+    return c_min, C, x_center
+
+
+def ellipsoid_transforms_3d(c_min, C, max_min_ratio):
+    """ellipsoid_transform_3d's C.L for MANY clouds at once: c_min (n,), C (n, 3, 3), max_min_ratio (n,) -> (n, 3, 3).
+    C @ diag(r) scales column j by r[j] (the products with the zeros of diag(r) add exact zeros), so the entries are the single
+    products C[i][j] * r[j] the reference's np.dot rounds to (tests/test_guidance_host.py compares the two)."""
+    c_min = np.asarray(c_min, dtype=np.float64)
+    c_max = c_min * np.asarray(max_min_ratio, dtype=np.float64)
+    # the squares are the reference's SCALAR `c_max ** 2` / `c_min ** 2`: numpy evaluates a float64 scalar's power through libm's
+    # pow(x, 2.0), which is not always the correctly rounded x * x an array's `** 2` (np.square) gives (82 of 100 000 arguments
+    # differ by an ulp with glibc 2.35)
+    sq_max = np.array([v ** 2 for v in c_max], dtype=np.float64)
+    sq_min = np.array([v ** 2 for v in c_min], dtype=np.float64)
+    rad = sq_max - sq_min
+    eps = np.where(rad < 0, 1e-6, 0.0)
+    r = np.empty((len(c_min), 3))
+    r[:, 0] = c_max / 2
+    r[:, 1] = r[:, 2] = np.sqrt(rad + eps) / 2
+    return np.asarray(C, dtype=np.float64) * r[:, np.newaxis, :]
+
+
+def ellipsoid_transform_3d(start_point, goal_point, max_min_ratio, frame=None):
+    """the constants of ellipsoid_candidates_3d's transform, formed like the reference forms them (point_cloud_mask_utils_3d.py:
+    137-150): (C.L (3, 3), x_center (3,)) - what the device-side candidate generation takes; `frame` = ellipsoid_frame_3d(...)
+    of the problem, if the caller keeps it"""
+    c_min, C, x_center = frame if frame is not None else ellipsoid_frame_3d(start_point, goal_point)
     c_max = c_min * max_min_ratio
     eps = 1e-6 if c_max ** 2 - c_min ** 2 < 0 else 0
     r = np.zeros(3)

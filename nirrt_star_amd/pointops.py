@@ -268,12 +268,28 @@ class CloudJob(C.Structure):
                 ("a", C.c_double * 20), ("clearance", C.c_double)]
 
 
+def cloud_job_table(n):
+    """n zeroed nirrt_cloud_job records as a numpy structured array (same layout as CloudJob): a batch's jobs are filled column by
+    column instead of one ctypes structure at a time (a refresh of hundreds of clouds spent longer filling structures than the
+    device spent making the clouds)"""
+    import numpy as np
+    dt = np.dtype([("words", "<u8"), ("free_tab", "<u8"), ("balls", "<u8"), ("boxes", "<u8"), ("mode", "<i4"), ("w", "<i4"), ("h", "<i4"),
+                   ("n_ball", "<i4"), ("n_box", "<i4"), ("pad", "<i4"), ("a", "<f8", (20,)), ("clearance", "<f8")], align=False)
+    assert dt.itemsize == C.sizeof(CloudJob)
+    return np.zeros(n, dtype=dt)
+
+
 def guidance_clouds(jobs, n_raw, n_points, clouds, device_id=0):
     """candidates -> down-sampling -> compaction of len(jobs) guidance clouds on the device (nirrt_guidance_clouds): `jobs` a
-    list of CloudJob, `clouds` a cuda float64 tensor (len(jobs), n_points, 3) that receives them -> (n_cand, n_out) int32 arrays"""
+    list of CloudJob or a cloud_job_table, `clouds` a cuda float64 tensor (len(jobs), n_points, 3) that receives them ->
+    (n_cand, n_out) int32 arrays"""
     import numpy as np
     n = len(jobs)
-    arr = (CloudJob * n)(*jobs)
+    if isinstance(jobs, np.ndarray):
+        assert jobs.dtype.itemsize == C.sizeof(CloudJob) and jobs.flags.c_contiguous
+        arr = C.c_void_p(jobs.ctypes.data)
+    else:
+        arr = (CloudJob * n)(*jobs)
     n_cand = np.zeros(n, dtype=np.int32)
     n_out = np.zeros(n, dtype=np.int32)
     assert clouds.is_cuda and clouds.dtype == torch.float64 and clouds.is_contiguous() and tuple(clouds.shape) == (n, n_points, 3)

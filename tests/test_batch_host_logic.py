@@ -343,6 +343,7 @@ def test_run_batch_refreshes_due_clouds_and_reports_failures(dev, monkeypatch):
               2: [(250, _hip.E_CAPACITY, np.inf)],
               3: [(10, _hip.E_ARG, np.inf)]}
     monkeypatch.setattr(_hip, "run_sampling", _planner(log, script))
+    monkeypatch.setenv("NIRRT_BATCH_OVERLAP", "0")      # launch, refresh, launch (the overlapped schedule has a test of its own below)
     g = FakeGuidance()
     r = batch.run_batch(trees, streams, 1500, _hip.F_IRRT, 2, problems=[{}] * 4, guidance=g, frames=[None] * 4, window=65536)
     # guided runs take short launches (a tree whose cloud is due idles until its launch ends)
@@ -356,6 +357,48 @@ def test_run_batch_refreshes_due_clouds_and_reports_failures(dev, monkeypatch):
     assert list(r["iters_done"]) == [1500, 1500, 250, 10]
     assert set(r["failed"]) == {2, 3} and "capacity" in r["failed"][2] and "randint" in r["failed"][3]
     assert sorted(r["clouds"]) == [0, 1, 2, 3]
+
+
+def test_overlapped_refresh_due_trees_sit_one_launch_out(dev, monkeypatch):
+    """Round 6: with one group the trees whose cloud is due are refreshed WHILE the others run their next launch and join the
+    launch after; every tree still runs exactly its budget with exactly its own refreshes (launch boundaries change no result)."""
+    trees = [PlanTree(i) for i in range(3)]
+    streams = [batch.ProblemStreams(i) for i in range(3)]
+    log = []
+    big = 10 ** 9
+    script = {0: [(400, _hip.E_CLOUD, 90.0), (300, _hip.E_CLOUD, 85.0)] + [(big, 0, 80.0)] * 8,
+              1: [(big, 0, 70.0)] * 8,
+              2: [(1024, _hip.E_PARK, np.inf), (100, _hip.E_CLOUD, 60.0)] + [(big, 0, 55.0)] * 8}
+    monkeypatch.setattr(_hip, "run_sampling", _planner(log, script))
+    g = FakeGuidance()
+    r = batch.run_batch(trees, streams, 3000, _hip.F_IRRT, 2, problems=[{}] * 3, guidance=g, frames=[None] * 3, window=65536)
+    assert g.calls[0] == ([0, 1, 2], [np.inf] * 3)                 # init_pc for everybody before the first launch
+    # tree 0 (due after launch 1) sits launch 2 out, tree 2 (due after launch 2) launch 3, tree 0 again launch 4
+    assert [l["names"] for l in log] == [[0, 1, 2], [1, 2], [1, 0], [2], [2, 0], [0], [0]]
+    assert [l["each"] for l in log] == [[1024] * 3, [1024, 1024], [952, 1024], [1024], [852, 1024], [1024], [252]]
+    assert g.calls[1:] == [([0], [90.0]), ([2], [60.0]), ([0], [85.0])]
+    assert list(r["iters_done"]) == [3000] * 3 and not r["failed"]
+    assert r["launches"] == len(log)
+    assert r["host_seconds"]["refresh_hidden"] <= r["host_seconds"]["refresh"]
+    # the budgets each launch hands out follow the trees, whatever launch they are in
+    for l in log:
+        assert len(l["each"]) == len(l["names"]) and all(0 < e <= 1024 for e in l["each"])
+
+
+def test_fps_starts_twin_of_the_torch_generator():
+    """ProblemStreams.fps_starts draws the FPS start indices of a forward from a numpy MT19937 seeded like torch's CPU generator:
+    draw by draw what `torch.randint(0, N, (1,), generator=torch.Generator().manual_seed(seed))` returns (pointnet2_utils.py:77)"""
+    import torch
+    for seed in (0, 1, 7, 4242, 2 ** 31 + 5, 2 ** 32 - 1):
+        s = batch.ProblemStreams(seed)
+        g = torch.Generator().manual_seed(seed)
+        for rep in range(200):      # (800 outputs: across a twist of the 624-word state)
+            sizes = (2048 if rep % 3 else 1777, 1024, 256, 64)
+            want = [int(torch.randint(0, n, (1,), generator=g, dtype=torch.long)) for n in sizes]
+            assert list(s.fps_starts(sizes)) == want, (seed, rep)
+        assert int(s.fps_start(2048)) == int(torch.randint(0, 2048, (1,), generator=g, dtype=torch.long))
+    with pytest.raises(ValueError):
+        batch.ProblemStreams(2 ** 32).fps_starts((64,))
 
 
 def test_guided_windows_are_paced_by_each_trees_own_speed(dev, monkeypatch):
