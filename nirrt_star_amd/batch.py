@@ -316,6 +316,18 @@ class Guidance:
         masks = pointops.farthest_point_down_sample_f64_batch(cands, self.n_points, self.device_id)
         return [c[m] for c, m in zip(cands, masks)]          # (n_b, 3) each
 
+    def _side_streams(self, dev, n):
+        """up to four streams for the forwards of one refresh (NIRRT_REFRESH_STREAMS, 0 / 1 = everything on the current stream)"""
+        import torch
+        want = min(n, max(0, int(os.environ.get("NIRRT_REFRESH_STREAMS", "4"))))
+        if want <= 1:
+            return []
+        pool = self.__dict__.setdefault("_streams", {})
+        key = str(dev)
+        while len(pool.setdefault(key, [])) < want:
+            pool[key].append(torch.cuda.Stream(device=dev))
+        return pool[key][:want]
+
     def cloud_words(self):
         """generator outputs one cloud's candidates consume: n_raw points x dim doubles x 2 words"""
         n_raw = self.n_points * self.scale
@@ -480,12 +492,30 @@ class Guidance:
             for j in range(nd):
                 s3[j, : self.dim], g3[j, : self.dim] = xs_l[j][: self.dim], xg_l[j][: self.dim]
             pred_dev = torch.zeros((nd, self.n_points), dtype=torch.uint8, device=dev)
-            for size in sorted(set(int(v) for v in n_out)):
-                grp = [j for j in range(nd) if n_out[j] == size]
-                x = pointops.net_input(clouds_dev, grp, size, s3[grp], g3[grp], self.radius)
-                pred = self.wrapper.classify_device(x, fps_starts=fps_starts_for(grp))
-                pred_dev[torch.as_tensor(grp, device=dev), :size] = (pred != 0).to(torch.uint8)
+            by_size = {}
+            for j in range(nd):
+                by_size.setdefault(int(n_out[j]), []).append(j)
+            # one forward per cloud size (a forward's sampling and grouping depend on N).  A refresh usually holds one large group
+            # (clouds that were down-sampled to n_points) and a few small ones (clouds with fewer candidates than that), and a
+            # small forward costs about what a large one does (its farthest-point samplings are ~1400 dependent steps): the groups
+            # run on streams of their own, largest first, so the small ones hide behind it
+            order = sorted(by_size, key=lambda n_: (-len(by_size[n_]), n_))
+            cur = torch.cuda.current_stream(dev)
+            side = self._side_streams(dev, len(order)) if len(order) > 1 else []
+            for k, size in enumerate(order):
+                grp = by_size[size]
+                starts = fps_starts_for(grp)      # (host: every problem's own generator, in batch order)
+                st = side[k % len(side)] if side else cur
+                if side:
+                    st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    x = pointops.net_input(clouds_dev, grp, size, s3[grp], g3[grp], self.radius)
+                    pred = self.wrapper.classify_device(x, fps_starts=starts)
+                    pred_dev[torch.as_tensor(grp, device=dev), :size] = (pred != 0).to(torch.uint8)
+                    del x, pred
                 self.calls += 1
+            for st in side:
+                cur.wait_stream(st)
             pred_host = pred_dev.cpu().numpy().astype(np.int64)
             for j in range(nd):
                 preds[j] = pred_host[j, : n_out[j]]

@@ -347,7 +347,127 @@ __global__ __launch_bounds__(FPS64_NT, 5) void k_fps_f64(const double *__restric
     }
 }
 
+// (round 6) the same down-sampling with the cloud IN REGISTERS.  k_fps_f64 re-reads every point of the cloud from the L2 in every
+// one of its S steps (N x 24 bytes: 245 KB per step and cloud, 500 MB per cloud, > 100 GB for a refresh of 256 clouds) and starts
+// every step with a dependent load of the last pick's coordinates; a step took 8 us, a cloud 16 ms - and a refresh cannot take
+// less than one cloud does, however few clouds are due (at pc_update_cost_ratio = 1.0: 770 refreshes per step of the bench).
+// Here a thread keeps its MAXP points and their running minima in registers (N <= 512 x 20 = the 5 x 2048 candidates of a guidance
+// cloud: 80 doubles per thread), a wave's winner travels through LDS together with its coordinates, and one barrier per step is
+// left (two alternating LDS rows).  Same arithmetic, same order of comparisons: the pick sequence is k_fps_f64's.
+// wave64 argmax of (value >= 0 as its bit pattern, lowest index on ties) without LDS traffic: four DPP steps leave every 16-lane row
+// holding its winner, v_readlane pulls the four row winners into scalars (wave_max_u64's scheme with the index as a third word -
+// six ds_bpermute round trips were a third of a step)
+template <int CTRL>
+__device__ __forceinline__ void dpp_argmax_step(unsigned long long &k, int &i)
+{
+    const unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+    const unsigned ol = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+    const unsigned oh = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+    const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false);
+    const unsigned long long o = ((unsigned long long)oh << 32) | ol;
+    const bool take = o > k || (o == k && oi < i);
+    k = take ? o : k;
+    i = take ? oi : i;
+}
+
+__device__ __forceinline__ void wave_argmax_u64(unsigned long long &k, int &i)
+{
+    dpp_argmax_step<0xB1>(k, i);    // quad_perm [1,0,3,2]
+    dpp_argmax_step<0x4E>(k, i);    // quad_perm [2,3,0,1]
+    dpp_argmax_step<0x141>(k, i);   // row_half_mirror
+    dpp_argmax_step<0x140>(k, i);   // row_mirror
+    const unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+    unsigned long long rk = 0;
+    int ri = 0x7fffffff;
+#pragma unroll
+    for (int row = 0; row < 4; row++) {
+        const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, row * 16) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)lo, row * 16);
+        const int oi = __builtin_amdgcn_readlane(i, row * 16);
+        const bool take = row == 0 || o > rk || (o == rk && oi < ri);
+        rk = take ? o : rk;
+        ri = take ? oi : ri;
+    }
+    k = rk; i = ri;
+}
+
+template <int MAXP, bool HAS_Z>
+__global__ __launch_bounds__(FPS64_NT) void k_fps_f64_reg(const double *__restrict__ buf, long long total, const long long *__restrict__ off,
+                                                        const int *__restrict__ cnt, const int *__restrict__ ns,
+                                                        unsigned char *__restrict__ sel_all)
+{
+    constexpr int NWV = FPS64_NT / 64;
+    __shared__ unsigned long long rk[2][NWV];
+    __shared__ double rx[2][NWV], ry[2][NWV], rz[2][NWV];
+    __shared__ int ri[2][NWV];
+    const long long o = off[blockIdx.x];
+    const int N = cnt[blockIdx.x], S = ns[blockIdx.x];
+    if (N <= S) return;   // nothing to drop (the callers keep such clouds whole)
+    const double *x = buf + o, *y = buf + total + o, *z = buf + 2 * total + o;
+    unsigned char *sel = sel_all + o;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double px[MAXP], py[MAXP], pz[MAXP], dist[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; j++) {
+        const int i = tid + j * FPS64_NT;
+        const bool in = i < N;
+        px[j] = in ? x[i] : 0.;
+        py[j] = in ? y[i] : 0.;
+        pz[j] = (HAS_Z && in) ? z[i] : 0.;
+        // a slot past the end never wins: every real maximum is >= 0 > -1, and min(d, -1) stays -1.  (Its arithmetic is done all the
+        // same: a branch around it - even a uniform one - ends the basic block, and the MAXP independent points of a step are what the
+        // scheduler interleaves to cover the latency of each point's dependent chain)
+        dist[j] = in ? __builtin_inf() : -1.;
+    }
+    for (int i = tid; i < N; i += FPS64_NT) sel[i] = 0;
+    double cx = x[0], cy = y[0], cz = HAS_Z ? z[0] : 0.;
+    int far = 0;
+    __syncthreads();
+    for (int s = 0; s < S; s++) {
+        if (tid == 0) sel[far] = 1;
+        double bv = -1.;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < MAXP; j++) {
+            const double dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+            const double d = dx * dx + dy * dy + dz * dz;
+            dist[j] = __builtin_fmin(dist[j], d);      // (`if (d < dist) dist = d` of k_fps_f64: no NaN ever gets here)
+            if (dist[j] > bv) { bv = dist[j]; bi = tid + j * FPS64_NT; }   // ascending index within the thread: the first maximum is kept
+        }
+        // squared distances are >= 0: their bit patterns order like the values (a thread without a point: key 0, index INT_MAX)
+        unsigned long long key = bv < 0. ? 0ull : (unsigned long long)__double_as_longlong(bv);
+        wave_argmax_u64(key, bi);
+        // the wave's winner (a scalar pair now) goes to LDS with its coordinates.  Those are read back from the cloud with SCALAR
+        // loads (bi is the same in every lane): picking them out of the owner lane's registers was a chain of 6 x MAXP conditional
+        // moves per step and wave - a fifth of the step
+        const int p = s & 1;
+        {
+            const int li = bi < N ? bi : 0;      // (a wave without a point - small clouds - reports key 0 / index INT_MAX: it never wins)
+            const double wx = x[li], wy = y[li], wz = HAS_Z ? z[li] : 0.;
+            if (lane == 0) { rk[p][w] = key; ri[p][w] = bi; rx[p][w] = wx; ry[p][w] = wy; rz[p][w] = wz; }
+        }
+        __syncthreads();
+        key = rk[p][0]; bi = ri[p][0];
+        int bw = 0;
+#pragma unroll
+        for (int i = 1; i < NWV; i++) {
+            const unsigned long long ok = rk[p][i];
+            const int oi = ri[p][i];
+            if (ok > key || (ok == key && oi < bi)) { key = ok; bi = oi; bw = i; }
+        }
+        far = bi;
+        cx = rx[p][bw]; cy = ry[p][bw]; cz = HAS_Z ? rz[p][bw] : 0.;
+        // (no second barrier: the next step writes the OTHER row, and nobody gets two steps ahead of a wave that still reads this one)
+    }
+}
+
 struct FpsScratch { void *p = nullptr; size_t cap = 0; };
+// NIRRT_FPS64_REG=0: the L2-streaming kernel of rounds 2 - 5 for clouds of up to 10240 points too (A/B and the parity test of the two)
+static bool fps64_in_registers()
+{
+    const char *e = getenv("NIRRT_FPS64_REG");
+    return !(e && *e == '0');
+}
 static std::mutex g_fps_mu;
 static FpsScratch g_fps_scratch[16];
 
@@ -395,7 +515,10 @@ extern "C" int nirrt_fps_f64_batch(const double *pts, int n_clouds, const int *c
     if (!rc) {
         int nmax = 0;
         for (int b = 0; b < n_clouds; b++) nmax = cnt[b] > nmax ? cnt[b] : nmax;
-        if (nmax <= 20 * FPS64_NT)
+        if (nmax <= 20 * FPS64_NT && fps64_in_registers())
+            hipLaunchKernelGGL((k_fps_f64_reg<20, true>), dim3(n_clouds), dim3(FPS64_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
+                               (const int *)d_cnt, (const int *)d_ns, ds);
+        else if (nmax <= 20 * FPS64_NT)
             hipLaunchKernelGGL(k_fps_f64<20>, dim3(n_clouds), dim3(FPS64_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
                                (const int *)d_cnt, (const int *)d_ns, ds, 1);
         else
@@ -661,7 +784,14 @@ extern "C" int nirrt_guidance_clouds(const nirrt_cloud_job *jobs, int n_jobs, in
         // for the other group's persistent kernel when the tree streams are blocking ones.)
         hipLaunchKernelGGL(k_cloud_candidates, dim3(n_jobs), dim3(CAND_NT), 0, 0, (const nirrt_cloud_job *)d_jobs, n_raw, d, total, d_cnt);
         // k_fps_f64 leaves clouds with cnt <= num_samples alone (k_cloud_compact keeps all of their points)
-        if (n_raw <= 20 * FPS64_NT)
+        if (n_raw <= 20 * FPS64_NT && fps64_in_registers()) {
+            if (jobs[0].mode >= 2)
+                hipLaunchKernelGGL((k_fps_f64_reg<20, true>), dim3(n_jobs), dim3(FPS64_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
+                                   (const int *)d_cnt, (const int *)d_ns, ds);
+            else
+                hipLaunchKernelGGL((k_fps_f64_reg<20, false>), dim3(n_jobs), dim3(FPS64_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
+                                   (const int *)d_cnt, (const int *)d_ns, ds);
+        } else if (n_raw <= 20 * FPS64_NT)
             hipLaunchKernelGGL(k_fps_f64<20>, dim3(n_jobs), dim3(FPS64_NT), 0, 0, (const double *)d, total, (const long long *)d_off,
                                (const int *)d_cnt, (const int *)d_ns, ds, jobs[0].mode >= 2 ? 1 : 0);
         else

@@ -131,6 +131,33 @@ def test_gpu_cloud_downsampling_equals_host_restatement():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("reg", ["1", "0"])
+def test_gpu_cloud_downsampling_both_kernels_on_ties_and_ragged_sizes(reg, monkeypatch):
+    """the register-resident down-sampling kernel (k_fps_f64_reg, round 6; NIRRT_FPS64_REG=0: the L2-streaming k_fps_f64) against
+    the numpy restatement of open3d's farthest_point_down_sample: clouds full of exact ties (lattice points, duplicates: the FIRST
+    maximum wins), sizes around the 512-thread / 64-lane boundaries, planar and spatial, several clouds in one launch"""
+    from nirrt_star_amd import pointops
+    from oracle import pointops_ref as ref
+    monkeypatch.setenv("NIRRT_FPS64_REG", reg)
+    rng = np.random.default_rng(17)
+    clouds, ns = [], []
+    for n, s in ((10240, 2048), (10239, 2048), (513, 512), (512, 100), (65, 64), (2049, 2048), (7777, 2048)):
+        lattice = rng.integers(0, 12, size=(n, 3)).astype(np.float64)          # many equal distances, many duplicate points
+        clouds.append(lattice)
+        ns.append(s)
+        planar = np.concatenate([rng.integers(0, 40, size=(n, 2)).astype(np.float64) * 0.5, np.zeros((n, 1))], axis=1)
+        clouds.append(planar)
+        ns.append(s)
+    clouds.append(rng.uniform(0, 50, size=(9000, 3)))
+    ns.append(2048)
+    for s in sorted(set(ns)):      # (one launch per sample count: several clouds each)
+        group = [c for c, s_ in zip(clouds, ns) if s_ == s]
+        masks = pointops.farthest_point_down_sample_f64_batch(group, s)
+        for c, m in zip(group, masks):
+            assert np.array_equal(np.asarray(m, dtype=bool), ref.farthest_point_down_sample_f64(c, s)), (len(c), s)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("level", [0, 1])
 def test_gpu_fused_mfma_set_abstraction_equals_library_gemms(level):
     """k_sa_mlp (gather + 3 x (GEMM + bias + ReLU) + max over the group on v_mfma_f32_16x16x4_f32 tiles) vs the same branch as
