@@ -110,7 +110,11 @@ def parse(argv=None):
 
 def config_key(args):
     size = ("set%d" % args.problems) if getattr(args, "scaling", "weak") == "strong" else str(args.trees)
-    return "%s_%dd_%s_%sx%d" % (args.algo, args.dim, args.world if args.dim == 2 else "ref3d", size, args.iters)
+    key = "%s_%dd_%s_%sx%d" % (args.algo, args.dim, args.world if args.dim == 2 else "ref3d", size, args.iters)
+    ratio = getattr(args, "pc_update_cost_ratio", 0.9)
+    if args.algo.startswith("nirrt") and ratio != 0.9:      # (another refresh policy is another workload: a key of its own)
+        key += "_ratio%g" % ratio
+    return key
 
 
 def rank_problem_ids(args, rank, world):
@@ -497,6 +501,9 @@ SECONDARY = [   # (label, bench arguments): each runs `--steps 1 --warmup 0` in 
     ("nirrt_2d", ["--algo", "nirrt", "--trees", "4096", "--warmup", "1"]),
     ("nirrt_c_2d (config 3)", ["--algo", "nirrt_c", "--trees", "2048", "--warmup", "1"]),
     ("nirrt_3d (config 4)", ["--algo", "nirrt", "--dim", "3", "--trees", "2048", "--warmup", "1"]),
+    # the reference's own 3D demo refreshes the cloud on EVERY improvement (demo_planning_3d.py:21: pc_update_cost_ratio = 1.0):
+    # ~65 refreshes per tree instead of ~4.5 (no warm-up step here: a step is half a minute)
+    ("nirrt_3d ratio 1.0 (config 4 at the 3D demo's refresh policy)", ["--algo", "nirrt", "--dim", "3", "--trees", "2048", "--pc-update-cost-ratio", "1.0"]),
     # BASELINE config 5 as written, on ONE GPU: the fixed 1000-problem evaluation set (the anchor of the strong-scaling curve)
     ("irrt_2d eval set (config 5, N = 1)", ["--algo", "irrt", "--scaling", "strong", "--problems", "1000"]),
 ]

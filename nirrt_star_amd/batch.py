@@ -317,9 +317,9 @@ class Guidance:
         return [c[m] for c, m in zip(cands, masks)]          # (n_b, 3) each
 
     def _side_streams(self, dev, n):
-        """up to four streams for the forwards of one refresh (NIRRT_REFRESH_STREAMS, 0 / 1 = everything on the current stream)"""
+        """streams for the forwards of one refresh (NIRRT_REFRESH_STREAMS, default 1 = everything on the current stream)"""
         import torch
-        want = min(n, max(0, int(os.environ.get("NIRRT_REFRESH_STREAMS", "4"))))
+        want = min(n, max(0, int(os.environ.get("NIRRT_REFRESH_STREAMS", "1"))))
         if want <= 1:
             return []
         pool = self.__dict__.setdefault("_streams", {})
@@ -497,8 +497,10 @@ class Guidance:
                 by_size.setdefault(int(n_out[j]), []).append(j)
             # one forward per cloud size (a forward's sampling and grouping depend on N).  A refresh usually holds one large group
             # (clouds that were down-sampled to n_points) and a few small ones (clouds with fewer candidates than that), and a
-            # small forward costs about what a large one does (its farthest-point samplings are ~1400 dependent steps): the groups
-            # run on streams of their own, largest first, so the small ones hide behind it
+            # small forward costs about what a large one does (its farthest-point samplings are ~1400 dependent steps).  With
+            # NIRRT_REFRESH_STREAMS > 1 the groups run on streams of their own, largest first - measured (round 6, config 4 at ratio
+            # 1.0: 12.2 s of forwards against 11.1 s on one stream; NIRRT* 2D: 2.3 against 1.4 s) it is a loss: the forwards are bound by
+            # the host's launch rate, which streams do not raise.  Default: one stream.
             order = sorted(by_size, key=lambda n_: (-len(by_size[n_]), n_))
             cur = torch.cuda.current_stream(dev)
             side = self._side_streams(dev, len(order)) if len(order) > 1 else []
@@ -684,12 +686,17 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
     window = int(os.environ.get("NIRRT_BATCH_WINDOW", window))
     n_groups = max(1, int(os.environ.get("NIRRT_BATCH_GROUPS", "1"))) if (png and B >= 2 * overlap_min) else 1
     in_flight = max(1, min(max(1, n_groups - 1), int(os.environ.get("NIRRT_BATCH_INFLIGHT", "1"))))   # launches on the device at once
-    # Overlapped refresh (round 6, one group): the trees whose cloud is due sit a launch out - the others are launched again at
-    # once, and the due trees' clouds (candidates, down-sampling, PointNet++ forward: device work on other streams + host
-    # bookkeeping) are made WHILE that launch runs; they join the launch after.  Nobody's results depend on launch boundaries.
-    # What it buys depends on how often clouds fall due: at pc_update_cost_ratio = 1.0 (demo_planning_3d.py:21) the refreshes were
-    # 40 % of a step that alternated strictly between launch and refresh.
-    overlap = png and n_groups == 1 and B > 1 and os.environ.get("NIRRT_BATCH_OVERLAP", "1") == "1"
+    # Overlapped refresh (round 6, one group, NIRRT_BATCH_OVERLAP=1; OFF by default): the trees whose cloud is due sit a launch out -
+    # the others are launched again at once, and the due trees' clouds (candidates, down-sampling, PointNet++ forward: device work
+    # on other streams + host bookkeeping) are made WHILE that launch runs; they join the launch after.  Nobody's results depend
+    # on launch boundaries.  Measured at pc_update_cost_ratio = 1.0 (demo_planning_3d.py:21; 2048 3D trees, profiles/README_r06.md):
+    # the refreshes are hidden (35 of 36 s), but the launches share the GPU with them and take 25.6 s instead of 14.6 s, and the
+    # smaller due sets mean more refreshes, each as long as its slowest cloud: 45.4 s per step against 43.5 s one after the other.
+    # AND IT IS NOT SAFE ON THIS STACK: like NIRRT_BATCH_GROUPS >= 2 (a persistent launch on one thread, refresh work on another) it
+    # ended full-size runs with trees whose best cost was below the straight start-goal distance, or with a GPU memory fault
+    # (gpurun_out of round 6: ov_full, c4r10_p25_g2) - small runs pass.  Both stay available for whoever hunts that down; nothing
+    # in the library turns them on.
+    overlap = png and n_groups == 1 and B > 1 and os.environ.get("NIRRT_BATCH_OVERLAP", "0") == "1"
     if overlap:
         active = list(range(B))
         if init_clouds:

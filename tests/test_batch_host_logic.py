@@ -343,7 +343,6 @@ def test_run_batch_refreshes_due_clouds_and_reports_failures(dev, monkeypatch):
               2: [(250, _hip.E_CAPACITY, np.inf)],
               3: [(10, _hip.E_ARG, np.inf)]}
     monkeypatch.setattr(_hip, "run_sampling", _planner(log, script))
-    monkeypatch.setenv("NIRRT_BATCH_OVERLAP", "0")      # launch, refresh, launch (the overlapped schedule has a test of its own below)
     g = FakeGuidance()
     r = batch.run_batch(trees, streams, 1500, _hip.F_IRRT, 2, problems=[{}] * 4, guidance=g, frames=[None] * 4, window=65536)
     # guided runs take short launches (a tree whose cloud is due idles until its launch ends)
@@ -360,8 +359,9 @@ def test_run_batch_refreshes_due_clouds_and_reports_failures(dev, monkeypatch):
 
 
 def test_overlapped_refresh_due_trees_sit_one_launch_out(dev, monkeypatch):
-    """Round 6: with one group the trees whose cloud is due are refreshed WHILE the others run their next launch and join the
-    launch after; every tree still runs exactly its budget with exactly its own refreshes (launch boundaries change no result)."""
+    """Round 6 (NIRRT_BATCH_OVERLAP=1, experimental): with one group the trees whose cloud is due are refreshed WHILE the others run
+    their next launch and join the launch after; every tree still runs exactly its budget with exactly its own refreshes (launch
+    boundaries change no result)."""
     trees = [PlanTree(i) for i in range(3)]
     streams = [batch.ProblemStreams(i) for i in range(3)]
     log = []
@@ -370,6 +370,7 @@ def test_overlapped_refresh_due_trees_sit_one_launch_out(dev, monkeypatch):
               1: [(big, 0, 70.0)] * 8,
               2: [(1024, _hip.E_PARK, np.inf), (100, _hip.E_CLOUD, 60.0)] + [(big, 0, 55.0)] * 8}
     monkeypatch.setattr(_hip, "run_sampling", _planner(log, script))
+    monkeypatch.setenv("NIRRT_BATCH_OVERLAP", "1")      # (off by default)
     g = FakeGuidance()
     r = batch.run_batch(trees, streams, 3000, _hip.F_IRRT, 2, problems=[{}] * 3, guidance=g, frames=[None] * 3, window=65536)
     assert g.calls[0] == ([0, 1, 2], [np.inf] * 3)                 # init_pc for everybody before the first launch

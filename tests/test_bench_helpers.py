@@ -101,6 +101,16 @@ def test_strong_scaling_line_has_a_traffic_key_of_its_own(monkeypatch):
     assert b.config_key(a) == "irrt_2d_b30r16_set1000x50000"      # (not the default line's key: 1000 problems are another launch)
 
 
+def test_another_refresh_policy_has_a_traffic_key_of_its_own(monkeypatch):
+    b = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--algo", "nirrt", "--dim", "3", "--trees", "2048"])
+    assert b.config_key(b.parse()) == "nirrt_3d_ref3d_2048x50000"
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--algo", "nirrt", "--dim", "3", "--trees", "2048", "--pc-update-cost-ratio", "1.0"])
+    assert b.config_key(b.parse()) == "nirrt_3d_ref3d_2048x50000_ratio1"      # (demo_planning_3d.py:21)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--pc-update-cost-ratio", "1.0"])
+    assert b.config_key(b.parse()) == "irrt_2d_b30r16_8192x50000"             # (an unguided line has no refresh policy)
+
+
 def test_every_bench_line_has_its_traffic_entry_in_the_committed_profile(monkeypatch):
     """the default line and every secondary line look their HBM traffic up in the round's traffic table (bench.py --traffic-file,
     default profiles/r06_traffic.json) by configuration key: a line added to bench.SECONDARY without its FETCH / WRITE passes would
