@@ -21,6 +21,16 @@ int nirrt_pn2_fps(const float *xyz, int B, int N, int S, const int64_t *start, i
  * first hit; xyz DEVICE f32 (B, N, 3), new_xyz DEVICE f32 (B, S, 3), out DEVICE i64 (B, S, K).  B*S must be a multiple of 4. */
 int nirrt_pn2_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, int K, float r2, int64_t *out, void *stream);
 
+/* Ragged batches (round 6): clouds of DIFFERENT sizes in one forward.  The reference classifies one cloud at a time
+ * (pointnet2_wrapper.py:43-58), so a batch may hold any clouds as long as each is treated as if it were alone: only the first
+ * set-abstraction level looks at the cloud itself (farthest-point sampling and the ball queries over its n points); everything
+ * behind it works on 1024 / 256 / 64 / 16 sampled points or per point.  n_valid DEVICE i32 (B,): cloud b has n_valid[b] <= N
+ * points in its N-point row (S <= n_valid[b], N <= 2048 for the sampling); the padding is never read.  n_valid = NULL: the
+ * functions above. */
+int nirrt_pn2_fps_ragged(const float *xyz, int B, int N, int S, const int64_t *start, const int32_t *n_valid, int64_t *out, void *stream);
+int nirrt_pn2_ball_query_ragged(const float *xyz, const float *new_xyz, int B, int N, int S, int K, float r2, const int32_t *n_valid,
+                                int64_t *out, void *stream);
+
 /* three nearest coarse points of every fine point (PointNetFeaturePropagation, pointnet2_utils.py:295-299: sort of
  * square_distance, first three): xyz1 DEVICE f32 (B, N, 3), xyz2 DEVICE f32 (B, S, 3) -> dist DEVICE f32 (B, N, 3) squared
  * distances ascending, idx DEVICE i64 (B, N, 3). */
@@ -44,6 +54,10 @@ int nirrt_pn2_sa_mlp(const float *feats, const float *xyz, const float *new_xyz,
  * n points), starts / goals f64 (n_rows, 3), out f32 (n_rows, 6, n).  n <= 12288. */
 int nirrt_pn2_net_input(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n, const double *starts,
                         const double *goals, double radius, float *out, void *stream);
+/* ragged: n_each DEVICE i32 (n_rows,) points of each cloud (<= n); out f32 (n_rows, 6, n), ZEROED by the caller - the columns
+ * behind a cloud's own points are left alone; mean and largest norm of pc_normalize are the cloud's own */
+int nirrt_pn2_net_input_ragged(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n, const int32_t *n_each,
+                               const double *starts, const double *goals, double radius, float *out, void *stream);
 
 /* the same block with GIVEN indicator channels: start_masks / goal_masks DEVICE bytes, cloud `row` at + row * mask_stride (the
  * masks of the neural-connect rounds are re-seeded at boundary points, pointnet2_wrapper_connect_bfs.py:181-216) */

@@ -282,6 +282,8 @@ class Guidance:
         self.calls = 0                      # PointNet++ forwards (batched ones count once)
         self.clouds_classified = 0
         self.seconds = {"candidates": 0.0, "downsample": 0.0, "classify": 0.0, "set_cloud": 0.0}   # host wall time per refresh stage
+        self.size_log = [] if os.environ.get("NIRRT_REFRESH_LOG", "0") == "1" else None
+        self.ragged = os.environ.get("NIRRT_RAGGED_FORWARD", "1") == "1"      # clouds of different sizes in ONE forward (refresh)
 
     # ---- cloud generation -------------------------------------------------------------------------------------------
     def _host_clouds(self, idx, problems, trees, streams, c_best, frames):
@@ -495,12 +497,29 @@ class Guidance:
             by_size = {}
             for j in range(nd):
                 by_size.setdefault(int(n_out[j]), []).append(j)
-            # one forward per cloud size (a forward's sampling and grouping depend on N).  A refresh usually holds one large group
-            # (clouds that were down-sampled to n_points) and a few small ones (clouds with fewer candidates than that), and a
-            # small forward costs about what a large one does (its farthest-point samplings are ~1400 dependent steps).  With
-            # NIRRT_REFRESH_STREAMS > 1 the groups run on streams of their own, largest first - measured (round 6, config 4 at ratio
-            # 1.0: 12.2 s of forwards against 11.1 s on one stream; NIRRT* 2D: 2.3 against 1.4 s) it is a loss: the forwards are bound by
-            # the host's launch rate, which streams do not raise.  Default: one stream.
+            if self.size_log is not None:      # (diagnostics: the clouds of every refresh as {cloud size: clouds})
+                self.size_log.append({n_: len(v) for n_, v in by_size.items()})
+            if self.ragged and len(by_size) > 1 and max(by_size) <= 2048:
+                # ONE forward over all due clouds, whatever their sizes (round 6).  A refresh holds one large group (clouds that were
+                # down-sampled to n_points) and a few clouds with fewer candidates than that - each of a size of its own, each a
+                # forward of its own before, and a forward over one cloud costs about what one over a hundred does (its
+                # farthest-point samplings are ~1400 dependent steps, its ~100 launches come from the host one by one): at
+                # pc_update_cost_ratio = 1.0 two thirds of the forwards were over ONE cloud.  Only the first set-abstraction level
+                # looks at a cloud as a whole; its sampling and ball queries take the clouds' own sizes (PointNet2.forward).
+                n_max = max(by_size)
+                grp = list(range(nd))
+                nv = torch.from_numpy(np.ascontiguousarray(n_out, dtype=np.int32)).to(dev)
+                st = np.stack([streams[due[j]].fps_starts((int(n_out[j]), 1024, 256, 64)) for j in grp])
+                starts = [torch.from_numpy(np.ascontiguousarray(st[:, k])) for k in range(4)]
+                x = pointops.net_input(clouds_dev, grp, n_max, s3, g3, self.radius, n_each=nv)
+                pred = self.wrapper.classify_device(x, fps_starts=starts, n_valid=nv)
+                pred_dev[:, :n_max] = (pred != 0).to(torch.uint8)      # (the labels behind a cloud's own points are never read)
+                self.calls += 1
+                by_size = {}
+            # otherwise one forward per cloud size (a forward's sampling and grouping depend on N).  With NIRRT_REFRESH_STREAMS > 1
+            # the groups run on streams of their own, largest first - measured (round 6, config 4 at ratio 1.0: 12.2 s of forwards
+            # against 11.1 s on one stream; NIRRT* 2D: 2.3 against 1.4 s) it is a loss: the forwards are bound by the host's launch
+            # rate, which streams do not raise.  Default: one stream.
             order = sorted(by_size, key=lambda n_: (-len(by_size[n_]), n_))
             cur = torch.cuda.current_stream(dev)
             side = self._side_streams(dev, len(order)) if len(order) > 1 else []

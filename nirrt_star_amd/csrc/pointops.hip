@@ -108,15 +108,18 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 // and the complemented index makes the lowest index win ties, as in k_fps.  NW > 1 waves exchange
 // their maxima through double-buffered LDS slots: one barrier per step.  The LDS copy of the cloud
 // only serves the centroid lookup.  Same arithmetic and tie-breaking as k_fps.
+// nv != nullptr (ragged batch): cloud b holds nv[b] <= N points in its N-point row of xyz, the rest of the row is padding that
+// is never looked at - the picks are those of a launch over that cloud alone.
 template <int PPL, int NW>
-__global__ __launch_bounds__(64 * NW) void k_fps_wave(const float *__restrict__ xyz, int N, int S, const long long *__restrict__ start,
-                                                     long long *__restrict__ out)
+__global__ __launch_bounds__(64 * NW) void k_fps_wave(const float *__restrict__ xyz, int N_stride, int S, const long long *__restrict__ start,
+                                                     long long *__restrict__ out, const int *__restrict__ nv)
 {
     constexpr int NT = 64 * NW;
     __shared__ float lp[NT * PPL * 3];
     __shared__ unsigned long long slot[2][NW];
     const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
-    const float *p = xyz + (size_t)b * N * 3;
+    const float *p = xyz + (size_t)b * N_stride * 3;
+    const int N = nv ? nv[b] : N_stride;
     float px[PPL], py[PPL], pz[PPL], dist[PPL];
 #pragma unroll
     for (int j = 0; j < PPL; j++) {
@@ -169,13 +172,15 @@ __device__ __forceinline__ float sqdist_ref(float qx, float qy, float qz, float 
 }
 
 // one wave per query: first K indices (ascending) with sqrdist <= r2, padded with the first hit
-__global__ __launch_bounds__(256) void k_ball_query(const float *__restrict__ xyz, const float *__restrict__ new_xyz, int N, int S,
-                                                   int K, float r2, long long *__restrict__ out)
+// (nv != nullptr: only the first nv[b] points of cloud b's N-point row exist, see k_fps_wave)
+__global__ __launch_bounds__(256) void k_ball_query(const float *__restrict__ xyz, const float *__restrict__ new_xyz, int N_stride, int S,
+                                                   int K, float r2, long long *__restrict__ out, const int *__restrict__ nv)
 {
     const int lane = threadIdx.x & 63;
     const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // global query id over B*S
     const int b = (int)(q / S);
-    const float *p = xyz + (size_t)b * N * 3;
+    const float *p = xyz + (size_t)b * N_stride * 3;
+    const int N = nv ? nv[b] : N_stride;
     const float qx = new_xyz[q * 3], qy = new_xyz[q * 3 + 1], qz = new_xyz[q * 3 + 2];
     const float sq = qx * qx + qy * qy + qz * qz;
     long long *o = out + q * K;
@@ -235,16 +240,18 @@ __global__ __launch_bounds__(64) void k_three_nn(const float *__restrict__ xyz1,
     idx_out[g * 3] = i0; idx_out[g * 3 + 1] = i1; idx_out[g * 3 + 2] = i2;
 }
 
-extern "C" int nirrt_pn2_fps(const float *xyz, int B, int N, int S, const int64_t *start, int64_t *out, void *stream)
+// n_valid (DEVICE, (B,) int32, or NULL): ragged batch - cloud b has n_valid[b] <= N points, S <= n_valid[b] (N <= 2048 then)
+extern "C" int nirrt_pn2_fps_ragged(const float *xyz, int B, int N, int S, const int64_t *start, const int32_t *n_valid, int64_t *out, void *stream)
 {
-    if (N > FPS_NT * FPS_MAX_PER_THREAD || N <= 0 || S <= 0) return -1;
+    if (N > FPS_NT * FPS_MAX_PER_THREAD || N <= 0 || S <= 0 || (n_valid && N > 2048)) return -1;
     hipStream_t st = (hipStream_t)stream;
     const long long *sp = (const long long *)start;
     long long *op = (long long *)out;
-    if (N <= 64) hipLaunchKernelGGL((k_fps_wave<1, 1>), dim3(B), dim3(64), 0, st, xyz, N, S, sp, op);
-    else if (N <= 256) hipLaunchKernelGGL((k_fps_wave<4, 1>), dim3(B), dim3(64), 0, st, xyz, N, S, sp, op);
-    else if (N <= 1024) hipLaunchKernelGGL((k_fps_wave<4, 4>), dim3(B), dim3(256), 0, st, xyz, N, S, sp, op);
-    else if (N <= 2048) hipLaunchKernelGGL((k_fps_wave<8, 4>), dim3(B), dim3(256), 0, st, xyz, N, S, sp, op);
+    const int *nv = (const int *)n_valid;
+    if (N <= 64) hipLaunchKernelGGL((k_fps_wave<1, 1>), dim3(B), dim3(64), 0, st, xyz, N, S, sp, op, nv);
+    else if (N <= 256) hipLaunchKernelGGL((k_fps_wave<4, 1>), dim3(B), dim3(64), 0, st, xyz, N, S, sp, op, nv);
+    else if (N <= 1024) hipLaunchKernelGGL((k_fps_wave<4, 4>), dim3(B), dim3(256), 0, st, xyz, N, S, sp, op, nv);
+    else if (N <= 2048) hipLaunchKernelGGL((k_fps_wave<8, 4>), dim3(B), dim3(256), 0, st, xyz, N, S, sp, op, nv);
     else {
         size_t lds = sizeof(float) * 3 * (size_t)N + 16 * sizeof(float) + 16 * sizeof(int);
         hipLaunchKernelGGL(k_fps, dim3(B), dim3(FPS_NT), lds, st, xyz, N, S, sp, op);
@@ -252,14 +259,25 @@ extern "C" int nirrt_pn2_fps(const float *xyz, int B, int N, int S, const int64_
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-extern "C" int nirrt_pn2_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, int K, float r2, int64_t *out,
-                                    void *stream)
+extern "C" int nirrt_pn2_fps(const float *xyz, int B, int N, int S, const int64_t *start, int64_t *out, void *stream)
+{
+    return nirrt_pn2_fps_ragged(xyz, B, N, S, start, nullptr, out, stream);
+}
+
+extern "C" int nirrt_pn2_ball_query_ragged(const float *xyz, const float *new_xyz, int B, int N, int S, int K, float r2,
+                                           const int32_t *n_valid, int64_t *out, void *stream)
 {
     long long queries = (long long)B * S;
     if (queries % 4 != 0) return -1;   // S is a multiple of 16 in this network
     hipLaunchKernelGGL(k_ball_query, dim3((unsigned)(queries / 4)), dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, N, S, K, r2,
-                       (long long *)out);
+                       (long long *)out, (const int *)n_valid);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int nirrt_pn2_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, int K, float r2, int64_t *out,
+                                    void *stream)
+{
+    return nirrt_pn2_ball_query_ragged(xyz, new_xyz, B, N, S, K, r2, nullptr, out, stream);
 }
 
 extern "C" int nirrt_pn2_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S, float *dist, int64_t *idx, void *stream)
@@ -819,13 +837,17 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 #define NI_NT 256
 // smask / gmask != nullptr: the indicator channels are given (one byte per point, row `row` at + row * mask_stride) - the masks of
 // the neural-connect rounds are re-seeded at boundary points (k_connect_masks) instead of following from the start / goal states
+// n_each != nullptr (ragged batch): cloud b has n_each[b] <= n_in points; the blocks are n_in wide all the same (the caller zeroes
+// the columns behind a cloud's own points) and everything that depends on the cloud's size (mean, largest norm) uses n_each[b]
 __global__ __launch_bounds__(NI_NT) void k_net_input(const double *__restrict__ clouds, long long stride_pts, const int *__restrict__ rows,
-                                                     int n, const double *__restrict__ starts, const double *__restrict__ goals,
-                                                     double radius, float *__restrict__ out, const unsigned char *__restrict__ smask,
-                                                     const unsigned char *__restrict__ gmask, long long mask_stride)
+                                                     int n_in, const double *__restrict__ starts, const double *__restrict__ goals,
+                                                     double radius, float *__restrict__ out_all, const unsigned char *__restrict__ smask,
+                                                     const unsigned char *__restrict__ gmask, long long mask_stride,
+                                                     const int *__restrict__ n_each)
 {
-    extern __shared__ float ni_lds[];          // 3 * n coordinates + reduction slots
-    float *px = ni_lds, *py = px + n, *pz = py + n;
+    extern __shared__ float ni_lds[];          // 3 * n_in coordinates + reduction slots
+    float *px = ni_lds, *py = px + n_in, *pz = py + n_in;
+    const int n = n_each ? n_each[blockIdx.x] : n_in;
     __shared__ float mean[3];
     __shared__ float red[NI_NT / 64];
     const int b = blockIdx.x, row = rows[b], tid = threadIdx.x;
@@ -833,7 +855,7 @@ __global__ __launch_bounds__(NI_NT) void k_net_input(const double *__restrict__ 
     const bool given = smask != nullptr;
     const double sx = given ? 0. : starts[3 * b], sy = given ? 0. : starts[3 * b + 1], sz = given ? 0. : starts[3 * b + 2];
     const double gx = given ? 0. : goals[3 * b], gy = given ? 0. : goals[3 * b + 1], gz = given ? 0. : goals[3 * b + 2];
-    float *o = out + (long long)b * 6 * n;
+    float *o = out_all + (long long)b * 6 * n_in;
     for (int i = tid; i < n; i += NI_NT) {
         const double x = c[3 * i], y = c[3 * i + 1], z = c[3 * i + 2];
         px[i] = (float)x; py[i] = (float)y; pz[i] = (float)z;
@@ -847,9 +869,9 @@ __global__ __launch_bounds__(NI_NT) void k_net_input(const double *__restrict__ 
             dx = x - gx; dy = y - gy; dz = z - gz;
             gm = sqrt((dx * dx + dy * dy) + dz * dz) < radius ? 1.f : 0.f;
         }
-        o[3 * n + i] = sm;
-        o[4 * n + i] = gm;
-        o[5 * n + i] = (sm + gm) == 0.f ? 1.f : 0.f;
+        o[3 * n_in + i] = sm;
+        o[4 * n_in + i] = gm;
+        o[5 * n_in + i] = (sm + gm) == 0.f ? 1.f : 0.f;
     }
     __syncthreads();
     if (tid < 3) {
@@ -873,18 +895,27 @@ __global__ __launch_bounds__(NI_NT) void k_net_input(const double *__restrict__ 
     for (int w = 1; w < NI_NT / 64; w++) big = fmaxf(big, red[w]);
     for (int i = tid; i < n; i += NI_NT) {
         o[i] = px[i] / big;
-        o[n + i] = py[i] / big;
-        o[2 * n + i] = pz[i] / big;
+        o[n_in + i] = py[i] / big;
+        o[2 * n_in + i] = pz[i] / big;
     }
+}
+
+// n_each (DEVICE, (n_rows,) int32, or NULL): ragged batch - row b's cloud has n_each[b] <= n points; out is (n_rows, 6, n) and the
+// caller has zeroed it (the columns behind a cloud's own points are not written)
+extern "C" int nirrt_pn2_net_input_ragged(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n, const int32_t *n_each,
+                                          const double *starts, const double *goals, double radius, float *out, void *stream)
+{
+    if (n_rows <= 0 || n <= 0 || n > 12288 || stride_pts < n) return -1;
+    hipLaunchKernelGGL(k_net_input, dim3((unsigned)n_rows), dim3(NI_NT), sizeof(float) * 3 * (size_t)n, (hipStream_t)stream, clouds,
+                       (long long)stride_pts, rows, n, starts, goals, radius, out, (const unsigned char *)nullptr, (const unsigned char *)nullptr, 0ll,
+                       (const int *)n_each);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 extern "C" int nirrt_pn2_net_input(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n, const double *starts,
                                    const double *goals, double radius, float *out, void *stream)
 {
-    if (n_rows <= 0 || n <= 0 || n > 12288 || stride_pts < n) return -1;
-    hipLaunchKernelGGL(k_net_input, dim3((unsigned)n_rows), dim3(NI_NT), sizeof(float) * 3 * (size_t)n, (hipStream_t)stream, clouds,
-                       (long long)stride_pts, rows, n, starts, goals, radius, out, (const unsigned char *)nullptr, (const unsigned char *)nullptr, 0ll);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return nirrt_pn2_net_input_ragged(clouds, stride_pts, rows, n_rows, n, nullptr, starts, goals, radius, out, stream);
 }
 
 extern "C" int nirrt_pn2_net_input_masks(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n,
@@ -893,7 +924,7 @@ extern "C" int nirrt_pn2_net_input_masks(const double *clouds, int64_t stride_pt
     if (n_rows <= 0 || n <= 0 || n > 12288 || stride_pts < n || mask_stride < n || !start_masks || !goal_masks) return -1;
     hipLaunchKernelGGL(k_net_input, dim3((unsigned)n_rows), dim3(NI_NT), sizeof(float) * 3 * (size_t)n, (hipStream_t)stream, clouds,
                        (long long)stride_pts, rows, n, (const double *)nullptr, (const double *)nullptr, 0.0, out, start_masks, goal_masks,
-                       (long long)mask_stride);
+                       (long long)mask_stride, (const int *)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -115,10 +115,15 @@ class PNGWrapper:
             score = torch.softmax(logp, dim=2)[:, :, 1]
             return pred.cpu().numpy(), score.cpu().numpy()
 
-    def classify_device(self, x, fps_starts=None):
-        """input blocks already on the device (pointops.net_input): x f32 (B, 6, N) -> path_pred int64 (B, N), left on the device"""
+    def classify_device(self, x, fps_starts=None, n_valid=None):
+        """input blocks already on the device (pointops.net_input): x f32 (B, 6, N) -> path_pred int64 (B, N), left on the device.
+        n_valid (B,) int32 on the device: ragged batch (clouds of different sizes, PointNet2.forward) - row b's first n_valid[b]
+        labels are the cloud's"""
         with torch.no_grad():
-            logp, _ = self.model(x, fps_starts=fps_starts)
+            if n_valid is not None:
+                logp, _ = self.model(x, fps_starts=fps_starts, n_valid=n_valid)
+            else:
+                logp, _ = self.model(x, fps_starts=fps_starts)
             return logp.argmax(dim=2)
 
     def _graph_forward(self, x, fps_starts):

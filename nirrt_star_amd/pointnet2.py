@@ -87,11 +87,13 @@ class SetAbstractionMSG(nn.Module):
             c_in = self.conv_blocks[0][0].weight.shape[1]
             self._fused = [pointops.sa_mlp_pack(layers, c_in, dev) for layers in self._folded]
 
-    def forward(self, xyz, feats, fps_start=None):
-        """xyz (B, N, 3), feats (B, N, C) -> new_xyz (B, S, 3), new_feats (B, S, sum C_out)"""
+    def forward(self, xyz, feats, fps_start=None, n_valid=None):
+        """xyz (B, N, 3), feats (B, N, C) -> new_xyz (B, S, 3), new_feats (B, S, sum C_out).  n_valid (B,) int32 (device): ragged
+        batch - cloud b holds n_valid[b] <= N points, the rest of its rows is padding the sampling and the ball queries skip"""
         B, N, _ = xyz.shape
         S = self.npoint
-        fps_idx = pointops.farthest_point_sample(xyz, S, fps_start)            # (B, S)
+        fps_idx = pointops.farthest_point_sample(xyz, S, fps_start, n_valid) if n_valid is not None else \
+            pointops.farthest_point_sample(xyz, S, fps_start)                  # (B, S)
         new_xyz = torch.gather(xyz, 1, fps_idx[..., None].expand(B, S, 3))
         fused = getattr(self, "_fused", None) if (self._folded is not None and not self.training and xyz.is_cuda) else None
         out_all, off = None, 0
@@ -99,7 +101,8 @@ class SetAbstractionMSG(nn.Module):
             out_all = torch.empty(B, S, sum(layers[-1][0].shape[0] for layers in self._folded), dtype=torch.float32, device=xyz.device)
         outs = []
         for bi, (radius, K) in enumerate(zip(self.radii, self.nsamples)):
-            gidx = pointops.ball_query(radius, K, xyz, new_xyz)                # (B, S, K)
+            gidx = pointops.ball_query(radius, K, xyz, new_xyz, n_valid) if n_valid is not None else \
+                pointops.ball_query(radius, K, xyz, new_xyz)                   # (B, S, K)
             if fused is not None:
                 width = self._folded[bi][-1][0].shape[0]
                 if fused[bi] is not None and pointops.sa_mlp(feats, xyz, new_xyz, gidx, fused[bi], out_all, off):
@@ -213,11 +216,16 @@ class get_model(nn.Module):
         self._head = _fold(self.conv1, self.bn1)
         return self
 
-    def forward(self, points, fps_starts=None):
+    def forward(self, points, fps_starts=None, n_valid=None):
+        """n_valid (B,) int32 on the device: a ragged batch - cloud b is the first n_valid[b] columns of its (6, N) block (zeros
+        behind them).  Only the first set-abstraction level looks at a cloud as a whole (its sampling and its ball queries); the
+        levels behind it work on 1024 / 256 / 64 / 16 sampled points, the feature propagation and the head per point: cloud b's
+        first n_valid[b] output rows are what a forward over that cloud alone gives (up to the library GEMMs' summation order,
+        as for any batch), the rows behind them mean nothing."""
         feats0 = points.permute(0, 2, 1).contiguous()       # (B, N, 6)
         xyz0 = feats0[:, :, :3].contiguous()
         st = fps_starts or [None] * 4
-        xyz1, f1, i1 = self.sa1(xyz0, feats0, st[0])
+        xyz1, f1, i1 = self.sa1(xyz0, feats0, st[0], n_valid) if n_valid is not None else self.sa1(xyz0, feats0, st[0])
         xyz2, f2, i2 = self.sa2(xyz1, f1, st[1])
         xyz3, f3, i3 = self.sa3(xyz2, f2, st[2])
         xyz4, f4, i4 = self.sa4(xyz3, f3, st[3])

@@ -34,6 +34,9 @@ def _lib():
         L.nirrt_pn2_fps.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         L.nirrt_pn2_ball_query.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
         L.nirrt_pn2_three_nn.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+        L.nirrt_pn2_fps_ragged.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+        L.nirrt_pn2_ball_query_ragged.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp]
+        L.nirrt_pn2_net_input_ragged.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, vp]
         L.nirrt_fps_f64.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
         L.nirrt_fps_f64_batch.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
         L.nirrt_guidance_clouds.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int]
@@ -47,7 +50,8 @@ def _lib():
         L.nirrt_connect_round.argtypes = [vp, C.c_int, C.c_double, vp, vp, vp, C.c_int]
         L.nirrt_connect_masks.argtypes = [vp, C.c_int, C.c_double, vp, C.c_int]
         for f in (L.nirrt_pn2_fps, L.nirrt_pn2_ball_query, L.nirrt_pn2_three_nn, L.nirrt_fps_f64, L.nirrt_fps_f64_batch,
-                  L.nirrt_pn2_sa_mlp, L.nirrt_pn2_group_rows, L.nirrt_pn2_fp_rows, L.nirrt_pn2_net_input):
+                  L.nirrt_pn2_sa_mlp, L.nirrt_pn2_group_rows, L.nirrt_pn2_fp_rows, L.nirrt_pn2_net_input, L.nirrt_pn2_fps_ragged,
+                  L.nirrt_pn2_ball_query_ragged, L.nirrt_pn2_net_input_ragged):
             f.restype = C.c_int
         L._pn2_ready = True
     return L
@@ -62,28 +66,43 @@ def _check(rc, what):
         raise RuntimeError("libnirrt_hip %s failed (%d)" % (what, rc))
 
 
-def farthest_point_sample(xyz, npoint, start=None):
-    """xyz (B, N, 3) -> indices (B, npoint) long; start (B,) long or drawn with torch.randint on the CPU generator"""
+def farthest_point_sample(xyz, npoint, start=None, n_valid=None):
+    """xyz (B, N, 3) -> indices (B, npoint) long; start (B,) long or drawn with torch.randint on the CPU generator.
+    n_valid (B,) int32 on the device: ragged batch - cloud b holds n_valid[b] <= N points, its picks are those of a call over that
+    cloud alone (start[b] < n_valid[b] is the caller's: the reference draws it with the cloud's own size)"""
     B, N, _ = xyz.shape
     if start is None:
+        if n_valid is not None:
+            raise ValueError("farthest_point_sample: a ragged batch needs its start indices (one draw per cloud with the cloud's own size)")
         start = torch.randint(0, N, (B,), dtype=torch.long)
     _need_cuda("farthest_point_sample", xyz)
     start = start.to(xyz.device)
     xyz = xyz.contiguous().float()
     out = torch.empty(B, npoint, dtype=torch.long, device=xyz.device)
-    _check(_lib().nirrt_pn2_fps(xyz.data_ptr(), B, N, npoint, start.contiguous().data_ptr(), out.data_ptr(), _stream(xyz)), "fps")
+    if n_valid is None:
+        _check(_lib().nirrt_pn2_fps(xyz.data_ptr(), B, N, npoint, start.contiguous().data_ptr(), out.data_ptr(), _stream(xyz)), "fps")
+    else:
+        assert n_valid.is_cuda and n_valid.dtype == torch.int32 and n_valid.numel() == B
+        _check(_lib().nirrt_pn2_fps_ragged(xyz.data_ptr(), B, N, npoint, start.contiguous().data_ptr(), n_valid.contiguous().data_ptr(),
+                                           out.data_ptr(), _stream(xyz)), "fps_ragged")
     return out
 
 
-def ball_query(radius, nsample, xyz, new_xyz):
-    """first `nsample` indices in ascending order within `radius` of each query, padded with the first -> (B, S, K) long"""
+def ball_query(radius, nsample, xyz, new_xyz, n_valid=None):
+    """first `nsample` indices in ascending order within `radius` of each query, padded with the first -> (B, S, K) long
+    (n_valid: ragged batch, see farthest_point_sample)"""
     _need_cuda("ball_query", xyz)
     B, N, _ = xyz.shape
     S = new_xyz.shape[1]
     out = torch.empty(B, S, nsample, dtype=torch.long, device=xyz.device)
     r2 = float(torch.tensor(radius ** 2, dtype=torch.float32))
-    _check(_lib().nirrt_pn2_ball_query(xyz.contiguous().data_ptr(), new_xyz.contiguous().data_ptr(), B, N, S, nsample,
-                                       C.c_float(r2), out.data_ptr(), _stream(xyz)), "ball_query")
+    if n_valid is None:
+        _check(_lib().nirrt_pn2_ball_query(xyz.contiguous().data_ptr(), new_xyz.contiguous().data_ptr(), B, N, S, nsample,
+                                           C.c_float(r2), out.data_ptr(), _stream(xyz)), "ball_query")
+    else:
+        assert n_valid.is_cuda and n_valid.dtype == torch.int32 and n_valid.numel() == B
+        _check(_lib().nirrt_pn2_ball_query_ragged(xyz.contiguous().data_ptr(), new_xyz.contiguous().data_ptr(), B, N, S, nsample,
+                                                  C.c_float(r2), n_valid.contiguous().data_ptr(), out.data_ptr(), _stream(xyz)), "ball_query_ragged")
     return out
 
 
@@ -99,15 +118,22 @@ def three_nn(xyz1, xyz2):
     return d, i
 
 
-def net_input(clouds, rows, n, starts, goals, radius):
+def net_input(clouds, rows, n, starts, goals, radius, n_each=None):
     """the network's input blocks of resident clouds (k_net_input): clouds f64 (n_clouds, stride, 3) on the device, rows = the
     clouds to take (all of n points), starts / goals (len(rows), 3) f64 -> x f32 (len(rows), 6, n), bit-equal to
-    PNGWrapper.network_input + get_point_cloud_mask_around_points on the host"""
+    PNGWrapper.network_input + get_point_cloud_mask_around_points on the host.  n_each (len(rows),) int32 on the device: ragged
+    batch - cloud b has n_each[b] <= n points, its block is what a call over that cloud alone gives, followed by zeros"""
     _need_cuda("net_input", clouds)
     dev = clouds.device
     rows_t = torch.as_tensor(rows, dtype=torch.int32).to(dev)
     st = torch.as_tensor(starts, dtype=torch.float64).reshape(-1, 3).to(dev)
     gl = torch.as_tensor(goals, dtype=torch.float64).reshape(-1, 3).to(dev)
+    if n_each is not None:      # ragged: blocks as wide as the largest cloud, zeros behind a cloud's own points
+        assert n_each.is_cuda and n_each.dtype == torch.int32 and n_each.numel() == len(rows_t)
+        out = torch.zeros(len(rows_t), 6, int(n), dtype=torch.float32, device=dev)
+        _check(_lib().nirrt_pn2_net_input_ragged(clouds.data_ptr(), clouds.shape[1], rows_t.data_ptr(), len(rows_t), int(n), n_each.data_ptr(),
+                                                 st.data_ptr(), gl.data_ptr(), float(radius), out.data_ptr(), _stream(clouds)), "net_input_ragged")
+        return out
     out = torch.empty(len(rows_t), 6, int(n), dtype=torch.float32, device=dev)
     _check(_lib().nirrt_pn2_net_input(clouds.data_ptr(), clouds.shape[1], rows_t.data_ptr(), len(rows_t), int(n), st.data_ptr(),
                                       gl.data_ptr(), float(radius), out.data_ptr(), _stream(clouds)), "net_input")

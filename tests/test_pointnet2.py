@@ -268,6 +268,56 @@ def test_gpu_net_input_bit_equal_to_host_assembly(dim):
             assert np.array_equal(got[k], ref), (n, j, np.abs(got[k] - ref).max())
 
 
+@pytest.mark.gpu
+def test_gpu_ragged_batch_equals_one_forward_per_cloud():
+    """Round 6: clouds of DIFFERENT sizes in one forward (PointNet2.forward(n_valid=...), the batched cloud refresh).  The
+    reference classifies one cloud at a time (pointnet2_wrapper.py:43-58); against one forward per cloud, the ragged batch must
+    give bit-equal input blocks (zeros behind a cloud's own points), identical sampling indices at all four levels, identical ball
+    queries at the first level, and the same log-probabilities up to the library GEMMs' summation order (<= 1e-4, labels >= 99.5 %)."""
+    from nirrt_star_amd import pointops
+    g = load_golden("pointnet2_ref")
+    m = _model(g, "cuda").fold()
+    rng = np.random.RandomState(23)
+    sizes = [2048, 1801, 2048, 1280, 2047, 1999, 1536]
+    n_max = max(sizes)
+    block = np.zeros((len(sizes), 2048, 3))
+    starts, goals = np.zeros((len(sizes), 3)), np.zeros((len(sizes), 3))
+    for j, n in enumerate(sizes):
+        block[j, :n, :2] = rng.uniform(0, 224, (n, 2))
+        starts[j] = block[j, rng.randint(n)] + 0.25
+        goals[j] = block[j, rng.randint(n)] - 0.5
+        starts[j, 2] = goals[j, 2] = 0.0
+    dev_block = torch.from_numpy(block).cuda()
+    fps = [[int(rng.randint(n)), int(rng.randint(1024)), int(rng.randint(256)), int(rng.randint(64))] for n in sizes]
+    nv = torch.tensor(sizes, dtype=torch.int32).cuda()
+    rows = list(range(len(sizes)))
+    x_all = pointops.net_input(dev_block, rows, n_max, starts, goals, 10.0, n_each=nv)
+    st_all = [torch.tensor([f[k] for f in fps]) for k in range(4)]
+    with torch.no_grad():
+        logp_all, _ = m(x_all, fps_starts=st_all, n_valid=nv)
+    fps_all = [t.cpu().numpy() for t in m.last_fps]
+    feats = x_all.permute(0, 2, 1).contiguous()
+    xyz = feats[:, :, :3].contiguous()
+    new_xyz = torch.gather(xyz, 1, m.last_fps[0][..., None].expand(len(sizes), 1024, 3))
+    balls_all = [pointops.ball_query(r, k, xyz, new_xyz, nv).cpu().numpy() for r, k in zip(m.sa1.radii, m.sa1.nsamples)]
+    agree = []
+    for j, n in enumerate(sizes):
+        x1 = pointops.net_input(dev_block, [j], n, starts[j:j + 1], goals[j:j + 1], 10.0)
+        assert torch.equal(x_all[j, :, :n], x1[0]) and float(x_all[j, :, n:].abs().max() if n < n_max else 0.0) == 0.0
+        with torch.no_grad():
+            logp1, _ = m(x1, fps_starts=[torch.tensor([v]) for v in fps[j]])
+        for lvl in range(4):
+            assert np.array_equal(m.last_fps[lvl][0].cpu().numpy(), fps_all[lvl][j]), (j, lvl)
+        xyz1 = x1.permute(0, 2, 1)[:, :, :3].contiguous()
+        nx1 = torch.gather(xyz1, 1, m.last_fps[0][..., None].expand(1, 1024, 3))
+        for bi, (r, k) in enumerate(zip(m.sa1.radii, m.sa1.nsamples)):
+            assert np.array_equal(pointops.ball_query(r, k, xyz1, nx1).cpu().numpy()[0], balls_all[bi][j]), (j, bi)
+        a, b = logp_all[j, :n].cpu().numpy(), logp1[0].cpu().numpy()
+        assert np.max(np.abs(a - b)) <= 1e-4, (j, float(np.max(np.abs(a - b))))
+        agree.append(np.mean(a.argmax(-1) == b.argmax(-1)))
+    assert min(agree) >= 0.995, agree
+
+
 def test_numpy_reduction_orders_the_device_input_assembly_relies_on():
     """k_net_input (csrc/pointops.hip) restates pc_normalize with the evaluation order numpy uses for it: np.mean over axis 0 of
     a C-contiguous (N, 3) float32 array adds the rows in index order (no pairwise blocking on the outer axis), the row norm is
