@@ -519,10 +519,16 @@ def secondary_runs(args):
                "--no-cpu-baseline", "--no-secondary", "--no-single"] + ([] if ttfs else ["--no-ttfs"]) + list(extra)
         t0 = time.perf_counter()
         try:
-            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            first_error = None
+            for attempt in (0, 1):      # (one retry: a line that dies says so in `retried_after` and gets a second chance at a number)
+                p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+                if p.returncode == 0 and line:
+                    break
+                err = "rc %d: %s" % (p.returncode, ([l for l in p.stderr.strip().splitlines() if "amdgpu.ids" not in l] or ["no output"])[-1][:160])
+                first_error = first_error or err
             if p.returncode != 0 or not line:
-                out[label] = {"error": "rc %d: %s" % (p.returncode, p.stderr.strip().splitlines()[-1] if p.stderr.strip() else "no output")}
+                out[label] = {"error": first_error}
                 continue
             d = json.loads(line[-1])
             cfg, rf = d["config"], d["roofline"]
@@ -535,6 +541,8 @@ def secondary_runs(args):
                           "kernel_share_of_step": rf.get("kernel_share_of_step"), "time_to_first_solution": d.get("time_to_first_solution"),
                           "workload": cfg.get("workload"),
                           "warning": d.get("warning"), "wall_s": time.perf_counter() - t0}
+            if first_error:
+                out[label]["retried_after"] = first_error
         except subprocess.TimeoutExpired:
             out[label] = {"error": "timed out after 900 s"}
     return out
@@ -555,7 +563,7 @@ def compact(v):
     t = v.get("time_to_first_solution")
     if t and t["single"]["median_seconds"] is not None and t["batch"]["median_seconds"] is not None:
         c["ttfs_ms"] = [round(t["single"]["median_seconds"] * 1e3, 2), round(t["batch"]["median_seconds"] * 1e3, 2)]
-    for k in ("resumed_s", "problems"):
+    for k in ("resumed_s", "problems", "retried_after"):
         if k in v:
             c[k] = v[k]
     if v.get("trees_stopped_early"):

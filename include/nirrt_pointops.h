@@ -63,6 +63,9 @@ int nirrt_pn2_net_input_ragged(const double *clouds, int64_t stride_pts, const i
  * masks of the neural-connect rounds are re-seeded at boundary points, pointnet2_wrapper_connect_bfs.py:181-216) */
 int nirrt_pn2_net_input_masks(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n,
                               const uint8_t *start_masks, const uint8_t *goal_masks, int64_t mask_stride, float *out, void *stream);
+/* (ragged, as nirrt_pn2_net_input_ragged) */
+int nirrt_pn2_net_input_masks_ragged(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n, const int32_t *n_each,
+                                     const uint8_t *start_masks, const uint8_t *goal_masks, int64_t mask_stride, float *out, void *stream);
 
 /* Input rows of the set-abstraction levels whose MLP runs as library GEMMs: sample_and_group's concatenation
  * (pointnet2_utils.py:247-250) in one pass.  DEVICE pointers as for nirrt_pn2_sa_mlp; C a multiple of 4;

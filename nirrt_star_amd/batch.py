@@ -465,10 +465,9 @@ class Guidance:
         xs_l = [np.asarray(problems[i]["x_start"], dtype=np.float64) for i in due]
         xg_l = [np.asarray(problems[i]["x_goal"], dtype=np.float64) for i in due]
 
-        def fps_starts_for(group):   # group: positions inside `due`
-            sizes = (int(n_out[group[0]]), 1024, 256, 64)
-            st = np.stack([streams[due[j]].fps_starts(sizes) for j in group])      # (len(group), 4): every problem draws from its own generator
-            return [torch.from_numpy(np.ascontiguousarray(st[:, k])) for k in range(len(sizes))]
+        def fps_starts_for(group):   # group: positions inside `due`; every cloud's first-level start is drawn with ITS size
+            st = np.stack([streams[due[j]].fps_starts((int(n_out[j]), 1024, 256, 64)) for j in group])      # (len(group), 4): every problem draws from its own generator
+            return [torch.from_numpy(np.ascontiguousarray(st[:, k])) for k in range(4)]
 
         preds = [None] * nd
         pred_dev = None
@@ -480,7 +479,7 @@ class Guidance:
             pred_host = pred_dev.cpu().numpy().astype(np.float32)
             for j in range(nd):
                 preds[j] = pred_host[j, : n_out[j]]
-            self.calls += int(runs.max()) if nd else 0
+            self.calls += int(getattr(connect_rounds_device, "last_forwards", 0) or (int(runs.max()) if nd else 0))
         elif self.connect:
             res = self.wrapper.generate_connected_path_points_batch([c.astype(np.float32) for c in clouds], xs_l, xg_l, self.radius,
                                                                     self.max_trials, fps_starts_for)
@@ -509,8 +508,7 @@ class Guidance:
                 n_max = max(by_size)
                 grp = list(range(nd))
                 nv = torch.from_numpy(np.ascontiguousarray(n_out, dtype=np.int32)).to(dev)
-                st = np.stack([streams[due[j]].fps_starts((int(n_out[j]), 1024, 256, 64)) for j in grp])
-                starts = [torch.from_numpy(np.ascontiguousarray(st[:, k])) for k in range(4)]
+                starts = fps_starts_for(grp)
                 x = pointops.net_input(clouds_dev, grp, n_max, s3, g3, self.radius, n_each=nv)
                 pred = self.wrapper.classify_device(x, fps_starts=starts, n_valid=nv)
                 pred_dev[:, :n_max] = (pred != 0).to(torch.uint8)      # (the labels behind a cloud's own points are never read)
@@ -596,7 +594,10 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
     pace = np.zeros(B)      # device ticks per iteration of every tree in its last launch (0: not run yet)
     paced = png and os.environ.get("NIRRT_BATCH_PACE", "1") == "1"
     pace_ref = float(os.environ.get("NIRRT_BATCH_PACE_REF", "1.25"))      # trees slower than this x the median get shorter windows
-    park_frac = float(os.environ.get("NIRRT_BATCH_PARK", "0.25"))        # a guided launch ends when this share of its trees waits for a refresh (0 = off)
+    # a guided launch ends when this share of its trees waits for a refresh (0 = off).  The -C planners keep their launches whole:
+    # a refresh of theirs is up to five rounds of forwards and searches, and fewer, larger refreshes beat idle slots (config 3,
+    # round 6: 13.9 M it/s without, 12.2 - 13.4 with; NIRRT* 3D: 7.6 -> 8.0 with, at pc_update_cost_ratio = 1.0 1.6 -> 2.1)
+    park_frac = float(os.environ.get("NIRRT_BATCH_PARK", "0" if (png and guidance.connect) else "0.25"))
     park_min = int(os.environ.get("NIRRT_BATCH_PARK_MIN", "16"))
 
     def launch(act):

@@ -918,14 +918,21 @@ extern "C" int nirrt_pn2_net_input(const double *clouds, int64_t stride_pts, con
     return nirrt_pn2_net_input_ragged(clouds, stride_pts, rows, n_rows, n, nullptr, starts, goals, radius, out, stream);
 }
 
-extern "C" int nirrt_pn2_net_input_masks(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n,
-                                         const uint8_t *start_masks, const uint8_t *goal_masks, int64_t mask_stride, float *out, void *stream)
+extern "C" int nirrt_pn2_net_input_masks_ragged(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n,
+                                                const int32_t *n_each, const uint8_t *start_masks, const uint8_t *goal_masks,
+                                                int64_t mask_stride, float *out, void *stream)
 {
     if (n_rows <= 0 || n <= 0 || n > 12288 || stride_pts < n || mask_stride < n || !start_masks || !goal_masks) return -1;
     hipLaunchKernelGGL(k_net_input, dim3((unsigned)n_rows), dim3(NI_NT), sizeof(float) * 3 * (size_t)n, (hipStream_t)stream, clouds,
                        (long long)stride_pts, rows, n, (const double *)nullptr, (const double *)nullptr, 0.0, out, start_masks, goal_masks,
-                       (long long)mask_stride, (const int *)nullptr);
+                       (long long)mask_stride, (const int *)n_each);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int nirrt_pn2_net_input_masks(const double *clouds, int64_t stride_pts, const int32_t *rows, int n_rows, int n,
+                                         const uint8_t *start_masks, const uint8_t *goal_masks, int64_t mask_stride, float *out, void *stream)
+{
+    return nirrt_pn2_net_input_masks_ragged(clouds, stride_pts, rows, n_rows, n, nullptr, start_masks, goal_masks, mask_stride, out, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -9,6 +9,8 @@ wrapper_3d twins (3D: no z padding, 3D checkpoint path).
 """
 from os.path import join
 
+import os
+
 import numpy as np
 import torch
 
@@ -228,15 +230,28 @@ def connect_rounds_device(wrapper, clouds_dev, n_out, starts, goals, radius, max
     pointops.connect_masks(jobs, radius, np.full((nd, 2), -2, dtype=np.int32), device_id)      # masks around the start / goal states
     has = np.zeros(nd, dtype=bool)
     trials = np.zeros(nd, dtype=np.int64)
+    wrapper_calls = 0
+    ragged = os.environ.get("NIRRT_RAGGED_FORWARD", "1") == "1"
     for _ in range(int(max_trial_attempts)):
         open_ = [j for j in range(nd) if not has[j]]
         if not open_:
             break
-        for size in sorted(set(int(n_out[j]) for j in open_)):
+        sizes = sorted(set(int(n_out[j]) for j in open_))
+        if ragged and len(sizes) > 1 and fps_starts_for is not None and sizes[-1] <= 2048:
+            # every open cloud of the round in ONE forward, whatever their sizes (PointNet2.forward(n_valid=...)); the labels
+            # behind a cloud's own points are never read (the searches take jobs[j].n points)
+            nv = torch.from_numpy(np.ascontiguousarray(n_out[open_], dtype=np.int32)).to(dev)
+            x = pointops.net_input_masks(clouds_dev, open_, sizes[-1], smask, gmask, n_each=nv)
+            p = wrapper.classify_device(x, fps_starts=fps_starts_for(open_), n_valid=nv)
+            pred[torch.as_tensor(open_, device=dev), :sizes[-1]] = (p != 0).to(torch.uint8)
+            wrapper_calls += 1
+            sizes = []
+        for size in sizes:
             grp = [j for j in open_ if n_out[j] == size]
             x = pointops.net_input_masks(clouds_dev, grp, size, smask, gmask)
             p = wrapper.classify_device(x, fps_starts=fps_starts_for(grp) if fps_starts_for else None)
             pred[torch.as_tensor(grp, device=dev), :size] = (p != 0).to(torch.uint8)
+            wrapper_calls += 1
         hp, seeds, ties = pointops.connect_round([jobs[j] for j in open_], radius, device_id)
         trials[open_] += 1
         for k, j in enumerate(open_):
@@ -255,6 +270,7 @@ def connect_rounds_device(wrapper, clouds_dev, n_out, starts, goals, radius, max
         still = [k for k, j in enumerate(open_) if not hp[k]]
         if still:
             pointops.connect_masks([jobs[open_[k]] for k in still], radius, seeds[still], device_id)
+    connect_rounds_device.last_forwards = wrapper_calls      # (forwards of this call: the caller's statistics)
     return has, trials, path
 
 

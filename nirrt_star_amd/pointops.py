@@ -37,6 +37,7 @@ def _lib():
         L.nirrt_pn2_fps_ragged.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
         L.nirrt_pn2_ball_query_ragged.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp]
         L.nirrt_pn2_net_input_ragged.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, vp]
+        L.nirrt_pn2_net_input_masks_ragged.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int64, vp, vp]
         L.nirrt_fps_f64.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
         L.nirrt_fps_f64_batch.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
         L.nirrt_guidance_clouds.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int]
@@ -51,7 +52,7 @@ def _lib():
         L.nirrt_connect_masks.argtypes = [vp, C.c_int, C.c_double, vp, C.c_int]
         for f in (L.nirrt_pn2_fps, L.nirrt_pn2_ball_query, L.nirrt_pn2_three_nn, L.nirrt_fps_f64, L.nirrt_fps_f64_batch,
                   L.nirrt_pn2_sa_mlp, L.nirrt_pn2_group_rows, L.nirrt_pn2_fp_rows, L.nirrt_pn2_net_input, L.nirrt_pn2_fps_ragged,
-                  L.nirrt_pn2_ball_query_ragged, L.nirrt_pn2_net_input_ragged):
+                  L.nirrt_pn2_ball_query_ragged, L.nirrt_pn2_net_input_ragged, L.nirrt_pn2_net_input_masks_ragged):
             f.restype = C.c_int
         L._pn2_ready = True
     return L
@@ -140,7 +141,7 @@ def net_input(clouds, rows, n, starts, goals, radius, n_each=None):
     return out
 
 
-def net_input_masks(clouds, rows, n, start_masks, goal_masks):
+def net_input_masks(clouds, rows, n, start_masks, goal_masks, n_each=None):
     """net_input with GIVEN indicator channels: start_masks / goal_masks uint8 (n_clouds, stride) on the device (the masks of
     the neural-connect rounds) -> x f32 (len(rows), 6, n)"""
     _need_cuda("net_input_masks", clouds)
@@ -148,6 +149,13 @@ def net_input_masks(clouds, rows, n, start_masks, goal_masks):
     assert start_masks.dtype == torch.uint8 and goal_masks.dtype == torch.uint8 and start_masks.is_contiguous() and goal_masks.is_contiguous()
     assert start_masks.shape == goal_masks.shape and start_masks.shape[0] == clouds.shape[0]
     rows_t = torch.as_tensor(rows, dtype=torch.int32).to(dev)
+    if n_each is not None:      # ragged (see net_input)
+        assert n_each.is_cuda and n_each.dtype == torch.int32 and n_each.numel() == len(rows_t)
+        out = torch.zeros(len(rows_t), 6, int(n), dtype=torch.float32, device=dev)
+        _check(_lib().nirrt_pn2_net_input_masks_ragged(clouds.data_ptr(), clouds.shape[1], rows_t.data_ptr(), len(rows_t), int(n), n_each.data_ptr(),
+                                                       start_masks.data_ptr(), goal_masks.data_ptr(), start_masks.shape[1], out.data_ptr(),
+                                                       _stream(clouds)), "net_input_masks_ragged")
+        return out
     out = torch.empty(len(rows_t), 6, int(n), dtype=torch.float32, device=dev)
     _check(_lib().nirrt_pn2_net_input_masks(clouds.data_ptr(), clouds.shape[1], rows_t.data_ptr(), len(rows_t), int(n),
                                             start_masks.data_ptr(), goal_masks.data_ptr(), start_masks.shape[1], out.data_ptr(),

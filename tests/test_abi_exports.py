@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), "missing export %s" % s
     assert set(_hip.EXPORTS) == set(syms)
     pn = _declared_symbols("nirrt_pointops.h")
-    assert len(pn) == 17      # (round 6: + the three _ragged entry points)
+    assert len(pn) == 18      # (round 6: + the four _ragged entry points)
     for s in pn:
         assert hasattr(L, s), "missing export %s" % s
 
