@@ -597,7 +597,7 @@ def run_batch(trees, streams, iters, flags, dim, problems=None, guidance=None, f
     # a guided launch ends when this share of its trees waits for a refresh (0 = off).  The -C planners keep their launches whole:
     # a refresh of theirs is up to five rounds of forwards and searches, and fewer, larger refreshes beat idle slots (config 3,
     # round 6: 13.9 M it/s without, 12.2 - 13.4 with; NIRRT* 3D: 7.6 -> 8.0 with, at pc_update_cost_ratio = 1.0 1.6 -> 2.1)
-    park_frac = float(os.environ.get("NIRRT_BATCH_PARK", "0" if (png and guidance.connect) else "0.25"))
+    park_frac = float(os.environ.get("NIRRT_BATCH_PARK", "0" if (png and getattr(guidance, "connect", False)) else "0.25"))
     park_min = int(os.environ.get("NIRRT_BATCH_PARK_MIN", "16"))
 
     def launch(act):
