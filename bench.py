@@ -263,6 +263,7 @@ def main():
     full_proc = start_cpu_full_run(args) if (rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_cpu_full) else None
     t_setup = time.perf_counter()
     probs = make_problems(args, rank)
+    synthesis_s = time.perf_counter() - t_setup      # the BENCHMARK's own work: 250 synthetic worlds drawn and rasterised in Python
     D, B, iters = args.dim, len(probs), args.iters   # (strong scaling: this rank's share of the fixed set)
     flags = _hip.F_IRRT if args.algo == "irrt" else 0
     # every tree of the rank in ONE creation call (nirrt_create_batch: host work per tree, one device pass), the informed-sampling
@@ -350,6 +351,9 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "process_group": (dist.get_backend() if grouped else None),
             "input_generation_s": input_generation_s, "setup_seconds_max_over_ranks": setup_max,
+            # (of which: the benchmark drawing and rasterising its synthetic worlds in Python / everything the library does for the
+            #  batch - nirrt_create_batch, informed frames, free-segment probes - plus seeding 2 B host generators; rank 0)
+            "setup_split_s": {"problem_synthesis": synthesis_s, "trees_and_generators": setup_s - synthesis_s},
             "end_to_end_value": total_iters / (elapsed_max + input_generation_s),   # incl. seeding every problem's generators on the host
             "config": {"workload": ("%s_star random_2d (%s: %s; clearance 3, step_len 10), %d problems/GPU x %d iters, "
                                     "device-resident batched loop with in-kernel sampling" % (args.algo, args.world, WORLDS[args.world], B, iters))
