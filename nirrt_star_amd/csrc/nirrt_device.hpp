@@ -1453,6 +1453,30 @@ NIRRT_FN __device__ void rg_publish(bool mine, int my_beg, int my_len, unsigned 
 {
     Lds<NT> &s = g_lds;
     const int tid = tidx<NT>();
+#if !NIRRT_RG_FAST
+    {
+        // the walk needs neither compaction nor start offsets: range i goes to slot i as it is (empty ranges are stepped over), the
+        // total is a wave sum - every contributor sits in wave 0 (at most GRID_RG_MAX = 64 rows, thread i holds row i).  Two barriers
+        // instead of the six of the compaction + scan below: on the 128- / 256-lane workgroups a barrier is the expensive part
+        static_assert(GRID_RG_MAX <= 64, "rows of a range list live in wave 0");
+        __syncthreads();      // (the list the visit before read is free)
+        const int len = mine && my_len > 0 ? my_len : 0;
+        const int R = __popcll(__ballot(mine));      // (wave 0: the contributors are threads 0 .. R - 1)
+        if (mine) { s.rg_beg[tid] = my_beg; s.rg_len[tid] = len; s.rg_flag[tid] = (unsigned char)my_flag; }
+        if (tid < 64) {
+            int sum = len;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+            if (tid == 0) {
+                const bool has_extra = extra_len > 0;
+                if (has_extra) { s.rg_beg[R] = extra_beg; s.rg_len[R] = extra_len; s.rg_flag[R] = (unsigned char)extra_flag; }
+                s.rg_n = R + (has_extra ? 1 : 0); s.rg_total = sum + (has_extra ? extra_len : 0); s.rg_fast = 0;
+            }
+        }
+        __syncthreads();
+        return;
+    }
+#endif
     const bool keep = mine && my_len > 0;
     int pos = 0, cs = 0;
     int R = block_compact<NT>(s, keep, pos);
@@ -1792,7 +1816,7 @@ NIRRT_FN __device__ void wg_query_fn()
         {
             const int total = uni(s.rg_total);
             visited += total;
-            if (__builtin_expect(uni(s.rg_fast) != 0, 1)) {
+            if (NIRRT_RG_FAST && __builtin_expect(uni(s.rg_fast) != 0, 1)) {      // (compiled out of the default build: one trip loop resident)
                 // range of a flat offset = (range starts at or below it) - 1: the wave's 64-offset window is one word of the start-bit
                 // map (a uniform LDS read), the starts before the window are carried along (windows are fetched in ascending order)
                 const int n_words = (total + 63) >> 6;
