@@ -1437,15 +1437,18 @@ NIRRT_FN __device__ void wg_grid_rebuild2(int n)
     __syncthreads();
 }
 
-// A range list goes to LDS through rg_publish: thread i contributes range i (mine), thread 0 may add one more behind them; empty
-// ranges are dropped, the kept ones get their start offsets (exclusive scan) and - for lists within RG_BITS slots - their start
-// bits.  Barriers inside; every thread calls it.  (Out of line: four call sites, two of them on rare paths.)
+// A range list goes to LDS through rg_publish: thread i contributes range i (mine), thread 0 may add one more behind them.
+// Barriers inside; every thread calls it.  (Out of line: four call sites, two of them on rare paths.)  Default build (the walk):
+// ranges as they are, total by a wave sum.  -DNIRRT_RG_FAST=1: empty ranges are dropped, the kept ones get their start offsets
+// (exclusive scan) and - for lists within RG_BITS slots - their start bits.
 #ifndef NIRRT_RG_FAST
 // 1: the start-bit map below (built because round 5's review asked for the walk out of `fetch`).  Measured on one box, each twice
 // (profiles/r06_sweep6 / 8 / 10): the walk wins wherever a workgroup has more than one wave - a publish with the bit map is a
 // compaction, a scan and atomics over up to four waves, four times per query - one problem alone 1.88 -> 1.77 s, the 1000-problem
 // set 16.2 -> 17.2 M it/s, 256 problems 5.1 -> 5.5 M - and is level or ahead on the one-wave lines (default 55.5 / 55.2 vs 56.1 /
 // 56.1, RRT* 3D 76.0 vs 74.7 the other way).  A lane leaves its range once per ~40 slots: the lookup was never the cost.
+// What did cost was the publish itself: without compaction and scan (below) the walk gained another 2.6 % on the default line,
+// 7.5 % on the 1000-problem set and 8 % for one problem alone (profiles/r06_sweep11_lean_publish.txt).
 #define NIRRT_RG_FAST 0
 #endif
 template <int NT>
