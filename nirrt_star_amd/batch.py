@@ -39,7 +39,7 @@ class ProblemStreams:
         self.seed = int(seed)
         self._rs = np.random.RandomState(self.seed)
         self._pyg = random.Random(self.seed)
-        self._torch = None
+        self._fps_rng = None
         self._tree = None                 # the tree that owns the states right now (None: the host objects are current)
         self._behind = [False, False]     # the device has drawn since the host object was last synchronised
         self._touched = [False, False]    # the host object was handed out since: the tree needs its state back
@@ -141,11 +141,11 @@ class ProblemStreams:
         2^32 is `next 32-bit output % N`; the same outputs come from a numpy MT19937 with the same seeding, a call of which costs
         a tenth of four torch.randint calls (at pc_update_cost_ratio = 1.0 a batch makes > 100 000 forwards' worth of them per
         step).  tests/test_batch_host_logic.py compares the two generators draw by draw."""
-        if self._torch is None:
+        if self._fps_rng is None:
             if not 0 <= self.seed < 2 ** 32:
                 raise ValueError("ProblemStreams: seeds of the torch generator twin must fit 32 bits")
-            self._torch = np.random.RandomState(self.seed)
-        raw = self._torch.randint(0, 2 ** 32, size=len(sizes), dtype=np.uint32).astype(np.int64)
+            self._fps_rng = np.random.RandomState(self.seed)
+        raw = self._fps_rng.randint(0, 2 ** 32, size=len(sizes), dtype=np.uint32).astype(np.int64)
         return raw % np.asarray(sizes, dtype=np.int64)
 
 
