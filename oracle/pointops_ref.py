@@ -79,11 +79,18 @@ def farthest_point_down_sample_f64_batch(clouds, num_samples, device_id=0):
 
 def cpu_operators():
     """name -> CPU stand-in with the signature of the nirrt_star_amd.pointops function of that name"""
-    def fps(xyz, npoint, start=None):
+    def fps(xyz, npoint, start=None, n_valid=None):
+        if n_valid is not None:      # ragged batch: every cloud on its own first n_valid[b] points (what the reference does: one cloud per call)
+            return torch.stack([farthest_point_sample(xyz[b:b + 1, : int(n_valid[b])], npoint, start[b:b + 1])[0] for b in range(xyz.shape[0])])
         if start is None:
             start = torch.randint(0, xyz.shape[1], (xyz.shape[0],), dtype=torch.long)
         return farthest_point_sample(xyz, npoint, start)
-    return {"farthest_point_sample": fps, "ball_query": ball_query, "three_nn": three_nn,
+
+    def bq(radius, nsample, xyz, new_xyz, n_valid=None):
+        if n_valid is not None:
+            return torch.stack([ball_query(radius, nsample, xyz[b:b + 1, : int(n_valid[b])], new_xyz[b:b + 1])[0] for b in range(xyz.shape[0])])
+        return ball_query(radius, nsample, xyz, new_xyz)
+    return {"farthest_point_sample": fps, "ball_query": bq, "three_nn": three_nn,
             "farthest_point_down_sample_f64": lambda pts, num_samples, device_id=0: farthest_point_down_sample_f64(pts, num_samples),
             "farthest_point_down_sample_f64_batch": farthest_point_down_sample_f64_batch}
 

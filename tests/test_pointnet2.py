@@ -41,6 +41,42 @@ def test_cpu_unfolded_and_folded_match_reference():
     _check(g, m.fold(), "cpu", 1e-3)
 
 
+@pytest.mark.oracle_pointops
+def test_cpu_ragged_batch_is_one_forward_per_cloud():
+    """The claim behind the ragged batches of round 6 (PointNet2.forward(n_valid=...)), checked with the reference's own torch
+    operators on the CPU: only the first set-abstraction level looks at a cloud as a whole - with ITS sampling and ball queries
+    restricted to the cloud's own points, a cloud inside a batch of clouds of other sizes (zeros behind its points) gets the labels
+    of a forward over that cloud alone (pointnet2_wrapper.py:43-58 classifies one cloud per call)."""
+    from nirrt_star_amd.pointnet2 import pc_normalize
+    g = load_golden("pointnet2_ref")
+    m = _model(g, "cpu").fold()
+    rng = np.random.RandomState(31)
+    sizes = [2048, 1500, 1333]
+    n_max = max(sizes)
+    blocks, fps = [], []
+    x_all = torch.zeros(len(sizes), 6, n_max)
+    for j, n in enumerate(sizes):
+        pc = np.concatenate([rng.uniform(0, 224, (n, 2)), np.zeros((n, 1))], axis=1).astype(np.float32)
+        sm = (rng.uniform(size=n) < 0.02).astype(np.float32)
+        gm = (rng.uniform(size=n) < 0.02).astype(np.float32)
+        blk = np.concatenate([pc_normalize(pc).T, sm[None], gm[None], ((sm + gm) == 0).astype(np.float32)[None]], axis=0)
+        blocks.append(torch.from_numpy(blk.astype(np.float32)))
+        x_all[j, :, :n] = blocks[-1]
+        fps.append([int(rng.randint(n)), int(rng.randint(1024)), int(rng.randint(256)), int(rng.randint(64))])
+    nv = torch.tensor(sizes, dtype=torch.int32)
+    with torch.no_grad():
+        logp_all, _ = m(x_all, fps_starts=[torch.tensor([f[k] for f in fps]) for k in range(4)], n_valid=nv)
+    fps_all = [t.clone() for t in m.last_fps]
+    for j, n in enumerate(sizes):
+        with torch.no_grad():
+            logp1, _ = m(blocks[j][None], fps_starts=[torch.tensor([v]) for v in fps[j]])
+        for lvl in range(4):
+            assert torch.equal(m.last_fps[lvl][0], fps_all[lvl][j]), (j, lvl)
+        a, b = logp_all[j, :n].numpy(), logp1[0].numpy()
+        assert np.max(np.abs(a - b)) <= 1e-4, (j, float(np.max(np.abs(a - b))))
+        assert np.mean(a.argmax(-1) == b.argmax(-1)) >= 0.995
+
+
 def test_state_dict_layout_is_the_reference_one():
     from nirrt_star_amd.pointnet2 import get_model
     keys = list(get_model(2).state_dict().keys())
