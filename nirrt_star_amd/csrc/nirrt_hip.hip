@@ -1739,8 +1739,9 @@ static int run_sampling(nirrt_tree *const *trees, int32_t n_trees, const nirrt_r
     HIPCHK_R(hipMemcpyAsync(d_nnp, nnp.data(), sizeof(long long) * nt, hipMemcpyHostToDevice, st));
     HIPCHK_R(hipMemcpyAsync(d_npy, npy.data(), sizeof(long long) * nt, hipMemcpyHostToDevice, st));
     long long *d_each = nullptr;
+    std::vector<long long> each;      // (function scope: the asynchronous copy below reads it; the stream is synchronized further down)
     if (a->iters_each) {
-        std::vector<long long> each(nt);
+        each.resize(nt);
         for (int j = 0; j < n_trees; j++) {
             const long long e = a->iters_each[perm[(size_t)j]];
             if (e < 0 || e > a->iters) { g_err = "nirrt_run: iters_each[i] must be in [0, iters]"; cleanup(); return NIRRT_E_ARG; }
