@@ -579,6 +579,11 @@ struct TreeList {
     TreeDev **d = nullptr;
     size_t got = 0;
     int device = 0;
+    // the host copy of the table lives as long as the list: tree_list() hands it to an ASYNCHRONOUS copy, and the stream is
+    // synchronized by the list's user, after tree_list() has returned (round 6: it was a local of tree_list() - a pageable source
+    // that is freed while the copy is pending is whatever the heap holds by then; the candidate cause of the round's two rare
+    // "Memory access fault" aborts, both in guided runs, whose every refresh comes through here)
+    std::vector<TreeDev *> host;
     ~TreeList() { if (d) g_scratch.give(device, got, d); }
 };
 }
@@ -590,11 +595,11 @@ static int tree_list(nirrt_tree *const *trees, int32_t n_trees, const char *who,
         if (!trees[i] || trees[i]->device != t0->device) { g_err = std::string(who) + ": all trees must live on one device"; return NIRRT_E_ARG; }
     HIPCHK(hipSetDevice(t0->device));
     for (int i = 0; i < n_trees; i++) HIPCHK(hipStreamSynchronize(trees[i]->stream));
-    std::vector<TreeDev *> ptrs((size_t)n_trees);
-    for (int i = 0; i < n_trees; i++) ptrs[(size_t)i] = trees[i]->dev;
+    tl.host.resize((size_t)n_trees);
+    for (int i = 0; i < n_trees; i++) tl.host[(size_t)i] = trees[i]->dev;
     tl.device = t0->device;
     HIPCHK(g_scratch.take(t0->device, sizeof(TreeDev *) * (size_t)n_trees, (void **)&tl.d, &tl.got));
-    HIPCHK(hipMemcpyAsync(tl.d, ptrs.data(), sizeof(TreeDev *) * (size_t)n_trees, hipMemcpyHostToDevice, t0->stream));
+    HIPCHK(hipMemcpyAsync(tl.d, tl.host.data(), sizeof(TreeDev *) * (size_t)n_trees, hipMemcpyHostToDevice, t0->stream));
     return NIRRT_OK;
 }
 
